@@ -1,0 +1,90 @@
+"""ctypes binding of libestd_hip.so (the C ABI declared in include/estd_hip.h).
+
+There is NO fallback: if the library is missing or a call returns a negative status a
+RuntimeError is raised (the same exception type ATen shape/device errors surface as in the
+reference).  Build with ``python -m estdepth_amd.build`` (or ``__graft_entry__.build()``).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libestd_hip.so")
+
+c_float_p = ctypes.c_void_p      # device pointers travel as integers
+c_stream = ctypes.c_void_p
+
+
+class Conv3dDesc(ctypes.Structure):
+    """Mirror of struct estd_conv3d_desc (include/estd_hip.h)."""
+    _fields_ = [
+        ("N", ctypes.c_int), ("D", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int),
+        ("cin_main", ctypes.c_int), ("in_stride", ctypes.c_int), ("n_tiles", ctypes.c_int),
+        ("in_main", ctypes.c_void_p), ("in_extra", ctypes.c_void_p),
+        ("w_main", ctypes.c_void_p), ("w_extra", ctypes.c_void_p),
+        ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
+        ("act_a", ctypes.c_int), ("act_b", ctypes.c_int), ("act_split", ctypes.c_int),
+        ("out_main", ctypes.c_void_p), ("out_stride", ctypes.c_int), ("out_channels", ctypes.c_int),
+        ("residual", ctypes.c_void_p), ("out_scale", ctypes.c_float), ("accumulate", ctypes.c_int),
+        ("out_extra", ctypes.c_void_p),
+        ("head_w", ctypes.c_void_p), ("head_b", ctypes.c_void_p), ("out_head", ctypes.c_void_p),
+        ("stats_partials", ctypes.c_void_p),
+    ]
+
+
+_SIGNATURES = {
+    "estd_version": (ctypes.c_int, []),
+    "estd_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "estd_cam_pair_proj": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_stream]),
+    "estd_cam_sweep_proj": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_stream]),
+    "estd_cam_volume_mats": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_stream]),
+    "estd_homo_warping": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
+    "estd_mix1x1_chw_to_hwc": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p,
+                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
+    "estd_homo_warp_costvol": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
+                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
+    "estd_conv3d_k3": (ctypes.c_int, [ctypes.POINTER(Conv3dDesc), c_stream]),
+    "estd_conv3d_k3_grid": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "estd_groupnorm_finalize": (ctypes.c_int, [c_float_p, ctypes.c_int, ctypes.c_double, ctypes.c_float,
+                                               c_float_p, c_stream]),
+    "estd_softargmin_up": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p,
+                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
+    "estd_warp_volume": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, ctypes.c_float, ctypes.c_float, c_float_p,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
+    "estd_warp_attention": (ctypes.c_int, [c_float_p, ctypes.POINTER(ctypes.c_void_p), c_float_p, ctypes.c_int,
+                                           c_float_p, ctypes.c_float, ctypes.c_float, c_float_p,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
+    "estd_attention_prewarped": (ctypes.c_int, [c_float_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, c_float_p,
+                                                ctypes.c_int64, c_stream]),
+    "estd_gru_reset_apply": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
+                                            ctypes.c_int64, c_stream]),
+    "estd_gru_blend": (ctypes.c_int, [c_float_p] * 10 + [ctypes.c_int, ctypes.c_int64, c_stream]),
+    "estd_cdhw_to_vol": (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, c_stream]),
+    "estd_vol_to_cdhw": (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, c_stream]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once.  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libestd_hip.so not found at %s -- build it with `python -m estdepth_amd.build` "
+                               "(there is no CPU/eager fallback)" % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().estd_status_string(status).decode()
+        raise RuntimeError("%s failed: %s (estd_status %d)" % (what, msg, status))

@@ -1,0 +1,187 @@
+"""2D networks around the hot path (NOT hand-written kernels: they run on PyTorch-ROCm / MIOpen).
+
+SURVEY.md §2 marks these OUT OF SCOPE for HIP kernels; they exist so that
+``DepthNetHybrid.forward`` is a complete drop-in and so that reference checkpoints load
+unchanged (parameter names must match the reference's state dict):
+
+  * ``PSMFeatures``   <-> networks/psm_submodule.py:40-116  (keys ``matchingFeature.*``)
+  * ``ResNetTrunk`` / ``SemanticEncoder`` <-> hybrid_models/resnet_encoder.py:17-51 over a
+    torchvision-layout ResNet (keys ``semanticFeature.encoder.*`` incl. the unused ``fc``)
+  * ``conv_bn2d`` / ``UpBlock`` <-> networks/layers_op.py:10-27, hybrid_depth_decoder.py:17-30
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def conv_bn2d(cin, cout, k, stride, pad, dilation):
+    """Conv2d(bias=False)+BatchNorm2d; padding = dilation when dilation > 1 (layers_op.py:10-13)."""
+    return nn.Sequential(
+        nn.Conv2d(cin, cout, k, stride, dilation if dilation > 1 else pad, dilation, bias=False),
+        nn.BatchNorm2d(cout))
+
+
+class _PSMBlock(nn.Module):
+    def __init__(self, cin, cout, stride, downsample, pad, dilation):
+        super().__init__()
+        self.conv1 = nn.Sequential(conv_bn2d(cin, cout, 3, stride, pad, dilation), nn.ReLU(inplace=True))
+        self.conv2 = conv_bn2d(cout, cout, 3, 1, pad, dilation)
+        self.downsample = downsample
+
+    def forward(self, x):
+        y = self.conv2(self.conv1(x))
+        return y + (x if self.downsample is None else self.downsample(x))
+
+
+class PSMFeatures(nn.Module):
+    """PSMNet feature extractor with SPP -> [N,32,H/4,W/4], no final BN/ReLU."""
+
+    def __init__(self):
+        super().__init__()
+        self._cin = 32
+        self.firstconv = nn.Sequential(
+            conv_bn2d(3, 32, 3, 2, 1, 1), nn.ReLU(inplace=True),
+            conv_bn2d(32, 32, 3, 1, 1, 1), nn.ReLU(inplace=True),
+            conv_bn2d(32, 32, 3, 1, 1, 1), nn.ReLU(inplace=True))
+        self.layer1 = self._stage(32, 3, 1, 1, 1)
+        self.layer2 = self._stage(64, 16, 2, 1, 1)
+        self.layer3 = self._stage(128, 3, 1, 1, 1)
+        self.layer4 = self._stage(128, 3, 1, 1, 2)
+        for i, p in zip((1, 2, 3, 4), (32, 16, 8, 4)):
+            setattr(self, "branch%d" % i, nn.Sequential(
+                nn.AvgPool2d((p, p), stride=(p, p)), conv_bn2d(128, 32, 1, 1, 0, 1), nn.ReLU(inplace=True)))
+        self.lastconv = nn.Sequential(conv_bn2d(320, 128, 3, 1, 1, 1), nn.ReLU(inplace=True),
+                                      nn.Conv2d(128, 32, 1, 1, 0, bias=False))
+        self.out_channels = [32]
+
+    def _stage(self, planes, blocks, stride, pad, dilation):
+        down = None
+        if stride != 1 or self._cin != planes:
+            down = nn.Sequential(nn.Conv2d(self._cin, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+        layers = [_PSMBlock(self._cin, planes, stride, down, pad, dilation)]
+        self._cin = planes
+        layers += [_PSMBlock(planes, planes, 1, None, pad, dilation) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        x = self.firstconv(x)
+        x = self.layer1(x)
+        raw = self.layer2(x)
+        skip = self.layer4(self.layer3(raw))
+        size = skip.shape[2:]
+        # F.upsample(mode='bilinear') == interpolate(align_corners=False) in the oracle torch version
+        ups = [F.interpolate(getattr(self, "branch%d" % i)(skip), size=size, mode="bilinear", align_corners=False)
+               for i in (4, 3, 2, 1)]
+        return self.lastconv(torch.cat([raw, skip] + ups, 1))
+
+
+# ------------------------------------------------------------------ torchvision-layout ResNet
+class _Basic(nn.Module):
+    expansion = 1
+
+    def __init__(self, cin, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+
+    def forward(self, x):
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        return self.relu(y + (x if self.downsample is None else self.downsample(x)))
+
+
+class _Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, cin, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)   # stride on the 3x3 (torchvision v1.5)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        return self.relu(y + (x if self.downsample is None else self.downsample(x)))
+
+
+_RESNET_CFG = {18: (_Basic, (2, 2, 2, 2)), 34: (_Basic, (3, 4, 6, 3)), 50: (_Bottleneck, (3, 4, 6, 3)),
+               101: (_Bottleneck, (3, 4, 23, 3)), 152: (_Bottleneck, (3, 8, 36, 3))}
+
+
+class ResNetTrunk(nn.Module):
+    """ResNet with torchvision's attribute names (conv1,bn1,relu,maxpool,layer1..4,avgpool,fc)."""
+
+    def __init__(self, depth):
+        super().__init__()
+        if depth not in _RESNET_CFG:
+            raise ValueError("{} is not a valid number of resnet layers".format(depth))
+        block, reps = _RESNET_CFG[depth]
+        self._cin = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = self._stage(block, 64, reps[0], 1)
+        self.layer2 = self._stage(block, 128, reps[1], 2)
+        self.layer3 = self._stage(block, 256, reps[2], 2)
+        self.layer4 = self._stage(block, 512, reps[3], 2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(512 * block.expansion, 1000)   # unused; kept for checkpoint key parity
+
+    def _stage(self, block, planes, n, stride):
+        down = None
+        if stride != 1 or self._cin != planes * block.expansion:
+            down = nn.Sequential(nn.Conv2d(self._cin, planes * block.expansion, 1, stride, bias=False),
+                                 nn.BatchNorm2d(planes * block.expansion))
+        layers = [block(self._cin, planes, stride, down)]
+        self._cin = planes * block.expansion
+        layers += [block(self._cin, planes, 1, None) for _ in range(1, n)]
+        return nn.Sequential(*layers)
+
+
+class SemanticEncoder(nn.Module):
+    """resnet_encoder.py:17-51: five ReLU-activated feature scales (1/2 .. 1/32)."""
+
+    def __init__(self, num_layers, pretrained=False, num_input_images=1):
+        super().__init__()
+        self.num_ch_enc = np.array([64, 64, 128, 256, 512])
+        self.encoder = ResNetTrunk(num_layers)     # no network here: weights come from a checkpoint
+        if num_layers > 34:
+            self.num_ch_enc[1:] *= 4
+
+    def forward(self, x):
+        e = self.encoder
+        f0 = e.relu(e.bn1(e.conv1(x)))
+        f1 = e.layer1(e.maxpool(f0))
+        f2 = e.layer2(f1)
+        f3 = e.layer3(f2)
+        f4 = e.layer4(f3)
+        return [f0, f1, f2, f3, f4]
+
+
+class UpBlock(nn.Module):
+    """ConvBlock of the 2D decoder: conv3x3+BN+ReLU (hybrid_depth_decoder.py:17-30)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = conv_bn2d(int(cin), int(cout), 3, 1, 1, 1)
+        self.nonlin = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return self.nonlin(self.conv(x))
+
+
+def up2(x):
+    return F.interpolate(x, scale_factor=2, mode="nearest")

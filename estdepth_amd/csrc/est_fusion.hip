@@ -1,0 +1,471 @@
+// est_fusion.hip -- epipolar spatio-temporal fusion: frustum-to-frustum volume warp + cross-view
+// attention, GroupNorm(1 group) plumbing, ConvGRU elementwise stages, soft-argmin and the layout
+// converters at the API edge.
+//
+// Reference semantics restated (file:line into the reference repo):
+//   utils/homo_utils.py:240-279 warp_volume (+ :26-62, :107-134, :170-205)      trilinear, zeros,
+//       align_corners=False, |norm|>1 -> 2, eps 1e-10
+//   transformer/epipolar_transformer.py:56-83 EpipolarTransformer.forward       softmax over views,
+//       MEAN of weighted values (Q10), GRU gates with GroupNorm(1,16)
+//   hybrid_models/hybrid_depth_decoder.py:33-38 depthlayer on x4 nearest-upsampled logits
+// All of these are HBM / gather-latency bound; the fused warp+attention kernel never materialises
+// the 2N warped volumes the reference writes and re-reads.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "estd_hip.h"
+#include "estd_common.h"
+
+namespace {
+
+struct Tri {
+    long long off[8];   // voxel offsets ((z*H+y)*W+x), 0 when masked
+    float w[8];         // trilinear weights, 0 when the corner is out of bounds
+};
+
+// homo_utils.py:51-54 (pixel2cam), :33-36 (cam2cam), :115-121 (cam2pixel_depth), :183-198 (normalise+mask),
+// then ATen grid_sampler_3d un-normalisation for align_corners=False.  M = [kinv(9) | m(12) | k(9)].
+__device__ __forceinline__ Tri volume_coords(const float* __restrict__ M, float dep, int x, int y,
+                                             float depth_min, float depth_interval, int D, int H, int W)
+{
+    const float fx = (float)x, fy = (float)y;
+    const float c0 = (M[0] * fx + M[1] * fy + M[2]) * dep;
+    const float c1 = (M[3] * fx + M[4] * fy + M[5]) * dep;
+    const float c2 = (M[6] * fx + M[7] * fy + M[8]) * dep;
+    const float s0 = M[9] * c0 + M[10] * c1 + M[11] * c2 + M[12];
+    const float s1 = M[13] * c0 + M[14] * c1 + M[15] * c2 + M[16];
+    const float s2 = M[17] * c0 + M[18] * c1 + M[19] * c2 + M[20];
+    const float q0 = M[21] * s0 + M[22] * s1 + M[23] * s2;
+    const float q1 = M[24] * s0 + M[25] * s1 + M[26] * s2;
+    const float q2 = M[27] * s0 + M[28] * s1 + M[29] * s2;
+    const float den = q2 + 1e-10f;
+    const float X = q0 / den, Y = q1 / den, Z = q2;
+    float xn = 2.0f * X / (float)(W - 1) - 1.0f;
+    float yn = 2.0f * Y / (float)(H - 1) - 1.0f;
+    float zn = 2.0f * ((Z - depth_min) / depth_interval) / (float)(D - 1) - 1.0f;
+    if (xn > 1.0f || xn < -1.0f) xn = 2.0f;
+    if (yn > 1.0f || yn < -1.0f) yn = 2.0f;
+    if (zn > 1.0f || zn < -1.0f) zn = 2.0f;
+    const float ix = ((xn + 1.0f) * (float)W - 1.0f) * 0.5f;
+    const float iy = ((yn + 1.0f) * (float)H - 1.0f) * 0.5f;
+    const float iz = ((zn + 1.0f) * (float)D - 1.0f) * 0.5f;
+    const float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
+    const float tx = ix - fx0, ty = iy - fy0, tz = iz - fz0;
+    const bool finite = (ix == ix) && (iy == iy) && (iz == iz);
+    const int x0 = finite ? (int)fx0 : -2, y0 = finite ? (int)fy0 : -2, z0 = finite ? (int)fz0 : -2;
+    Tri t;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int dx = k & 1, dy = (k >> 1) & 1, dz = (k >> 2) & 1;
+        const int xx = x0 + dx, yy = y0 + dy, zz = z0 + dz;
+        const bool ok = xx >= 0 && xx < W && yy >= 0 && yy < H && zz >= 0 && zz < D;
+        const float wgt = (dx ? tx : 1.0f - tx) * (dy ? ty : 1.0f - ty) * (dz ? tz : 1.0f - tz);
+        t.w[k] = ok ? wgt : 0.0f;
+        t.off[k] = ok ? ((long long)zz * H + yy) * W + xx : 0;
+    }
+    return t;
+}
+
+// Level-1 operator (NCDHW in/out): one thread per target voxel, loop over channels.
+__global__ __launch_bounds__(256) void warp_volume_kernel(const float* __restrict__ vol, const float* __restrict__ M,
+                                                          const float* __restrict__ dvals, float depth_min, float depth_interval,
+                                                          float* __restrict__ out, int C, int D, int H, int W)
+{
+    const long long HW = (long long)H * W, S = (long long)D * HW;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < S; idx += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W);
+        const int y = (int)((idx / W) % H);
+        const int d = (int)(idx / HW);
+        const Tri t = volume_coords(M, dvals[d], x, y, depth_min, depth_interval, D, H, W);
+        for (int c = 0; c < C; ++c) {
+            const float* s = vol + (long long)c * S;
+            float v = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v += s[t.off[k]] * t.w[k];
+            out[(long long)c * S + idx] = v;
+        }
+    }
+}
+
+// Fused warp(K_j), warp(V_j) + attention.  4 lanes per target voxel; lane c owns float4 chunk c of
+// the 16 value channels and chunk c of the 16 key channels (kv record = [V(16) | K(16)] = 128 B).
+struct WarpAttnArgs {
+    const float* kv_src[8];
+};
+
+__global__ __launch_bounds__(256) void warp_attention_kernel(const float* __restrict__ kv_t, WarpAttnArgs srcs,
+                                                             const float* __restrict__ mats, int n_src,
+                                                             const float* __restrict__ dvals, float depth_min, float depth_interval,
+                                                             float* __restrict__ xh, int D, int H, int W)
+{
+    const long long HW = (long long)H * W, S = (long long)D * HW;
+    const int sub = threadIdx.x & 3;
+    const long long idx = (long long)blockIdx.x * 64 + (threadIdx.x >> 2);
+    if (idx >= S) return;    // whole 4-lane groups exit together
+    const int x = (int)(idx % W);
+    const int y = (int)((idx / W) % H);
+    const int d = (int)(idx / HW);
+    const float dep = dvals[d];
+
+    const float4* t4 = reinterpret_cast<const float4*>(kv_t) + idx * 8;
+    const float4 vt = t4[sub];        // target value chunk
+    const float4 kt = t4[4 + sub];    // target key chunk
+
+    float corr[8];
+    float4 wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j < n_src) {
+            const Tri t = volume_coords(mats + j * 30, dep, x, y, depth_min, depth_interval, D, H, W);
+            const float4* s4 = reinterpret_cast<const float4*>(srcs.kv_src[j]);
+            float4 av = make_float4(0.f, 0.f, 0.f, 0.f), ak = av;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float4 v = s4[t.off[k] * 8 + sub];
+                const float4 kk = s4[t.off[k] * 8 + 4 + sub];
+                const float w = t.w[k];
+                av.x += v.x * w; av.y += v.y * w; av.z += v.z * w; av.w += v.w * w;
+                ak.x += kk.x * w; ak.y += kk.y * w; ak.z += kk.z * w; ak.w += kk.w * w;
+            }
+            float c = kt.x * ak.x + kt.y * ak.y + kt.z * ak.z + kt.w * ak.w;   // epipolar_transformer.py:65
+            c += __shfl_xor(c, 1);
+            c += __shfl_xor(c, 2);
+            corr[j] = c;
+            wv[j] = av;
+        }
+    }
+    // softmax over views (:69) and mean of the weighted values (:73)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (j < n_src) mx = fmaxf(mx, corr[j]);
+    float den = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (j < n_src) { corr[j] = expf(corr[j] - mx); den += corr[j]; }
+    float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (j < n_src) {
+        const float a = corr[j] / den;
+        h.x += wv[j].x * a; h.y += wv[j].y * a; h.z += wv[j].z * a; h.w += wv[j].w * a;
+    }
+    const float inv_n = 1.0f / (float)n_src;
+    h.x *= inv_n; h.y *= inv_n; h.z *= inv_n; h.w *= inv_n;
+    float4* o4 = reinterpret_cast<float4*>(xh) + idx * 8;
+    o4[sub] = vt;
+    o4[4 + sub] = h;
+}
+
+// Attention over ALREADY WARPED key/value volumes (the level-1 EpipolarTransformer.forward signature,
+// transformer/epipolar_transformer.py:56-73).  Same lane mapping as the fused kernel, no gather.
+__global__ __launch_bounds__(256) void attention_prewarped_kernel(const float* __restrict__ kv_t, WarpAttnArgs srcs, int n_src,
+                                                                  float* __restrict__ xh, long long S)
+{
+    const int sub = threadIdx.x & 3;
+    const long long idx = (long long)blockIdx.x * 64 + (threadIdx.x >> 2);
+    if (idx >= S) return;
+    const float4* t4 = reinterpret_cast<const float4*>(kv_t) + idx * 8;
+    const float4 vt = t4[sub];
+    const float4 kt = t4[4 + sub];
+    float corr[8];
+    float4 wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j < n_src) {
+            const float4* s4 = reinterpret_cast<const float4*>(srcs.kv_src[j]) + idx * 8;
+            wv[j] = s4[sub];
+            const float4 kk = s4[4 + sub];
+            float c = kt.x * kk.x + kt.y * kk.y + kt.z * kk.z + kt.w * kk.w;
+            c += __shfl_xor(c, 1);
+            c += __shfl_xor(c, 2);
+            corr[j] = c;
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (j < n_src) mx = fmaxf(mx, corr[j]);
+    float den = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (j < n_src) { corr[j] = expf(corr[j] - mx); den += corr[j]; }
+    float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (j < n_src) {
+        const float a = corr[j] / den;
+        h.x += wv[j].x * a; h.y += wv[j].y * a; h.z += wv[j].z * a; h.w += wv[j].w * a;
+    }
+    const float inv_n = 1.0f / (float)n_src;
+    h.x *= inv_n; h.y *= inv_n; h.z *= inv_n; h.w *= inv_n;
+    float4* o4 = reinterpret_cast<float4*>(xh) + idx * 8;
+    o4[sub] = vt;
+    o4[4 + sub] = h;
+}
+
+__global__ void groupnorm_finalize_kernel(const double* __restrict__ partials, int n_blocks, double count, float eps,
+                                          float* __restrict__ out4)
+{
+    // one block of 256 threads; fixed-order tree reduction -> deterministic
+    __shared__ double red[256 * 4];
+    double a[4] = {0, 0, 0, 0};
+    for (int b = threadIdx.x; b < n_blocks; b += 256)
+        for (int k = 0; k < 4; ++k) a[k] += partials[(size_t)b * 4 + k];
+    for (int k = 0; k < 4; ++k) red[threadIdx.x * 4 + k] = a[k];
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            for (int k = 0; k < 4; ++k) red[threadIdx.x * 4 + k] += red[(threadIdx.x + s) * 4 + k];
+        __syncthreads();
+    }
+    if (threadIdx.x < 2) {
+        const int gidx = threadIdx.x;
+        const double mean = red[gidx * 2] / count;
+        double var = red[gidx * 2 + 1] / count - mean * mean;   // fp64 sums: cancellation-safe at these sizes
+        if (var < 0.0) var = 0.0;
+        out4[gidx * 2] = (float)mean;
+        out4[gidx * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// xrh = [x, sigmoid(GN(r_raw)) * h]; one lane per float4 of the 16-channel halves
+__global__ __launch_bounds__(256) void gru_reset_kernel(const float* __restrict__ xh, const float* __restrict__ ru,
+                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ xrh, long long n_vox)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one per (voxel, chunk of 4)
+    if (t >= n_vox * 4) return;
+    const long long vox = t >> 2;
+    const int c = (int)(t & 3);
+    const float mean = stats[0], rstd = stats[1];
+    const float4 x = reinterpret_cast<const float4*>(xh)[vox * 8 + c];
+    const float4 h = reinterpret_cast<const float4*>(xh)[vox * 8 + 4 + c];
+    const float4 r = reinterpret_cast<const float4*>(ru)[vox * 8 + c];
+    const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+    const float4 b = reinterpret_cast<const float4*>(beta)[c];
+    float4 o;
+    o.x = sigmoidf_((r.x - mean) * rstd * g.x + b.x) * h.x;
+    o.y = sigmoidf_((r.y - mean) * rstd * g.y + b.y) * h.y;
+    o.z = sigmoidf_((r.z - mean) * rstd * g.z + b.z) * h.z;
+    o.w = sigmoidf_((r.w - mean) * rstd * g.w + b.w) * h.w;
+    reinterpret_cast<float4*>(xrh)[vox * 8 + c] = x;
+    reinterpret_cast<float4*>(xrh)[vox * 8 + 4 + c] = o;
+}
+
+__global__ __launch_bounds__(256) void gru_blend_kernel(const float* __restrict__ xh, const float* __restrict__ ru,
+                                                        const float* __restrict__ o_raw, const float* __restrict__ st_ru,
+                                                        const float* __restrict__ st_o, const float* __restrict__ gamma_u,
+                                                        const float* __restrict__ beta_u, const float* __restrict__ gamma_o,
+                                                        const float* __restrict__ beta_o, float* __restrict__ out, int out_stride,
+                                                        long long n_vox)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_vox * 4) return;
+    const long long vox = t >> 2;
+    const int c = (int)(t & 3);
+    const float mu = st_ru[2], ru_ = st_ru[3];     // update gate = group 1 of the gate conv
+    const float mo = st_o[0], ro = st_o[1];
+    const float4 h = reinterpret_cast<const float4*>(xh)[vox * 8 + 4 + c];
+    const float4 u = reinterpret_cast<const float4*>(ru)[vox * 8 + 4 + c];
+    const float4 o = reinterpret_cast<const float4*>(o_raw)[vox * 4 + c];
+    const float4 gu = reinterpret_cast<const float4*>(gamma_u)[c], bu = reinterpret_cast<const float4*>(beta_u)[c];
+    const float4 go = reinterpret_cast<const float4*>(gamma_o)[c], bo = reinterpret_cast<const float4*>(beta_o)[c];
+    float4 r;
+    {
+        const float uu = sigmoidf_((u.x - mu) * ru_ * gu.x + bu.x);
+        const float yy = tanhf((o.x - mo) * ro * go.x + bo.x);
+        r.x = uu * h.x + (1.0f - uu) * yy;
+    }
+    {
+        const float uu = sigmoidf_((u.y - mu) * ru_ * gu.y + bu.y);
+        const float yy = tanhf((o.y - mo) * ro * go.y + bo.y);
+        r.y = uu * h.y + (1.0f - uu) * yy;
+    }
+    {
+        const float uu = sigmoidf_((u.z - mu) * ru_ * gu.z + bu.z);
+        const float yy = tanhf((o.z - mo) * ro * go.z + bo.z);
+        r.z = uu * h.z + (1.0f - uu) * yy;
+    }
+    {
+        const float uu = sigmoidf_((u.w - mu) * ru_ * gu.w + bu.w);
+        const float yy = tanhf((o.w - mo) * ro * go.w + bo.w);
+        r.w = uu * h.w + (1.0f - uu) * yy;
+    }
+    *reinterpret_cast<float4*>(out + vox * out_stride + c * 4) = r;
+}
+
+// soft-argmin at low resolution, replicated s x s.  One thread per low-res pixel; loads are coalesced
+// along W for every depth plane; two passes over D (max, then sums) like the max-subtracted softmax.
+__global__ __launch_bounds__(256) void softargmin_up_kernel(const float* __restrict__ logits, const float* __restrict__ dvals,
+                                                            float* __restrict__ depth, float* __restrict__ prob,
+                                                            int N, int D, int H, int W, int s)
+{
+    const long long HW = (long long)H * W;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)N * HW) return;
+    const int n = (int)(t / HW);
+    const long long pix = t % HW;
+    const int y = (int)(pix / W), x = (int)(pix % W);
+    const float* l = logits + (long long)n * D * HW + pix;
+    float mx = -INFINITY;
+    for (int d = 0; d < D; ++d) mx = fmaxf(mx, l[(long long)d * HW]);
+    float den = 0.0f, num = 0.0f;
+    for (int d = 0; d < D; ++d) {
+        const float e = expf(l[(long long)d * HW] - mx);
+        den += e;
+        num += e * dvals[d];
+    }
+    const float dep = num / den;
+    const float pm = 1.0f / den;        // max_d softmax = exp(0)/den
+    const int Wo = W * s;
+    float* dd = depth + (long long)n * HW * s * s + (long long)y * s * Wo + (long long)x * s;
+    float* pp = prob + (long long)n * HW * s * s + (long long)y * s * Wo + (long long)x * s;
+    for (int r = 0; r < s; ++r) {
+        if (s == 4) {
+            *reinterpret_cast<float4*>(dd + (long long)r * Wo) = make_float4(dep, dep, dep, dep);
+            *reinterpret_cast<float4*>(pp + (long long)r * Wo) = make_float4(pm, pm, pm, pm);
+        } else {
+            for (int c = 0; c < s; ++c) { dd[(long long)r * Wo + c] = dep; pp[(long long)r * Wo + c] = pm; }
+        }
+    }
+}
+
+// [C][S] planes <-> [S][stride] channels-last records, through an LDS tile so both sides coalesce
+__global__ __launch_bounds__(256) void cdhw_to_vol_kernel(const float* __restrict__ src, float* __restrict__ dst, int C,
+                                                          long long S, int dst_stride, int dst_off)
+{
+    __shared__ float tile[32][65];
+    const long long s0 = (long long)blockIdx.x * 64;
+    for (int e = threadIdx.x; e < C * 64; e += 256) {
+        const int c = e / 64, k = e % 64;
+        tile[c][k] = (s0 + k < S) ? src[(long long)c * S + s0 + k] : 0.0f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < C * 64; e += 256) {
+        const int k = e / C, c = e % C;
+        if (s0 + k < S) dst[(s0 + k) * dst_stride + dst_off + c] = tile[c][k];
+    }
+}
+
+__global__ __launch_bounds__(256) void vol_to_cdhw_kernel(const float* __restrict__ src, float* __restrict__ dst, int C,
+                                                          long long S, int src_stride, int src_off)
+{
+    __shared__ float tile[32][65];
+    const long long s0 = (long long)blockIdx.x * 64;
+    for (int e = threadIdx.x; e < C * 64; e += 256) {
+        const int k = e / C, c = e % C;
+        tile[c][k] = (s0 + k < S) ? src[(s0 + k) * src_stride + src_off + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < C * 64; e += 256) {
+        const int c = e / 64, k = e % 64;
+        if (s0 + k < S) dst[(long long)c * S + s0 + k] = tile[c][k];
+    }
+}
+
+}  // namespace
+
+extern "C" int estd_warp_volume(const float* vol, const float* mats30, const float* dvals, float depth_min,
+                                float depth_interval, float* out, int C, int D, int H, int W, estd_stream_t s)
+{
+    if (!vol || !mats30 || !dvals || !out || C <= 0 || D <= 1 || H <= 1 || W <= 1) return ESTD_ERR_ARG;
+    const long long S = (long long)D * H * W;
+    const long long nb = (S + 255) / 256;
+    hipLaunchKernelGGL(warp_volume_kernel, dim3((unsigned)(nb > 1048576 ? 1048576 : nb)), dim3(256), 0, estd_stream(s),
+                       vol, mats30, dvals, depth_min, depth_interval, out, C, D, H, W);
+    return ESTD_LAUNCH_CHECK();
+}
+
+extern "C" int estd_warp_attention(const float* kv_target, const float* const* kv_src, const float* mats_dev,
+                                   int n_src, const float* dvals, float depth_min, float depth_interval,
+                                   float* xh_out, int D, int H, int W, estd_stream_t s)
+{
+    if (!kv_target || !kv_src || !mats_dev || !dvals || !xh_out) return ESTD_ERR_ARG;
+    if (n_src < 1 || n_src > 8 || D <= 1 || H <= 1 || W <= 1) return ESTD_ERR_ARG;
+    WarpAttnArgs a;
+    for (int j = 0; j < 8; ++j) a.kv_src[j] = j < n_src ? kv_src[j] : kv_src[0];
+    for (int j = 0; j < n_src; ++j) if (!kv_src[j]) return ESTD_ERR_ARG;
+    const long long S = (long long)D * H * W;
+    hipLaunchKernelGGL(warp_attention_kernel, dim3((unsigned)((S + 63) / 64)), dim3(256), 0, estd_stream(s),
+                       kv_target, a, mats_dev, n_src, dvals, depth_min, depth_interval, xh_out, D, H, W);
+    return ESTD_LAUNCH_CHECK();
+}
+
+extern "C" int estd_attention_prewarped(const float* kv_target, const float* const* kv_src, int n_src,
+                                        float* xh_out, int64_t n_vox, estd_stream_t s)
+{
+    if (!kv_target || !kv_src || !xh_out || n_src < 1 || n_src > 8 || n_vox <= 0) return ESTD_ERR_ARG;
+    WarpAttnArgs a;
+    for (int j = 0; j < n_src; ++j) if (!kv_src[j]) return ESTD_ERR_ARG;
+    for (int j = 0; j < 8; ++j) a.kv_src[j] = j < n_src ? kv_src[j] : kv_src[0];
+    hipLaunchKernelGGL(attention_prewarped_kernel, dim3((unsigned)((n_vox + 63) / 64)), dim3(256), 0, estd_stream(s),
+                       kv_target, a, n_src, xh_out, (long long)n_vox);
+    return ESTD_LAUNCH_CHECK();
+}
+
+extern "C" int estd_groupnorm_finalize(const double* partials, int n_blocks, double count, float eps, float* out4,
+                                       estd_stream_t s)
+{
+    if (!partials || !out4 || n_blocks <= 0 || count <= 0) return ESTD_ERR_ARG;
+    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(1), dim3(256), 0, estd_stream(s), partials, n_blocks, count, eps, out4);
+    return ESTD_LAUNCH_CHECK();
+}
+
+extern "C" int estd_gru_reset_apply(const float* xh, const float* ru, const float* stats4, const float* gamma_r,
+                                    const float* beta_r, float* xrh, int64_t n_vox, estd_stream_t s)
+{
+    if (!xh || !ru || !stats4 || !gamma_r || !beta_r || !xrh || n_vox <= 0) return ESTD_ERR_ARG;
+    hipLaunchKernelGGL(gru_reset_kernel, dim3((unsigned)((n_vox * 4 + 255) / 256)), dim3(256), 0, estd_stream(s),
+                       xh, ru, stats4, gamma_r, beta_r, xrh, (long long)n_vox);
+    return ESTD_LAUNCH_CHECK();
+}
+
+extern "C" int estd_gru_blend(const float* xh, const float* ru, const float* o_raw, const float* stats_ru4,
+                              const float* stats_o4, const float* gamma_u, const float* beta_u, const float* gamma_o,
+                              const float* beta_o, float* out_value, int out_stride, int64_t n_vox, estd_stream_t s)
+{
+    if (!xh || !ru || !o_raw || !stats_ru4 || !stats_o4 || !gamma_u || !beta_u || !gamma_o || !beta_o || !out_value)
+        return ESTD_ERR_ARG;
+    if (n_vox <= 0 || out_stride < 16 || (out_stride & 3)) return ESTD_ERR_ARG;
+    hipLaunchKernelGGL(gru_blend_kernel, dim3((unsigned)((n_vox * 4 + 255) / 256)), dim3(256), 0, estd_stream(s),
+                       xh, ru, o_raw, stats_ru4, stats_o4, gamma_u, beta_u, gamma_o, beta_o, out_value, out_stride,
+                       (long long)n_vox);
+    return ESTD_LAUNCH_CHECK();
+}
+
+extern "C" int estd_softargmin_up(const float* logits, const float* dvals, float* depth, float* prob,
+                                  int N, int D, int H, int W, int sc, estd_stream_t s)
+{
+    if (!logits || !dvals || !depth || !prob || N <= 0 || D <= 0 || H <= 0 || W <= 0 || sc <= 0) return ESTD_ERR_ARG;
+    const long long T = (long long)N * H * W;
+    hipLaunchKernelGGL(softargmin_up_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, estd_stream(s),
+                       logits, dvals, depth, prob, N, D, H, W, sc);
+    return ESTD_LAUNCH_CHECK();
+}
+
+extern "C" int estd_cdhw_to_vol(const float* src, float* dst, int C, int64_t S, int dst_stride, int dst_off, estd_stream_t s)
+{
+    if (!src || !dst || C <= 0 || C > 32 || S <= 0 || dst_stride < dst_off + C) return ESTD_ERR_ARG;
+    hipLaunchKernelGGL(cdhw_to_vol_kernel, dim3((unsigned)((S + 63) / 64)), dim3(256), 0, estd_stream(s),
+                       src, dst, C, (long long)S, dst_stride, dst_off);
+    return ESTD_LAUNCH_CHECK();
+}
+
+extern "C" int estd_vol_to_cdhw(const float* src, float* dst, int C, int64_t S, int src_stride, int src_off, estd_stream_t s)
+{
+    if (!src || !dst || C <= 0 || C > 32 || S <= 0 || src_stride < src_off + C) return ESTD_ERR_ARG;
+    hipLaunchKernelGGL(vol_to_cdhw_kernel, dim3((unsigned)((S + 63) / 64)), dim3(256), 0, estd_stream(s),
+                       src, dst, C, (long long)S, src_stride, src_off);
+    return ESTD_LAUNCH_CHECK();
+}
+
+extern "C" int estd_version(void) { return 100; }
+
+extern "C" const char* estd_status_string(int st)
+{
+    switch (st) {
+        case ESTD_OK: return "ok";
+        case ESTD_ERR_ARG: return "invalid argument (null pointer, non-positive size or unsupported channel count)";
+        case ESTD_ERR_LAUNCH: return "HIP kernel launch failed";
+        case ESTD_ERR_UNSUPPORTED: return "unsupported configuration";
+        default: return "unknown status";
+    }
+}

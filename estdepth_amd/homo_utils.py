@@ -1,0 +1,60 @@
+"""Level-1 geometric operators with the reference's names and signatures
+(utils/homo_utils.py), executed by the HIP kernels of libestd_hip.so.
+
+Semantics kept verbatim (hard parts): align_corners=False un-normalisation although
+coordinates are normalised with the (size-1) formula, |norm| > 1 -> 2 masking, no z>0 test,
+eps 1e-8 (2D) vs 1e-10 (3D).
+"""
+import torch
+
+from . import ops
+
+
+def set_id_grid(h, w):
+    """utils/homo_utils.py:7-14 -> [1,3,H,W] rows (x, y, 1), float32 on CPU like the reference."""
+    i_range = torch.arange(0, h).view(1, h, 1).expand(1, h, w).to(torch.float32)
+    j_range = torch.arange(0, w).view(1, 1, w).expand(1, h, w).to(torch.float32)
+    ones = torch.ones(1, h, w, dtype=torch.float32)
+    return torch.stack((j_range, i_range, ones), dim=1)
+
+
+def _depth_vector(depth_values, batch, num_depth):
+    dv = depth_values.reshape(batch, num_depth, -1)
+    if dv.shape[2] != 1:
+        # the reference also admits per-pixel depth hypotheses [B,D,H,W]; every caller on the hybrid
+        # path passes per-plane constants, which is what the kernels implement
+        if not bool((dv == dv[:, :, :1]).all()):
+            raise RuntimeError("homo_warping: per-pixel depth hypotheses are not supported (per-plane only)")
+        dv = dv[:, :, :1]
+    return dv.reshape(batch, num_depth).contiguous().float()
+
+
+def homo_warping(src_fea, src_proj, ref_proj, depth_values):
+    """utils/homo_utils.py:458-504.  src_fea [B,C,H,W]; src_proj/ref_proj [B,4,4];
+    depth_values [B,D] or [B,D,1,1] -> [B,C,D,H,W]."""
+    batch, channels, height, width = src_fea.shape
+    num_depth = depth_values.shape[1]
+    dv = _depth_vector(depth_values, batch, num_depth)
+    outs = []
+    for b in range(batch):
+        proj = ops.cam_pair_proj(src_proj[b].contiguous().float(), ref_proj[b].contiguous().float())
+        outs.append(ops.homo_warping_chw(src_fea[b].contiguous(), proj, dv[b], num_depth))
+    return torch.stack(outs, 0)
+
+
+def warp_volume(feat_volume, depth, pose, cam_intr, pixel_coords, depth_min, depth_interval,
+                padding_mode='zeros', padding_value=0., disp_min=None, disp_interval=None, inter_mode='bilinear'):
+    """utils/homo_utils.py:240-279.  feat_volume [N,C,D,H,W]; depth [N,1,D,H*W] (per-plane constants);
+    pose [N,4,4] relative pose (the function applies inverse(pose) like the reference); cam_intr [N,3,3].
+    ``pixel_coords`` (the cached id grid) is accepted for signature parity and regenerated in-kernel.
+    Works for any D >= 2 (the reference crashes for D < 63 because of a debug leftover)."""
+    if padding_mode != 'zeros' or disp_min is not None or inter_mode != 'bilinear':
+        raise RuntimeError("warp_volume: only padding_mode='zeros', depth planes, inter_mode='bilinear' "
+                           "(the only combination the hybrid path uses)")
+    N, C, D, H, W = feat_volume.shape
+    dv = _depth_vector(depth.reshape(N, D, H * W), N, D)
+    outs = []
+    for b in range(N):
+        mats = ops.cam_volume_mats(pose[b].contiguous().float(), None, cam_intr[b].contiguous().float())
+        outs.append(ops.warp_volume_cdhw(feat_volume[b].contiguous(), mats, dv[b], depth_min, depth_interval))
+    return torch.stack(outs, 0)

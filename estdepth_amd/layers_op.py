@@ -1,0 +1,99 @@
+"""Conv+BN(+act) factories with the reference's names and parameter layout
+(networks/layers_op.py:10-39).  The 3D variants return an ``nn.Sequential`` subclass whose forward
+runs the HIP implicit-GEMM convolution (csrc/conv3d_mfma.hip) -- there is no ATen/MIOpen conv3d on
+the hot path.  The 2D variants are plain PyTorch-ROCm modules (2D backbones are out of scope).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops, packing
+from .backbones import conv_bn2d
+
+
+def convbn(in_planes, out_planes, kernel_size, stride, pad, dilation):
+    return conv_bn2d(in_planes, out_planes, kernel_size, stride, pad, dilation)
+
+
+def convbnrelu(in_planes, out_planes, kernel_size, stride, pad, dilation):
+    seq = conv_bn2d(in_planes, out_planes, kernel_size, stride, pad, dilation)
+    seq.add_module("2", nn.ReLU(inplace=True))
+    return seq
+
+
+def _params_version(mod):
+    return tuple((p.data_ptr(), p._version) for p in list(mod.parameters()) + list(mod.buffers()))
+
+
+class PlanCache:
+    """Packed-weight cache of one module: rebuilt when a parameter is rewritten or moved."""
+
+    def __init__(self):
+        self._key = None
+        self._plans = None
+
+    def get(self, mod, builder):
+        key = _params_version(mod)
+        if key != self._key:
+            self._plans = builder()
+            self._key = key
+        return self._plans
+
+
+class ConvBN3d(nn.Sequential):
+    """Conv3d(k, bias=False) -> BatchNorm3d -> [ReLU | Tanh]; children named "0","1","2" like the reference."""
+
+    def __init__(self, in_planes, out_planes, kernel_size, stride, pad, act):
+        layers = [nn.Conv3d(in_planes, out_planes, kernel_size=kernel_size, padding=pad, stride=stride, bias=False),
+                  nn.BatchNorm3d(out_planes)]
+        if act == "relu":
+            layers.append(nn.ReLU(inplace=True))
+        elif act == "tanh":
+            layers.append(nn.Tanh())
+        super().__init__(*layers)
+        self.act = act
+        self._cache = PlanCache()
+
+    # ---- pieces used by the fused pipelines ----
+    def folded(self, out_idx=None):
+        conv, bn = self[0], self[1]
+        out_idx = list(range(conv.out_channels)) if out_idx is None else out_idx
+        return packing.fold_bn_fp32(bn, out_idx)
+
+    def plan(self, main_idx=None, extra_idx=None, out_idx=None, n_tiles=None, head=None):
+        conv = self[0]
+        if conv.kernel_size != (3, 3, 3) or conv.stride != (1, 1, 1) or conv.padding != (1, 1, 1):
+            raise RuntimeError("only 3x3x3 / stride 1 / pad 1 Conv3d runs on the MFMA kernel")
+        main_idx = list(range(conv.in_channels)) if main_idx is None else main_idx
+        out_idx = list(range(conv.out_channels)) if out_idx is None else out_idx
+        n_tiles = (len(out_idx) + 15) // 16 if n_tiles is None else n_tiles
+        sc, sh = self.folded(out_idx)
+        hw, hb = (None, None) if head is None else (head.weight.detach().reshape(-1), head.bias.detach().reshape(-1))
+        return ops.Conv3dPlan(conv.weight, main_idx, extra_idx, out_idx, n_tiles, sc, sh, act_a=self.act or "none",
+                              head_w=hw, head_b=hb, device=conv.weight.device)
+
+    def forward(self, x):
+        """Level-1 call on an NCDHW tensor (B,Cin,D,H,W) with Cin in {16,32}: converts to channels-last,
+        runs the HIP kernel, converts back.  The fused pipelines bypass this and stay channels-last."""
+        if self.training:
+            raise RuntimeError("estdepth_amd is inference-only (BatchNorm must be in eval mode)")
+        conv = self[0]
+        if conv.in_channels not in (16, 32) or conv.out_channels not in (16, 32):
+            raise RuntimeError("standalone ConvBN3d forward supports 16/32 channels; other layers only run fused")
+        B, C, D, H, W = x.shape
+        plan = self._cache.get(self, lambda: self.plan())
+        xin = x.permute(0, 2, 3, 4, 1).contiguous()
+        out = torch.empty((B, D, H, W, conv.out_channels), device=x.device, dtype=torch.float32)
+        plan.run(xin, (B, D, H, W), out=out, out_stride=conv.out_channels)
+        return out.permute(0, 4, 1, 2, 3)
+
+
+def convbn_3d(in_planes, out_planes, kernel_size, stride, pad):
+    return ConvBN3d(in_planes, out_planes, kernel_size, stride, pad, None)
+
+
+def convbnrelu_3d(in_planes, out_planes, kernel_size, stride, pad):
+    return ConvBN3d(in_planes, out_planes, kernel_size, stride, pad, "relu")
+
+
+def convbntanh_3d(in_planes, out_planes, kernel_size, stride, pad):
+    return ConvBN3d(in_planes, out_planes, kernel_size, stride, pad, "tanh")

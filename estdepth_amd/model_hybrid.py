@@ -1,0 +1,148 @@
+"""DepthNetHybrid: drop-in for hybrid_models/model_hybrid.py:14-184 (constructor, state-dict keys,
+``forward`` signature and return values), with the plane-sweep / cost-volume build, 3D regularisation,
+EST fusion and soft-argmin executed by hand-written gfx950 kernels.
+
+Inference only ('val' / 'test' style calls); the loss/metric bookkeeping of the reference's 'train'
+mode is outside this path.  abs_rel (model_hybrid.py:306) is provided for the benchmark report.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .backbones import PSMFeatures, SemanticEncoder
+from .hybrid_depth_decoder import DepthHybridDecoder
+from .homo_utils import homo_warping  # noqa: F401  (re-exported like the reference module does)
+from .layers_op import PlanCache, convbn_3d, convbnrelu_3d
+
+Align_Corners_Range = False
+
+
+class DepthNetHybrid(nn.Module):
+    def __init__(self, ndepths=64, depth_min=0.01, depth_max=10.0, resnet=50, IF_EST_transformer=True):
+        super().__init__()
+        self.ndepths = ndepths
+        self.depth_min = depth_min
+        self.depth_max = depth_max
+        self.depth_interval = (depth_max - depth_min) / (ndepths - 1)
+        # same fp32 arithmetic as model_hybrid.py:32-33 (plain attribute, not a buffer)
+        self.depth_cands = torch.arange(0, ndepths, requires_grad=False).reshape(1, -1).to(
+            torch.float32) * self.depth_interval + self.depth_min
+        self.IF_EST_transformer = IF_EST_transformer
+        self.matchingFeature = PSMFeatures()
+        self.semanticFeature = SemanticEncoder(resnet, "pretrained")
+        self.stage_infos = {"stage1": {"scale": 4.0}, "stage2": {"scale": 2.0}, "stage3": {"scale": 1.0}}
+        self.CostRegNet = DepthHybridDecoder(self.semanticFeature.num_ch_enc, num_output_channels=1, use_skips=True,
+                                             ndepths=self.ndepths, depth_max=self.depth_max,
+                                             IF_EST_transformer=self.IF_EST_transformer)
+        self.pre0 = convbn_3d(64, 32, 1, 1, 0)
+        self.pre1 = convbnrelu_3d(32, 32, 3, 1, 1)
+        self.pre2 = convbn_3d(32, 32, 3, 1, 1)
+        self._cache = PlanCache()
+
+    # ------------------------------------------------------------------------------ packed weights
+    def _plans(self):
+        def build():
+            dev = self.pre0[0].weight.device
+            w0 = self.pre0[0].weight.detach().reshape(32, 64).float().cpu()
+            sc, sh = self.pre0.folded()
+            # pre0(cat[ref, warped]) = (sc*W[:, :32]) ref + sh  +  warp((sc*W[:, 32:]) src)      (:93-94)
+            return {"w_ref": (sc[:, None] * w0[:, :32]).contiguous().to(dev), "b_ref": sh.contiguous().to(dev),
+                    "w_src": (sc[:, None] * w0[:, 32:]).contiguous().to(dev),
+                    "pre1": self.pre1.plan(), "pre2": self.pre2.plan()}
+        return self._cache.get(self, build)
+
+    def _costvolume(self, ref_mix, src_mixes, ref_pose, src_poses, cam_intr, depth_values):
+        """Fused get_costvolume on pre-mixed 2D features (model_hybrid.py:76-99) -> [D,H,W,32]."""
+        P = self._plans()
+        H, W, _ = ref_mix.shape
+        D = self.ndepths
+        dims = (1, D, H, W)
+        cost = torch.empty((D, H, W, 32), device=ref_mix.device, dtype=torch.float32)
+        y = torch.empty_like(cost)
+        n_src = len(src_mixes)
+        for k, (src_mix, src_pose) in enumerate(zip(src_mixes, src_poses)):
+            proj = ops.cam_sweep_proj(ref_pose, src_pose, cam_intr)                       # :74-88 + homo_utils.py:469
+            x = ops.homo_warp_costvol(src_mix, ref_mix, proj, depth_values, D)            # :90-94
+            P["pre1"].run(x, dims, out=y, out_stride=32)                                  # :95
+            P["pre2"].run(y, dims, out=cost, out_stride=32, residual=x,
+                          out_scale=1.0 / n_src, accumulate=(k > 0))                      # :95-99
+        return cost
+
+    def _mix(self, feature_chw, which):
+        P = self._plans()
+        if which == "ref":
+            return ops.mix1x1(feature_chw, P["w_ref"], P["b_ref"])
+        return ops.mix1x1(feature_chw, P["w_src"], None)
+
+    def get_costvolume(self, features, cam_poses, cam_intr, depth_values):
+        """model_hybrid.py:62-102.  features: sequence of V tensors [1,32,H,W] (middle = reference view);
+        cam_poses [1,V,4,4]; cam_intr [1,3,3] at 1/4 scale; depth_values [1,D,1,1].
+        Returns [1,32,D,H,W] (a channels-last view: same values/shape as the reference's tensor)."""
+        num_views = len(features)
+        if features[0].shape[0] != 1:
+            raise RuntimeError("estdepth_amd runs one sequence per call (batch 1)")
+        mid = num_views // 2
+        dv = depth_values.reshape(-1)[:self.ndepths].contiguous().float()
+        ref_mix = self._mix(features[mid][0].contiguous(), "ref")
+        srcs = [v for v in range(num_views) if v != mid]
+        src_mixes = [self._mix(features[v][0].contiguous(), "src") for v in srcs]
+        poses = cam_poses[0].contiguous().float()
+        cost = self._costvolume(ref_mix, src_mixes, poses[mid], [poses[v] for v in srcs], cam_intr[0].contiguous().float(), dv)
+        return cost.permute(3, 0, 1, 2).unsqueeze(0)
+
+    def scale_cam_intr(self, cam_intr, scale):
+        cam_intr_new = cam_intr.clone()
+        cam_intr_new[:, :2, :] *= scale
+        return cam_intr_new
+
+    def forward(self, imgs, cam_poses, cam_intr, sample, pre_costs=None, pre_cam_poses=None, mode='train'):
+        """model_hybrid.py:110-184.  imgs [1,V,3,Hi,Wi] in 0..255; cam_poses [1,V,4,4] camera-to-world;
+        cam_intr [1,3,3] full-resolution pixels; returns (outputs, cur_costs, cur_cam_poses) for
+        inference modes."""
+        if mode == 'train' or self.training:
+            raise RuntimeError("estdepth_amd implements the inference path (mode='val'/'test'); training is out of scope")
+        imgs = 2 * (imgs / 255.) - 1.
+        batch_size, views_num, _, height_img, width_img = imgs.shape
+        height, width = height_img // 4, width_img // 4
+        assert views_num > 2  # the views_num should be larger than 2 (model_hybrid.py:123)
+        if batch_size != 1:
+            raise RuntimeError("estdepth_amd runs one sequence per call (the reference's view() also fails for batch > 1)")
+        target_num = views_num - 2
+
+        matching = self.matchingFeature(imgs.reshape(batch_size * views_num, 3, height_img, width_img))      # :128
+        semantic_features = self.semanticFeature(
+            imgs[:, 1:1 + target_num].reshape(batch_size * target_num, -1, height_img, width_img))         # :138-139
+        cam_intr_stage1 = self.scale_cam_intr(cam_intr, scale=1. / self.stage_infos["stage1"]["scale"])     # :142
+        depth_values = self.depth_cands.view(1, self.ndepths, 1, 1).to(imgs.dtype).to(imgs.device)          # :144-145
+        dv = depth_values.reshape(-1).contiguous()
+        intr = cam_intr_stage1[0].contiguous().float()
+        poses = cam_poses[0].contiguous().float()
+
+        # every view is a source for up to two targets: mix each 2D feature once (pre0 pushed in front of the warp)
+        src_mix = [self._mix(matching[v].contiguous(), "src") for v in range(views_num)]
+        cost_volumes, target_cam_poses = [], []
+        for t in range(target_num):                                                                        # :152-164
+            ref_mix = self._mix(matching[t + 1].contiguous(), "ref")
+            cost = self._costvolume(ref_mix, [src_mix[t], src_mix[t + 2]], poses[t + 1], [poses[t], poses[t + 2]], intr, dv)
+            cost_volumes.append(cost.permute(3, 0, 1, 2).unsqueeze(0))
+            target_cam_poses.append(cam_poses[:, t + 1, :, :])
+
+        outputs, cur_costs, cur_cam_poses = self.CostRegNet(cost_volumes, semantic_features, target_cam_poses,
+                                                            cam_intr_stage1, depth_values, self.depth_min,
+                                                            self.depth_interval, pre_costs, pre_cam_poses, mode)   # :166
+        if mode == 'test':
+            metrics = {}
+            for s in (0, 2):
+                vals = []
+                for t in range(target_num):
+                    gt = sample["dmaps"][:, t + 1]
+                    mask = sample["dmasks"][:, t + 1]
+                    vals.append(abs_rel(outputs[("depth", t, s)][mask], gt[mask]))
+                metrics["abs_rel_{}".format(s)] = torch.stack(vals).mean()
+            return outputs, metrics
+        return outputs, cur_costs, cur_cam_poses
+
+
+def abs_rel(pred, gt):
+    """mean(|gt - pred| / gt)  (model_hybrid.py:306, metric.py:131-150)."""
+    return torch.mean(torch.abs(gt - pred) / gt)

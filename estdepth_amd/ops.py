@@ -1,0 +1,222 @@
+"""Torch-tensor front-end of the C ABI (device memory, streams and allocation are PyTorch-ROCm's;
+the arithmetic is libestd_hip.so's).  Every function enqueues on the current HIP stream and
+returns tensors owned by the caching allocator.  CUDA(ROCm)-only: CPU tensors raise RuntimeError.
+"""
+import ctypes
+
+import torch
+
+from . import _native as N
+from . import packing
+
+ACT = {"none": 0, "relu": 1, "tanh": 2}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise RuntimeError("%s must be a tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on a ROCm device (estdepth_amd has no CPU path); got %s" % (name, t.device))
+    if t.dtype != dtype:
+        raise RuntimeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    return t
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+# ---------------------------------------------------------------------------------- camera algebra
+def cam_pair_proj(src_proj, ref_proj):
+    """rot|trans of src_proj @ inverse(ref_proj) for one batch element -> [12]."""
+    out = torch.empty(12, device=src_proj.device, dtype=torch.float32)
+    N.check(N.lib().estd_cam_pair_proj(_p(_chk(src_proj, "src_proj")), _p(_chk(ref_proj, "ref_proj")), _p(out), _stream()),
+            "estd_cam_pair_proj")
+    return out
+
+
+def cam_sweep_proj(ref_pose, src_pose, intr):
+    out = torch.empty(12, device=ref_pose.device, dtype=torch.float32)
+    N.check(N.lib().estd_cam_sweep_proj(_p(_chk(ref_pose, "ref_pose")), _p(_chk(src_pose, "src_pose")),
+                                        _p(_chk(intr, "cam_intr")), _p(out), _stream()), "estd_cam_sweep_proj")
+    return out
+
+
+def cam_volume_mats(pose_j, pose_i, intr, out=None):
+    if out is None:
+        out = torch.empty(30, device=pose_j.device, dtype=torch.float32)
+    N.check(N.lib().estd_cam_volume_mats(_p(_chk(pose_j, "pose_j")), _p(_chk(pose_i, "pose_i")) if pose_i is not None else None,
+                                         _p(_chk(intr, "cam_intr")), _p(out), _stream()), "estd_cam_volume_mats")
+    return out
+
+
+# ---------------------------------------------------------------------------------- plane sweep
+def homo_warping_chw(src_chw, proj12, depth_values, D):
+    C, H, W = src_chw.shape
+    out = torch.empty((C, D, H, W), device=src_chw.device, dtype=torch.float32)
+    N.check(N.lib().estd_homo_warping(_p(_chk(src_chw, "src_fea")), _p(proj12), _p(_chk(depth_values, "depth_values")),
+                                      _p(out), C, D, H, W, _stream()), "estd_homo_warping")
+    return out
+
+
+def mix1x1(in_chw, w, bias):
+    """[Cin,H,W] -> [H,W,Cout] channel mix."""
+    Cin, H, W = in_chw.shape
+    Cout = w.shape[0]
+    out = torch.empty((H, W, Cout), device=in_chw.device, dtype=torch.float32)
+    N.check(N.lib().estd_mix1x1_chw_to_hwc(_p(_chk(in_chw, "feature")), _p(_chk(w, "mix weight")),
+                                           _p(bias) if bias is not None else None, _p(out), Cin, Cout, H * W, _stream()),
+            "estd_mix1x1_chw_to_hwc")
+    return out
+
+
+def homo_warp_costvol(src_mix, ref_mix, proj12, depth_values, D):
+    H, W, _ = src_mix.shape
+    out = torch.empty((D, H, W, 32), device=src_mix.device, dtype=torch.float32)
+    N.check(N.lib().estd_homo_warp_costvol(_p(_chk(src_mix, "src_mix")), _p(_chk(ref_mix, "ref_mix")), _p(proj12),
+                                           _p(_chk(depth_values, "depth_values")), _p(out), D, H, W, _stream()),
+            "estd_homo_warp_costvol")
+    return out
+
+
+# ---------------------------------------------------------------------------------- conv3d
+class Conv3dPlan:
+    """Packed weights + epilogue constants of one 3x3x3 convolution, resident on a device."""
+
+    def __init__(self, weight, main_idx, extra_idx, out_idx, n_tiles, scale, shift, act_a="none", act_b=None,
+                 act_split=0, head_w=None, head_b=None, device="cuda"):
+        wm, wx = packing.pack_conv3d(weight, main_idx, extra_idx, out_idx, n_tiles)
+        self.cin_main = len(main_idx)
+        self.n_tiles = n_tiles
+        self.n_out = len(out_idx)
+        self.w_main = wm.to(device)
+        self.w_extra = wx.to(device) if wx is not None else None
+        self.scale = scale.float().contiguous().to(device)
+        self.shift = shift.float().contiguous().to(device)
+        self.act_a = ACT[act_a]
+        self.act_b = ACT[act_b if act_b is not None else act_a]
+        self.act_split = act_split if act_b is not None else 0
+        self.head_w = head_w.float().contiguous().to(device) if head_w is not None else None
+        self.head_b = head_b.float().contiguous().to(device) if head_b is not None else None
+
+    def run(self, x, dims, in_stride=None, in_extra=None, out=None, out_stride=None, out_channels=None,
+            residual=None, out_scale=1.0, accumulate=False, out_extra=None, out_head=None, stats_partials=None):
+        """x: channels-last volume(s) [N,D,H,W,in_stride] (or a base view of it); dims = (N,D,H,W)."""
+        Nn, D, H, W = dims
+        d = N.Conv3dDesc()
+        d.N, d.D, d.H, d.W = Nn, D, H, W
+        d.cin_main = self.cin_main
+        d.in_stride = in_stride if in_stride is not None else self.cin_main
+        d.n_tiles = self.n_tiles
+        d.in_main = x.data_ptr()
+        d.in_extra = in_extra.data_ptr() if in_extra is not None else None
+        d.w_main = self.w_main.data_ptr()
+        d.w_extra = self.w_extra.data_ptr() if self.w_extra is not None else None
+        if (in_extra is None) != (self.w_extra is None):
+            raise RuntimeError("conv3d plan/extra-channel mismatch")
+        d.scale = self.scale.data_ptr()
+        d.shift = self.shift.data_ptr()
+        d.act_a, d.act_b, d.act_split = self.act_a, self.act_b, self.act_split
+        d.out_main = out.data_ptr() if out is not None else None
+        d.out_stride = out_stride if out_stride is not None else (16 * min(self.n_tiles, 2))
+        d.out_channels = out_channels if out_channels is not None else 16 * min(self.n_tiles, 2)
+        d.residual = residual.data_ptr() if residual is not None else None
+        d.out_scale = float(out_scale)
+        d.accumulate = 1 if accumulate else 0
+        d.out_extra = out_extra.data_ptr() if out_extra is not None else None
+        d.head_w = self.head_w.data_ptr() if (self.head_w is not None and out_head is not None) else None
+        d.head_b = self.head_b.data_ptr() if (self.head_b is not None and out_head is not None) else None
+        d.out_head = out_head.data_ptr() if out_head is not None else None
+        d.stats_partials = stats_partials.data_ptr() if stats_partials is not None else None
+        N.check(N.lib().estd_conv3d_k3(ctypes.byref(d), _stream()), "estd_conv3d_k3")
+
+
+def conv3d_grid(Nn, D, H, W):
+    g = N.lib().estd_conv3d_k3_grid(Nn, D, H, W)
+    if g < 0:
+        N.check(g, "estd_conv3d_k3_grid")
+    return g
+
+
+def groupnorm_finalize(partials, n_blocks, count, eps=1e-5):
+    out = torch.empty(4, device=partials.device, dtype=torch.float32)
+    N.check(N.lib().estd_groupnorm_finalize(_p(partials), n_blocks, float(count), float(eps), _p(out), _stream()),
+            "estd_groupnorm_finalize")
+    return out
+
+
+# ---------------------------------------------------------------------------------- soft-argmin
+def softargmin_up(logits, depth_values, scale=4):
+    """logits [N,D,H,W] -> (depth, prob) each [N,1,scale*H,scale*W]."""
+    Nn, D, H, W = logits.shape
+    depth = torch.empty((Nn, 1, H * scale, W * scale), device=logits.device, dtype=torch.float32)
+    prob = torch.empty_like(depth)
+    N.check(N.lib().estd_softargmin_up(_p(_chk(logits, "logits")), _p(_chk(depth_values, "depth_values")), _p(depth), _p(prob),
+                                       Nn, D, H, W, scale, _stream()), "estd_softargmin_up")
+    return depth, prob
+
+
+# ---------------------------------------------------------------------------------- EST fusion
+def warp_volume_cdhw(vol, mats30, depth_values, depth_min, depth_interval):
+    C, D, H, W = vol.shape
+    out = torch.empty_like(vol)
+    N.check(N.lib().estd_warp_volume(_p(_chk(vol, "feat_volume")), _p(mats30), _p(_chk(depth_values, "depth")),
+                                     float(depth_min), float(depth_interval), _p(out), C, D, H, W, _stream()),
+            "estd_warp_volume")
+    return out
+
+
+def warp_attention(kv_target, kv_sources, mats, depth_values, depth_min, depth_interval):
+    """kv_target [D,H,W,32]; kv_sources list of the same; mats [n,30] -> xh [D,H,W,32] = [V_t | h]."""
+    D, H, W, _ = kv_target.shape
+    n = len(kv_sources)
+    arr = (ctypes.c_void_p * n)(*[_chk(k, "kv source").data_ptr() for k in kv_sources])
+    xh = torch.empty((D, H, W, 32), device=kv_target.device, dtype=torch.float32)
+    N.check(N.lib().estd_warp_attention(_p(_chk(kv_target, "kv target")), arr, _p(_chk(mats, "mats")), n,
+                                        _p(_chk(depth_values, "depth_values")), float(depth_min), float(depth_interval),
+                                        _p(xh), D, H, W, _stream()), "estd_warp_attention")
+    return xh
+
+
+def attention_prewarped(kv_target, kv_sources):
+    n = len(kv_sources)
+    arr = (ctypes.c_void_p * n)(*[_chk(k, "kv source").data_ptr() for k in kv_sources])
+    xh = torch.empty_like(kv_target)
+    N.check(N.lib().estd_attention_prewarped(_p(_chk(kv_target, "kv target")), arr, n, _p(xh), kv_target.numel() // 32,
+                                             _stream()), "estd_attention_prewarped")
+    return xh
+
+
+def gru_reset_apply(xh, ru, stats4, gamma_r, beta_r):
+    xrh = torch.empty_like(xh)
+    n_vox = xh.numel() // 32
+    N.check(N.lib().estd_gru_reset_apply(_p(xh), _p(ru), _p(stats4), _p(gamma_r), _p(beta_r), _p(xrh), n_vox, _stream()),
+            "estd_gru_reset_apply")
+    return xrh
+
+
+def gru_blend(xh, ru, o_raw, stats_ru, stats_o, gamma_u, beta_u, gamma_o, beta_o, out_value, out_stride):
+    n_vox = xh.numel() // 32
+    N.check(N.lib().estd_gru_blend(_p(xh), _p(ru), _p(o_raw), _p(stats_ru), _p(stats_o), _p(gamma_u), _p(beta_u),
+                                   _p(gamma_o), _p(beta_o), _p(out_value), out_stride, n_vox, _stream()), "estd_gru_blend")
+
+
+# ---------------------------------------------------------------------------------- layout converters
+def cdhw_to_vol(src, dst, dst_stride, dst_off):
+    """src [C,D,H,W] contiguous -> channels dst_off.. of the channels-last records of dst."""
+    C = src.shape[0]
+    S = src.numel() // C
+    N.check(N.lib().estd_cdhw_to_vol(_p(_chk(src, "volume")), _p(dst), C, S, dst_stride, dst_off, _stream()), "estd_cdhw_to_vol")
+
+
+def vol_to_cdhw(src, C, dims, src_stride, src_off):
+    D, H, W = dims
+    out = torch.empty((C, D, H, W), device=src.device, dtype=torch.float32)
+    N.check(N.lib().estd_vol_to_cdhw(_p(src), _p(out), C, D * H * W, src_stride, src_off, _stream()), "estd_vol_to_cdhw")
+    return out

@@ -1,0 +1,103 @@
+"""Host-side packing of Conv3d weights into the MFMA fragment order consumed by
+csrc/conv3d_mfma.hip, and BatchNorm folding.
+
+Fragment order (v_mfma_f32_16x16x4_f32: lane l -> k group g = l >> 4, column j = l & 15):
+  * input channel consumed by lane group g at k-step t of a tap:
+        CM = 32:  ch(g,t) = 4g + t            for t < 4
+                  ch(g,t) = 16 + 4g + (t-4)   for t >= 4
+        CM = 16:  ch(g,t) = 4g + t
+    (so a lane fetches its 8 A operands of a tap with two 16-byte LDS reads)
+  * output channel position of (N tile n, column j):
+        n_tiles = 1:  pos = j
+        n_tiles >= 2: pos = 2j + n for n < 2 ;  n == 2: pos = 32 for j == 0, unused otherwise
+    (a lane owns two adjacent channels -> 8-byte epilogue stores that tile whole voxel records)
+  * main buffer  : float32 [28 taps][QN][64 lanes][4]   QN = (CM/4)*n_tiles/4, flat index
+                   idx = t*n_tiles + n -> (quad idx//4, element idx%4); tap 27 is zero padding that the
+                   kernel's one-tap-ahead prefetch may read.
+  * extra buffer : float32 [XQ][64 lanes][4] for the single scalar input channel whose 27 taps form
+                   7 more k-steps: lane group g at step s multiplies tap 4s+g (tap 27 = zero).
+"""
+import numpy as np
+import torch
+
+
+def _ch(cm, g, t):
+    if cm == 32:
+        return 4 * g + t if t < 4 else 16 + 4 * g + (t - 4)
+    return 4 * g + t
+
+
+def _pos(n_tiles, n, j):
+    if n_tiles == 1:
+        return j
+    if n < 2:
+        return 2 * j + n
+    return 32 if j == 0 else -1
+
+
+def pack_conv3d(weight, main_idx, extra_idx, out_idx, n_tiles):
+    """weight: [Cout, Cin, 3,3,3] tensor.  main_idx: list of 16/32 input-channel indices (order = main
+    channel order in memory).  extra_idx: index of the scalar input channel or None.
+    out_idx: original output channel for each output position.  Returns (w_main, w_extra|None) float32 CPU."""
+    w = weight.detach().float().cpu().numpy().reshape(weight.shape[0], weight.shape[1], 27)
+    cm = len(main_idx)
+    assert cm in (16, 32)
+    ks = cm // 4
+    qn = ks * n_tiles // 4
+    assert ks * n_tiles % 4 == 0
+    main = np.zeros((28, qn, 64, 4), np.float32)
+    for lane in range(64):
+        g, j = lane >> 4, lane & 15
+        for t in range(ks):
+            ci = main_idx[_ch(cm, g, t)]
+            for n in range(n_tiles):
+                pos = _pos(n_tiles, n, j)
+                if pos < 0 or pos >= len(out_idx):
+                    continue
+                idx = t * n_tiles + n
+                main[:27, idx // 4, lane, idx % 4] = w[out_idx[pos], ci, :]
+    extra = None
+    if extra_idx is not None:
+        xq = (7 * n_tiles + 3) // 4
+        extra = np.zeros((xq, 64, 4), np.float32)
+        for lane in range(64):
+            g, j = lane >> 4, lane & 15
+            for s in range(7):
+                tap = 4 * s + g
+                if tap > 26:
+                    continue
+                for n in range(n_tiles):
+                    pos = _pos(n_tiles, n, j)
+                    if pos < 0 or pos >= len(out_idx):
+                        continue
+                    idx = s * n_tiles + n
+                    extra[idx // 4, lane, idx % 4] = w[out_idx[pos], extra_idx, tap]
+        extra = torch.from_numpy(extra)
+    return torch.from_numpy(main), extra
+
+
+def fold_bn(bn, out_idx, eps=None):
+    """BatchNorm3d (eval) -> per-position (scale, shift): y = x*scale + shift
+    (scale = g*rsqrt(var+eps), shift = b - mean*scale; networks/layers_op.py:19,32,38)."""
+    eps = bn.eps if eps is None else eps
+    g = bn.weight.detach().double().cpu()
+    b = bn.bias.detach().double().cpu()
+    m = bn.running_mean.detach().double().cpu()
+    v = bn.running_var.detach().double().cpu()
+    sc = (g / torch.sqrt(v + eps))
+    sh = b - m * sc
+    idx = torch.as_tensor(out_idx, dtype=torch.long)
+    return sc[idx].float(), sh[idx].float()
+
+
+def fold_bn_fp32(bn, out_idx):
+    """Same folding done in fp32 exactly like ATen's native_batch_norm (invstd = 1/sqrt(var+eps))."""
+    g = bn.weight.detach().float().cpu()
+    b = bn.bias.detach().float().cpu()
+    m = bn.running_mean.detach().float().cpu()
+    v = bn.running_var.detach().float().cpu()
+    invstd = 1.0 / torch.sqrt(v + bn.eps)
+    sc = g * invstd
+    sh = b - m * sc
+    idx = torch.as_tensor(out_idx, dtype=torch.long)
+    return sc[idx].contiguous(), sh[idx].contiguous()

@@ -1,0 +1,170 @@
+/*
+ * estd_hip.h -- C ABI of libestd_hip.so: the MI355X (gfx950) kernels of ESTDepth's
+ * plane-sweep + EST-transformer hot path.
+ *
+ * The reference (xxlong0/ESTDepth) has no native layer at all: every op below replaces a
+ * composition of ATen calls inside the Python functions cited per entry point.  The ABI is
+ * therefore ours: plain device pointers + sizes + a hipStream_t, int status return (0 = OK,
+ * negative = estd_status), no exceptions, no torch types.  All pointers are DEVICE pointers to
+ * fp32 unless stated; every call only enqueues work on `stream` (no hidden synchronisation).
+ *
+ * Internal volume layouts (private to the library + its host wrapper):
+ *   vol32  : [N][D][H][W][32]  channels-last cost / feature volumes
+ *   kv     : [D][H][W][32]     value = channels 0..15, key = channels 16..31
+ *   scalar : [N][D][H][W]      1-channel volumes (semantic plane scores, logits, 33rd channel)
+ */
+#ifndef ESTD_HIP_H
+#define ESTD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* estd_stream_t; /* hipStream_t */
+
+enum estd_status {
+    ESTD_OK = 0,
+    ESTD_ERR_ARG = -1,      /* null pointer / non-positive size / unsupported channel count */
+    ESTD_ERR_LAUNCH = -2,   /* hipLaunch / hipGetLastError failure */
+    ESTD_ERR_UNSUPPORTED = -3
+};
+
+enum estd_act { ESTD_ACT_NONE = 0, ESTD_ACT_RELU = 1, ESTD_ACT_TANH = 2 };
+
+int estd_version(void);
+const char* estd_status_string(int status);
+
+/* ---- camera algebra on device (tiny fp64 kernels; keeps the forward free of host syncs) ------
+ * Replaces the torch.inverse / matmul calls at hybrid_models/model_hybrid.py:74-88,
+ * utils/homo_utils.py:469-471, hybrid_models/hybrid_depth_decoder.py:235 and
+ * utils/homo_utils.py:51,:258.  */
+
+/* proj12 = rows 0..2 of (src_proj @ inverse(ref_proj)) as rot[9] | trans[3]  (homo_utils.py:469-471) */
+int estd_cam_pair_proj(const float* src_proj16, const float* ref_proj16, float* proj12, estd_stream_t stream);
+
+/* Same, starting from camera-to-world poses and the 1/4-scale intrinsics, i.e. including
+ * model_hybrid.py:74-88 (extrinsic = inverse(pose); proj[:3,:4] = K @ extrinsic[:3,:4]). */
+int estd_cam_sweep_proj(const float* ref_pose16, const float* src_pose16, const float* intr9,
+                        float* proj12, estd_stream_t stream);
+
+/* mats30 = inverse(K)[9] | inverse(pose_j @ inverse(pose_i))[rows 0..2 = 12] | K[9]
+ * (hybrid_depth_decoder.py:235 then homo_utils.py:51,:258).  If pose_i == NULL, pose_j is taken
+ * as the already-formed relative pose (the level-1 warp_volume() call). */
+int estd_cam_volume_mats(const float* pose_j16, const float* pose_i16, const float* intr9,
+                         float* mats30, estd_stream_t stream);
+
+/* ---- plane sweep ----------------------------------------------------------------------------- */
+
+/* Level-1 operator utils/homo_utils.py:458-504 homo_warping(): src [C][H][W] -> out [C][D][H][W]. */
+int estd_homo_warping(const float* src_chw, const float* proj12, const float* depth_values,
+                      float* out_cdhw, int C, int D, int H, int W, estd_stream_t stream);
+
+/* 1x1 channel mix of a 2D feature map, NCHW in -> HWC out: out[p][o] = sum_c w[o][c]*in[c][p] + b[o].
+ * Used to push pre0 (model_hybrid.py:58,:93-94: 1x1x1 conv 64->32 + BN over cat[ref, warped]) in
+ * front of the warp: pre0(cat[ref,warp(src)]) = mix_ref(ref)+shift + warp(mix_src(src)). Cin,Cout<=64 */
+int estd_mix1x1_chw_to_hwc(const float* in_chw, const float* w, const float* bias, float* out_hwc,
+                           int Cin, int Cout, int HW, estd_stream_t stream);
+
+/* Fused homo_warping + pre0: out[d][y][x][:] = ref_mix[y][x][:] + bilinear(src_mix)(d,y,x)  (32 ch). */
+int estd_homo_warp_costvol(const float* src_mix_hwc, const float* ref_mix_hwc, const float* proj12,
+                           const float* depth_values, float* out_vol32, int D, int H, int W,
+                           estd_stream_t stream);
+
+/* ---- 3x3x3 convolution, implicit GEMM on fp32 MFMA (v_mfma_f32_16x16x4_f32) -------------------
+ * Replaces networks/layers_op.py:16-39 (Conv3d bias=False + BatchNorm3d eval + ReLU/Tanh) as used at
+ * model_hybrid.py:59-60,:95 and hybrid_depth_decoder.py:84-112,:190-200,:256,:377, and the two biased
+ * Conv3d of transformer/epipolar_transformer.py:21,:26.  Weights are pre-packed by the host wrapper
+ * (estdepth_amd/packing.py documents the fragment order). */
+typedef struct estd_conv3d_desc {
+    int N, D, H, W;
+    int cin_main;             /* 16 or 32 channels read from in_main */
+    int in_stride;            /* floats between consecutive voxels of in_main (>= cin_main) */
+    int n_tiles;              /* output 16-channel tiles: 1, 2 or 3 (3 = 32 + one extra channel) */
+    const float* in_main;     /* [N][D][H][W][in_stride] */
+    const float* in_extra;    /* [N][D][H][W] scalar input channel, or NULL */
+    const float* w_main;      /* packed, see packing.py */
+    const float* w_extra;     /* packed extra-channel taps, or NULL */
+    const float* scale;       /* [n_out] folded BN scale per output channel (n_out = 16, 32 or 33) */
+    const float* shift;       /* [n_out] folded BN shift / conv bias */
+    int act_a, act_b, act_split;  /* channels < act_split use act_a, others act_b */
+    /* main output (channels-last, out_stride floats per voxel, may alias a sub-range of a wider tensor) */
+    float* out_main;          /* NULL when only the head output is wanted */
+    int out_stride;
+    int out_channels;         /* 16 or 32 real channels written to out_main */
+    const float* residual;    /* vol with the layout of out_main added after the activation, or NULL */
+    float out_scale;          /* applied after the residual add (1.0 = none) */
+    int accumulate;           /* 1: out_main += result (running sum over source views) */
+    float* out_extra;         /* scalar volume receiving output channel 32 (n_tiles == 3), or NULL */
+    /* fused 1x1x1 head (stereo_head*.1, hybrid_depth_decoder.py:106,:111): logit = sum_c head_w[c]*y[c] + head_b */
+    const float* head_w;      /* [16] or NULL (requires n_tiles == 1) */
+    const float* head_b;      /* device pointer to 1 float */
+    float* out_head;          /* scalar volume [N][D][H][W] */
+    /* GroupNorm(1 group) statistics of the raw outputs, per 16-channel group: partial sums per block,
+     * double[grid][2 groups][2] = {sum, sumsq}; finalised by estd_groupnorm_finalize. */
+    double* stats_partials;   /* or NULL */
+} estd_conv3d_desc;
+
+int estd_conv3d_k3(const estd_conv3d_desc* desc, estd_stream_t stream);
+/* number of thread blocks estd_conv3d_k3 launches for a volume (size of stats_partials / 4 doubles) */
+int estd_conv3d_k3_grid(int N, int D, int H, int W);
+
+/* mean/rstd from the partials: stats_out = {mean_g0, rstd_g0, mean_g1, rstd_g1}; count = 16*D*H*W per group
+ * (transformer/epipolar_transformer.py:22-23,:27 GroupNorm(1, 16, eps=1e-5)). */
+int estd_groupnorm_finalize(const double* partials, int n_blocks, double count, float eps, float* stats_out4,
+                            estd_stream_t stream);
+
+/* ---- soft-argmin ------------------------------------------------------------------------------
+ * hybrid_depth_decoder.py:33-38 depthlayer() applied to F.interpolate(logits, scale_factor=s) (nearest;
+ * :202-204,:259-260,:359-361,:379-381), computed at low resolution and replicated s x s.
+ * logits [N][D][H][W] -> depth, prob [N][s*H][s*W]. */
+int estd_softargmin_up(const float* logits, const float* depth_values, float* depth, float* prob,
+                       int N, int D, int H, int W, int s, estd_stream_t stream);
+
+/* ---- EST transformer --------------------------------------------------------------------------*/
+
+/* Level-1 operator utils/homo_utils.py:240-279 warp_volume() (zeros padding, trilinear):
+ * vol [C][D][H][W] -> out [C][D][H][W]; depth_values [D] are the plane depths (the reference passes
+ * depth_values.repeat(H,W), hybrid_depth_decoder.py:237). */
+int estd_warp_volume(const float* vol_cdhw, const float* mats30, const float* depth_values,
+                     float depth_min, float depth_interval, float* out_cdhw,
+                     int C, int D, int H, int W, estd_stream_t stream);
+
+/* Fused warp_volume(K_j), warp_volume(V_j) for all sources j + epipolar attention
+ * (hybrid_depth_decoder.py:233-246 + transformer/epipolar_transformer.py:62-73):
+ *   xh[vox][0:16] = V_t ; xh[vox][16:32] = h = mean_j( softmax_j(K_t . warp(K_j)) * warp(V_j) ).
+ * kv_src: HOST array of n_src device pointers to kv volumes (copied into the launch arguments);
+ * mats_dev: device [n_src][30] from estd_cam_volume_mats.  n_src in 1..8. */
+int estd_warp_attention(const float* kv_target, const float* const* kv_src, const float* mats_dev,
+                        int n_src, const float* depth_values, float depth_min, float depth_interval,
+                        float* xh_out, int D, int H, int W, estd_stream_t stream);
+
+/* Attention over already-warped kv volumes (the level-1 EpipolarTransformer.forward signature,
+ * transformer/epipolar_transformer.py:56-73): same output as estd_warp_attention without the gather. */
+int estd_attention_prewarped(const float* kv_target, const float* const* kv_src, int n_src,
+                             float* xh_out, int64_t n_vox, estd_stream_t stream);
+
+/* xrh[vox] = [ x , sigmoid(GN(r_raw)) * h ]  (epipolar_transformer.py:44,:46,:51):
+ * xh = [x,h]; ru = raw gate conv output [r(0..15), u(16..31)];
+ * stats4 from estd_groupnorm_finalize; gamma/beta = reset_gate_norm affine [16]. */
+int estd_gru_reset_apply(const float* xh, const float* ru, const float* stats4, const float* gamma_r,
+                         const float* beta_r, float* xrh, int64_t n_vox, estd_stream_t stream);
+
+/* out_value[vox][0:16] (stride out_stride) = u*h + (1-u)*tanh(GN(o_raw)),  u = sigmoid(GN(u_raw))
+ * (epipolar_transformer.py:45,:47,:53,:82-83). */
+int estd_gru_blend(const float* xh, const float* ru, const float* o_raw, const float* stats_ru4,
+                   const float* stats_o4, const float* gamma_u, const float* beta_u, const float* gamma_o,
+                   const float* beta_o, float* out_value, int out_stride, int64_t n_vox, estd_stream_t stream);
+
+/* ---- layout conversion at the API edge (reference tensors are NCDHW) -------------------------- */
+/* [C][S] (channel planes, S = D*H*W) -> [S][dst_stride] at channel offset dst_off */
+int estd_cdhw_to_vol(const float* src_cdhw, float* dst, int C, int64_t S, int dst_stride, int dst_off,
+                     estd_stream_t stream);
+int estd_vol_to_cdhw(const float* src, float* dst_cdhw, int C, int64_t S, int src_stride, int src_off,
+                     estd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESTD_HIP_H */

@@ -1,0 +1,106 @@
+"""Deterministic INPUT recipes of the golden fixtures (tests/golden/*.npz hold only expected outputs).
+
+Shared by tools/gen_golden.py (which feeds them to the reference) and by the tests (which feed
+them to the oracle and to the HIP path).  Everything is generated on CPU with seeded generators.
+"""
+import numpy as np
+import torch
+
+from estdepth_amd import synth
+
+
+def _t(seed, *shape, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def poses_list(n, first=0):
+    return [torch.from_numpy(synth.camera_pose(first + v))[None] for v in range(n)]
+
+
+# ---------------------------------------------------------------- G1 homo_warping
+def g1_cases():
+    cases = []
+    for name, (C, H, W, D, seed) in {"a": (8, 24, 32, 16, 11), "b": (4, 12, 16, 64, 12)}.items():
+        src = _t(seed, 1, C, H, W)
+        K = torch.from_numpy(synth.intrinsics(H * 4, W * 4)).clone()
+        K[:2] *= 0.25
+        def proj(v):
+            e = torch.inverse(torch.from_numpy(synth.camera_pose(v, motion=2.0)))
+            p = e.clone()
+            p[:3, :4] = K @ e[:3, :4]
+            return p[None]
+        dv = (torch.arange(D, dtype=torch.float32) * ((10.0 - 0.1) / (D - 1)) + 0.1).view(1, D, 1, 1)
+        cases.append((name, src, proj(0), proj(1), dv))
+    return cases
+
+
+# ---------------------------------------------------------------- G3 warp_volume
+def g3_case():
+    C, D, H, W = 16, 64, 12, 16
+    vol = _t(31, 1, C, D, H, W)
+    K = torch.from_numpy(synth.intrinsics(H * 4, W * 4)).clone()
+    K[:2] *= 0.25
+    depth_min, depth_max = 0.1, 10.0
+    interval = (depth_max - depth_min) / (D - 1)
+    dv = (torch.arange(D, dtype=torch.float32) * interval + depth_min).view(1, D, 1, 1)
+    depth = dv.repeat(1, 1, H, W).view(1, 1, D, H * W)
+    pi = torch.from_numpy(synth.camera_pose(1, motion=1.5))
+    pj = torch.from_numpy(synth.camera_pose(3, motion=1.5))
+    rel = (pj @ torch.inverse(pi))[None]
+    return vol, depth, rel, K[None], depth_min, interval
+
+
+# ---------------------------------------------------------------- G4 EpipolarTransformer
+def g4_case(n_views):
+    C, D, H, W = 16, 8, 12, 16
+    tk = torch.relu(_t(41, 1, C, D, H, W))
+    tv = torch.tanh(_t(42, 1, C, D, H, W))
+    wk = [torch.relu(_t(43 + i, 1, C, D, H, W)) for i in range(n_views)]
+    wv = [torch.tanh(_t(53 + i, 1, C, D, H, W)) for i in range(n_views)]
+    return tk, tv, wv, wk
+
+
+# ---------------------------------------------------------------- G5 depthlayer
+def g5_cases():
+    D, H, W = 16, 6, 8
+    dv = (torch.arange(D, dtype=torch.float32) * 0.66 + 0.1).view(1, D, 1, 1)
+    flat = torch.zeros(1, D, H, W)
+    peaky = _t(61, 1, D, H, W, scale=25.0)
+    tie = torch.zeros(1, D, H, W)
+    tie[:, 3] = 5.0
+    tie[:, 9] = 5.0
+    return dv, {"flat": flat, "peaky": peaky, "tie": tie, "rand": _t(62, 1, D, H, W, scale=3.0)}
+
+
+# ---------------------------------------------------------------- G6 decoder
+def g6_inputs(resnet, T, H=24, W=32, D=64, seed=70):
+    ch = [64, 64, 128, 256, 512] if resnet <= 34 else [64, 256, 512, 1024, 2048]
+    sem = [torch.relu(_t(seed + s, T, ch[s], (4 * H) >> (s + 1), (4 * W) >> (s + 1))) for s in range(5)]
+    cvs = [_t(seed + 10 + t, 1, 32, D, H, W, scale=0.7) for t in range(T)]
+    K = torch.from_numpy(synth.intrinsics(H * 4, W * 4)).clone()
+    K[:2] *= 0.25
+    dmin, dmax = 0.1, 10.0
+    interval = (dmax - dmin) / (D - 1)
+    dv = (torch.arange(D, dtype=torch.float32) * interval + dmin).view(1, D, 1, 1)
+    poses = poses_list(T, first=1)
+    return cvs, sem, poses, K[None], dv, dmin, interval
+
+
+def g6_memory(n, H=24, W=32, D=64, seed=90):
+    keys = [torch.relu(_t(seed + i, 1, 16, D, H, W)) for i in range(n)]
+    vals = [torch.tanh(_t(seed + 5 + i, 1, 16, D, H, W)) for i in range(n)]
+    poses = [torch.from_numpy(synth.camera_pose(-1 - i))[None] for i in range(n)]
+    return {"keys": keys, "values": vals}, poses
+
+
+# ---------------------------------------------------------------- G7-G9 end to end
+def e2e_inputs(n_views, hi, wi, seed, first_frame=0):
+    imgs = synth.smooth_images(n_views, hi, wi, seed)
+    poses = torch.from_numpy(np.stack([synth.camera_pose(first_frame + v) for v in range(n_views)]))[None]
+    intr = torch.from_numpy(synth.intrinsics(hi, wi))[None]
+    sample = {"dmaps": torch.ones(1, n_views, 1, hi, wi), "dmasks": torch.ones(1, n_views, 1, hi, wi, dtype=torch.bool)}
+    return imgs, poses, intr, sample
+
+
+E2E_HI, E2E_WI = 128, 160

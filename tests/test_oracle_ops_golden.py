@@ -1,0 +1,94 @@
+"""Pin the C oracle's per-op restatements against golden vectors generated from the reference
+(tools/gen_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import torch
+
+import fixtures_spec as S
+from oracle import ref_ops as O
+from oracle import ref_model as M
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_g1_homo_warping(golden_dir):
+    g = _load(golden_dir, "g1_homo_warping.npz")
+    for name, src, sp, rp, dv in S.g1_cases():
+        out = O.homo_warping(src.numpy(), sp.numpy(), rp.numpy(), dv.numpy())
+        ref = g[name]
+        diff = np.abs(out - ref)
+        # mask discontinuity (|xn|>1 -> 2): a 1-ulp coordinate difference may flip single samples
+        assert (diff > 1e-4).mean() < 2e-4, (name, diff.max())
+        assert np.median(diff) < 5e-6
+        assert (ref != 0).mean() > 0.3
+
+
+def test_g3_warp_volume(golden_dir):
+    g = _load(golden_dir, "g3_warp_volume.npz")
+    vol, depth, rel, K, dmin, dint = S.g3_case()
+    out = O.warp_volume(vol.numpy(), depth.numpy(), rel.numpy(), K.numpy(), None, dmin, dint)
+    diff = np.abs(out - g["out"])
+    assert (diff > 1e-4).mean() < 2e-4, diff.max()
+    assert np.median(diff) < 5e-6
+    assert abs((out == 0).mean() - float(g["zero_frac"])) < 1e-3
+
+
+def test_g4_epipolar_transformer(golden_dir):
+    from estdepth_amd import synth
+    from estdepth_amd.epipolar_transformer import EpipolarTransformer
+    g = _load(golden_dir, "g4_epipolar_transformer.npz")
+    tr = EpipolarTransformer(16, 16, 3)
+    synth.fill_state_dict(tr, seed=4)
+    P = {"t." + k: v.numpy() for k, v in tr.state_dict().items()}
+    for n in (1, 2, 3):
+        tk, tv, wv, wk = S.g4_case(n)
+        out = M.epipolar_transformer(P, "t", tk.numpy(), tv.numpy(), [w.numpy() for w in wv], [w.numpy() for w in wk])
+        assert np.abs(out - g["n%d" % n]).max() < 2e-5
+
+
+def test_g5_depthlayer(golden_dir):
+    g = _load(golden_dir, "g5_depthlayer.npz")
+    dv, cases = S.g5_cases()
+    for name, lg in cases.items():
+        d, p = O.depthlayer_upsampled(lg.numpy(), dv.numpy(), 4)
+        assert np.abs(d - g[name + "_depth"]).max() < 2e-5, name
+        assert np.abs(p - g[name + "_prob"]).max() < 2e-6, name
+    # closed-form known answers: uniform logits -> mean depth, prob 1/D
+    d, p = O.depthlayer_upsampled(cases["flat"].numpy(), dv.numpy(), 4)
+    assert np.allclose(d, dv.numpy().mean(), atol=1e-5) and np.allclose(p, 1.0 / 16, atol=1e-7)
+
+
+def test_g2_get_costvolume(golden_dir):
+    from estdepth_amd import synth
+    from estdepth_amd.model_hybrid import DepthNetHybrid
+    g = _load(golden_dir, "g2_get_costvolume.npz")
+    m = DepthNetHybrid(ndepths=16, depth_min=0.1, depth_max=10.0, resnet=18, IF_EST_transformer=False)
+    synth.fill_state_dict(m, seed=1)
+    P = {k: v.numpy() for k, v in m.state_dict().items() if k.startswith("pre")}
+    feats = [S._t(20 + i, 1, 32, 16, 20).numpy() for i in range(3)]
+    poses = np.stack([synth.camera_pose(v) for v in range(3)])[None]
+    K = synth.intrinsics(64, 80).copy()
+    K[:2] *= 0.25
+    dv = m.depth_cands.view(1, 16, 1, 1).numpy()
+    out = M.get_costvolume(P, feats, poses, K[None], dv, 16)
+    diff = np.abs(out - g["out"])
+    assert (diff > 1e-4).mean() < 5e-4, diff.max()
+    assert np.median(diff) < 2e-6
+
+
+def test_identity_pose_known_answer():
+    """identity pose => homo_warping resamples src at x*W/(W-1)-0.5 (Q5), not identity."""
+    C, H, W, D = 2, 6, 9, 3
+    src = np.random.RandomState(0).randn(1, C, H, W).astype(np.float32)
+    eye = np.eye(4, dtype=np.float32)[None]
+    dv = np.array([1.0, 2.0, 3.0], np.float32).reshape(1, D, 1, 1)
+    out = O.homo_warping(src, eye, eye, dv)
+    t = torch.from_numpy(src)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    grid = torch.stack([xs / ((W - 1) / 2) - 1, ys / ((H - 1) / 2) - 1], -1)[None]
+    exp = torch.nn.functional.grid_sample(t, grid, mode="bilinear", padding_mode="zeros", align_corners=False).numpy()
+    for d in range(D):
+        assert np.abs(out[:, :, d] - exp).max() < 1e-5

@@ -1,0 +1,183 @@
+"""Generate tests/golden/*.npz by running the REFERENCE itself (imported read-only from
+/root/reference) on the deterministic inputs of tests/fixtures_spec.py.
+
+Runs only in the build container (the reference does not exist on the GPU box).  Nothing from the
+reference is copied: the fixtures hold expected OUTPUT tensors only.  ``torchvision`` is absent in
+this image; the reference's ResnetEncoder only touches conv1/bn1/relu/maxpool/layer1..4 of a
+torchvision-layout ResNet, so a stub module that returns our own torchvision-layout trunk
+(estdepth_amd.backbones.ResNetTrunk) is registered before the import.
+
+    python tools/gen_golden.py
+"""
+import os
+import sys
+import types
+
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+from estdepth_amd import backbones, synth
+import fixtures_spec as S
+
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+    for d in (18, 34, 50, 101, 152):
+        setattr(tvm, "resnet%d" % d, (lambda depth: (lambda pretrained=False: backbones.ResNetTrunk(depth)))(d))
+    tv.models = tvm
+    tv.utils = types.ModuleType("torchvision.utils")
+    tv.transforms = types.ModuleType("torchvision.transforms")
+    sys.modules.update({"torchvision": tv, "torchvision.models": tvm, "torchvision.utils": tv.utils,
+                        "torchvision.transforms": tv.transforms})
+    sys.path.insert(0, REF)
+    import utils.homo_utils as hu
+    import transformer.epipolar_transformer as et
+    import hybrid_models.hybrid_depth_decoder as hd
+    import hybrid_models.model_hybrid as mh
+    return hu, et, hd, mh
+
+
+def npy(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+def checksum(t):
+    a = t.detach().double().flatten()
+    idx = torch.linspace(0, a.numel() - 1, 64).long()
+    return np.concatenate([[a.sum().item(), a.abs().sum().item()], a[idx].numpy()])
+
+
+def main():
+    torch.set_grad_enabled(False)
+    torch.manual_seed(0)
+    hu, et, hd, mh = import_reference()
+    os.makedirs(OUT, exist_ok=True)
+
+    # G1 homo_warping
+    out = {}
+    for name, src, sp, rp, dv in S.g1_cases():
+        out[name] = npy(hu.homo_warping(src, sp, rp, dv))
+    np.savez(os.path.join(OUT, "g1_homo_warping.npz"), **out)
+
+    # G3 warp_volume
+    vol, depth, rel, K, dmin, dint = S.g3_case()
+    D, H, W = vol.shape[2:]
+    grid = hu.set_id_grid(H, W).view(1, 3, 1, H * W).repeat(1, 1, D, 1)
+    w = hu.warp_volume(vol, depth, rel, K, grid, dmin, dint)
+    np.savez(os.path.join(OUT, "g3_warp_volume.npz"), out=npy(w), zero_frac=np.float32((w == 0).float().mean().item()))
+    print("G3 zero fraction", (w == 0).float().mean().item())
+
+    # G4 EpipolarTransformer
+    tr = et.EpipolarTransformer(16, 16, 3).eval()
+    synth.fill_state_dict(tr, seed=4)
+    out = {}
+    for n in (1, 2, 3):
+        tk, tv_, wv, wk = S.g4_case(n)
+        out["n%d" % n] = npy(tr(target_key=tk, target_value=tv_, warped_values=wv, warped_keys=wk))
+    np.savez(os.path.join(OUT, "g4_epipolar_transformer.npz"), **out)
+
+    # G5 depthlayer (on x4 nearest-upsampled logits, as the decoder calls it)
+    dv, cases = S.g5_cases()
+    out = {}
+    for name, lg in cases.items():
+        up = torch.nn.functional.interpolate(lg, scale_factor=4)
+        d, p = hd.depthlayer(up, dv.repeat(1, 1, up.shape[2], up.shape[3]))
+        out[name + "_depth"], out[name + "_prob"] = npy(d), npy(p)
+    np.savez(os.path.join(OUT, "g5_depthlayer.npz"), **out)
+
+    # G2 get_costvolume + G7 end-to-end cfg1 (R18, D=16, 128x160, EST off)
+    m = mh.DepthNetHybrid(ndepths=16, depth_min=0.1, depth_max=10.0, resnet=18, IF_EST_transformer=False).eval()
+    synth.fill_state_dict(m, seed=1)
+    feats = [S._t(20 + i, 1, 32, 16, 20) for i in range(3)]
+    poses = torch.from_numpy(np.stack([synth.camera_pose(v) for v in range(3)]))[None]
+    K = torch.from_numpy(synth.intrinsics(64, 80)).clone()
+    K[:2] *= 0.25
+    dv = m.depth_cands.view(1, 16, 1, 1)
+    cv = m.get_costvolume(feats, poses, K[None], dv)
+    np.savez(os.path.join(OUT, "g2_get_costvolume.npz"), out=npy(cv))
+
+    imgs, poses, intr, sample = S.e2e_inputs(3, S.E2E_HI, S.E2E_WI, seed=1001)
+    outputs, costs, cposes = m(imgs, poses, intr, sample, None, None, mode="val")
+    out = {"|".join(map(str, k)): npy(v) for k, v in outputs.items()}
+    out["key_ck"], out["value_ck"], out["pose"] = checksum(costs["keys"][0]), checksum(costs["values"][0]), npy(cposes[0])
+    np.savez(os.path.join(OUT, "g7_e2e_cfg1.npz"), **out)
+    print("G7 depth range", outputs[("depth", 0, 2)].min().item(), outputs[("depth", 0, 2)].max().item(),
+          "refined", outputs[("depth", 0, 0)].min().item(), outputs[("depth", 0, 0)].max().item(),
+          outputs[("depth", 0, 0)].std().item(), "prob", outputs[("fused_prob", 0)].mean().item())
+
+    # G6 decoder, both branches, R18 and R50 channel sets
+    for resnet in (18, 50):
+        ch = np.array([64, 64, 128, 256, 512]) if resnet == 18 else np.array([64, 256, 512, 1024, 2048])
+        dec = hd.DepthHybridDecoder(ch, ndepths=64, depth_max=10.0, IF_EST_transformer=True).eval()
+        synth.fill_state_dict(dec, seed=6)
+        for tag, T, nmem in (("nomem", 2, 0), ("mem1", 2, 1), ("mem2", 1, 2)):
+            if resnet == 50 and tag != "mem1":
+                continue
+            cvs, sem, cposes, K, dv, dmin, dint = S.g6_inputs(resnet, T)
+            pre_costs, pre_poses = (None, None) if nmem == 0 else S.g6_memory(nmem)
+            dec.pixel_grid = None
+            outputs, costs, rposes = dec(cvs, sem, cposes, K, dv, dmin, dint, pre_costs, pre_poses, mode="val")
+            out = {"|".join(map(str, k)): npy(v) for k, v in outputs.items()}
+            out["key_ck"], out["value_ck"], out["pose"] = checksum(costs["keys"][0]), checksum(costs["values"][0]), npy(rposes[0])
+            np.savez(os.path.join(OUT, "g6_decoder_r%d_%s.npz" % (resnet, tag)), **out)
+            d2 = outputs[("depth", 0, 2)]
+            print("G6", resnet, tag, "depth2 range", d2.min().item(), d2.max().item(),
+                  "prob", outputs[("fused_prob", 0)].mean().item())
+
+    # G8 streaming ESTM: 6 frames -> 4 sliding windows of 3, memory 2 (eval_hybrid_seq.py:160-193)
+    m = mh.DepthNetHybrid(ndepths=64, depth_min=0.1, depth_max=10.0, resnet=18, IF_EST_transformer=True).eval()
+    synth.fill_state_dict(m, seed=2)
+    imgs, poses, intr, sample = S.e2e_inputs(6, S.E2E_HI, S.E2E_WI, seed=1003)
+    mem_costs, mem_poses = [], []
+    out = {}
+    for w_ in range(4):
+        sl = slice(w_, w_ + 3)
+        smp = {k: v[:, sl] for k, v in sample.items()}
+        if mem_poses:   # lw2batch (eval_hybrid_seq.py:102-115)
+            pre_costs = {"keys": [c["keys"][0] for c in mem_costs], "values": [c["values"][0] for c in mem_costs]}
+            pre_poses = [p[0] for p in mem_poses]
+        else:
+            pre_costs, pre_poses = None, None
+        outputs, costs, cposes = m(imgs[:, sl], poses[:, sl], intr, smp, pre_costs, pre_poses, mode="val")
+        mem_costs.append(costs)
+        mem_poses.append(cposes)
+        if len(mem_costs) > 2:
+            mem_costs.pop(0)
+            mem_poses.pop(0)
+        for k, v in outputs.items():
+            out["w%d|" % w_ + "|".join(map(str, k))] = npy(v)
+        out["w%d|pose" % w_] = npy(cposes[0])
+        out["w%d|value_ck" % w_] = checksum(costs["values"][0])
+        print("G8 window", w_, "depth2", outputs[("depth", 0, 2)].mean().item(), "depth0", outputs[("depth", 0, 0)].mean().item())
+    np.savez(os.path.join(OUT, "g8_estm_stream.npz"), **out)
+
+    # G9 Joint with carry-over: two consecutive 5-frame calls (eval_hybrid.py:229-243), stride seq_len-2
+    imgs, poses, intr, sample = S.e2e_inputs(8, S.E2E_HI, S.E2E_WI, seed=1004)
+    pre_costs, pre_poses = None, None
+    out = {}
+    for call in range(2):
+        sl = slice(3 * call, 3 * call + 5)
+        smp = {k: v[:, sl] for k, v in sample.items()}
+        outputs, pre_costs, pre_poses = m(imgs[:, sl], poses[:, sl], intr, smp, pre_costs, pre_poses, mode="val")
+        for k, v in outputs.items():
+            if k[0] == "depth" and k[2] == 1 or k[0] == "init_prob":
+                continue
+            out["c%d|" % call + "|".join(map(str, k))] = npy(v)
+        out["c%d|pose" % call] = npy(pre_poses[0])
+        out["c%d|value_ck" % call] = checksum(pre_costs["values"][0])
+    np.savez(os.path.join(OUT, "g9_joint_carry.npz"), **out)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
