@@ -1,0 +1,203 @@
+"""Benchmark of the ESTDepth hot path on MI355X (contract: see the task statement / DESIGN.md §Measurement).
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload joint|estm|cfg1] [--no-cpu-baseline]
+
+A "step" is one ``DepthNetHybrid.forward`` over one synthetic sequence resident in HBM:
+  * joint (default, BASELINE.json configs[1]): seq_len=5, 480x640, D=64, ResNet-50, Joint-mode steady state
+    (memory carried from the previous call => EST transformer on, 3 depth frames per step);
+  * estm  (configs[2]): steady-state ESTM window (3 frames, 2 memory volumes, 1 depth frame per step).
+For N > 1 one process per GPU (launched by torch.distributed.run) runs its own sequence (weak scaling);
+after every step the ranks all-gather their memory bank {K, V_fused, pose} over RCCL so any
+rank could continue any stream; ``value`` = depth frames of all ranks / max-over-ranks time.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="joint", choices=["joint", "estm", "cfg1"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-allgather", action="store_true")
+    return ap.parse_args()
+
+
+def build_model(workload, device):
+    from estdepth_amd import DepthNetHybrid, synth
+    if workload == "cfg1":
+        m = DepthNetHybrid(ndepths=16, depth_min=0.1, depth_max=10.0, resnet=18, IF_EST_transformer=False)
+    else:
+        m = DepthNetHybrid(ndepths=64, depth_min=0.1, depth_max=10.0, resnet=50, IF_EST_transformer=True)
+    synth.fill_state_dict(m, seed=0, head_gain=1.0)
+    return m.eval().to(device)
+
+
+def make_inputs(workload, rank, device):
+    from estdepth_amd import synth
+    if workload == "cfg1":
+        v, hi, wi = 3, 128, 160
+    elif workload == "joint":
+        v, hi, wi = 8, 480, 640      # two consecutive 5-frame calls with stride seq_len-2 (general_eval.py:52)
+    else:
+        v, hi, wi = 5, 480, 640      # three sliding windows of 3
+    imgs, poses, intr, sample = synth.make_sequence(v, hi, wi, seed=1000 + rank)
+    to = lambda t: t.to(device)
+    return to(imgs), to(poses), to(intr), {k: to(t) for k, t in sample.items()}
+
+
+def cpu_baseline(model, workload):
+    """Oracle (C port, OpenMP) timed on the host cores on a bounded sample: ONE get_costvolume at the
+    workload's size (2 plane sweeps + pre0 + 2x(pre1,pre2): 281.8 GF of the 2496 GF 3D hot path of a
+    Joint sequence), scaled by the FLOP ratio, plus the 2D networks timed with torch on the same cores."""
+    import numpy as np
+    from oracle import ref_model as M, ref_ops as O
+    from estdepth_amd import synth
+    cores = O.num_threads()
+    P = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if k.startswith("pre")}
+    D = model.ndepths
+    H, W = (32, 40) if workload == "cfg1" else (120, 160)
+    rng = np.random.RandomState(0)
+    feats = [rng.randn(1, 32, H, W).astype(np.float32) for _ in range(3)]
+    poses = np.stack([synth.camera_pose(v) for v in range(3)])[None]
+    K = synth.intrinsics(H * 4, W * 4).copy()
+    K[:2] *= 0.25
+    dv = model.depth_cands.view(1, D, 1, 1).numpy()
+    t0 = time.time()
+    M.get_costvolume(P, feats, poses, K[None], dv, D)
+    t_cv = time.time() - t0
+    # 2D networks on the same cores (torch CPU): PSM on V images, ResNet + 2D decoder on T images
+    cpu_model = build_model(workload, "cpu")
+    V, T = (3, 1) if workload != "joint" else (5, 3)
+    hi, wi = H * 4, W * 4
+    with torch.no_grad():
+        x = torch.randn(V, 3, hi, wi)
+        t0 = time.time()
+        cpu_model.matchingFeature(x)
+        sem = cpu_model.semanticFeature(x[:T])
+        sv = cpu_model.CostRegNet._semantic_vs(sem)
+        cpu_model.CostRegNet._refine(sv, torch.randn(T, D, H, W), sem)
+        t_2d = time.time() - t0
+    vox = D * H * W
+    gf_cv = (2 * 2 * 27 * 32 * 32 * 2 + 2 * 2 * 64 * 32) * vox / 1e9                   # one get_costvolume
+    conv = lambda ci, co: 2 * 27 * ci * co * vox / 1e9
+    per_target = gf_cv + 4 * conv(32, 32) + conv(33, 33) + 2 * conv(33, 16) + 2 * conv(16, 16)
+    est = conv(32, 32) + conv(32, 16) if workload != "cfg1" else 0.0
+    gf_3d = T * (per_target + est)
+    t_seq = t_cv * gf_3d / gf_cv + t_2d
+    return {"value": round(T / t_seq, 4), "unit": "depth frames/s", "cores": cores, "kind": "port",
+            "sample": "oracle (C/OpenMP) get_costvolume for 1 target at full size: %.2f s for %.1f GF, scaled x%.2f to the "
+                      "3D hot path of one step, + 2D networks on torch-CPU %.2f s" % (t_cv, gf_cv, gf_3d / gf_cv, t_2d)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=device)
+    torch.backends.cudnn.benchmark = True
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+
+    from estdepth_amd import ops, parallel
+    model = build_model(args.workload, device)
+    imgs, poses, intr, sample = make_inputs(args.workload, rank, device)
+    sub = lambda sl: {k: v[:, sl] for k, v in sample.items()}
+
+    # ---- establish the steady state (untimed): memory bank from the preceding call(s) ----
+    with torch.no_grad():
+        if args.workload == "joint":
+            _, pre_costs, pre_poses = model(imgs[:, 0:5], poses[:, 0:5], intr, sub(slice(0, 5)), None, None, mode="val")
+            sl, frames = slice(3, 8), 3
+        elif args.workload == "estm":
+            _, c0, p0 = model(imgs[:, 0:3], poses[:, 0:3], intr, sub(slice(0, 3)), None, None, mode="val")
+            _, c1, p1 = model(imgs[:, 1:4], poses[:, 1:4], intr, sub(slice(1, 4)),
+                              {"keys": [c0["keys"][0]], "values": [c0["values"][0]]}, [p0[0]], mode="val")
+            pre_costs = {"keys": [c0["keys"][0], c1["keys"][0]], "values": [c0["values"][0], c1["values"][0]]}
+            pre_poses = [p0[0], p1[0]]
+            sl, frames = slice(2, 5), 1
+        else:
+            pre_costs, pre_poses, sl, frames = None, None, slice(0, 3), 1
+    x_imgs, x_poses, x_sample = imgs[:, sl].contiguous(), poses[:, sl].contiguous(), sub(sl)
+
+    def step():
+        with torch.no_grad():
+            out, costs, cposes = model(x_imgs, x_poses, intr, x_sample, pre_costs, list(pre_poses) if pre_poses else None, mode="val")
+            if world > 1 and not args.no_allgather:
+                parallel.allgather_memory_bank(costs, cposes)
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ops.PROFILE = []                       # HIP-event pairs around the dominant kernel, on its launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+
+    if rank == 0:
+        value = frames * world * args.steps / elapsed
+        tot_ms = sum(s.elapsed_time(e) for (_, s, e) in prof)
+        tot_flop = sum(f for (f, _, _) in prof)
+        achieved = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        line = {
+            "metric": "depth frames/sec (seq_len=5, 480x640, D=64)" if args.workload == "joint" else "depth frames/sec",
+            "value": round(value, 3), "unit": "depth frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": {"joint": "cfg2: seq_len=5, 480x640, ndepths=64, ResNet-50, Joint mode steady state (carried memory, EST on)",
+                                    "estm": "cfg3: ESTM steady-state window (3 frames, memory 2), 480x640, ndepths=64, ResNet-50",
+                                    "cfg1": "cfg1: seq_len=3, 128x160, ndepths=16, ResNet-18, EST off"}[args.workload],
+                       "depth_frames_per_step": frames, "input_frames_per_step": x_imgs.shape[1],
+                       "input_frames_per_s": round(x_imgs.shape[1] * world * args.steps / elapsed, 3),
+                       "parallelism": "1 sequence per GPU" + ("; RCCL all-gather of {K,V,pose} per step" if world > 1 and not args.no_allgather else "")},
+            "roofline": {"bound": "mfma", "kernel": "conv3d_k3_kernel<32,2> (3x3x3 conv 32->32, fp32 MFMA 16x16x4)",
+                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": None,
+                         "launches": len(prof), "avg_launch_ms": round(tot_ms / max(len(prof), 1), 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(model.cpu(), args.workload)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

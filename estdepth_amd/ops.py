@@ -11,6 +11,10 @@ from . import packing
 
 ACT = {"none": 0, "relu": 1, "tanh": 2}
 
+# bench.py sets this to a list to collect (flops, start_event, end_event) around every launch of the
+# dominant kernel (3x3x3 conv 32->32 without extra channel) on the stream it is launched on.
+PROFILE = None
+
 
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -134,7 +138,15 @@ class Conv3dPlan:
         d.head_b = self.head_b.data_ptr() if (self.head_b is not None and out_head is not None) else None
         d.out_head = out_head.data_ptr() if out_head is not None else None
         d.stats_partials = stats_partials.data_ptr() if stats_partials is not None else None
+        prof = PROFILE is not None and self.cin_main == 32 and self.n_tiles == 2 and self.w_extra is None
+        if prof:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream())
         N.check(N.lib().estd_conv3d_k3(ctypes.byref(d), _stream()), "estd_conv3d_k3")
+        if prof:
+            e1.record(torch.cuda.current_stream())
+            PROFILE.append((2.0 * 27 * 32 * 32 * Nn * D * H * W, e0, e1))
 
 
 def conv3d_grid(Nn, D, H, W):

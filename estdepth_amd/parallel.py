@@ -1,0 +1,49 @@
+"""Multi-GPU layer: one process per GPU, one video stream per process.
+
+The hot path itself shards at sequence granularity with NO data-path collective (the reference
+cannot even batch sequences, Q15).  The one exchange step with a reference-side meaning is the
+temporal-fusion memory bank: after a window, every rank all-gathers {key, fused value, pose} of
+its stream so that any rank can continue any stream (and so the collective's bandwidth over xGMI
+is exercised and reported).  Backend "nccl" is RCCL on ROCm; CPU tests use gloo.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_sequences(n_sequences, rank=None, world=None):
+    """Round-robin assignment of independent sequences to ranks."""
+    rank = dist.get_rank() if rank is None else rank
+    world = dist.get_world_size() if world is None else world
+    return [s for s in range(n_sequences) if s % world == rank]
+
+
+def allgather_memory_bank(costs, cam_poses, group=None):
+    """costs = {"keys": [K], "values": [V]} with K, V [1,16,D,H,W]; cam_poses = [pose [1,4,4]].
+    Returns a list (one entry per rank) of (costs, cam_poses) in the same structure; entry[rank] aliases
+    nothing of the input.  One fused buffer per rank -> a single all-gather (per-link bound on xGMI:
+    prefer one large message over three small ones)."""
+    world = dist.get_world_size(group)
+    key, value, pose = costs["keys"][0], costs["values"][0], cam_poses[0]
+    kv = getattr(value, "_estd_kv", None)
+    if kv is not None and getattr(key, "_estd_kv", None) is kv:
+        flat = kv.reshape(-1)                      # already one contiguous [D,H,W,32] record stream
+        channels_last = True
+    else:
+        flat = torch.cat([value.reshape(-1), key.reshape(-1)])
+        channels_last = False
+    send = torch.cat([flat, pose.reshape(-1).to(flat.dtype)])
+    recv = torch.empty(world * send.numel(), device=send.device, dtype=send.dtype)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.view(world, send.numel())
+    n = flat.numel()
+    out = []
+    for r in range(world):
+        p = recv[r, n:].reshape(pose.shape)
+        if channels_last:
+            from .hybrid_depth_decoder import kv_views
+            k, v = kv_views(recv[r, :n].reshape(kv.shape))
+        else:
+            v = recv[r, :n // 2].reshape(value.shape)
+            k = recv[r, n // 2:n].reshape(key.shape)
+        out.append(({"keys": [k], "values": [v]}, [p]))
+    return out

@@ -10,10 +10,14 @@ logits straddle zero (otherwise ``relu(all_fused_logits)`` is identically 0 and 
 outputs ignore the matching branch).
 """
 import math
+import re
 import zlib
 
 import numpy as np
 import torch
+
+
+_RESIDUAL_BN = re.compile(r"(layer\d+\.\d+\.conv2\.1|layer\d+\.\d+\.bn[23])\.weight$")
 
 
 def _rng(key, seed):
@@ -48,6 +52,10 @@ def fill_state_dict(module, seed=0, head_gain=10.0, disp_gain=0.1):
     for key in new:
         if key.endswith("stereo_head0.1.weight") or key.endswith("stereo_head1.1.weight"):
             new[key] = new[key] * head_gain
+        if _RESIDUAL_BN.search(key):
+            new[key] = new[key] * 0.25           # damp every residual branch: 25+ blocks would otherwise blow up to 1e5
+        if key.endswith("lastconv.2.weight"):
+            new[key] = new[key] * 0.25           # matching features ~O(1)
         if key.endswith("dispconv_0.weight") or key.endswith("dispconv_1.weight"):
             new[key] = new[key] * disp_gain      # keep depth_max*sigmoid(.) out of saturation
     module.load_state_dict(new)

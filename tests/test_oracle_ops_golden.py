@@ -66,7 +66,7 @@ def test_g2_get_costvolume(golden_dir):
     from estdepth_amd.model_hybrid import DepthNetHybrid
     g = _load(golden_dir, "g2_get_costvolume.npz")
     m = DepthNetHybrid(ndepths=16, depth_min=0.1, depth_max=10.0, resnet=18, IF_EST_transformer=False)
-    synth.fill_state_dict(m, seed=1)
+    synth.fill_state_dict(m, seed=1, head_gain=3.0)
     P = {k: v.numpy() for k, v in m.state_dict().items() if k.startswith("pre")}
     feats = [S._t(20 + i, 1, 32, 16, 20).numpy() for i in range(3)]
     poses = np.stack([synth.camera_pose(v) for v in range(3)])[None]

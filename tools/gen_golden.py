@@ -97,7 +97,7 @@ def main():
 
     # G2 get_costvolume + G7 end-to-end cfg1 (R18, D=16, 128x160, EST off)
     m = mh.DepthNetHybrid(ndepths=16, depth_min=0.1, depth_max=10.0, resnet=18, IF_EST_transformer=False).eval()
-    synth.fill_state_dict(m, seed=1)
+    synth.fill_state_dict(m, seed=1, head_gain=3.0)
     feats = [S._t(20 + i, 1, 32, 16, 20) for i in range(3)]
     poses = torch.from_numpy(np.stack([synth.camera_pose(v) for v in range(3)]))[None]
     K = torch.from_numpy(synth.intrinsics(64, 80)).clone()
@@ -136,7 +136,7 @@ def main():
 
     # G8 streaming ESTM: 6 frames -> 4 sliding windows of 3, memory 2 (eval_hybrid_seq.py:160-193)
     m = mh.DepthNetHybrid(ndepths=64, depth_min=0.1, depth_max=10.0, resnet=18, IF_EST_transformer=True).eval()
-    synth.fill_state_dict(m, seed=2)
+    synth.fill_state_dict(m, seed=2, head_gain=1.0)
     imgs, poses, intr, sample = S.e2e_inputs(6, S.E2E_HI, S.E2E_WI, seed=1003)
     mem_costs, mem_poses = [], []
     out = {}
