@@ -302,5 +302,6 @@ def test_foreign_memory_tensors_are_repacked(golden_dir):
                     [p0[0]], mode="val")
         plain = {"keys": [c0["keys"][0].contiguous().clone()], "values": [c0["values"][0].contiguous().clone()]}
         b, _, _ = m(imgs[:, 1:4], poses[:, 1:4], intr, smp(slice(1, 4)), plain, [p0[0].clone()], mode="val")
+    # not bit-exact: the MIOpen 2D backbones are not run-to-run deterministic at the ulp level
     for k in a:
-        assert torch.equal(a[k], b[k]), k
+        assert (a[k] - b[k]).abs().max().item() < 2e-5, k
