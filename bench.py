@@ -159,9 +159,11 @@ def main():
         step()
     barrier()
     ops.PROFILE = []                       # HIP-event pairs around the dominant kernel, on its launch stream
+    ops.profile_mark(0)                    # estd_mark_kernel brackets the timed region in a rocprofv3 trace
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    ops.profile_mark(1)
     barrier()
     elapsed = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None

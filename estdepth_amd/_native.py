@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libestd_hip.so")
+LIB_PATH = os.environ.get("ESTD_LIB", os.path.join(_HERE, "lib", "libestd_hip.so"))
 
 c_float_p = ctypes.c_void_p      # device pointers travel as integers
 c_stream = ctypes.c_void_p
@@ -34,6 +34,7 @@ class Conv3dDesc(ctypes.Structure):
 _SIGNATURES = {
     "estd_version": (ctypes.c_int, []),
     "estd_status_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "estd_profile_mark": (ctypes.c_int, [ctypes.c_int, c_stream]),
     "estd_cam_pair_proj": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_stream]),
     "estd_cam_sweep_proj": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_stream]),
     "estd_cam_volume_mats": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_stream]),

@@ -11,8 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
-OBJ_DIR = os.path.join(OUT_DIR, "obj")
-LIB = os.path.join(OUT_DIR, "libestd_hip.so")
+OBJ_DIR = os.path.join(OUT_DIR, "obj" + os.environ.get("ESTD_LIB_SUFFIX", ""))
+LIB = os.path.join(OUT_DIR, "libestd_hip%s.so" % os.environ.get("ESTD_LIB_SUFFIX", ""))
 SOURCES = ["conv3d_mfma.hip", "plane_sweep.hip", "est_fusion.hip"]
 HEADERS = [os.path.join(ROOT, "include", "estd_hip.h"), os.path.join(CSRC, "estd_common.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
@@ -43,7 +43,7 @@ def build(force=False, verbose=False):
         o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
-            cmd = [hipcc] + FLAGS + (["-Rpass-analysis=kernel-resource-usage"] if verbose else []) + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + os.environ.get("ESTD_BUILD_DEFS", "").split() + (["-Rpass-analysis=kernel-resource-usage"] if verbose else []) + ["-c", s, "-o", o]
             jobs.append(cmd)
 
     def run(cmd):

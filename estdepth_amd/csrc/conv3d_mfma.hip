@@ -27,9 +27,14 @@
 //     so neighbouring bricks (shared halos) hit the same private L2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "estd_hip.h"
 #include "estd_common.h"
+
+#ifndef ESTD_ABL
+#define ESTD_ABL 0   // timing ablations only (tools/ablate_conv.sh); results are wrong when != 0
+#endif
 
 namespace {
 
@@ -54,110 +59,211 @@ __device__ __forceinline__ int lds_chunk_off(int v, int c) {
     else          return v * 64 + ((c ^ ((v >> 2) & 3)) << 4);
 }
 
+typedef unsigned int u32x4 __attribute__((__vector_size__(16)));   // the type raw_buffer_load_b128 returns (GCC vector)
+typedef unsigned int u32x2 __attribute__((__vector_size__(8)));
+constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;    // beyond num_records of any descriptor: loads return 0, stores are dropped
+
+__device__ __forceinline__ float4 as_float4(u32x4 v)
+{
+    // NB: __builtin_bit_cast(float, v[i]) on a vector element is miscompiled by this clang (every lane reads
+    // element 0); a whole-object copy is the safe form.
+    float4 f;
+    __builtin_memcpy(&f, &v, 16);
+    return f;
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, size_t elems)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(elems * 4), 0x00020000);
+}
+
+constexpr int SL_VOX = IN_H * IN_W;     // 180 voxels per input slice (one depth plane of the brick, with halo)
+
+// Persistent workgroups with a SLIDING DEPTH WINDOW.
+//   * The flattened tile list (column-major: tiles of one (n, h-tile, w-tile) column are consecutive in d) is cut
+//     into gridDim.x equal ranges; XCD x owns a contiguous block of ranges (L2 locality of the shared halos).
+//   * Inside a range the workgroup walks d upwards keeping the three input slices d-1, d, d+1 in a 3-slot LDS
+//     ring: per tile only ONE new slice (180 voxels) is fetched instead of the whole 540-voxel brick.
+//   * The next slice is fetched into registers while the 864 MFMAs of the current tile run (one 16-byte load in
+//     each of the first taps), then written to the free ring slot between two barriers.
+//   * All global traffic uses wave-uniform buffer descriptors: per-lane 32-bit offsets are computed once per
+//     column segment, the per-tile part is a scalar offset, out-of-volume lanes read zeros / drop stores.
 template <int CM, int NT, bool EXTRA>
-__global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h)
+__global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int total_tiles)
 {
     constexpr int CH = CM / 4;          // 16-byte chunks per voxel
     constexpr int KS = CM / 4;          // MFMA k-steps per tap
     constexpr int QN = (KS * NT) / 4;   // float4 weight quads per lane per tap
     constexpr int XS = 7;               // k-steps of the extra (scalar) input channel: 27 taps padded to 28
     constexpr int XQ = (XS * NT + 3) / 4;
+    constexpr int SL_EL = SL_VOX * CH;                 // 16-byte chunks per slice: 1440 (CM=32) / 720 (CM=16)
+    constexpr int SIT = (SL_EL + 255) / 256;           // chunk loads per thread per slice: 6 / 3
+    constexpr int SLICE_BYTES = SL_VOX * CM * 4;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* lds_main = smem;
-    float* lds_extra = reinterpret_cast<float*>(smem + NVOX_IN * CM * 4);
+    char* lds_main = smem;                                                  // [3][SLICE_BYTES]
+    float* lds_extra = reinterpret_cast<float*>(smem + 3 * SLICE_BYTES);    // [3][SL_VOX]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4;            // k index inside an MFMA
     const int i = lane & 15;            // M row (A) / N column (B, D)
-
-    // ---- XCD-aware tile id (bijective) ----
-    const int nwg = gridDim.x;
-    int tile;
-    {
-        const int bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    int t = tile;
-    const int twi = t % tiles_w; t /= tiles_w;
-    const int thi = t % tiles_h; t /= tiles_h;
-    const int d0 = t % p.D;
-    const int n = t / p.D;
-    const int tw0 = twi * TW, th0 = thi * TH;
     const int D = p.D, H = p.H, W = p.W;
 
-    // ---- stage the input brick in LDS (zero padded) ----
+    // ---- range of the flattened tile list owned by this workgroup ----
+    int u, u_end;
     {
-        const float* __restrict__ in = p.in_main + (size_t)n * D * H * W * p.in_stride;
-        constexpr int NEL = NVOX_IN * CH;
-        constexpr int ITER = (NEL + 255) / 256;
-        float4 vals[ITER];
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int e = tid + it * 256;
-            const int v = e / CH, c = e % CH;
-            const int zx = v % IN_W;
-            const int t2 = v / IN_W;
-            const int zy = t2 % IN_H, zd = t2 / IN_H;
-            const int gx = tw0 - 1 + zx, gy = th0 - 1 + zy, gd = d0 - 1 + zd;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < NEL && gx >= 0 && gx < W && gy >= 0 && gy < H && gd >= 0 && gd < D)
-                val = *reinterpret_cast<const float4*>(in + ((size_t)(gd * H + gy) * W + gx) * p.in_stride + c * 4);
-            vals[it] = val;
-        }
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int e = tid + it * 256;
-            if (e < NEL) {
-                const int v = e / CH, c = e % CH;
-                *reinterpret_cast<float4*>(lds_main + lds_chunk_off<CM>(v, c)) = vals[it];
-            }
-        }
-        if (EXTRA) {
-            const float* __restrict__ ex = p.in_extra + (size_t)n * D * H * W;
-            for (int v = tid; v < NVOX_IN; v += 256) {
-                const int zx = v % IN_W;
-                const int t2 = v / IN_W;
-                const int zy = t2 % IN_H, zd = t2 / IN_H;
-                const int gx = tw0 - 1 + zx, gy = th0 - 1 + zy, gd = d0 - 1 + zd;
-                float val = 0.f;
-                if (gx >= 0 && gx < W && gy >= 0 && gy < H && gd >= 0 && gd < D)
-                    val = ex[(size_t)(gd * H + gy) * W + gx];
-                lds_extra[v] = val;
-            }
-        }
+        const int G = gridDim.x, bid = blockIdx.x;
+        const int r = ((G & 7) == 0) ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;
+        u = (int)((long long)total_tiles * r / G);
+        u_end = (int)((long long)total_tiles * (r + 1) / G);
     }
-    __syncthreads();
+    if (u >= u_end) return;
 
-    // ---- main loop: 27 taps x KS k-steps ----
-    f32x4 acc[MT][NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int nn = 0; nn < NT; ++nn) acc[m][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // per-lane constants of the epilogue
+    const int cbase = (NT == 1) ? i : 2 * i;
+    float sc[2], sh[2];
+    sc[0] = p.scale[cbase]; sh[0] = p.shift[cbase];
+    sc[1] = sc[0]; sh[1] = sh[0];
+    if (NT >= 2) { sc[1] = p.scale[cbase + 1]; sh[1] = p.shift[cbase + 1]; }
+    const int act0 = cbase < p.act_split ? p.act_a : p.act_b;   // both channels of a lane share the range (split is even)
+    float sc2 = 0.f, sh2 = 0.f;
+    if (NT == 3) { sc2 = p.scale[32]; sh2 = p.shift[32]; }
+    float hw = 0.f, hb = 0.f;
+    if (NT == 1 && p.head_w) { hw = p.head_w[i]; hb = p.head_b[0]; }
 
-    const float4* __restrict__ wq = reinterpret_cast<const float4*>(p.w_main) + lane;
-    float4 bcur[QN], bnext[QN];
-#pragma unroll
-    for (int q = 0; q < QN; ++q) bcur[q] = wq[q * 64];
-
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w_main, (size_t)28 * QN * 256);
+    const size_t vol = (size_t)D * H * W;
+    const int HW = H * W;
     const int row0 = wave * MT;   // first tile row of this wave
-    int tap = 0;
-    for (int kd = 0; kd < 3; ++kd) {
-        for (int kh = 0; kh < 3; ++kh) {
+    const int wlane = lane * 16;
+    const int nrows = tiles_h * tiles_w;
+
+    while (u < u_end) {
+        // ---- column segment [u, seg_end): same (n, h-tile, w-tile), consecutive d ----
+        const int col = u / D;
+        int d = u - col * D;
+        const int twi = col % tiles_w, c2 = col / tiles_w;
+        const int thi = c2 % tiles_h, n = c2 / tiles_h;
+        const int tw0 = twi * TW, th0 = thi * TH;
+        const int seg_end = min(u_end, (col + 1) * D);
+        (void)nrows;
+
+        const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in_main + (size_t)n * vol * p.in_stride, vol * p.in_stride);
+        __amdgpu_buffer_rsrc_t rs_ex = rs_in;
+        if (EXTRA) rs_ex = make_rsrc(p.in_extra + (size_t)n * vol, vol);
+
+        // per-thread slice-element constants of this segment (validity in y/x does not depend on d)
+        unsigned voff[SIT];
+        int loff[SIT];
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw, ++tap) {
-                // prefetch next tap's weights (the packed buffer carries one padding tap)
+        for (int it = 0; it < SIT; ++it) {
+            const int e = tid + it * 256;
+            const int vs = e / CH, c = e % CH;
+            const int zy = vs / IN_W, zx = vs % IN_W;
+            const int gy = th0 - 1 + zy, gx = tw0 - 1 + zx;
+            const bool ok = e < SL_EL && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            voff[it] = ok ? (unsigned)((gy * W + gx) * p.in_stride + c * 4) * 4u : OOB_OFFSET;
+            loff[it] = e < SL_EL ? lds_chunk_off<CM>(vs, c) : -1;
+        }
+        unsigned voffx = OOB_OFFSET;
+        if (EXTRA) {
+            const int zy = tid / IN_W, zx = tid % IN_W;
+            const int gy = th0 - 1 + zy, gx = tw0 - 1 + zx;
+            const bool ok = tid < SL_VOX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            voffx = ok ? (unsigned)(gy * W + gx) * 4u : OOB_OFFSET;
+        }
+        const int in_slice_bytes = HW * p.in_stride * 4;
+
+        // epilogue lane offsets (bytes inside one depth plane); rows/columns past the volume are dropped
+        const int ey0 = th0 + row0, ex0 = tw0 + 4 * g;
+
+        float4 pf[SIT];
+        float pfx = 0.f;
+        bool first = true;
+
+        for (; u < seg_end; ++u, ++d) {
+            const int dm = d % 3;                                 // ring slot of slice d-1
+            const int sb0 = dm * SLICE_BYTES;
+            const int sb1 = (dm == 2 ? 0 : dm + 1) * SLICE_BYTES;
+            const int sb2 = (dm == 0 ? 2 : dm - 1) * SLICE_BYTES;  // (dm+2)%3 : slot of slice d+1
+            const int xb0 = dm * SL_VOX, xb1 = (dm == 2 ? 0 : dm + 1) * SL_VOX, xb2 = (dm == 0 ? 2 : dm - 1) * SL_VOX;
+
+            __syncthreads();                      // every wave is done with the previous tile's slices
+            if (first) {
+                // prime the ring: slices d-1 and d straight to LDS, slice d+1 into the prefetch registers
 #pragma unroll
-                for (int q = 0; q < QN; ++q) bnext[q] = wq[((tap + 1) * QN + q) * 64];
+                for (int s = 0; s < 2; ++s) {
+                    const int sd = d - 1 + s;
+                    const bool sv = (unsigned)sd < (unsigned)D;
+                    float4 tmp[SIT];
+#pragma unroll
+                    for (int it = 0; it < SIT; ++it)
+                        tmp[it] = sv ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[it], sd * in_slice_bytes, 0))
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float tx = 0.f;
+                    if (EXTRA && sv) tx = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ex, voffx, sd * HW * 4, 0));
+#pragma unroll
+                    for (int it = 0; it < SIT; ++it)
+                        if (it < SIT - 1 || loff[it] >= 0)
+                            *reinterpret_cast<float4*>(lds_main + (s == 0 ? sb0 : sb1) + loff[it]) = tmp[it];
+                    if (EXTRA && tid < SL_VOX) lds_extra[(s == 0 ? xb0 : xb1) + tid] = tx;
+                }
+                {
+                    const int sd = d + 1;
+                    const bool sv = sd < D;
+#pragma unroll
+                    for (int it = 0; it < SIT; ++it)
+                        pf[it] = sv ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[it], sd * in_slice_bytes, 0))
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (EXTRA) pfx = sv ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ex, voffx, sd * HW * 4, 0)) : 0.f;
+                }
+                first = false;
+            }
+            // slice d+1 (prefetched during the previous tile) -> its ring slot
+#pragma unroll
+            for (int it = 0; it < SIT; ++it)
+                if (it < SIT - 1 || loff[it] >= 0)
+                    *reinterpret_cast<float4*>(lds_main + sb2 + loff[it]) = pf[it];
+            if (EXTRA && tid < SL_VOX) lds_extra[xb2 + tid] = pfx;
+            __syncthreads();
+
+            const bool has_next = (u + 1 < seg_end);            // wave-uniform
+            const bool next_valid = (d + 2 < D);
+            const int next_soff = (d + 2) * in_slice_bytes;
+
+            // ---- main loop: 27 taps x KS k-steps ----
+            f32x4 acc[MT][NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int nn = 0; nn < NT; ++nn) acc[m][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+            float4 bcur[QN], bnext[QN];
+#pragma unroll
+            for (int q = 0; q < QN; ++q) bcur[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, q * 1024, 0));
+
+#pragma unroll
+            for (int tap = 0; tap < 27; ++tap) {
+                const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+                const int sb = kd == 0 ? sb0 : kd == 1 ? sb1 : sb2;
+                // next tap's weights (the packed buffer carries one padding tap)
+#pragma unroll
+                for (int q = 0; q < QN; ++q)
+                    bnext[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, ((tap + 1) * QN + q) * 1024, 0));
+                // one chunk of the NEXT tile's new slice per tap
+                if (has_next) {
+                    if (tap < SIT)
+                        pf[tap] = next_valid ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[tap], next_soff, 0))
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (EXTRA && tap == SIT)
+                        pfx = next_valid ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ex, voffx, (d + 2) * HW * 4, 0)) : 0.f;
+                }
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    const int v = (kd * IN_H + (row0 + m + kh)) * IN_W + kw + i;
-                    const int off0 = lds_chunk_off<CM>(v, g);
+                    const int vs = (row0 + m + kh) * IN_W + kw + i;
+                    const int off0 = sb + lds_chunk_off<CM>(vs, g);
                     const float4 a0 = *reinterpret_cast<const float4*>(lds_main + off0);
                     float4 a1 = a0;
                     if (CM == 32) a1 = *reinterpret_cast<const float4*>(lds_main + (off0 ^ 64));
@@ -175,142 +281,137 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
                 }
 #pragma unroll
                 for (int q = 0; q < QN; ++q) bcur[q] = bnext[q];
+                __builtin_amdgcn_sched_barrier(0);   // keep each tap's loads inside the tap (bounds live registers)
             }
-        }
-    }
 
-    // ---- extra scalar input channel: its 27 taps form one more K chunk (28 = 7 x 4) ----
-    if (EXTRA) {
-        const float4* __restrict__ xq = reinterpret_cast<const float4*>(p.w_extra) + lane;
-        float4 bx[XQ];
+            // ---- extra scalar input channel: its 27 taps form one more K chunk (28 = 7 x 4) ----
+            if (EXTRA) {
+                const __amdgpu_buffer_rsrc_t rs_wx = make_rsrc(p.w_extra, (size_t)XQ * 256);
+                float4 bx[XQ];
 #pragma unroll
-        for (int q = 0; q < XQ; ++q) bx[q] = xq[q * 64];
+                for (int q = 0; q < XQ; ++q) bx[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_wx, wlane, q * 1024, 0));
 #pragma unroll
-        for (int s = 0; s < XS; ++s) {
-            int tp = 4 * s + g;
-            tp = tp > 26 ? 26 : tp;           // tap 27 is padding (zero weight)
-            const int kd = tp / 9, kh = (tp / 3) % 3, kw = tp % 3;
+                for (int s = 0; s < XS; ++s) {
+                    int tp = 4 * s + g;
+                    tp = tp > 26 ? 26 : tp;           // tap 27 is padding (zero weight)
+                    const int kd = tp / 9, kh = (tp / 3) % 3, kw = tp % 3;
+                    const int xb = kd == 0 ? xb0 : kd == 1 ? xb1 : xb2;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const float a = lds_extra[xb + (row0 + m + kh) * IN_W + kw + i];
+#pragma unroll
+                        for (int nn = 0; nn < NT; ++nn) {
+                            const int idx = s * NT + nn;
+                            const float4 bq = bx[idx >> 2];
+                            const float b = (idx & 3) == 0 ? bq.x : (idx & 3) == 1 ? bq.y : (idx & 3) == 2 ? bq.z : bq.w;
+                            acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[m][nn], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+
+            // ---- epilogue ----
+            // D layout: lane holds column j = i (N index) and rows 4g..4g+3 (M index = voxel along W).
+            // channel of (tile nn, column j): NT==1 -> j ; NT>=2 -> 2j+nn for nn<2 ; nn==2 -> 32 (only j==0).
+            double s_sum = 0.0, s_sq = 0.0;     // GroupNorm partials of this lane (its channels are in one group)
+            const size_t plane = (size_t)n * vol + (size_t)d * HW;     // voxel index of (n, d, 0, 0)
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const int v = (kd * IN_H + (row0 + m + kh)) * IN_W + kw + i;
-                const float a = lds_extra[v];
+                const int y = ey0 + m;
 #pragma unroll
-                for (int nn = 0; nn < NT; ++nn) {
-                    const int idx = s * NT + nn;
-                    const float4 bq = bx[idx >> 2];
-                    const float b = (idx & 3) == 0 ? bq.x : (idx & 3) == 1 ? bq.y : (idx & 3) == 2 ? bq.z : bq.w;
-                    acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[m][nn], 0, 0, 0);
-                }
-            }
-        }
-    }
-
-    // ---- epilogue ----
-    // D layout: lane holds column j = i (N index) and rows 4g..4g+3 (M index = voxel along W).
-    // channel of (tile nn, column j): NT==1 -> j ; NT>=2 -> 2j+nn for nn<2 ; nn==2 -> 32 (only j==0).
-    const int cbase = (NT == 1) ? i : 2 * i;
-    float sc[2], sh[2];
-    sc[0] = p.scale[cbase]; sh[0] = p.shift[cbase];
-    sc[1] = sc[0]; sh[1] = sh[0];
-    if (NT >= 2) { sc[1] = p.scale[cbase + 1]; sh[1] = p.shift[cbase + 1]; }
-    const int act0 = cbase < p.act_split ? p.act_a : p.act_b;   // both channels of a lane share the range (split is even)
-    float sc2 = 0.f, sh2 = 0.f;
-    if (NT == 3) { sc2 = p.scale[32]; sh2 = p.shift[32]; }
-    float hw = 0.f, hb = 0.f;
-    if (NT == 1 && p.head_w) { hw = p.head_w[i]; hb = p.head_b[0]; }
-
-    double s_sum = 0.0, s_sq = 0.0;     // GroupNorm partials of this lane (its channels are in one group)
-    const size_t vol_base = (size_t)n * D * H * W;
-
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int y = th0 + row0 + m;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int x = tw0 + 4 * g + r;
-            const bool valid = (y < H) && (x < W);
-            const size_t vox = vol_base + ((size_t)d0 * H + y) * W + x;
-            float v0 = acc[m][0][r] * sc[0] + sh[0];
-            float v1 = 0.f;
-            if (NT >= 2) v1 = acc[m][1][r] * sc[1] + sh[1];
-            if (p.stats_partials && valid) {
-                s_sum += (double)v0; s_sq += (double)v0 * (double)v0;
-                if (NT >= 2) { s_sum += (double)v1; s_sq += (double)v1 * (double)v1; }
-            }
-            v0 = act_apply(v0, act0);
-            if (NT >= 2) v1 = act_apply(v1, act0);
-            if (NT == 1 && p.head_w) {
-                // 1x1x1 head: reduce over the 16 channel lanes of this row group
-                float hsum = v0 * hw;
-                hsum += __shfl_xor(hsum, 1);
-                hsum += __shfl_xor(hsum, 2);
-                hsum += __shfl_xor(hsum, 4);
-                hsum += __shfl_xor(hsum, 8);
-                if (valid && i == 0) p.out_head[vox] = hsum + hb;
-            }
-            if (p.out_main && valid) {
-                float* o = p.out_main + vox * p.out_stride + cbase;
-                if (NT == 1) {
-                    if (p.residual) v0 += p.residual[vox * p.out_stride + cbase];
-                    v0 *= p.out_scale;
-                    if (p.accumulate) v0 += *o;
-                    *o = v0;
-                } else {
-                    if (p.residual) {
-                        const float2 rr = *reinterpret_cast<const float2*>(p.residual + vox * p.out_stride + cbase);
-                        v0 += rr.x; v1 += rr.y;
+                for (int r = 0; r < 4; ++r) {
+                    const int x = ex0 + r;
+                    const bool valid = (y < H) && (x < W);
+                    const size_t vox = plane + (size_t)y * W + x;
+                    float v0 = acc[m][0][r] * sc[0] + sh[0];
+                    float v1 = 0.f;
+                    if (NT >= 2) v1 = acc[m][1][r] * sc[1] + sh[1];
+                    if (p.stats_partials && valid) {
+                        s_sum += (double)v0; s_sq += (double)v0 * (double)v0;
+                        if (NT >= 2) { s_sum += (double)v1; s_sq += (double)v1 * (double)v1; }
                     }
-                    v0 *= p.out_scale; v1 *= p.out_scale;
-                    if (p.accumulate) {
-                        const float2 pr = *reinterpret_cast<const float2*>(o);
-                        v0 += pr.x; v1 += pr.y;
+                    v0 = act_apply(v0, act0);
+                    if (NT >= 2) v1 = act_apply(v1, act0);
+                    if (NT == 1 && p.head_w) {
+                        // 1x1x1 head: reduce over the 16 channel lanes of this row group
+                        float hsum = v0 * hw;
+                        hsum += __shfl_xor(hsum, 1);
+                        hsum += __shfl_xor(hsum, 2);
+                        hsum += __shfl_xor(hsum, 4);
+                        hsum += __shfl_xor(hsum, 8);
+                        if (valid && i == 0) p.out_head[vox] = hsum + hb;
                     }
-                    *reinterpret_cast<float2*>(o) = make_float2(v0, v1);
+                    if (p.out_main && valid && !(ESTD_ABL & 1)) {
+                        float* o = p.out_main + vox * p.out_stride + cbase;
+                        if (NT == 1) {
+                            if (p.residual) v0 += p.residual[vox * p.out_stride + cbase];
+                            v0 *= p.out_scale;
+                            if (p.accumulate) v0 += *o;
+                            *o = v0;
+                        } else {
+                            if (p.residual) {
+                                const float2 rr = *reinterpret_cast<const float2*>(p.residual + vox * p.out_stride + cbase);
+                                v0 += rr.x; v1 += rr.y;
+                            }
+                            v0 *= p.out_scale; v1 *= p.out_scale;
+                            if (p.accumulate) {
+                                const float2 pr = *reinterpret_cast<const float2*>(o);
+                                v0 += pr.x; v1 += pr.y;
+                            }
+                            *reinterpret_cast<float2*>(o) = make_float2(v0, v1);
+                        }
+                    }
+                    if (NT == 3) {
+                        if (valid && i == 0 && p.out_extra) {
+                            float v2 = acc[m][2][r] * sc2 + sh2;
+                            p.out_extra[vox] = act_apply(v2, p.act_b);
+                        }
+                    }
                 }
             }
-            if (NT == 3) {
-                if (valid && i == 0 && p.out_extra) {
-                    float v2 = acc[m][2][r] * sc2 + sh2;
-                    p.out_extra[vox] = act_apply(v2, p.act_b);
-                }
-            }
-        }
-    }
 
-    if (p.stats_partials) {
-        // group 0 = channels 0..15, group 1 = channels 16..31.  Lane's channels: cbase(,+1).
-        const int grp = (cbase >= 16) ? 1 : 0;
-        double a0 = grp == 0 ? s_sum : 0.0, q0 = grp == 0 ? s_sq : 0.0;
-        double a1 = grp == 1 ? s_sum : 0.0, q1 = grp == 1 ? s_sq : 0.0;
+            if (p.stats_partials) {
+                // group 0 = channels 0..15, group 1 = channels 16..31.  Lane's channels: cbase(,+1).
+                const int grp = (cbase >= 16) ? 1 : 0;
+                double a0 = grp == 0 ? s_sum : 0.0, q0 = grp == 0 ? s_sq : 0.0;
+                double a1 = grp == 1 ? s_sum : 0.0, q1 = grp == 1 ? s_sq : 0.0;
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            a0 += __shfl_xor(a0, o); q0 += __shfl_xor(q0, o);
-            a1 += __shfl_xor(a1, o); q1 += __shfl_xor(q1, o);
-        }
-        __syncthreads();   // LDS brick no longer needed: reuse it for the cross-wave reduction
-        double* red = reinterpret_cast<double*>(smem);
-        if (lane == 0) { red[wave * 4 + 0] = a0; red[wave * 4 + 1] = q0; red[wave * 4 + 2] = a1; red[wave * 4 + 3] = q1; }
-        __syncthreads();
-        if (tid < 4) {
-            const double tot = red[tid] + red[4 + tid] + red[8 + tid] + red[12 + tid];
-            p.stats_partials[(size_t)tile * 4 + tid] = tot;
+                for (int o = 32; o >= 1; o >>= 1) {
+                    a0 += __shfl_xor(a0, o); q0 += __shfl_xor(q0, o);
+                    a1 += __shfl_xor(a1, o); q1 += __shfl_xor(q1, o);
+                }
+                // cross-wave reduction through a small LDS scratch placed after the ring
+                double* red = reinterpret_cast<double*>(smem + 3 * SLICE_BYTES + (EXTRA ? 3 * SL_VOX * 4 : 0));
+                if (lane == 0) { red[wave * 4 + 0] = a0; red[wave * 4 + 1] = q0; red[wave * 4 + 2] = a1; red[wave * 4 + 3] = q1; }
+                __syncthreads();
+                if (tid < 4) {
+                    const double tot = red[tid] + red[4 + tid] + red[8 + tid] + red[12 + tid];
+                    // partial index = canonical tile id (n, d, thi, twi) so the finalize order is launch-independent
+                    const size_t tile_id = (((size_t)n * D + d) * tiles_h + thi) * tiles_w + twi;
+                    p.stats_partials[tile_id * 4 + tid] = tot;
+                }
+            }
         }
     }
 }
+
+constexpr int PERSISTENT_WGS = 512;     // 256 CUs x 2 resident workgroups (LDS-limited)
 
 template <int CM, int NT, bool EXTRA>
 int launch(const estd_conv3d_desc& d, hipStream_t stream)
 {
     const int tiles_w = (d.W + TW - 1) / TW, tiles_h = (d.H + TH - 1) / TH;
-    const int grid = d.N * d.D * tiles_h * tiles_w;
-    const size_t lds = (size_t)NVOX_IN * CM * 4 + (EXTRA ? NVOX_IN * 4 : 0);
+    const int total = d.N * d.D * tiles_h * tiles_w;
+    int grid = total < PERSISTENT_WGS ? total : PERSISTENT_WGS;
+    if (grid >= 8) grid &= ~7;
+    const size_t lds = (size_t)3 * SL_VOX * CM * 4 + (EXTRA ? 3 * SL_VOX * 4 : 0) + 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_kernel<CM, NT, EXTRA>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_kernel<CM, NT, EXTRA>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3d_k3_kernel<CM, NT, EXTRA>), dim3(grid), dim3(256), lds, stream, d, tiles_w, tiles_h);
+    hipLaunchKernelGGL((conv3d_k3_kernel<CM, NT, EXTRA>), dim3(grid), dim3(256), lds, stream, d, tiles_w, tiles_h, total);
     return hipGetLastError() == hipSuccess ? ESTD_OK : ESTD_ERR_LAUNCH;
 }
 

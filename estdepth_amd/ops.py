@@ -36,6 +36,10 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def profile_mark(idx):
+    N.check(N.lib().estd_profile_mark(int(idx), _stream()), "estd_profile_mark")
+
+
 # ---------------------------------------------------------------------------------- camera algebra
 def cam_pair_proj(src_proj, ref_proj):
     """rot|trans of src_proj @ inverse(ref_proj) for one batch element -> [12]."""

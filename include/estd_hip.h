@@ -34,6 +34,8 @@ enum estd_status {
 enum estd_act { ESTD_ACT_NONE = 0, ESTD_ACT_RELU = 1, ESTD_ACT_TANH = 2 };
 
 int estd_version(void);
+/* launches the empty kernel `estd_mark_kernel` so a rocprofv3 kernel trace can be cut to a timed region */
+int estd_profile_mark(int id, estd_stream_t stream);
 const char* estd_status_string(int status);
 
 /* ---- camera algebra on device (tiny fp64 kernels; keeps the forward free of host syncs) ------

@@ -1,0 +1,28 @@
+"""Time the dominant kernel (3x3x3 conv 32->32, cfg2 volume) in isolation.  python tools/conv_bench.py [N] [iters]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from estdepth_amd import synth, ops
+from estdepth_amd.layers_op import ConvBN3d
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+D, H, W = 64, 120, 160
+dev = torch.device("cuda:0")
+mod = ConvBN3d(32, 32, 3, 1, 1, "relu").eval()
+synth.fill_state_dict(mod, seed=1)
+plan = mod.to(dev).plan()
+x = torch.randn(N, D, H, W, 32, device=dev)
+y = torch.empty_like(x)
+for _ in range(3):
+    plan.run(x, (N, D, H, W), out=y, out_stride=32)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(iters):
+    plan.run(x, (N, D, H, W), out=y, out_stride=32)
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / iters
+print("conv3d 32->32 N=%d: %.4f ms  %.1f TFLOP/s  (%.1f%% of 157.3)" % (N, ms, N * 67.95 / ms, N * 67.95 / ms / 157.3 * 100))
