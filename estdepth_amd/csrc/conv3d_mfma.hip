@@ -77,6 +77,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, s
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(elems * 4), 0x00020000);
 }
 
+// Workgroup barrier that only orders LDS traffic.  __syncthreads() would also drain vmcnt, i.e. wait for the
+// previous tile's output stores (and the in-flight prefetch) to complete on every tile.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 constexpr int SL_VOX = IN_H * IN_W;     // 180 voxels per input slice (one depth plane of the brick, with halo)
 
 // Persistent workgroups with a SLIDING DEPTH WINDOW.
@@ -89,7 +96,8 @@ constexpr int SL_VOX = IN_H * IN_W;     // 180 voxels per input slice (one depth
 //   * All global traffic uses wave-uniform buffer descriptors: per-lane 32-bit offsets are computed once per
 //     column segment, the per-tile part is a scalar offset, out-of-volume lanes read zeros / drop stores.
 template <int CM, int NT, bool EXTRA>
-__global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int total_tiles)
+__global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int total_tiles,
+                                                           int stagger)
 {
     constexpr int CH = CM / 4;          // 16-byte chunks per voxel
     constexpr int KS = CM / 4;          // MFMA k-steps per tap
@@ -120,6 +128,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
         u_end = (int)((long long)total_tiles * (r + 1) / G);
     }
     if (u >= u_end) return;
+    if (stagger > 0) {
+        const int mode = stagger >> 8, cnt = stagger & 255;
+        const bool sel = mode == 0 ? ((int)blockIdx.x >= (int)(gridDim.x >> 1)) : mode == 1 ? (((blockIdx.x >> 3) & 1) != 0)
+                                                                                             : (((blockIdx.x >> 4) & 1) != 0);
+        if (sel) for (int k = 0; k < cnt; ++k) __builtin_amdgcn_s_sleep(127);
+    }
 
     // per-lane constants of the epilogue
     const int cbase = (NT == 1) ? i : 2 * i;
@@ -179,6 +193,113 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
         // epilogue lane offsets (bytes inside one depth plane); rows/columns past the volume are dropped
         const int ey0 = th0 + row0, ex0 = tw0 + 4 * g;
 
+        // output descriptors and per-lane output offsets of this segment (bytes inside one depth plane)
+        __amdgpu_buffer_rsrc_t rs_out = rs_in, rs_res = rs_in;
+        if (p.out_main) rs_out = make_rsrc(p.out_main + (size_t)n * vol * p.out_stride, vol * p.out_stride);
+        if (p.residual) rs_res = make_rsrc(p.residual + (size_t)n * vol * p.out_stride, vol * p.out_stride);
+        const int out_plane_bytes = HW * p.out_stride * 4;
+        unsigned eoff[MT][4];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int y = ey0 + m, x = ex0 + r;
+                eoff[m][r] = (y < H && x < W) ? (unsigned)((y * W + x) * p.out_stride + cbase) * 4u : OOB_OFFSET;
+            }
+
+        // ---- epilogue of one finished tile (depth plane dd of this column) ----
+        auto epilogue = [&](const f32x4 (&a)[MT][NT], int dd) {
+            // D layout: lane holds column j = i (N index) and rows 4g..4g+3 (M index = voxel along W).
+            // channel of (tile nn, column j): NT==1 -> j ; NT>=2 -> 2j+nn for nn<2 ; nn==2 -> 32 (only j==0).
+            double s_sum = 0.0, s_sq = 0.0;     // GroupNorm partials of this lane (its channels are in one group)
+            const size_t plane = (size_t)n * vol + (size_t)dd * HW;     // voxel index of (n, d, 0, 0)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int y = ey0 + m;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int x = ex0 + r;
+                    const bool valid = (y < H) && (x < W);
+                    const size_t vox = plane + (size_t)y * W + x;
+                    float v0 = a[m][0][r] * sc[0] + sh[0];
+                    float v1 = 0.f;
+                    if (NT >= 2) v1 = a[m][1][r] * sc[1] + sh[1];
+                    if (p.stats_partials && valid) {
+                        s_sum += (double)v0; s_sq += (double)v0 * (double)v0;
+                        if (NT >= 2) { s_sum += (double)v1; s_sq += (double)v1 * (double)v1; }
+                    }
+                    v0 = act_apply(v0, act0);
+                    if (NT >= 2) v1 = act_apply(v1, act0);
+                    if (NT == 1 && p.head_w) {
+                        // 1x1x1 head: reduce over the 16 channel lanes of this row group
+                        float hsum = v0 * hw;
+                        hsum += __shfl_xor(hsum, 1);
+                        hsum += __shfl_xor(hsum, 2);
+                        hsum += __shfl_xor(hsum, 4);
+                        hsum += __shfl_xor(hsum, 8);
+                        if (valid && i == 0) p.out_head[vox] = hsum + hb;
+                    }
+                    if (p.out_main && !(ESTD_ABL & 1)) {
+                        // bounds-checked buffer ops: lanes outside the volume carry OOB_OFFSET (loads give 0, stores drop)
+                        const unsigned eo = eoff[m][r];
+                        const int so = dd * out_plane_bytes;
+                        if (NT == 1) {
+                            if (p.residual) v0 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, eo, so, 0));
+                            v0 *= p.out_scale;
+                            if (p.accumulate) v0 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_out, eo, so, 0));
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_out, eo, so, 0);
+                        } else {
+                            if (p.residual) {
+                                const u32x2 rv = __builtin_amdgcn_raw_buffer_load_b64(rs_res, eo, so, 0);
+                                float2 rr; __builtin_memcpy(&rr, &rv, 8);
+                                v0 += rr.x; v1 += rr.y;
+                            }
+                            v0 *= p.out_scale; v1 *= p.out_scale;
+                            if (p.accumulate) {
+                                const u32x2 pv = __builtin_amdgcn_raw_buffer_load_b64(rs_out, eo, so, 0);
+                                float2 pr; __builtin_memcpy(&pr, &pv, 8);
+                                v0 += pr.x; v1 += pr.y;
+                            }
+                            const float2 ov = make_float2(v0, v1);
+                            u32x2 od; __builtin_memcpy(&od, &ov, 8);
+                            __builtin_amdgcn_raw_buffer_store_b64(od, rs_out, eo, so, 0);
+                        }
+                    }
+                    if (NT == 3) {
+                        if (valid && i == 0 && p.out_extra) {
+                            float v2 = a[m][2][r] * sc2 + sh2;
+                            p.out_extra[vox] = act_apply(v2, p.act_b);
+                        }
+                    }
+                }
+            }
+
+            if (p.stats_partials) {
+                // group 0 = channels 0..15, group 1 = channels 16..31.  Lane's channels: cbase(,+1).
+                const int grp = (cbase >= 16) ? 1 : 0;
+                double a0 = grp == 0 ? s_sum : 0.0, q0 = grp == 0 ? s_sq : 0.0;
+                double a1 = grp == 1 ? s_sum : 0.0, q1 = grp == 1 ? s_sq : 0.0;
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) {
+                    a0 += __shfl_xor(a0, o); q0 += __shfl_xor(q0, o);
+                    a1 += __shfl_xor(a1, o); q1 += __shfl_xor(q1, o);
+                }
+                // cross-wave reduction through a small LDS scratch placed after the ring
+                double* red = reinterpret_cast<double*>(smem + 3 * SLICE_BYTES + (EXTRA ? 3 * SL_VOX * 4 : 0));
+                if (lane == 0) { red[wave * 4 + 0] = a0; red[wave * 4 + 1] = q0; red[wave * 4 + 2] = a1; red[wave * 4 + 3] = q1; }
+                __syncthreads();
+                if (tid < 4) {
+                    const double tot = red[tid] + red[4 + tid] + red[8 + tid] + red[12 + tid];
+                    // partial index = canonical tile id (n, d, thi, twi) so the finalize order is launch-independent
+                    const size_t tile_id = (((size_t)n * D + dd) * tiles_h + thi) * tiles_w + twi;
+                    p.stats_partials[tile_id * 4 + tid] = tot;
+                }
+            }
+        };
+        f32x4 pend[MT][NT];
+        int pend_d = 0;
+        bool have_pend = false;
+
         float4 pf[SIT];
         float pfx = 0.f;
         bool first = true;
@@ -190,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
             const int sb2 = (dm == 0 ? 2 : dm - 1) * SLICE_BYTES;  // (dm+2)%3 : slot of slice d+1
             const int xb0 = dm * SL_VOX, xb1 = (dm == 2 ? 0 : dm + 1) * SL_VOX, xb2 = (dm == 0 ? 2 : dm - 1) * SL_VOX;
 
-            __syncthreads();                      // every wave is done with the previous tile's slices
+            lds_barrier();                        // every wave is done with the previous tile's slices
             if (first) {
                 // prime the ring: slices d-1 and d straight to LDS, slice d+1 into the prefetch registers
 #pragma unroll
@@ -224,10 +345,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
             // slice d+1 (prefetched during the previous tile) -> its ring slot
 #pragma unroll
             for (int it = 0; it < SIT; ++it)
-                if (it < SIT - 1 || loff[it] >= 0)
+                if ((it < SIT - 1 || loff[it] >= 0) && !(ESTD_ABL & 8))
                     *reinterpret_cast<float4*>(lds_main + sb2 + loff[it]) = pf[it];
             if (EXTRA && tid < SL_VOX) lds_extra[xb2 + tid] = pfx;
-            __syncthreads();
+            lds_barrier();
+            if (have_pend) epilogue(pend, pend_d);
 
             const bool has_next = (u + 1 < seg_end);            // wave-uniform
             const bool next_valid = (d + 2 < D);
@@ -250,10 +372,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
                 const int sb = kd == 0 ? sb0 : kd == 1 ? sb1 : sb2;
                 // next tap's weights (the packed buffer carries one padding tap)
 #pragma unroll
-                for (int q = 0; q < QN; ++q)
-                    bnext[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, ((tap + 1) * QN + q) * 1024, 0));
+                for (int q = 0; q < QN; ++q) {
+                    if (ESTD_ABL & 2) { bnext[q] = bcur[q]; asm volatile("" : "+v"(bnext[q].x)); }
+                    else bnext[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, ((tap + 1) * QN + q) * 1024, 0));
+                }
                 // one chunk of the NEXT tile's new slice per tap
-                if (has_next) {
+                if (has_next && !(ESTD_ABL & 8)) {
                     if (tap < SIT)
                         pf[tap] = next_valid ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[tap], next_soff, 0))
                                              : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -264,9 +388,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
                 for (int m = 0; m < MT; ++m) {
                     const int vs = (row0 + m + kh) * IN_W + kw + i;
                     const int off0 = sb + lds_chunk_off<CM>(vs, g);
-                    const float4 a0 = *reinterpret_cast<const float4*>(lds_main + off0);
+                    float4 a0 = bcur[0];
+                    if (!(ESTD_ABL & 4)) a0 = *reinterpret_cast<const float4*>(lds_main + off0);
                     float4 a1 = a0;
-                    if (CM == 32) a1 = *reinterpret_cast<const float4*>(lds_main + (off0 ^ 64));
+                    if (CM == 32 && !(ESTD_ABL & 4)) a1 = *reinterpret_cast<const float4*>(lds_main + (off0 ^ 64));
                     const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
@@ -310,88 +435,16 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
                 }
             }
 
-            // ---- epilogue ----
-            // D layout: lane holds column j = i (N index) and rows 4g..4g+3 (M index = voxel along W).
-            // channel of (tile nn, column j): NT==1 -> j ; NT>=2 -> 2j+nn for nn<2 ; nn==2 -> 32 (only j==0).
-            double s_sum = 0.0, s_sq = 0.0;     // GroupNorm partials of this lane (its channels are in one group)
-            const size_t plane = (size_t)n * vol + (size_t)d * HW;     // voxel index of (n, d, 0, 0)
+            // the epilogue of this tile (global stores) is issued after the NEXT tile's ring update, so the
+            // vmcnt(0) in front of that update never has to drain fresh stores
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int y = ey0 + m;
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int x = ex0 + r;
-                    const bool valid = (y < H) && (x < W);
-                    const size_t vox = plane + (size_t)y * W + x;
-                    float v0 = acc[m][0][r] * sc[0] + sh[0];
-                    float v1 = 0.f;
-                    if (NT >= 2) v1 = acc[m][1][r] * sc[1] + sh[1];
-                    if (p.stats_partials && valid) {
-                        s_sum += (double)v0; s_sq += (double)v0 * (double)v0;
-                        if (NT >= 2) { s_sum += (double)v1; s_sq += (double)v1 * (double)v1; }
-                    }
-                    v0 = act_apply(v0, act0);
-                    if (NT >= 2) v1 = act_apply(v1, act0);
-                    if (NT == 1 && p.head_w) {
-                        // 1x1x1 head: reduce over the 16 channel lanes of this row group
-                        float hsum = v0 * hw;
-                        hsum += __shfl_xor(hsum, 1);
-                        hsum += __shfl_xor(hsum, 2);
-                        hsum += __shfl_xor(hsum, 4);
-                        hsum += __shfl_xor(hsum, 8);
-                        if (valid && i == 0) p.out_head[vox] = hsum + hb;
-                    }
-                    if (p.out_main && valid && !(ESTD_ABL & 1)) {
-                        float* o = p.out_main + vox * p.out_stride + cbase;
-                        if (NT == 1) {
-                            if (p.residual) v0 += p.residual[vox * p.out_stride + cbase];
-                            v0 *= p.out_scale;
-                            if (p.accumulate) v0 += *o;
-                            *o = v0;
-                        } else {
-                            if (p.residual) {
-                                const float2 rr = *reinterpret_cast<const float2*>(p.residual + vox * p.out_stride + cbase);
-                                v0 += rr.x; v1 += rr.y;
-                            }
-                            v0 *= p.out_scale; v1 *= p.out_scale;
-                            if (p.accumulate) {
-                                const float2 pr = *reinterpret_cast<const float2*>(o);
-                                v0 += pr.x; v1 += pr.y;
-                            }
-                            *reinterpret_cast<float2*>(o) = make_float2(v0, v1);
-                        }
-                    }
-                    if (NT == 3) {
-                        if (valid && i == 0 && p.out_extra) {
-                            float v2 = acc[m][2][r] * sc2 + sh2;
-                            p.out_extra[vox] = act_apply(v2, p.act_b);
-                        }
-                    }
-                }
-            }
-
-            if (p.stats_partials) {
-                // group 0 = channels 0..15, group 1 = channels 16..31.  Lane's channels: cbase(,+1).
-                const int grp = (cbase >= 16) ? 1 : 0;
-                double a0 = grp == 0 ? s_sum : 0.0, q0 = grp == 0 ? s_sq : 0.0;
-                double a1 = grp == 1 ? s_sum : 0.0, q1 = grp == 1 ? s_sq : 0.0;
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) {
-                    a0 += __shfl_xor(a0, o); q0 += __shfl_xor(q0, o);
-                    a1 += __shfl_xor(a1, o); q1 += __shfl_xor(q1, o);
-                }
-                // cross-wave reduction through a small LDS scratch placed after the ring
-                double* red = reinterpret_cast<double*>(smem + 3 * SLICE_BYTES + (EXTRA ? 3 * SL_VOX * 4 : 0));
-                if (lane == 0) { red[wave * 4 + 0] = a0; red[wave * 4 + 1] = q0; red[wave * 4 + 2] = a1; red[wave * 4 + 3] = q1; }
-                __syncthreads();
-                if (tid < 4) {
-                    const double tot = red[tid] + red[4 + tid] + red[8 + tid] + red[12 + tid];
-                    // partial index = canonical tile id (n, d, thi, twi) so the finalize order is launch-independent
-                    const size_t tile_id = (((size_t)n * D + d) * tiles_h + thi) * tiles_w + twi;
-                    p.stats_partials[tile_id * 4 + tid] = tot;
-                }
-            }
+                for (int nn = 0; nn < NT; ++nn) pend[m][nn] = acc[m][nn];
+            pend_d = d;
+            have_pend = true;
         }
+        if (have_pend) epilogue(pend, pend_d);     // last tile of the segment
     }
 }
 
@@ -411,7 +464,9 @@ int launch(const estd_conv3d_desc& d, hipStream_t stream)
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3d_k3_kernel<CM, NT, EXTRA>), dim3(grid), dim3(256), lds, stream, d, tiles_w, tiles_h, total);
+    static int stagger = -1;
+    if (stagger < 0) { const char* e = getenv("ESTD_CONV_STAGGER"); stagger = e ? atoi(e) : 0; }
+    hipLaunchKernelGGL((conv3d_k3_kernel<CM, NT, EXTRA>), dim3(grid), dim3(256), lds, stream, d, tiles_w, tiles_h, total, stagger);
     return hipGetLastError() == hipSuccess ? ESTD_OK : ESTD_ERR_LAUNCH;
 }
 
@@ -439,6 +494,11 @@ extern "C" int estd_conv3d_k3(const estd_conv3d_desc* dp, estd_stream_t s)
     if (extra && !d.w_extra) return ESTD_ERR_ARG;
     if (d.n_tiles == 3 && !d.out_extra) return ESTD_ERR_ARG;
     if ((long long)d.N * d.D * ((d.H + TH - 1) / TH) * ((d.W + TW - 1) / TW) > 0x7fffffffLL) return ESTD_ERR_ARG;
+    {   // buffer descriptors address one volume of the batch with 32-bit byte offsets
+        const long long vox = (long long)d.D * d.H * d.W;
+        const int widest = d.in_stride > d.out_stride ? d.in_stride : d.out_stride;
+        if (vox * widest * 4 >= 0x7fffff00LL) return ESTD_ERR_UNSUPPORTED;
+    }
 
     if (d.cin_main == 32 && d.n_tiles == 2 && !extra) return launch<32, 2, false>(d, stream);
     if (d.cin_main == 32 && d.n_tiles == 2 && extra)  return launch<32, 2, true>(d, stream);

@@ -8,7 +8,7 @@ from estdepth_amd.layers_op import ConvBN3d
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-D, H, W = 64, 120, 160
+D = int(os.environ.get('CB_D', '64')); H = int(os.environ.get('CB_H', '120')); W = int(os.environ.get('CB_W', '160'))
 dev = torch.device("cuda:0")
 mod = ConvBN3d(32, 32, 3, 1, 1, "relu").eval()
 synth.fill_state_dict(mod, seed=1)
@@ -25,4 +25,5 @@ for _ in range(iters):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
-print("conv3d 32->32 N=%d: %.4f ms  %.1f TFLOP/s  (%.1f%% of 157.3)" % (N, ms, N * 67.95 / ms, N * 67.95 / ms / 157.3 * 100))
+gf = N * 2 * 27 * 32 * 32 * D * H * W / 1e9
+print("conv3d 32->32 N=%d D=%d: %.4f ms  %.1f TFLOP/s  (%.1f%% of 157.3)" % (N, D, ms, gf / ms, gf / ms / 157.3 * 100))
