@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--workload", default="joint", choices=["joint", "estm", "cfg1"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     return ap.parse_args()
 
 
@@ -143,9 +144,13 @@ def main():
             pre_costs, pre_poses, sl, frames = None, None, slice(0, 3), 1
     x_imgs, x_poses, x_sample = imgs[:, sl].contiguous(), poses[:, sl].contiguous(), sub(sl)
 
-    def step():
+    from estdepth_amd.graph import GraphedForward
+    fwd = model if args.no_graph else GraphedForward(model)     # hipGraph replay of the same forward (same kernels)
+
+    def step(f=None):
+        f = fwd if f is None else f
         with torch.no_grad():
-            out, costs, cposes = model(x_imgs, x_poses, intr, x_sample, pre_costs, list(pre_poses) if pre_poses else None, mode="val")
+            out, costs, cposes = f(x_imgs, x_poses, intr, x_sample, pre_costs, list(pre_poses) if pre_poses else None, mode="val")
             if world > 1 and not args.no_allgather:
                 parallel.allgather_memory_bank(costs, cposes)
         return out
@@ -158,7 +163,6 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ops.PROFILE = []                       # HIP-event pairs around the dominant kernel, on its launch stream
     ops.profile_mark(0)                    # estd_mark_kernel brackets the timed region in a rocprofv3 trace
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -166,6 +170,12 @@ def main():
     ops.profile_mark(1)
     barrier()
     elapsed = time.perf_counter() - t0
+    # Roofline of the dominant kernel: the same steps once more, launched eagerly, with a HIP-event pair around
+    # every launch of that kernel on its launch stream (events cannot bracket nodes inside a graph replay).
+    ops.PROFILE = []
+    for _ in range(args.steps):
+        step(model)
+    barrier()
     prof, ops.PROFILE = ops.PROFILE, None
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -187,6 +197,7 @@ def main():
                                     "cfg1": "cfg1: seq_len=3, 128x160, ndepths=16, ResNet-18, EST off"}[args.workload],
                        "depth_frames_per_step": frames, "input_frames_per_step": x_imgs.shape[1],
                        "input_frames_per_s": round(x_imgs.shape[1] * world * args.steps / elapsed, 3),
+                       "launch": "eager" if args.no_graph else "hipGraph replay",
                        "parallelism": "1 sequence per GPU" + ("; RCCL all-gather of {K,V,pose} per step" if world > 1 and not args.no_allgather else "")},
             "roofline": {"bound": "mfma", "kernel": "conv3d_k3_kernel<32,2> (3x3x3 conv 32->32, fp32 MFMA 16x16x4)",
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",

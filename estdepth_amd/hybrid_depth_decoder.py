@@ -196,7 +196,13 @@ class DepthHybridDecoder(nn.Module):
             raise RuntimeError("estdepth_amd runs one sequence per call (batch 1), like every reference script (SURVEY Q15)")
         dev = costvolumes[0].device
         P = self._plans()
-        x = torch.stack([self._as_vol32(cv) for cv in costvolumes], 0) if T > 1 else self._as_vol32(costvolumes[0]).unsqueeze(0)
+        vols = [self._as_vol32(cv) for cv in costvolumes]
+        step = D * H * W * 32 * 4
+        if all(v.data_ptr() == vols[0].data_ptr() + k * step for k, v in enumerate(vols)) and \
+                vols[0].untyped_storage().nbytes() - vols[0].storage_offset() * 4 >= T * step:
+            x = torch.as_strided(vols[0], (T, D, H, W, 32), (D * H * W * 32, H * W * 32, W * 32, 32, 1))   # already batched
+        else:
+            x = torch.stack(vols, 0)
         dims = (T, D, H, W)
         a = torch.empty_like(x)
         b = torch.empty_like(x)

@@ -51,22 +51,32 @@ class DepthNetHybrid(nn.Module):
                     "pre1": self.pre1.plan(), "pre2": self.pre2.plan()}
         return self._cache.get(self, build)
 
-    def _costvolume(self, ref_mix, src_mixes, ref_pose, src_poses, cam_intr, depth_values):
-        """Fused get_costvolume on pre-mixed 2D features (model_hybrid.py:76-99) -> [D,H,W,32]."""
+    def _costvolumes(self, ref_mixes, src_mix_pairs, ref_poses, src_pose_pairs, cam_intr, depth_values):
+        """Fused get_costvolume for T targets at once on pre-mixed 2D features (model_hybrid.py:76-99).
+        ref_mixes: T tensors [H,W,32]; src_mix_pairs: T lists of source mixes; returns [T,D,H,W,32].
+        The k-th sources of all targets share one batched convolution launch (N = T), and the running mean
+        over sources is the second launch's accumulate epilogue -- no race, same arithmetic as :97-99."""
         P = self._plans()
-        H, W, _ = ref_mix.shape
+        T = len(ref_mixes)
+        H, W, _ = ref_mixes[0].shape
         D = self.ndepths
-        dims = (1, D, H, W)
-        cost = torch.empty((D, H, W, 32), device=ref_mix.device, dtype=torch.float32)
+        dims = (T, D, H, W)
+        dev = ref_mixes[0].device
+        cost = torch.empty((T, D, H, W, 32), device=dev, dtype=torch.float32)
+        x = torch.empty_like(cost)
         y = torch.empty_like(cost)
-        n_src = len(src_mixes)
-        for k, (src_mix, src_pose) in enumerate(zip(src_mixes, src_poses)):
-            proj = ops.cam_sweep_proj(ref_pose, src_pose, cam_intr)                       # :74-88 + homo_utils.py:469
-            x = ops.homo_warp_costvol(src_mix, ref_mix, proj, depth_values, D)            # :90-94
-            P["pre1"].run(x, dims, out=y, out_stride=32)                                  # :95
+        n_src = len(src_mix_pairs[0])
+        for k in range(n_src):
+            for t in range(T):
+                proj = ops.cam_sweep_proj(ref_poses[t], src_pose_pairs[t][k], cam_intr)          # :74-88 + homo_utils.py:469
+                ops.homo_warp_costvol(src_mix_pairs[t][k], ref_mixes[t], proj, depth_values, D, out=x[t])   # :90-94
+            P["pre1"].run(x, dims, out=y, out_stride=32)                                          # :95
             P["pre2"].run(y, dims, out=cost, out_stride=32, residual=x,
-                          out_scale=1.0 / n_src, accumulate=(k > 0))                      # :95-99
+                          out_scale=1.0 / n_src, accumulate=(k > 0))                              # :95-99
         return cost
+
+    def _costvolume(self, ref_mix, src_mixes, ref_pose, src_poses, cam_intr, depth_values):
+        return self._costvolumes([ref_mix], [src_mixes], [ref_pose], [src_poses], cam_intr, depth_values)[0]
 
     def _mix(self, feature_chw, which):
         P = self._plans()
@@ -113,19 +123,22 @@ class DepthNetHybrid(nn.Module):
         semantic_features = self.semanticFeature(
             imgs[:, 1:1 + target_num].reshape(batch_size * target_num, -1, height_img, width_img))         # :138-139
         cam_intr_stage1 = self.scale_cam_intr(cam_intr, scale=1. / self.stage_infos["stage1"]["scale"])     # :142
-        depth_values = self.depth_cands.view(1, self.ndepths, 1, 1).to(imgs.dtype).to(imgs.device)          # :144-145
+        dkey = (imgs.device, imgs.dtype)
+        if getattr(self, "_dv_cache", None) is None or self._dv_cache[0] != dkey:      # one H2D copy, not one per call
+            self._dv_cache = (dkey, self.depth_cands.view(1, self.ndepths, 1, 1).to(imgs.dtype).to(imgs.device))
+        depth_values = self._dv_cache[1]                                                                     # :144-145
         dv = depth_values.reshape(-1).contiguous()
         intr = cam_intr_stage1[0].contiguous().float()
         poses = cam_poses[0].contiguous().float()
 
         # every view is a source for up to two targets: mix each 2D feature once (pre0 pushed in front of the warp)
         src_mix = [self._mix(matching[v].contiguous(), "src") for v in range(views_num)]
-        cost_volumes, target_cam_poses = [], []
-        for t in range(target_num):                                                                        # :152-164
-            ref_mix = self._mix(matching[t + 1].contiguous(), "ref")
-            cost = self._costvolume(ref_mix, [src_mix[t], src_mix[t + 2]], poses[t + 1], [poses[t], poses[t + 2]], intr, dv)
-            cost_volumes.append(cost.permute(3, 0, 1, 2).unsqueeze(0))
-            target_cam_poses.append(cam_poses[:, t + 1, :, :])
+        ref_mix = [self._mix(matching[t + 1].contiguous(), "ref") for t in range(target_num)]
+        costs = self._costvolumes(ref_mix, [[src_mix[t], src_mix[t + 2]] for t in range(target_num)],
+                                  [poses[t + 1] for t in range(target_num)],
+                                  [[poses[t], poses[t + 2]] for t in range(target_num)], intr, dv)      # :152-156
+        cost_volumes = [costs[t].permute(3, 0, 1, 2).unsqueeze(0) for t in range(target_num)]
+        target_cam_poses = [cam_poses[:, t + 1, :, :] for t in range(target_num)]                            # :161
 
         outputs, cur_costs, cur_cam_poses = self.CostRegNet(cost_volumes, semantic_features, target_cam_poses,
                                                             cam_intr_stage1, depth_values, self.depth_min,

@@ -84,9 +84,10 @@ def mix1x1(in_chw, w, bias):
     return out
 
 
-def homo_warp_costvol(src_mix, ref_mix, proj12, depth_values, D):
+def homo_warp_costvol(src_mix, ref_mix, proj12, depth_values, D, out=None):
     H, W, _ = src_mix.shape
-    out = torch.empty((D, H, W, 32), device=src_mix.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((D, H, W, 32), device=src_mix.device, dtype=torch.float32)
     N.check(N.lib().estd_homo_warp_costvol(_p(_chk(src_mix, "src_mix")), _p(_chk(ref_mix, "ref_mix")), _p(proj12),
                                            _p(_chk(depth_values, "depth_values")), _p(out), D, H, W, _stream()),
             "estd_homo_warp_costvol")

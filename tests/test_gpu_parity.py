@@ -305,3 +305,26 @@ def test_foreign_memory_tensors_are_repacked(golden_dir):
     # not bit-exact: the MIOpen 2D backbones are not run-to-run deterministic at the ulp level
     for k in a:
         assert (a[k] - b[k]).abs().max().item() < 2e-5, k
+
+
+def test_graph_replay_matches_eager():
+    """GraphedForward (hipGraph capture/replay) must return what the eager forward returns, across calls with
+    changing inputs and carried memory."""
+    from estdepth_amd.graph import GraphedForward
+    m = _stream_model()
+    gf = GraphedForward(m)
+    imgs, poses, intr, sample = S.e2e_inputs(6, S.E2E_HI, S.E2E_WI, seed=1003)
+    imgs, poses, intr = imgs.to(DEV), poses.to(DEV), intr.to(DEV)
+    smp = lambda sl: {k: v[:, sl].to(DEV) for k, v in sample.items()}
+    with torch.no_grad():
+        o0, c0, p0 = m(imgs[:, 0:3], poses[:, 0:3], intr, smp(slice(0, 3)), None, None, mode="val")
+        for w in (1, 2, 1):
+            sl = slice(w, w + 3)
+            pc = {"keys": [c0["keys"][0]], "values": [c0["values"][0]]}
+            e, ec, ep = m(imgs[:, sl], poses[:, sl], intr, smp(sl), pc, [p0[0]], mode="val")
+            e = {k: v.clone() for k, v in e.items()}
+            g, gc, gp = gf(imgs[:, sl], poses[:, sl], intr, smp(sl), pc, [p0[0]], mode="val")
+            for k in e:
+                assert (e[k] - g[k]).abs().max().item() < 2e-5, (w, k)
+            assert torch.equal(ep[0], gp[0])
+            assert (ec["values"][0] - gc["values"][0]).abs().max().item() < 2e-5
