@@ -187,6 +187,14 @@ def main():
         tot_ms = sum(s.elapsed_time(e) for (_, s, e) in prof)
         tot_flop = sum(f for (f, _, _) in prof)
         achieved = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE, see
+        # profiles/r1_conv3d_pmc.json), scaled to this run's average volumes per launch; null if the file is absent
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "r1_conv3d_pmc.json")
+        if os.path.exists(pmc_file) and prof and args.workload != "cfg1":
+            per_vol = json.load(open(pmc_file))["hbm_bytes_per_volume"]
+            vols = tot_flop / (2.0 * 27 * 32 * 32 * 64 * 120 * 160)
+            traffic = round(per_vol * vols / len(prof))
         line = {
             "metric": "depth frames/sec (seq_len=5, 480x640, D=64)" if args.workload == "joint" else "depth frames/sec",
             "value": round(value, 3), "unit": "depth frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -201,7 +209,8 @@ def main():
                        "parallelism": "1 sequence per GPU" + ("; RCCL all-gather of {K,V,pose} per step" if world > 1 and not args.no_allgather else "")},
             "roofline": {"bound": "mfma", "kernel": "conv3d_k3_kernel<32,2> (3x3x3 conv 32->32, fp32 MFMA 16x16x4)",
                          "achieved": round(achieved, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_conv3d_pmc.json)",
                          "launches": len(prof), "avg_launch_ms": round(tot_ms / max(len(prof), 1), 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
