@@ -20,7 +20,7 @@ class Conv3dDesc(ctypes.Structure):
         ("N", ctypes.c_int), ("D", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int),
         ("cin_main", ctypes.c_int), ("in_stride", ctypes.c_int), ("n_tiles", ctypes.c_int),
         ("in_main", ctypes.c_void_p), ("in_extra", ctypes.c_void_p),
-        ("w_main", ctypes.c_void_p), ("w_extra", ctypes.c_void_p),
+        ("w_main", ctypes.c_void_p), ("w_extra", ctypes.c_void_p), ("w_xout", ctypes.c_void_p),
         ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
         ("act_a", ctypes.c_int), ("act_b", ctypes.c_int), ("act_split", ctypes.c_int),
         ("out_main", ctypes.c_void_p), ("out_stride", ctypes.c_int), ("out_channels", ctypes.c_int),

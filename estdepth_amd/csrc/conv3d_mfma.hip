@@ -32,6 +32,11 @@
 #include "estd_hip.h"
 #include "estd_common.h"
 
+#ifdef ESTD_TIMELINE
+#define ESTD_STATS_ON 0
+#else
+#define ESTD_STATS_ON 1
+#endif
 #ifndef ESTD_ABL
 #define ESTD_ABL 0   // timing ablations only (tools/ablate_conv.sh); results are wrong when != 0
 #endif
@@ -95,7 +100,7 @@ constexpr int SL_VOX = IN_H * IN_W;     // 180 voxels per input slice (one depth
 //     each of the first taps), then written to the free ring slot between two barriers.
 //   * All global traffic uses wave-uniform buffer descriptors: per-lane 32-bit offsets are computed once per
 //     column segment, the per-tile part is a scalar offset, out-of-volume lanes read zeros / drop stores.
-template <int CM, int NT, bool EXTRA>
+template <int CM, int NT, bool EXTRA, bool XOUT>
 __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int total_tiles,
                                                            int stagger)
 {
@@ -128,12 +133,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
         u_end = (int)((long long)total_tiles * (r + 1) / G);
     }
     if (u >= u_end) return;
-    if (stagger > 0) {
-        const int mode = stagger >> 8, cnt = stagger & 255;
-        const bool sel = mode == 0 ? ((int)blockIdx.x >= (int)(gridDim.x >> 1)) : mode == 1 ? (((blockIdx.x >> 3) & 1) != 0)
-                                                                                             : (((blockIdx.x >> 4) & 1) != 0);
-        if (sel) for (int k = 0; k < cnt; ++k) __builtin_amdgcn_s_sleep(127);
-    }
+    (void)stagger;
 
     // per-lane constants of the epilogue
     const int cbase = (NT == 1) ? i : 2 * i;
@@ -143,11 +143,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
     if (NT >= 2) { sc[1] = p.scale[cbase + 1]; sh[1] = p.shift[cbase + 1]; }
     const int act0 = cbase < p.act_split ? p.act_a : p.act_b;   // both channels of a lane share the range (split is even)
     float sc2 = 0.f, sh2 = 0.f;
-    if (NT == 3) { sc2 = p.scale[32]; sh2 = p.shift[32]; }
+    if (XOUT) { sc2 = p.scale[32]; sh2 = p.shift[32]; }
     float hw = 0.f, hb = 0.f;
     if (NT == 1 && p.head_w) { hw = p.head_w[i]; hb = p.head_b[0]; }
 
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w_main, (size_t)28 * QN * 256);
+    // 33rd OUTPUT channel (dres2): a GEMV, 1/16 efficient on MFMA -> computed on the VALU in the MFMA shadow from the
+    // A fragments already in registers: w_xout = [28 taps][2 quads][64 lanes][4] + [2][64][4] extra-input taps
+    const __amdgpu_buffer_rsrc_t rs_wxo = make_rsrc(XOUT ? p.w_xout : p.w_main, (size_t)(28 * 2 + 2) * 256);
     const size_t vol = (size_t)D * H * W;
     const int HW = H * W;
     const int row0 = wave * MT;   // first tile row of this wave
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
             }
 
         // ---- epilogue of one finished tile (depth plane dd of this column) ----
-        auto epilogue = [&](const f32x4 (&a)[MT][NT], int dd) {
+        auto epilogue = [&](const f32x4 (&a)[MT][NT], const float (&ax)[MT], int dd) {
             // D layout: lane holds column j = i (N index) and rows 4g..4g+3 (M index = voxel along W).
             // channel of (tile nn, column j): NT==1 -> j ; NT>=2 -> 2j+nn for nn<2 ; nn==2 -> 32 (only j==0).
             double s_sum = 0.0, s_sq = 0.0;     // GroupNorm partials of this lane (its channels are in one group)
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
                     float v0 = a[m][0][r] * sc[0] + sh[0];
                     float v1 = 0.f;
                     if (NT >= 2) v1 = a[m][1][r] * sc[1] + sh[1];
-                    if (p.stats_partials && valid) {
+                    if (ESTD_STATS_ON && p.stats_partials && valid) {
                         s_sum += (double)v0; s_sq += (double)v0 * (double)v0;
                         if (NT >= 2) { s_sum += (double)v1; s_sq += (double)v1 * (double)v1; }
                     }
@@ -265,16 +268,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
                             __builtin_amdgcn_raw_buffer_store_b64(od, rs_out, eo, so, 0);
                         }
                     }
-                    if (NT == 3) {
-                        if (valid && i == 0 && p.out_extra) {
-                            float v2 = a[m][2][r] * sc2 + sh2;
-                            p.out_extra[vox] = act_apply(v2, p.act_b);
-                        }
-                    }
+                }
+                if (XOUT) {
+                    // ax[m] = channel 32 of voxel (row m, column i), identical in the four lane groups
+                    const int xx = tw0 + i;
+                    if (g == 0 && y < H && xx < W) p.out_extra[plane + (size_t)y * W + xx] = act_apply(ax[m] * sc2 + sh2, p.act_b);
                 }
             }
 
-            if (p.stats_partials) {
+            if (ESTD_STATS_ON && p.stats_partials) {
                 // group 0 = channels 0..15, group 1 = channels 16..31.  Lane's channels: cbase(,+1).
                 const int grp = (cbase >= 16) ? 1 : 0;
                 double a0 = grp == 0 ? s_sum : 0.0, q0 = grp == 0 ? s_sq : 0.0;
@@ -297,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
             }
         };
         f32x4 pend[MT][NT];
+        float pend_x[MT] = {};
         int pend_d = 0;
         bool have_pend = false;
 
@@ -349,9 +352,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
                     *reinterpret_cast<float4*>(lds_main + sb2 + loff[it]) = pf[it];
             if (EXTRA && tid < SL_VOX) lds_extra[xb2 + tid] = pfx;
             lds_barrier();
-            if (have_pend) epilogue(pend, pend_d);
+#ifdef ESTD_TIMELINE
+            if (tid == 0 && p.stats_partials) {     // debug build only: per-tile start stamps instead of GroupNorm sums
+                const size_t tile_id = (((size_t)n * D + d) * tiles_h + thi) * tiles_w + twi;
+                p.stats_partials[tile_id * 4 + 0] = (double)__builtin_amdgcn_s_memtime();
+                p.stats_partials[tile_id * 4 + 1] = (double)blockIdx.x;
+                p.stats_partials[tile_id * 4 + 2] = (double)wall_clock64();
+            }
+#endif
+            if (have_pend) epilogue(pend, pend_x, pend_d);
 
             const bool has_next = (u + 1 < seg_end);            // wave-uniform
+            // The XOUT variant is register-tight: make the lane ids opaque per tile so the 54 loop-invariant LDS offsets
+            // are recomputed in the MFMA shadow instead of being hoisted out of the tile loop (which spills).
+            int gi = g, ii = i;
+            if (XOUT) asm volatile("" : "+v"(gi), "+v"(ii));
             const bool next_valid = (d + 2 < D);
             const int next_soff = (d + 2) * in_slice_bytes;
 
@@ -363,6 +378,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
                 for (int nn = 0; nn < NT; ++nn) acc[m][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
             float4 bcur[QN], bnext[QN];
+            float4 xo_cur[2], xo_next[2];
+            float xacc[MT] = {};
+            if (XOUT) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) xo_cur[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_wxo, wlane, q * 1024, 0));
+            }
 #pragma unroll
             for (int q = 0; q < QN; ++q) bcur[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, q * 1024, 0));
 
@@ -376,6 +397,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
                     if (ESTD_ABL & 2) { bnext[q] = bcur[q]; asm volatile("" : "+v"(bnext[q].x)); }
                     else bnext[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, ((tap + 1) * QN + q) * 1024, 0));
                 }
+                if (XOUT) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        xo_next[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_wxo, wlane, ((tap + 1) * 2 + q) * 1024, 0));
+                }
                 // one chunk of the NEXT tile's new slice per tap
                 if (has_next && !(ESTD_ABL & 8)) {
                     if (tap < SIT)
@@ -386,13 +412,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
                 }
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    const int vs = (row0 + m + kh) * IN_W + kw + i;
-                    const int off0 = sb + lds_chunk_off<CM>(vs, g);
+                    const int vs = (row0 + m + kh) * IN_W + kw + ii;
+                    const int off0 = sb + lds_chunk_off<CM>(vs, gi);
                     float4 a0 = bcur[0];
                     if (!(ESTD_ABL & 4)) a0 = *reinterpret_cast<const float4*>(lds_main + off0);
                     float4 a1 = a0;
                     if (CM == 32 && !(ESTD_ABL & 4)) a1 = *reinterpret_cast<const float4*>(lds_main + (off0 ^ 64));
                     const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    if (XOUT) {
+                        const float wo[8] = {xo_cur[0].x, xo_cur[0].y, xo_cur[0].z, xo_cur[0].w, xo_cur[1].x, xo_cur[1].y, xo_cur[1].z, xo_cur[1].w};
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) xacc[m] = fmaf(av[ks], wo[ks], xacc[m]);
+                    }
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -406,12 +437,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
                 }
 #pragma unroll
                 for (int q = 0; q < QN; ++q) bcur[q] = bnext[q];
+                if (XOUT) { xo_cur[0] = xo_next[0]; xo_cur[1] = xo_next[1]; }
                 __builtin_amdgcn_sched_barrier(0);   // keep each tap's loads inside the tap (bounds live registers)
             }
 
             // ---- extra scalar input channel: its 27 taps form one more K chunk (28 = 7 x 4) ----
             if (EXTRA) {
                 const __amdgpu_buffer_rsrc_t rs_wx = make_rsrc(p.w_extra, (size_t)XQ * 256);
+                float4 wxx[2];
+                if (XOUT) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) wxx[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_wxo, wlane, (28 * 2 + q) * 1024, 0));
+                }
                 float4 bx[XQ];
 #pragma unroll
                 for (int q = 0; q < XQ; ++q) bx[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_wx, wlane, q * 1024, 0));
@@ -424,6 +461,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         const float a = lds_extra[xb + (row0 + m + kh) * IN_W + kw + i];
+                        if (XOUT) {
+                            const float4 wq4 = wxx[s >> 2];
+                            const float wv = (s & 3) == 0 ? wq4.x : (s & 3) == 1 ? wq4.y : (s & 3) == 2 ? wq4.z : wq4.w;
+                            xacc[m] = fmaf(a, wv, xacc[m]);
+                        }
 #pragma unroll
                         for (int nn = 0; nn < NT; ++nn) {
                             const int idx = s * NT + nn;
@@ -441,16 +483,25 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int nn = 0; nn < NT; ++nn) pend[m][nn] = acc[m][nn];
+            if (XOUT) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    float v = xacc[m];                    // sum the four lane groups (4 x 8 channels of the same voxel)
+                    v += __shfl_xor(v, 16);
+                    v += __shfl_xor(v, 32);
+                    pend_x[m] = v;
+                }
+            }
             pend_d = d;
             have_pend = true;
         }
-        if (have_pend) epilogue(pend, pend_d);     // last tile of the segment
+        if (have_pend) epilogue(pend, pend_x, pend_d);     // last tile of the segment
     }
 }
 
 constexpr int PERSISTENT_WGS = 512;     // 256 CUs x 2 resident workgroups (LDS-limited)
 
-template <int CM, int NT, bool EXTRA>
+template <int CM, int NT, bool EXTRA, bool XOUT>
 int launch(const estd_conv3d_desc& d, hipStream_t stream)
 {
     const int tiles_w = (d.W + TW - 1) / TW, tiles_h = (d.H + TH - 1) / TH;
@@ -460,13 +511,13 @@ int launch(const estd_conv3d_desc& d, hipStream_t stream)
     const size_t lds = (size_t)3 * SL_VOX * CM * 4 + (EXTRA ? 3 * SL_VOX * 4 : 0) + 128;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_kernel<CM, NT, EXTRA>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_kernel<CM, NT, EXTRA, XOUT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     static int stagger = -1;
     if (stagger < 0) { const char* e = getenv("ESTD_CONV_STAGGER"); stagger = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL((conv3d_k3_kernel<CM, NT, EXTRA>), dim3(grid), dim3(256), lds, stream, d, tiles_w, tiles_h, total, stagger);
+    hipLaunchKernelGGL((conv3d_k3_kernel<CM, NT, EXTRA, XOUT>), dim3(grid), dim3(256), lds, stream, d, tiles_w, tiles_h, total, stagger);
     return hipGetLastError() == hipSuccess ? ESTD_OK : ESTD_ERR_LAUNCH;
 }
 
@@ -492,7 +543,7 @@ extern "C" int estd_conv3d_k3(const estd_conv3d_desc* dp, estd_stream_t s)
     if (d.head_w && (d.n_tiles != 1 || !d.head_b || !d.out_head)) return ESTD_ERR_ARG;
     const bool extra = d.in_extra != nullptr;
     if (extra && !d.w_extra) return ESTD_ERR_ARG;
-    if (d.n_tiles == 3 && !d.out_extra) return ESTD_ERR_ARG;
+    if (d.n_tiles == 3 && (!d.out_extra || !d.w_xout)) return ESTD_ERR_ARG;
     if ((long long)d.N * d.D * ((d.H + TH - 1) / TH) * ((d.W + TW - 1) / TW) > 0x7fffffffLL) return ESTD_ERR_ARG;
     {   // buffer descriptors address one volume of the batch with 32-bit byte offsets
         const long long vox = (long long)d.D * d.H * d.W;
@@ -500,10 +551,10 @@ extern "C" int estd_conv3d_k3(const estd_conv3d_desc* dp, estd_stream_t s)
         if (vox * widest * 4 >= 0x7fffff00LL) return ESTD_ERR_UNSUPPORTED;
     }
 
-    if (d.cin_main == 32 && d.n_tiles == 2 && !extra) return launch<32, 2, false>(d, stream);
-    if (d.cin_main == 32 && d.n_tiles == 2 && extra)  return launch<32, 2, true>(d, stream);
-    if (d.cin_main == 32 && d.n_tiles == 3 && extra)  return launch<32, 3, true>(d, stream);
-    if (d.cin_main == 32 && d.n_tiles == 1 && !extra) return launch<32, 1, false>(d, stream);
-    if (d.cin_main == 16 && d.n_tiles == 1 && !extra) return launch<16, 1, false>(d, stream);
+    if (d.cin_main == 32 && d.n_tiles == 2 && !extra) return launch<32, 2, false, false>(d, stream);
+    if (d.cin_main == 32 && d.n_tiles == 2 && extra)  return launch<32, 2, true, false>(d, stream);
+    if (d.cin_main == 32 && d.n_tiles == 3 && extra)  return launch<32, 2, true, true>(d, stream);
+    if (d.cin_main == 32 && d.n_tiles == 1 && !extra) return launch<32, 1, false, false>(d, stream);
+    if (d.cin_main == 16 && d.n_tiles == 1 && !extra) return launch<16, 1, false, false>(d, stream);
     return ESTD_ERR_UNSUPPORTED;
 }

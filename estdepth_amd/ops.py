@@ -101,6 +101,7 @@ class Conv3dPlan:
     def __init__(self, weight, main_idx, extra_idx, out_idx, n_tiles, scale, shift, act_a="none", act_b=None,
                  act_split=0, head_w=None, head_b=None, device="cuda"):
         wm, wx = packing.pack_conv3d(weight, main_idx, extra_idx, out_idx, n_tiles)
+        self.w_xout = packing.pack_xout(weight, main_idx, extra_idx, out_idx[32]).to(device) if n_tiles == 3 else None
         self.cin_main = len(main_idx)
         self.n_tiles = n_tiles
         self.n_out = len(out_idx)
@@ -127,6 +128,7 @@ class Conv3dPlan:
         d.in_extra = in_extra.data_ptr() if in_extra is not None else None
         d.w_main = self.w_main.data_ptr()
         d.w_extra = self.w_extra.data_ptr() if self.w_extra is not None else None
+        d.w_xout = self.w_xout.data_ptr() if self.w_xout is not None else None
         if (in_extra is None) != (self.w_extra is None):
             raise RuntimeError("conv3d plan/extra-channel mismatch")
         d.scale = self.scale.data_ptr()

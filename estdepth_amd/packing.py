@@ -9,7 +9,7 @@ Fragment order (v_mfma_f32_16x16x4_f32: lane l -> k group g = l >> 4, column j =
     (so a lane fetches its 8 A operands of a tap with two 16-byte LDS reads)
   * output channel position of (N tile n, column j):
         n_tiles = 1:  pos = j
-        n_tiles >= 2: pos = 2j + n for n < 2 ;  n == 2: pos = 32 for j == 0, unused otherwise
+        n_tiles == 2: pos = 2j + n   (n_tiles == 3 = these 32 channels + channel 32 on the VALU, pack_xout)
     (a lane owns two adjacent channels -> 8-byte epilogue stores that tile whole voxel records)
   * main buffer  : float32 [28 taps][QN][64 lanes][4]   QN = (CM/4)*n_tiles/4, flat index
                    idx = t*n_tiles + n -> (quad idx//4, element idx%4); tap 27 is zero padding that the
@@ -35,10 +35,32 @@ def _pos(n_tiles, n, j):
     return 32 if j == 0 else -1
 
 
+def pack_xout(weight, main_idx, extra_idx, out_channel):
+    """33rd output channel (n_tiles == 3): evaluated on the VALU from the A fragments, so its weights are packed in
+    A order: [28 taps][2 quads][64 lanes][4] with element t of lane group g = w[out_channel][ch(g,t)][tap], followed by
+    [2][64][4] = the extra input channel's taps 4s+g (s = 0..6)."""
+    w = weight.detach().float().cpu().numpy().reshape(weight.shape[0], weight.shape[1], 27)
+    out = np.zeros((28 * 2 + 2, 64, 4), np.float32)
+    for lane in range(64):
+        g = lane >> 4
+        for t in range(8):
+            out[np.arange(27) * 2 + t // 4, lane, t % 4] = w[out_channel, main_idx[_ch(32, g, t)], :]
+        if extra_idx is not None:
+            for s_ in range(7):
+                tap = 4 * s_ + g
+                if tap <= 26:
+                    out[56 + s_ // 4, lane, s_ % 4] = w[out_channel, extra_idx, tap]
+    return torch.from_numpy(out)
+
+
 def pack_conv3d(weight, main_idx, extra_idx, out_idx, n_tiles):
     """weight: [Cout, Cin, 3,3,3] tensor.  main_idx: list of 16/32 input-channel indices (order = main
     channel order in memory).  extra_idx: index of the scalar input channel or None.
-    out_idx: original output channel for each output position.  Returns (w_main, w_extra|None) float32 CPU."""
+    out_idx: original output channel for each output position.  Returns (w_main, w_extra|None) float32 CPU.
+    n_tiles == 3 (32 + one channel) packs the MFMA part with 2 tiles; the 33rd channel goes through pack_xout."""
+    if n_tiles == 3:
+        n_tiles = 2
+        out_idx = list(out_idx)[:32]
     w = weight.detach().float().cpu().numpy().reshape(weight.shape[0], weight.shape[1], 27)
     cm = len(main_idx)
     assert cm in (16, 32)

@@ -83,11 +83,12 @@ typedef struct estd_conv3d_desc {
     int N, D, H, W;
     int cin_main;             /* 16 or 32 channels read from in_main */
     int in_stride;            /* floats between consecutive voxels of in_main (>= cin_main) */
-    int n_tiles;              /* output 16-channel tiles: 1, 2 or 3 (3 = 32 + one extra channel) */
+    int n_tiles;              /* output 16-channel tiles: 1 or 2; 3 = 32 channels on MFMA + a 33rd channel on the VALU */
     const float* in_main;     /* [N][D][H][W][in_stride] */
     const float* in_extra;    /* [N][D][H][W] scalar input channel, or NULL */
     const float* w_main;      /* packed, see packing.py */
     const float* w_extra;     /* packed extra-channel taps, or NULL */
+    const float* w_xout;      /* n_tiles == 3 only: output channel 32 in A-fragment order (packing.py), else NULL */
     const float* scale;       /* [n_out] folded BN scale per output channel (n_out = 16, 32 or 33) */
     const float* shift;       /* [n_out] folded BN shift / conv bias */
     int act_a, act_b, act_split;  /* channels < act_split use act_a, others act_b */
