@@ -20,7 +20,7 @@
 namespace {
 
 struct Tri {
-    long long off[8];   // voxel offsets ((z*H+y)*W+x), 0 when masked
+    int off[8];         // voxel offsets ((z*H+y)*W+x), 0 when masked (volumes are < 2^31 voxels)
     float w[8];         // trilinear weights, 0 when the corner is out of bounds
 };
 
@@ -62,7 +62,7 @@ __device__ __forceinline__ Tri volume_coords(const float* __restrict__ M, float 
         const bool ok = xx >= 0 && xx < W && yy >= 0 && yy < H && zz >= 0 && zz < D;
         const float wgt = (dx ? tx : 1.0f - tx) * (dy ? ty : 1.0f - ty) * (dz ? tz : 1.0f - tz);
         t.w[k] = ok ? wgt : 0.0f;
-        t.off[k] = ok ? ((long long)zz * H + yy) * W + xx : 0;
+        t.off[k] = ok ? (zz * H + yy) * W + xx : 0;
     }
     return t;
 }
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void warp_volume_kernel(const float* __restric
             const float* s = vol + (long long)c * S;
             float v = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v += s[t.off[k]] * t.w[k];
+            for (int k = 0; k < 8; ++k) v += s[(long long)t.off[k]] * t.w[k];
             out[(long long)c * S + idx] = v;
         }
     }
@@ -94,11 +94,14 @@ struct WarpAttnArgs {
     const float* kv_src[8];
 };
 
+template <int NS>
 __global__ __launch_bounds__(256) void warp_attention_kernel(const float* __restrict__ kv_t, WarpAttnArgs srcs,
                                                              const float* __restrict__ mats, int n_src,
                                                              const float* __restrict__ dvals, float depth_min, float depth_interval,
                                                              float* __restrict__ xh, int D, int H, int W)
 {
+    // NS = compile-time source count (1..4) or 8 = generic loop bounded by n_src: registers follow the real count,
+    // which keeps occupancy up for this gather-latency-bound kernel.
     const long long HW = (long long)H * W, S = (long long)D * HW;
     const int sub = threadIdx.x & 3;
     const long long idx = (long long)blockIdx.x * 64 + (threadIdx.x >> 2);
@@ -112,21 +115,27 @@ __global__ __launch_bounds__(256) void warp_attention_kernel(const float* __rest
     const float4 vt = t4[sub];        // target value chunk
     const float4 kt = t4[4 + sub];    // target key chunk
 
-    float corr[8];
-    float4 wv[8];
+    float corr[NS];
+    float4 wv[NS];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        if (j < n_src) {
+    for (int j = 0; j < NS; ++j) {
+        corr[j] = -INFINITY;
+        wv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (NS < 8 || j < n_src) {
             const Tri t = volume_coords(mats + j * 30, dep, x, y, depth_min, depth_interval, D, H, W);
-            const float4* s4 = reinterpret_cast<const float4*>(srcs.kv_src[j]);
+            const float4* s4 = reinterpret_cast<const float4*>(srcs.kv_src[j]) + sub;
+            float4 cv[8], ck[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {          // issue all 16 gathers of this source before using any
+                cv[k] = s4[(long long)t.off[k] * 8];
+                ck[k] = s4[(long long)t.off[k] * 8 + 4];
+            }
             float4 av = make_float4(0.f, 0.f, 0.f, 0.f), ak = av;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float4 v = s4[t.off[k] * 8 + sub];
-                const float4 kk = s4[t.off[k] * 8 + 4 + sub];
                 const float w = t.w[k];
-                av.x += v.x * w; av.y += v.y * w; av.z += v.z * w; av.w += v.w * w;
-                ak.x += kk.x * w; ak.y += kk.y * w; ak.z += kk.z * w; ak.w += kk.w * w;
+                av.x += cv[k].x * w; av.y += cv[k].y * w; av.z += cv[k].z * w; av.w += cv[k].w * w;
+                ak.x += ck[k].x * w; ak.y += ck[k].y * w; ak.z += ck[k].z * w; ak.w += ck[k].w * w;
             }
             float c = kt.x * ak.x + kt.y * ak.y + kt.z * ak.z + kt.w * ak.w;   // epipolar_transformer.py:65
             c += __shfl_xor(c, 1);
@@ -135,16 +144,16 @@ __global__ __launch_bounds__(256) void warp_attention_kernel(const float* __rest
             wv[j] = av;
         }
     }
-    // softmax over views (:69) and mean of the weighted values (:73)
-    float mx = -INFINITY;
+    // softmax over views (:69) and mean of the weighted values (:73); unused generic slots hold -inf -> weight 0
+    float mx = corr[0];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) if (j < n_src) mx = fmaxf(mx, corr[j]);
+    for (int j = 1; j < NS; ++j) mx = fmaxf(mx, corr[j]);
     float den = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) if (j < n_src) { corr[j] = expf(corr[j] - mx); den += corr[j]; }
+    for (int j = 0; j < NS; ++j) { corr[j] = expf(corr[j] - mx); den += corr[j]; }
     float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) if (j < n_src) {
+    for (int j = 0; j < NS; ++j) {
         const float a = corr[j] / den;
         h.x += wv[j].x * a; h.y += wv[j].y * a; h.z += wv[j].z * a; h.w += wv[j].w * a;
     }
@@ -384,8 +393,17 @@ extern "C" int estd_warp_attention(const float* kv_target, const float* const* k
     for (int j = 0; j < 8; ++j) a.kv_src[j] = j < n_src ? kv_src[j] : kv_src[0];
     for (int j = 0; j < n_src; ++j) if (!kv_src[j]) return ESTD_ERR_ARG;
     const long long S = (long long)D * H * W;
-    hipLaunchKernelGGL(warp_attention_kernel, dim3((unsigned)((S + 63) / 64)), dim3(256), 0, estd_stream(s),
-                       kv_target, a, mats_dev, n_src, dvals, depth_min, depth_interval, xh_out, D, H, W);
+    const dim3 grid((unsigned)((S + 63) / 64));
+#define ESTD_WA_LAUNCH(NS) hipLaunchKernelGGL(warp_attention_kernel<NS>, grid, dim3(256), 0, estd_stream(s), kv_target, a, \
+                                              mats_dev, n_src, dvals, depth_min, depth_interval, xh_out, D, H, W)
+    switch (n_src) {
+        case 1: ESTD_WA_LAUNCH(8); break;     /* measured: the generic body (132 VGPRs) beats the 1-source specialisation */
+        case 2: ESTD_WA_LAUNCH(2); break;
+        case 3: ESTD_WA_LAUNCH(3); break;
+        case 4: ESTD_WA_LAUNCH(4); break;
+        default: ESTD_WA_LAUNCH(8); break;
+    }
+#undef ESTD_WA_LAUNCH
     return ESTD_LAUNCH_CHECK();
 }
 
