@@ -45,7 +45,10 @@ def build_model(workload, device):
     else:
         m = DepthNetHybrid(ndepths=64, depth_min=0.1, depth_max=10.0, resnet=50, IF_EST_transformer=True)
     synth.fill_state_dict(m, seed=0, head_gain=1.0)
-    return m.eval().to(device)
+    m = m.eval().to(device)
+    if str(device) != "cpu" and os.environ.get("ESTD_NCHW_2D", "0") != "1":
+        m.use_channels_last_2d()
+    return m
 
 
 def make_inputs(workload, rank, device):

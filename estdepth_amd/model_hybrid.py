@@ -105,6 +105,18 @@ class DepthNetHybrid(nn.Module):
         cam_intr_new[:, :2, :] *= scale
         return cam_intr_new
 
+    def use_channels_last_2d(self, enable=True):
+        """Opt-in: run the 2D backbones (PSM, ResNet, 2D decoder -- MIOpen, outside the hot path) in NHWC.
+        ~1.4 ms/step faster at cfg2; feature differences vs NCHW are ~1e-5 (different MIOpen solvers)."""
+        self._channels_last_2d = bool(enable)
+        fmt = torch.channels_last if enable else torch.contiguous_format
+        for mod in (self.matchingFeature, self.semanticFeature):
+            mod.to(memory_format=fmt)
+        for name, child in self.CostRegNet.named_children():
+            if name.startswith("upconv") or name.startswith("dispconv"):
+                child.to(memory_format=fmt)
+        return self
+
     def forward(self, imgs, cam_poses, cam_intr, sample, pre_costs=None, pre_cam_poses=None, mode='train'):
         """model_hybrid.py:110-184.  imgs [1,V,3,Hi,Wi] in 0..255; cam_poses [1,V,4,4] camera-to-world;
         cam_intr [1,3,3] full-resolution pixels; returns (outputs, cur_costs, cur_cam_poses) for
@@ -119,9 +131,11 @@ class DepthNetHybrid(nn.Module):
             raise RuntimeError("estdepth_amd runs one sequence per call (the reference's view() also fails for batch > 1)")
         target_num = views_num - 2
 
-        matching = self.matchingFeature(imgs.reshape(batch_size * views_num, 3, height_img, width_img))      # :128
-        semantic_features = self.semanticFeature(
-            imgs[:, 1:1 + target_num].reshape(batch_size * target_num, -1, height_img, width_img))         # :138-139
+        flat = imgs.reshape(batch_size * views_num, 3, height_img, width_img)
+        if getattr(self, "_channels_last_2d", False):
+            flat = flat.contiguous(memory_format=torch.channels_last)      # MIOpen NHWC kernels for the 2D backbones
+        matching = self.matchingFeature(flat)                                                               # :128
+        semantic_features = self.semanticFeature(flat[1:1 + target_num])                                   # :138-139 (batch 1)
         cam_intr_stage1 = self.scale_cam_intr(cam_intr, scale=1. / self.stage_infos["stage1"]["scale"])     # :142
         dkey = (imgs.device, imgs.dtype)
         if getattr(self, "_dv_cache", None) is None or self._dv_cache[0] != dkey:      # one H2D copy, not one per call

@@ -328,3 +328,21 @@ def test_graph_replay_matches_eager():
                 assert (e[k] - g[k]).abs().max().item() < 2e-5, (w, k)
             assert torch.equal(ep[0], gp[0])
             assert (ec["values"][0] - gc["values"][0]).abs().max().item() < 2e-5
+
+
+def test_channels_last_2d_backbones_keep_parity(golden_dir):
+    """use_channels_last_2d() only changes the MIOpen layout of the 2D backbones: golden parity must hold."""
+    g = _g(golden_dir, "g8_estm_stream.npz")
+    m = _stream_model().use_channels_last_2d()
+    imgs, poses, intr, sample = S.e2e_inputs(6, S.E2E_HI, S.E2E_WI, seed=1003)
+    imgs, poses, intr = imgs.to(DEV), poses.to(DEV), intr.to(DEV)
+    mem_costs, mem_poses = [], []
+    for w in range(3):
+        sl = slice(w, w + 3)
+        pc = {"keys": [c["keys"][0] for c in mem_costs], "values": [c["values"][0] for c in mem_costs]} if mem_costs else None
+        pp = [p[0] for p in mem_poses] if mem_poses else None
+        with torch.no_grad():
+            outputs, costs, cposes = m(imgs[:, sl], poses[:, sl], intr, {k: v[:, sl] for k, v in sample.items()}, pc, pp, mode="val")
+        mem_costs.append(costs); mem_poses.append(cposes)
+        mem_costs, mem_poses = mem_costs[-2:], mem_poses[-2:]
+        _cmp_outputs(outputs, g, prefix="w%d|" % w)
