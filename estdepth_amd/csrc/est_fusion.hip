@@ -29,6 +29,9 @@ struct Tri {
 __device__ __forceinline__ Tri volume_coords(const float* __restrict__ M, float dep, int x, int y,
                                              float depth_min, float depth_interval, int D, int H, int W)
 {
+    // no FMA contraction: separate rounded ops like the reference's ATen composition, and bit-identical coordinates in
+    // every kernel that inlines this function (the masks and floor() are discontinuous)
+#pragma clang fp contract(off)
     const float fx = (float)x, fy = (float)y;
     const float c0 = (M[0] * fx + M[1] * fy + M[2]) * dep;
     const float c1 = (M[3] * fx + M[4] * fy + M[5]) * dep;

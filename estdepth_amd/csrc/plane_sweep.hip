@@ -131,6 +131,9 @@ struct Bilin {
 // homo_utils.py:479-501 for one (x, y, depth plane)
 __device__ __forceinline__ Bilin sweep_coords(const float* __restrict__ P, float dv, int x, int y, int H, int W)
 {
+    // no FMA contraction: the reference evaluates these as separate rounded ATen ops, and every kernel that inlines this
+    // function must produce bit-identical coordinates (the |norm| > 1 mask and floor() are discontinuous)
+#pragma clang fp contract(off)
     const float fx = (float)x, fy = (float)y;
     const float r0 = P[0] * fx + P[1] * fy + P[2];
     const float r1 = P[3] * fx + P[4] * fy + P[5];

@@ -1,0 +1,178 @@
+"""GPU edge cases: ragged volume sizes (H % 8, W % 16 != 0, tiny D), every conv3d template variant, the fused
+warp+attention for 1..5 sources, argument validation through the C ABI, and full-size properties at BASELINE
+configs[2]/[4] sizes that the oracle cannot run in seconds."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import sd_numpy
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a ROCm device")
+    from estdepth_amd import _native
+    _native.lib()
+    yield
+
+
+def _t(seed, *shape, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+@pytest.mark.parametrize("dims", [(1, 1, 3, 5), (2, 2, 7, 15), (1, 3, 9, 17), (3, 4, 8, 16), (1, 5, 13, 21)])
+def test_conv3d_ragged_sizes(dims):
+    from estdepth_amd import synth
+    from estdepth_amd.layers_op import ConvBN3d
+    from oracle import ref_model as M
+    N, D, H, W = dims
+    mod = ConvBN3d(32, 32, 3, 1, 1, "relu").eval()
+    synth.fill_state_dict(mod, seed=9)
+    x = _t(sum(dims), N, 32, D, H, W)
+    ref = M.convbn3d({"m." + k: v for k, v in sd_numpy(mod).items()}, "m", x.numpy(), "relu")
+    out = mod.to(DEV)(x.to(DEV)).cpu().numpy()
+    assert np.abs(out - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("T,D,H,W", [(2, 5, 13, 21), (1, 3, 8, 16), (3, 2, 9, 33)])
+def test_regulariser_variants_ragged(T, D, H, W):
+    """dres0/1 (32->32), dres2 (33->33: extra input + VALU 33rd output), fused key|value (33->32, tanh|relu split),
+    stereo_head0 (16->16 + 1x1x1 head) against the oracle on ragged sizes."""
+    from estdepth_amd import synth, DepthHybridDecoder
+    from oracle import ref_model as M
+    dec = DepthHybridDecoder(np.array([64, 64, 128, 256, 512]), ndepths=D, depth_max=10.0).eval()
+    synth.fill_state_dict(dec, seed=12)
+    P = {"C." + k: v for k, v in sd_numpy(dec).items()}
+    cvs = [_t(100 + t, 1, 32, D, H, W, scale=0.7) for t in range(T)]
+    sem = torch.relu(_t(7, T, D, H, W))
+    # oracle
+    cv = np.stack([c.numpy() for c in cvs], 1).reshape(T, 32, D, H, W)
+    m = M.convbn3d(P, "C.dres0.1", M.convbn3d(P, "C.dres0.0", cv, "relu"), "relu")
+    m = M.convbn3d(P, "C.dres1.1", M.convbn3d(P, "C.dres1.0", m, "relu"), "relu")
+    x = M.convbn3d(P, "C.dres2.0", np.concatenate([sem.numpy()[:, None], m], 1), "relu")
+    value = M.convbn3d(P, "C.value_layer.0", x, "tanh")
+    key = M.convbn3d(P, "C.key_layer.0", x, "relu")
+    logits = M._head(P, "C.stereo_head0", value)
+    # HIP
+    dec = dec.to(DEV)
+    dv = torch.linspace(0.1, 10.0, D).view(1, D, 1, 1).to(DEV)
+    with torch.no_grad():
+        kv, init_logits, d3, p3, _ = dec._regularise([c.to(DEV) for c in cvs], sem.to(DEV), dv)
+    kvn = kv.cpu().numpy()                                  # [T,D,H,W,32] = [V | K]
+    assert np.abs(np.moveaxis(kvn[..., :16], -1, 1) - value).max() < 5e-5
+    assert np.abs(np.moveaxis(kvn[..., 16:], -1, 1) - key).max() < 5e-5
+    assert np.abs(init_logits.cpu().numpy() - logits).max() < 2e-4 * max(1.0, np.abs(logits).max())
+    assert tuple(d3.shape) == (T, 1, 4 * H, 4 * W)
+
+
+@pytest.mark.parametrize("n_src", [1, 2, 3, 4, 5])
+def test_warp_attention_vs_oracle(n_src):
+    from estdepth_amd import synth, ops
+    from oracle import ref_ops as O
+    D, H, W = 6, 11, 19
+    K = synth.intrinsics(H * 4, W * 4).copy()
+    K[:2] *= 0.25
+    dv = np.linspace(0.5, 4.0, D).astype(np.float32)
+    dint = float(dv[1] - dv[0])
+    kv_t = _t(1, D, H, W, 32)
+    kvs = [_t(2 + j, D, H, W, 32) for j in range(n_src)]
+    pose_t = synth.camera_pose(0)
+    poses = [synth.camera_pose(j + 1, motion=0.7) for j in range(n_src)]
+    # oracle: warp_volume of K and V of every source, then attention
+    depth = np.broadcast_to(dv.reshape(1, 1, D, 1), (1, 1, D, H * W))
+    to_c = lambda kv, sl: np.ascontiguousarray(np.moveaxis(kv.numpy()[..., sl], -1, 0))[None]
+    wk, wv = [], []
+    for j in range(n_src):
+        rel = (poses[j] @ O.inv(pose_t)).astype(np.float32)[None]
+        wv.append(O.warp_volume(to_c(kvs[j], slice(0, 16)), depth, rel, K[None], None, 0.5, dint))
+        wk.append(O.warp_volume(to_c(kvs[j], slice(16, 32)), depth, rel, K[None], None, 0.5, dint))
+    h_ref = O.epipolar_attention(to_c(kv_t, slice(16, 32)), wk, wv)[0]          # [16,D,H,W]
+    # HIP
+    Kd = torch.from_numpy(K).to(DEV)
+    mats = torch.stack([ops.cam_volume_mats(torch.from_numpy(poses[j]).to(DEV), torch.from_numpy(pose_t).to(DEV), Kd)
+                        for j in range(n_src)])
+    xh = ops.warp_attention(kv_t.to(DEV), [k.to(DEV) for k in kvs], mats, torch.from_numpy(dv).to(DEV), 0.5, dint).cpu().numpy()
+    assert np.array_equal(xh[..., :16], kv_t.numpy()[..., :16])                 # x = target value, copied through
+    d = np.abs(np.moveaxis(xh[..., 16:], -1, 0) - h_ref)
+    assert (d > 1e-4).mean() < 2e-3 and np.median(d) < 5e-6, (float(d.max()), float((d > 1e-4).mean()))
+
+
+def test_abi_rejects_bad_arguments():
+    from estdepth_amd import ops, _native
+    x = torch.zeros(4, 4, 4, 32, device=DEV)
+    with pytest.raises(RuntimeError, match="estd_status"):
+        ops.warp_attention(x, [x] * 9, torch.zeros(9, 30, device=DEV), torch.ones(4, device=DEV), 0.1, 0.1)   # > 8 sources
+    with pytest.raises(RuntimeError):
+        ops.softargmin_up(torch.zeros(1, 4, 4, 4, device=DEV, dtype=torch.float64), torch.ones(4, device=DEV), 4)   # dtype
+    d = _native.Conv3dDesc()
+    d.N = d.D = d.H = d.W = 4
+    assert _native.lib().estd_conv3d_k3(d, None) == -1                          # null pointers
+
+
+def test_full_size_cfg3_properties():
+    """BASELINE configs[2] size (64x120x160): size-independent properties of the fused EST step.
+    (a) one source with the target's own pose and K_j = K_t: softmax over one view == 1, so h = warp(V_j);
+    (b) permuting the sources leaves h unchanged (softmax/mean are symmetric);
+    (c) soft-argmin of uniform logits = mean of the depth candidates, prob = 1/D."""
+    from estdepth_amd import synth, ops
+    D, H, W = 64, 120, 160
+    g = torch.Generator(device=DEV).manual_seed(3)
+    K = torch.from_numpy(synth.intrinsics(480, 640)).clone()
+    K[:2] *= 0.25
+    K = K.to(DEV)
+    dv = (torch.arange(D, dtype=torch.float32) * (9.9 / 63) + 0.1).to(DEV)
+    poses = [torch.from_numpy(synth.camera_pose(v)).to(DEV) for v in range(3)]
+    kv = [torch.randn(D, H, W, 32, device=DEV, generator=g) for _ in range(3)]
+    m01 = ops.cam_volume_mats(poses[1], poses[0], K)
+    m02 = ops.cam_volume_mats(poses[2], poses[0], K)
+    one = ops.warp_attention(kv[0], [kv[1]], m01[None], dv, 0.1, 9.9 / 63)
+    v1 = kv[1][..., :16].permute(3, 0, 1, 2).contiguous()
+    warped = ops.warp_volume_cdhw(v1, m01, dv, 0.1, 9.9 / 63)                   # level-1 operator, same mats
+    assert (one[..., 16:].permute(3, 0, 1, 2) - warped).abs().max().item() < 1e-5
+    a = ops.warp_attention(kv[0], [kv[1], kv[2]], torch.stack([m01, m02]), dv, 0.1, 9.9 / 63)
+    b = ops.warp_attention(kv[0], [kv[2], kv[1]], torch.stack([m02, m01]), dv, 0.1, 9.9 / 63)
+    assert (a - b).abs().max().item() < 1e-5
+    d, p = ops.softargmin_up(torch.zeros(1, D, H, W, device=DEV), dv, 4)
+    assert (d - dv.mean()).abs().max().item() < 1e-4 and (p - 1.0 / D).abs().max().item() < 1e-7
+
+
+def test_full_size_cfg5_conv_and_sweep():
+    """BASELINE configs[4] size (128x240x320): the plane-sweep front and one 32->32 convolution on a 1.26 GB volume:
+    fused warp+pre0 == level-1 homo_warping followed by the 1x1x1 mix (sampled planes), and conv linearity."""
+    from estdepth_amd import synth, ops
+    from estdepth_amd.layers_op import ConvBN3d
+    D, H, W = 128, 240, 320
+    g = torch.Generator(device=DEV).manual_seed(5)
+    K = torch.from_numpy(synth.intrinsics(960, 1280)).clone()
+    K[:2] *= 0.25
+    K = K.to(DEV)
+    dv = (torch.arange(D, dtype=torch.float32) * (9.9 / 127) + 0.1).to(DEV)
+    p0, p1 = [torch.from_numpy(synth.camera_pose(v)).to(DEV) for v in range(2)]
+    src = torch.randn(32, H, W, device=DEV, generator=g)
+    ref = torch.randn(32, H, W, device=DEV, generator=g)
+    w = torch.randn(32, 64, device=DEV, generator=g) * 0.2
+    bias = torch.randn(32, device=DEV, generator=g)
+    proj = ops.cam_sweep_proj(p0, p1, K)
+    fused = ops.homo_warp_costvol(ops.mix1x1(src, w[:, 32:].contiguous(), None), ops.mix1x1(ref, w[:, :32].contiguous(), bias), proj, dv, D)
+    warped = ops.homo_warping_chw(src, proj, dv, D)                             # [32,D,H,W]
+    for d in (0, 17, 127):
+        cat = torch.cat([ref, warped[:, d]], 0).reshape(64, -1).double()          # fp64 arbiter (rocBLAS fp32 is not exact enough)
+        expect = (w.double() @ cat + bias.double()[:, None]).reshape(32, H, W).permute(1, 2, 0)
+        assert (fused[d].double() - expect).abs().max().item() < 5e-5
+    del warped
+    mod = ConvBN3d(32, 32, 3, 1, 1, None).eval()
+    synth.fill_state_dict(mod, seed=77)
+    with torch.no_grad():
+        mod[1].bias.zero_(); mod[1].running_mean.zero_()
+    plan = mod.to(DEV).plan()
+    x = fused[None]
+    y1 = torch.empty_like(x); y2 = torch.empty_like(x)
+    plan.run(x, (1, D, H, W), out=y1, out_stride=32)
+    x.mul_(-3.0)
+    plan.run(x, (1, D, H, W), out=y2, out_stride=32)
+    assert (y2 + 3.0 * y1).abs().max().item() < 1e-3 * y1.abs().max().item()
+    assert bool(torch.isfinite(y1).all())
