@@ -47,7 +47,9 @@ def build_model(workload, device):
     synth.fill_state_dict(m, seed=0, head_gain=1.0)
     m = m.eval().to(device)
     if str(device) != "cpu" and os.environ.get("ESTD_NCHW_2D", "0") != "1":
-        m.use_channels_last_2d()
+        m.use_channels_last_2d()                      # NHWC MIOpen kernels for the 2D backbones
+        if os.environ.get("ESTD_PSM", "hip") == "hip":
+            m.use_hip_psm()                           # PSM 3x3 convs on the MFMA conv2d kernel
     return m
 
 

@@ -31,6 +31,17 @@ class Conv3dDesc(ctypes.Structure):
     ]
 
 
+class Conv2dDesc(ctypes.Structure):
+    """Mirror of struct estd_conv2d_desc (include/estd_hip.h)."""
+    _fields_ = [
+        ("N", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("cin", ctypes.c_int), ("cout", ctypes.c_int),
+        ("dilation", ctypes.c_int), ("group_tiles", ctypes.c_int),
+        ("in_", ctypes.c_void_p), ("w", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
+        ("relu_before_residual", ctypes.c_int), ("relu_after_residual", ctypes.c_int),
+        ("residual", ctypes.c_void_p), ("out", ctypes.c_void_p),
+    ]
+
+
 _SIGNATURES = {
     "estd_version": (ctypes.c_int, []),
     "estd_status_string": (ctypes.c_char_p, [ctypes.c_int]),
@@ -45,6 +56,7 @@ _SIGNATURES = {
     "estd_homo_warp_costvol": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
                                               ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
     "estd_conv3d_k3": (ctypes.c_int, [ctypes.POINTER(Conv3dDesc), c_stream]),
+    "estd_conv2d_k3": (ctypes.c_int, [ctypes.POINTER(Conv2dDesc), c_stream]),
     "estd_conv3d_k3_grid": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "estd_groupnorm_finalize": (ctypes.c_int, [c_float_p, ctypes.c_int, ctypes.c_double, ctypes.c_float,
                                                c_float_p, c_stream]),

@@ -64,7 +64,69 @@ class PSMFeatures(nn.Module):
         layers += [_PSMBlock(planes, planes, 1, None, pad, dilation) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
+    # ---- HIP path: every 3x3 / stride-1 conv+BN(+ReLU)(+residual) on csrc/conv2d_mfma.hip ----
+    def use_hip_convs(self, enable=True):
+        """Opt-in.  Stride-2 convs, 1x1 convs, pooling and upsampling stay on PyTorch-ROCm; activations travel as
+        NHWC (channels_last) tensors so both sides share buffers without copies."""
+        self._hip = bool(enable)
+        self._hip_plans = None
+        if enable:
+            self.to(memory_format=torch.channels_last)
+        return self
+
+    def _plans(self):
+        from . import ops
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if getattr(self, "_hip_plans", None) is None or self._hip_plans[0] != key:
+            plans = {}
+            fc = self.firstconv
+            plans["first1"] = ops.Conv2dPlan(fc[2][0], fc[2][1], relu_before=True)
+            plans["first2"] = ops.Conv2dPlan(fc[4][0], fc[4][1], relu_before=True)
+            for lname in ("layer1", "layer2", "layer3", "layer4"):
+                for bi, blk in enumerate(getattr(self, lname)):
+                    c1 = blk.conv1[0]
+                    if c1[0].stride == (1, 1):
+                        plans[(lname, bi, 1)] = ops.Conv2dPlan(c1[0], c1[1], relu_before=True)
+                    plans[(lname, bi, 2)] = ops.Conv2dPlan(blk.conv2[0], blk.conv2[1])       # + residual, no ReLU (psm_submodule.py:26-37)
+            plans["last"] = ops.Conv2dPlan(self.lastconv[0][0], self.lastconv[0][1], relu_before=True)
+            self._hip_plans = (key, plans)
+        return self._hip_plans[1]
+
+    @staticmethod
+    def _nhwc(t):      # NCHW tensor in channels_last memory -> contiguous [N,H,W,C] view
+        return t.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+
+    @staticmethod
+    def _nchw(t):      # contiguous [N,H,W,C] -> NCHW view (channels_last memory)
+        return t.permute(0, 3, 1, 2)
+
+    def _forward_hip(self, x):
+        P = self._plans()
+        fc = self.firstconv
+        x = fc[1](fc[0](x.contiguous(memory_format=torch.channels_last)))      # 3->32 stride 2: MIOpen
+        x = P["first2"].run(P["first1"].run(self._nhwc(x)))
+        for lname in ("layer1", "layer2", "layer3", "layer4"):
+            for bi, blk in enumerate(getattr(self, lname)):
+                if (lname, bi, 1) in P:
+                    y = P[(lname, bi, 1)].run(x)
+                else:                                                             # stride-2 conv1 (layer2.0): MIOpen
+                    y = self._nhwc(blk.conv1(self._nchw(x)))
+                res = x if blk.downsample is None else self._nhwc(blk.downsample(self._nchw(x)))
+                x = P[(lname, bi, 2)].run(y, residual=res)
+            if lname == "layer2":
+                raw = x
+        skip = x
+        skip_nchw = self._nchw(skip)
+        size = skip_nchw.shape[2:]
+        ups = [F.interpolate(getattr(self, "branch%d" % i)(skip_nchw), size=size, mode="bilinear", align_corners=False)
+               for i in (4, 3, 2, 1)]
+        cat = torch.cat([self._nchw(raw), skip_nchw] + ups, 1)
+        y = P["last"].run(self._nhwc(cat))
+        return self.lastconv[2](self._nchw(y))
+
     def forward(self, x):
+        if getattr(self, "_hip", False) and x.is_cuda and not self.training:
+            return self._forward_hip(x)
         x = self.firstconv(x)
         x = self.layer1(x)
         raw = self.layer2(x)

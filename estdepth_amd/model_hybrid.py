@@ -117,6 +117,13 @@ class DepthNetHybrid(nn.Module):
                 child.to(memory_format=fmt)
         return self
 
+    def use_hip_psm(self, enable=True):
+        """Opt-in: the 3x3 convolutions of the PSM matching-feature extractor on the MFMA conv2d kernel
+        (SURVEY §8f rank 2).  Implies NHWC 2D backbones."""
+        self.use_channels_last_2d(True)
+        self.matchingFeature.use_hip_convs(enable)
+        return self
+
     def forward(self, imgs, cam_poses, cam_intr, sample, pre_costs=None, pre_cam_poses=None, mode='train'):
         """model_hybrid.py:110-184.  imgs [1,V,3,Hi,Wi] in 0..255; cam_poses [1,V,4,4] camera-to-world;
         cam_intr [1,3,3] full-resolution pixels; returns (outputs, cur_costs, cur_cam_poses) for

@@ -156,6 +156,44 @@ class Conv3dPlan:
             PROFILE.append((2.0 * 27 * 32 * 32 * Nn * D * H * W, e0, e1))
 
 
+class Conv2dPlan:
+    """3x3 Conv2d (stride 1, dilation 1|2) + folded BatchNorm2d [+ReLU] [+residual] on NHWC tensors
+    (csrc/conv2d_mfma.hip).  ``conv`` / ``bn`` are the torch modules holding the parameters."""
+
+    def __init__(self, conv, bn, relu_before=False, relu_after=False):
+        if conv.kernel_size != (3, 3) or conv.stride != (1, 1) or conv.groups != 1 or conv.bias is not None:
+            raise RuntimeError("Conv2dPlan: 3x3 / stride 1 / bias-free convolutions only")
+        if conv.dilation not in ((1, 1), (2, 2)) or conv.padding != conv.dilation:
+            raise RuntimeError("Conv2dPlan: dilation 1 or 2 with padding = dilation only")
+        if conv.in_channels % 32 or conv.out_channels % 32:
+            raise RuntimeError("Conv2dPlan: channel counts must be multiples of 32")
+        dev = conv.weight.device
+        self.cin, self.cout, self.dil = conv.in_channels, conv.out_channels, conv.dilation[0]
+        self.nt = 4 if self.cout % 64 == 0 else 2
+        self.w = packing.pack_conv2d(conv.weight, self.nt).to(dev)
+        sc, sh = packing.fold_bn_fp32(bn, list(range(self.cout)))
+        self.scale, self.shift = sc.to(dev), sh.to(dev)
+        self.relu_before, self.relu_after = int(relu_before), int(relu_after)
+
+    def run(self, x_nhwc, residual=None):
+        """x_nhwc [N,H,W,Cin] contiguous -> [N,H,W,Cout]."""
+        Nn, H, W, C = x_nhwc.shape
+        if C != self.cin or not x_nhwc.is_contiguous():
+            raise RuntimeError("Conv2dPlan.run: expected contiguous NHWC input with %d channels" % self.cin)
+        out = torch.empty((Nn, H, W, self.cout), device=x_nhwc.device, dtype=torch.float32)
+        d = N.Conv2dDesc()
+        d.N, d.H, d.W, d.cin, d.cout, d.dilation, d.group_tiles = Nn, H, W, self.cin, self.cout, self.dil, self.nt
+        d.in_ = x_nhwc.data_ptr()
+        d.w, d.scale, d.shift = self.w.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr()
+        d.relu_before_residual, d.relu_after_residual = self.relu_before, self.relu_after
+        if residual is not None and (tuple(residual.shape) != tuple(out.shape) or not residual.is_contiguous()):
+            raise RuntimeError("Conv2dPlan.run: residual must be contiguous NHWC of the output shape")
+        d.residual = residual.data_ptr() if residual is not None else None
+        d.out = out.data_ptr()
+        N.check(N.lib().estd_conv2d_k3(ctypes.byref(d), _stream()), "estd_conv2d_k3")
+        return out
+
+
 def conv3d_grid(Nn, D, H, W):
     g = N.lib().estd_conv3d_k3_grid(Nn, D, H, W)
     if g < 0:

@@ -123,3 +123,29 @@ def fold_bn_fp32(bn, out_idx):
     sh = b - m * sc
     idx = torch.as_tensor(out_idx, dtype=torch.long)
     return sc[idx].contiguous(), sh[idx].contiguous()
+
+
+def pack_conv2d(weight, group_tiles):
+    """3x3 Conv2d weight [Cout, Cin, 3, 3] (Cin, Cout multiples of 32) -> float32
+    [Cout/(16*NT)][Cin/32][10 taps (9 + zero pad)][2*NT quads][64 lanes][4] for csrc/conv2d_mfma.hip:
+    lane (g, j), k-step t, N tile n  ->  quad (t*NT+n)//4, element (t*NT+n)%4,
+    input channel 32*chunk + ch(g,t) (same K permutation as the 3D kernel), output channel 16*NT*grp + NT*j + n."""
+    nt = group_tiles
+    w = weight.detach().float().cpu().numpy()
+    cout, cin = w.shape[:2]
+    assert cin % 32 == 0 and cout % (16 * nt) == 0 and w.shape[2:] == (3, 3)
+    w = w.reshape(cout, cin, 9)
+    groups, chunks = cout // (16 * nt), cin // 32
+    out = np.zeros((groups, chunks, 10, 2 * nt, 64, 4), np.float32)
+    lane = np.arange(64)
+    g, j = lane >> 4, lane & 15
+    for t in range(8):
+        ci_in_chunk = np.array([_ch(32, int(gg), t) for gg in g])           # [64]
+        for n in range(nt):
+            idx = t * nt + n
+            for grp in range(groups):
+                co = grp * 16 * nt + nt * j + n                             # [64]
+                for c in range(chunks):
+                    # value[tap, lane] = w[co[lane], c*32 + ci[lane], tap]
+                    out[grp, c, :9, idx // 4, :, idx % 4] = w[co, c * 32 + ci_in_chunk, :].T
+    return torch.from_numpy(out)

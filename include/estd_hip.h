@@ -113,6 +113,27 @@ int estd_conv3d_k3(const estd_conv3d_desc* desc, estd_stream_t stream);
 /* number of thread blocks estd_conv3d_k3 launches for a volume (size of stats_partials / 4 doubles) */
 int estd_conv3d_k3_grid(int N, int D, int H, int W);
 
+/* ---- 3x3 2D convolution on NHWC maps (PSMNet matching features) ------------------------------
+ * Replaces Conv2d(3x3, stride 1, dilation 1|2, bias=False) + BatchNorm2d(eval) [+ReLU] [+residual add] of
+ * networks/layers_op.py:10-27 as used by networks/psm_submodule.py:14-37,43-60,112-114.  Cin, Cout multiples of 32.
+ * Weights packed by estdepth_amd/packing.py::pack_conv2d in groups of 16*group_tiles output channels. */
+typedef struct estd_conv2d_desc {
+    int N, H, W;
+    int cin, cout;
+    int dilation;             /* 1 or 2 (padding = dilation) */
+    int group_tiles;          /* 2 or 4: output channels per work item = 16*group_tiles */
+    const float* in;          /* [N][H][W][cin] */
+    const float* w;           /* packed [cout/(16*group_tiles)][cin/32][10 taps (9 + 1 pad)][2*group_tiles][64][4] */
+    const float* scale;       /* [cout] folded BN scale */
+    const float* shift;       /* [cout] folded BN shift */
+    int relu_before_residual; /* conv-bn-relu */
+    int relu_after_residual;  /* relu(conv-bn + residual) */
+    const float* residual;    /* [N][H][W][cout] or NULL */
+    float* out;               /* [N][H][W][cout] */
+} estd_conv2d_desc;
+
+int estd_conv2d_k3(const estd_conv2d_desc* desc, estd_stream_t stream);
+
 /* mean/rstd from the partials: stats_out = {mean_g0, rstd_g0, mean_g1, rstd_g1}; count = 16*D*H*W per group
  * (transformer/epipolar_transformer.py:22-23,:27 GroupNorm(1, 16, eps=1e-5)). */
 int estd_groupnorm_finalize(const double* partials, int n_blocks, double count, float eps, float* stats_out4,

@@ -1,0 +1,71 @@
+"""GPU: the MFMA conv2d kernel and the fused PSM path against PyTorch fp32 references of the same ops."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("cin,cout,dil,dims,relu,res", [(32, 32, 1, (2, 13, 21), True, False), (64, 64, 1, (1, 24, 32), False, True),
+                                                        (128, 128, 2, (1, 17, 35), True, False), (96, 64, 1, (1, 8, 16), False, False),
+                                                        (320, 128, 1, (1, 9, 20), True, False)])
+def test_conv2d_mfma_vs_torch_fp64(cin, cout, dil, dims, relu, res):
+    from estdepth_amd import synth, ops
+    from estdepth_amd.backbones import conv_bn2d
+    N, H, W = dims
+    mod = conv_bn2d(cin, cout, 3, 1, dil, dil).eval()
+    synth.fill_state_dict(mod, seed=cin + cout + dil)
+    g = torch.Generator().manual_seed(cin * 3 + cout)
+    x = torch.randn(N, cin, H, W, generator=g)
+    r = torch.randn(N, cout, H, W, generator=g) if res else None
+    with torch.no_grad():
+        ref = mod.double()(x.double())
+        if relu:
+            ref = torch.relu(ref)
+        if res:
+            ref = ref + r.double()
+    mod = mod.float().to(DEV)
+    plan = ops.Conv2dPlan(mod[0], mod[1], relu_before=relu)
+    xin = x.to(DEV).permute(0, 2, 3, 1).contiguous()
+    rin = r.to(DEV).permute(0, 2, 3, 1).contiguous() if res else None
+    out = plan.run(xin, residual=rin).permute(0, 3, 1, 2).cpu().double()
+    assert (out - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_psm_hip_path_matches_torch_path():
+    from estdepth_amd import synth
+    from estdepth_amd.backbones import PSMFeatures
+    m = PSMFeatures().eval()
+    synth.fill_state_dict(m, seed=21)
+    x = torch.randn(2, 3, 128, 160, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        ref = m(x)                                   # CPU fp32 torch path (what the oracle-side tests use)
+        out = m.to(DEV).use_hip_convs()(x.to(DEV)).cpu()
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+
+
+def test_e2e_golden_with_hip_psm(golden_dir):
+    """streaming golden (G8) with the PSM 3x3 convs on the MFMA kernel: depth still within 1e-4 of the reference."""
+    import os
+    import fixtures_spec as S
+    from estdepth_amd import synth, DepthNetHybrid
+    g = np.load(os.path.join(golden_dir, "g8_estm_stream.npz"))
+    m = DepthNetHybrid(ndepths=64, depth_min=0.1, depth_max=10.0, resnet=18, IF_EST_transformer=True).eval()
+    synth.fill_state_dict(m, seed=2, head_gain=1.0)
+    m = m.to(DEV).use_hip_psm()
+    imgs, poses, intr, sample = S.e2e_inputs(6, S.E2E_HI, S.E2E_WI, seed=1003)
+    imgs, poses, intr = imgs.to(DEV), poses.to(DEV), intr.to(DEV)
+    mem_costs, mem_poses = [], []
+    for w in range(3):
+        sl = slice(w, w + 3)
+        pc = {"keys": [c["keys"][0] for c in mem_costs], "values": [c["values"][0] for c in mem_costs]} if mem_costs else None
+        pp = [p[0] for p in mem_poses] if mem_poses else None
+        with torch.no_grad():
+            outputs, costs, cposes = m(imgs[:, sl], poses[:, sl], intr, {k: v[:, sl] for k, v in sample.items()}, pc, pp, mode="val")
+        mem_costs.append(costs); mem_poses.append(cposes)
+        mem_costs, mem_poses = mem_costs[-2:], mem_poses[-2:]
+        for k, v in outputs.items():
+            name = "w%d|" % w + "|".join(map(str, k))
+            assert np.abs(v.cpu().numpy() - g[name]).max() < 1e-4, name

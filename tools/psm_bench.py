@@ -28,3 +28,12 @@ with torch.no_grad():
     print("PSM channels_last ms", timeit(lambda: m2(xc)), "max diff vs NCHW", (out - ref).abs().max().item())
     r2 = m.semanticFeature.to(memory_format=torch.channels_last)
     print("R50 channels_last ms", timeit(lambda: r2(xc[:3])))
+
+with torch.no_grad():
+    m3 = m.matchingFeature.use_hip_convs()
+    out3 = m3(xc)
+    print("PSM HIP convs ms", timeit(lambda: m3(xc)), "max diff vs NCHW torch", (out3 - ref).abs().max().item())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        y = m3(xc)
+    print("PSM HIP convs graph ms", timeit(lambda: g.replay()))
