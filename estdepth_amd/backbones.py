@@ -242,6 +242,17 @@ class UpBlock(nn.Module):
         self.nonlin = nn.ReLU(inplace=True)
 
     def forward(self, x):
+        if getattr(self, "_hip", False) and x.is_cuda and not self.training:
+            conv = self.conv[0]
+            n, _, h, w = x.shape
+            items = n * ((h + 7) // 8) * ((w + 15) // 16) * (conv.out_channels // (64 if conv.out_channels % 64 == 0 else 32))
+            if conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0 and items >= 256:     # enough tiles to fill 256 CUs
+                from . import ops
+                key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+                if getattr(self, "_plan", None) is None or self._plan[0] != key:
+                    self._plan = (key, ops.Conv2dPlan(conv, self.conv[1], relu_before=True))
+                y = self._plan[1].run(x.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1))
+                return y.permute(0, 3, 1, 2)
         return self.nonlin(self.conv(x))
 
 

@@ -122,6 +122,9 @@ class DepthNetHybrid(nn.Module):
         (SURVEY §8f rank 2).  Implies NHWC 2D backbones."""
         self.use_channels_last_2d(True)
         self.matchingFeature.use_hip_convs(enable)
+        for name, child in self.CostRegNet.named_children():      # 2D decoder ConvBlocks with enough tiles (120x160 and up)
+            if name.startswith("upconv"):
+                child._hip = bool(enable)
         return self
 
     def forward(self, imgs, cam_poses, cam_intr, sample, pre_costs=None, pre_cam_poses=None, mode='train'):
