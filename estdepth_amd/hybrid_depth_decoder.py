@@ -168,6 +168,16 @@ class DepthHybridDecoder(nn.Module):
             x += [semantic_features[1]]
         return self.upconv_2_1(torch.cat(x, 1))
 
+    def _take_semantic_vs(self, semantic_features):
+        """semantic plane scores: computed here, or taken from DepthNetHybrid's side-stream precomputation."""
+        pre = getattr(self, "_semantic_vs_pre", None)
+        if pre is not None:
+            self._semantic_vs_pre = None
+            stream, sv = pre
+            torch.cuda.current_stream().wait_stream(stream)           # join the semantic branch
+            return sv
+        return self._semantic_vs(semantic_features)
+
     def _refine(self, semantic_vs, all_fused_logits, semantic_features):
         """scales 1,0 (:267-290 / :392-415) -> (depth_s1 [T,1,4H,4W], depth_s0 [T,1,4H,4W])."""
         x = self.upconv_1_0(torch.cat([semantic_vs, torch.relu(all_fused_logits)], dim=1))
@@ -228,7 +238,7 @@ class DepthHybridDecoder(nn.Module):
         num = len(costvolumes)
         B, C, D, H, W = costvolumes[0].shape
         outputs = {}
-        semantic_vs = self._semantic_vs(semantic_features)
+        semantic_vs = self._take_semantic_vs(semantic_features)
         kv, init_logits, d3, p3, dv = self._regularise(costvolumes, semantic_vs, depth_values)
         for i in range(num):
             outputs[("depth", i, 3)] = d3[i:i + 1]
@@ -275,7 +285,7 @@ class DepthHybridDecoder(nn.Module):
         num = len(costvolumes)
         B, C, D, H, W = costvolumes[0].shape
         outputs = {}
-        semantic_vs = self._semantic_vs(semantic_features)
+        semantic_vs = self._take_semantic_vs(semantic_features)
         kv, init_logits, d3, p3, dv = self._regularise(costvolumes, semantic_vs, depth_values)
         P = self._plans()
         fused_logits = torch.empty((num, D, H, W), device=kv.device, dtype=torch.float32)

@@ -117,6 +117,11 @@ class DepthNetHybrid(nn.Module):
                 child.to(memory_format=fmt)
         return self
 
+    def overlap_semantic_branch(self, enable=True):
+        """Opt-in: run the semantic branch on a second HIP stream (captured as a parallel graph branch)."""
+        self._overlap_semantic = bool(enable)
+        return self
+
     def use_hip_psm(self, enable=True):
         """Opt-in: the 3x3 convolutions of the PSM matching-feature extractor on the MFMA conv2d kernel
         (SURVEY §8f rank 2).  Implies NHWC 2D backbones."""
@@ -144,8 +149,24 @@ class DepthNetHybrid(nn.Module):
         flat = imgs.reshape(batch_size * views_num, 3, height_img, width_img)
         if getattr(self, "_channels_last_2d", False):
             flat = flat.contiguous(memory_format=torch.channels_last)      # MIOpen NHWC kernels for the 2D backbones
-        matching = self.matchingFeature(flat)                                                               # :128
-        semantic_features = self.semanticFeature(flat[1:1 + target_num])                                   # :138-139 (batch 1)
+        if getattr(self, "_overlap_semantic", False):
+            # fork: ResNet + 2D decoder scales 4..2 (many small MIOpen kernels) on a side stream, concurrently with the
+            # PSM -> plane sweep -> pre1/pre2 chain; joined in the decoder right before dres2 needs the plane scores
+            main = torch.cuda.current_stream()
+            if getattr(self, "_side_stream", None) is None:
+                self._side_stream = torch.cuda.Stream()
+            side = self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                semantic_features = self.semanticFeature(flat[1:1 + target_num])                           # :138-139
+                sv = self.CostRegNet._semantic_vs(semantic_features)
+            for t_ in list(semantic_features) + [sv]:
+                t_.record_stream(main)
+            self.CostRegNet._semantic_vs_pre = (side, sv)
+            matching = self.matchingFeature(flat)                                                           # :128
+        else:
+            matching = self.matchingFeature(flat)                                                           # :128
+            semantic_features = self.semanticFeature(flat[1:1 + target_num])                               # :138-139 (batch 1)
         cam_intr_stage1 = self.scale_cam_intr(cam_intr, scale=1. / self.stage_infos["stage1"]["scale"])     # :142
         dkey = (imgs.device, imgs.dtype)
         if getattr(self, "_dv_cache", None) is None or self._dv_cache[0] != dkey:      # one H2D copy, not one per call

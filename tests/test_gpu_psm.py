@@ -69,3 +69,30 @@ def test_e2e_golden_with_hip_psm(golden_dir):
         for k, v in outputs.items():
             name = "w%d|" % w + "|".join(map(str, k))
             assert np.abs(v.cpu().numpy() - g[name]).max() < 1e-4, name
+
+
+def test_overlapped_semantic_branch_and_all_accelerators_match_plain_path():
+    """use_hip_psm + overlap_semantic_branch + hipGraph replay (what bench.py runs) == plain eager forward."""
+    import fixtures_spec as S
+    from estdepth_amd import synth, DepthNetHybrid
+    from estdepth_amd.graph import GraphedForward
+    def make():
+        m = DepthNetHybrid(ndepths=64, depth_min=0.1, depth_max=10.0, resnet=18, IF_EST_transformer=True).eval()
+        synth.fill_state_dict(m, seed=2, head_gain=1.0)
+        return m.to(DEV)
+    plain, fast = make(), make().use_hip_psm().overlap_semantic_branch()
+    gf = GraphedForward(fast)
+    imgs, poses, intr, sample = S.e2e_inputs(8, S.E2E_HI, S.E2E_WI, seed=1004)
+    imgs, poses, intr = imgs.to(DEV), poses.to(DEV), intr.to(DEV)
+    pc_a = pp_a = pc_b = pp_b = None
+    for call in range(2):
+        sl = slice(3 * call, 3 * call + 5)
+        smp = {k: v[:, sl].to(DEV) for k, v in sample.items()}
+        with torch.no_grad():
+            a, pc_a, pp_a = plain(imgs[:, sl], poses[:, sl], intr, smp, pc_a, pp_a, mode="val")
+            b, cb, pb = gf(imgs[:, sl], poses[:, sl], intr, smp, pc_b, pp_b, mode="val")
+            for k in a:
+                assert (a[k] - b[k]).abs().max().item() < 5e-5, (call, k)
+            # the graph's outputs are static buffers: detach the memory we carry to the next call
+            pc_b = {"keys": [cb["keys"][0].contiguous().clone()], "values": [cb["values"][0].contiguous().clone()]}
+            pp_b = [pb[0].clone()]
