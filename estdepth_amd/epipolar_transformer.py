@@ -39,7 +39,7 @@ class EpipolarTransformer(nn.Module):
             return gate, outp
         return self._cache.get(self, build)
 
-    def gru(self, xh, dims, out_value, out_stride):
+    def gru(self, xh, dims, out_value, out_stride, before_write=None):
         """xh [D,H,W,32] = [x | h]  ->  writes u*h + (1-u)*tanh(GN(o)) to out_value (16 ch, out_stride)."""
         D, H, W = dims
         gate, outp = self._plans()
@@ -54,16 +54,18 @@ class EpipolarTransformer(nn.Module):
         o_raw = torch.empty((D, H, W, 16), device=xh.device, dtype=torch.float32)
         outp.run(xrh, (1, D, H, W), out=o_raw, out_stride=16, stats_partials=part2)              # :52
         st_o = ops.groupnorm_finalize(part2, nblk, 16.0 * n_vox, self.output_norm.eps)           # :53
+        if before_write is not None:
+            before_write()            # e.g. join a side stream that still reads the value half we are about to overwrite
         ops.gru_blend(xh, ru, o_raw, st_ru, st_o, self.update_gate_norm.weight, self.update_gate_norm.bias,
                       self.output_norm.weight, self.output_norm.bias, out_value, out_stride)     # :47,:82-83
 
-    def fuse_kv(self, kv_target, kv_sources, mats, depth_values, depth_min, depth_interval):
+    def fuse_kv(self, kv_target, kv_sources, mats, depth_values, depth_min, depth_interval, before_write=None):
         """Fast path used by DepthHybridDecoder: warp every source kv into the target frustum, attend,
         run the GRU and overwrite the VALUE half of ``kv_target`` in place (values[i] = fused,
         hybrid_depth_decoder.py:253)."""
         D, H, W, _ = kv_target.shape
         xh = ops.warp_attention(kv_target, kv_sources, mats, depth_values, depth_min, depth_interval)
-        self.gru(xh, (D, H, W), kv_target, 32)
+        self.gru(xh, (D, H, W), kv_target, 32, before_write=before_write)
         return kv_target
 
     def forward(self, target_key, target_value, warped_values=None, warped_keys=None):

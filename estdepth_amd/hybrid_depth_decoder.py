@@ -198,7 +198,16 @@ class DepthHybridDecoder(nn.Module):
         v = cv[0].permute(1, 2, 3, 0)
         return v if v.is_contiguous() else v.contiguous()
 
-    def _regularise(self, costvolumes, semantic_vs, depth_values):
+    def _heads_stream(self):
+        """side stream for the (MFMA-light) stereo-head convs + soft-argmin when stream overlap is enabled: they fill the
+        matrix pipe while the main chain runs its HBM-bound kernels (warp+attention, GRU elementwise)."""
+        if not getattr(self, "_overlap_heads", False):
+            return None
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream()
+        return self._side_stream
+
+    def _regularise(self, costvolumes, semantic_vs, depth_values, side=None):
         """dres0/1/2, key/value, stereo_head0, soft-argmin (:187-209).  Returns kv [T,D,H,W,32] and outputs."""
         T = len(costvolumes)
         B, C, D, H, W = costvolumes[0].shape
@@ -226,9 +235,18 @@ class DepthHybridDecoder(nn.Module):
         kv = torch.empty((T, D, H, W, 32), device=dev, dtype=torch.float32)
         P["kv"].run(a, dims, in_extra=extra, out=kv, out_stride=32)
         init_logits = torch.empty((T, D, H, W), device=dev, dtype=torch.float32)
-        P["head0"].run(kv, dims, in_stride=32, out_head=init_logits)             # stereo_head0(value)
         dv = depth_values.reshape(-1)[:D].contiguous().float()
-        d3, p3 = ops.softargmin_up(init_logits, dv, 4)
+        if side is None:
+            P["head0"].run(kv, dims, in_stride=32, out_head=init_logits)         # stereo_head0(value)
+            d3, p3 = ops.softargmin_up(init_logits, dv, 4)
+        else:                                                                    # fork; the caller joins `side`
+            main = torch.cuda.current_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                P["head0"].run(kv, dims, in_stride=32, out_head=init_logits)
+                d3, p3 = ops.softargmin_up(init_logits, dv, 4)
+            d3.record_stream(main)
+            p3.record_stream(main)
         return kv, init_logits, d3, p3, dv
 
     def forward_transformer(self, costvolumes, semantic_features, cam_poses, cam_intr,
@@ -239,7 +257,9 @@ class DepthHybridDecoder(nn.Module):
         B, C, D, H, W = costvolumes[0].shape
         outputs = {}
         semantic_vs = self._take_semantic_vs(semantic_features)
-        kv, init_logits, d3, p3, dv = self._regularise(costvolumes, semantic_vs, depth_values)
+        side = self._heads_stream()
+        main = torch.cuda.current_stream() if side is not None else None
+        kv, init_logits, d3, p3, dv = self._regularise(costvolumes, semantic_vs, depth_values, side)
         for i in range(num):
             outputs[("depth", i, 3)] = d3[i:i + 1]
             outputs[("init_prob", i)] = p3[i:i + 1]
@@ -264,8 +284,18 @@ class DepthHybridDecoder(nn.Module):
             mats = torch.empty((len(others), 30), device=kv.device, dtype=torch.float32)
             for r, j in enumerate(others):
                 ops.cam_volume_mats(poses[j], poses[i], intr, out=mats[r])      # :235 (Q8) + homo_utils.py:51,:258
-            self.epipolar_transformer.fuse_kv(kvs[i], [kvs[j] for j in others], mats, dv, depth_min, depth_interval)
-            P["head1"].run(kvs[i], (1, D, H, W), in_stride=32, out_head=fused_logits[i])   # :256
+            # stereo_head0 (side stream) reads every UNFUSED value: it must be done before the first value is overwritten
+            join = (lambda: main.wait_stream(side)) if (side is not None and i == 0) else None
+            self.epipolar_transformer.fuse_kv(kvs[i], [kvs[j] for j in others], mats, dv, depth_min, depth_interval,
+                                              before_write=join)
+            if side is None:
+                P["head1"].run(kvs[i], (1, D, H, W), in_stride=32, out_head=fused_logits[i])   # :256
+            else:                                   # head of target i overlaps the (HBM-bound) start of target i+1
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    P["head1"].run(kvs[i], (1, D, H, W), in_stride=32, out_head=fused_logits[i])
+        if side is not None:
+            main.wait_stream(side)
         d2, p2 = ops.softargmin_up(fused_logits, dv, 4)                   # :259-260
         for i in range(num):
             outputs[("depth", i, 2)] = d2[i:i + 1]
@@ -286,10 +316,13 @@ class DepthHybridDecoder(nn.Module):
         B, C, D, H, W = costvolumes[0].shape
         outputs = {}
         semantic_vs = self._take_semantic_vs(semantic_features)
-        kv, init_logits, d3, p3, dv = self._regularise(costvolumes, semantic_vs, depth_values)
+        side = self._heads_stream()
+        kv, init_logits, d3, p3, dv = self._regularise(costvolumes, semantic_vs, depth_values, side)
         P = self._plans()
         fused_logits = torch.empty((num, D, H, W), device=kv.device, dtype=torch.float32)
         P["head1"].run(kv, (num, D, H, W), in_stride=32, out_head=fused_logits)              # :377
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         d2, p2 = ops.softargmin_up(fused_logits, dv, 4)                                      # :379-381
         s1, s0 = self._refine(semantic_vs, fused_logits, semantic_features)
         for i in range(num):

@@ -120,6 +120,7 @@ class DepthNetHybrid(nn.Module):
     def overlap_semantic_branch(self, enable=True):
         """Opt-in: run the semantic branch on a second HIP stream (captured as a parallel graph branch)."""
         self._overlap_semantic = bool(enable)
+        self.CostRegNet._overlap_heads = bool(enable)      # stereo-head convs + soft-argmin on a side stream as well
         return self
 
     def use_hip_psm(self, enable=True):
