@@ -50,7 +50,8 @@ class GraphedForward:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(g):
+        # thread_local: other threads (e.g. the RCCL watchdog polling events) may keep issuing HIP calls during capture
+        with torch.no_grad(), torch.cuda.graph(g, capture_error_mode="thread_local"):
             out = run()
         st["graph"], st["out"] = g, out
         self._graphs[key] = st

@@ -17,6 +17,50 @@ def shard_sequences(n_sequences, rank=None, world=None):
     return [s for s in range(n_sequences) if s % world == rank]
 
 
+class _PendingBank:
+    """Handle of an in-flight memory-bank all-gather (runs on the communication stream, overlapping compute)."""
+
+    def __init__(self, work, recv, n, meta):
+        self.work, self.recv, self.n, self.meta = work, recv, n, meta
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()            # the current stream waits for the collective; the host does not block
+            self.work = None
+        return _unpack_bank(self.recv, self.n, *self.meta)
+
+
+def _unpack_bank(recv, n, world, kv_shape, key_shape, value_shape, pose_shape, channels_last):
+    out = []
+    for r in range(world):
+        p = recv[r, n:].reshape(pose_shape)
+        if channels_last:
+            from .hybrid_depth_decoder import kv_views
+            k, v = kv_views(recv[r, :n].reshape(kv_shape))
+        else:
+            v = recv[r, :n // 2].reshape(value_shape)
+            k = recv[r, n // 2:n].reshape(key_shape)
+        out.append(({"keys": [k], "values": [v]}, [p]))
+    return out
+
+
+def allgather_memory_bank_async(costs, cam_poses, group=None):
+    """Non-blocking variant: stages {K, V_fused, pose} into one send buffer (so the source may be overwritten by the
+    next forward / graph replay) and starts ONE all-gather on the communication stream.  ``.wait()`` returns the bank."""
+    world = dist.get_world_size(group)
+    key, value, pose = costs["keys"][0], costs["values"][0], cam_poses[0]
+    kv = getattr(value, "_estd_kv", None)
+    channels_last = kv is not None and getattr(key, "_estd_kv", None) is kv
+    flat = kv.reshape(-1) if channels_last else torch.cat([value.reshape(-1), key.reshape(-1)])
+    send = torch.cat([flat, pose.reshape(-1).to(flat.dtype)])
+    recv = torch.empty(world * send.numel(), device=send.device, dtype=send.dtype)
+    work = dist.all_gather_into_tensor(recv, send, group=group, async_op=True)
+    meta = (world, tuple(kv.shape) if channels_last else None, tuple(key.shape), tuple(value.shape), tuple(pose.shape), channels_last)
+    pend = _PendingBank(work, recv.view(world, send.numel()), flat.numel(), meta)
+    pend._send = send                   # keep the staging buffer alive until the collective has run
+    return pend
+
+
 def allgather_memory_bank(costs, cam_poses, group=None):
     """costs = {"keys": [K], "values": [V]} with K, V [1,16,D,H,W]; cam_poses = [pose [1,4,4]].
     Returns a list (one entry per rank) of (costs, cam_poses) in the same structure; entry[rank] aliases

@@ -43,6 +43,13 @@ def _worker(rank, world, port, ret):
         rk, rv = kv_views(ref)
         ok = ok and torch.equal(bank2[r][0]["keys"][0], rk) and torch.equal(bank2[r][0]["values"][0], rv)
         ok = ok and bank2[r][0]["keys"][0].shape == (1, 16, 4, 3, 5)
+    # asynchronous variant (what bench.py overlaps with the next step)
+    pend = parallel.allgather_memory_bank_async({"keys": [k2], "values": [v2]}, [pose])
+    kv.add_(1.0)                                             # the source may be overwritten while the collective is in flight
+    bank3 = pend.wait()
+    for r in range(world):
+        ref = torch.randn(4, 3, 5, 32, generator=torch.Generator().manual_seed(200 + r))
+        ok = ok and torch.equal(bank3[r][0]["values"][0], kv_views(ref)[1])
     ret[rank] = bool(ok)
     dist.destroy_process_group()
 
