@@ -101,8 +101,7 @@ constexpr int SL_VOX = IN_H * IN_W;     // 180 voxels per input slice (one depth
 //   * All global traffic uses wave-uniform buffer descriptors: per-lane 32-bit offsets are computed once per
 //     column segment, the per-tile part is a scalar offset, out-of-volume lanes read zeros / drop stores.
 template <int CM, int NT, bool EXTRA, bool XOUT>
-__global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int total_tiles,
-                                                           int stagger)
+__global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int total_tiles)
 {
     constexpr int CH = CM / 4;          // 16-byte chunks per voxel
     constexpr int KS = CM / 4;          // MFMA k-steps per tap
@@ -133,8 +132,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
         u_end = (int)((long long)total_tiles * (r + 1) / G);
     }
     if (u >= u_end) return;
-    (void)stagger;
-
     // per-lane constants of the epilogue
     const int cbase = (NT == 1) ? i : 2 * i;
     float sc[2], sh[2];
@@ -155,7 +152,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
     const int HW = H * W;
     const int row0 = wave * MT;   // first tile row of this wave
     const int wlane = lane * 16;
-    const int nrows = tiles_h * tiles_w;
 
     while (u < u_end) {
         // ---- column segment [u, seg_end): same (n, h-tile, w-tile), consecutive d ----
@@ -165,7 +161,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
         const int thi = c2 % tiles_h, n = c2 / tiles_h;
         const int tw0 = twi * TW, th0 = thi * TH;
         const int seg_end = min(u_end, (col + 1) * D);
-        (void)nrows;
 
         const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in_main + (size_t)n * vol * p.in_stride, vol * p.in_stride);
         __amdgpu_buffer_rsrc_t rs_ex = rs_in;
@@ -515,9 +510,7 @@ int launch(const estd_conv3d_desc& d, hipStream_t stream)
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    static int stagger = -1;
-    if (stagger < 0) { const char* e = getenv("ESTD_CONV_STAGGER"); stagger = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL((conv3d_k3_kernel<CM, NT, EXTRA, XOUT>), dim3(grid), dim3(256), lds, stream, d, tiles_w, tiles_h, total, stagger);
+    hipLaunchKernelGGL((conv3d_k3_kernel<CM, NT, EXTRA, XOUT>), dim3(grid), dim3(256), lds, stream, d, tiles_w, tiles_h, total);
     return hipGetLastError() == hipSuccess ? ESTD_OK : ESTD_ERR_LAUNCH;
 }
 

@@ -117,6 +117,10 @@ class DepthNetHybrid(nn.Module):
                 child.to(memory_format=fmt)
         return self
 
+    def normalise_images(self, imgs):
+        """2*(imgs/255)-1 (model_hybrid.py:119), exposed for callers that cache per-frame matching features."""
+        return 2 * (imgs / 255.) - 1.
+
     def overlap_semantic_branch(self, enable=True):
         """Opt-in: run the semantic branch on a second HIP stream (captured as a parallel graph branch)."""
         self._overlap_semantic = bool(enable)
@@ -133,8 +137,10 @@ class DepthNetHybrid(nn.Module):
                 child._hip = bool(enable)
         return self
 
-    def forward(self, imgs, cam_poses, cam_intr, sample, pre_costs=None, pre_cam_poses=None, mode='train'):
-        """model_hybrid.py:110-184.  imgs [1,V,3,Hi,Wi] in 0..255; cam_poses [1,V,4,4] camera-to-world;
+    def forward(self, imgs, cam_poses, cam_intr, sample, pre_costs=None, pre_cam_poses=None, mode='train',
+                matching_features=None):
+        """model_hybrid.py:110-184 (``matching_features`` is an optional extension used by estdepth_amd.streaming:
+        precomputed PSM features [V,32,H/4,W/4] of the frames, so overlapping windows do not recompute them).  imgs [1,V,3,Hi,Wi] in 0..255; cam_poses [1,V,4,4] camera-to-world;
         cam_intr [1,3,3] full-resolution pixels; returns (outputs, cur_costs, cur_cam_poses) for
         inference modes."""
         if mode == 'train' or self.training:
@@ -164,9 +170,9 @@ class DepthNetHybrid(nn.Module):
             for t_ in list(semantic_features) + [sv]:
                 t_.record_stream(main)
             self.CostRegNet._semantic_vs_pre = (side, sv)
-            matching = self.matchingFeature(flat)                                                           # :128
+            matching = matching_features if matching_features is not None else self.matchingFeature(flat)   # :128
         else:
-            matching = self.matchingFeature(flat)                                                           # :128
+            matching = matching_features if matching_features is not None else self.matchingFeature(flat)   # :128
             semantic_features = self.semanticFeature(flat[1:1 + target_num])                               # :138-139 (batch 1)
         cam_intr_stage1 = self.scale_cam_intr(cam_intr, scale=1. / self.stage_infos["stage1"]["scale"])     # :142
         dkey = (imgs.device, imgs.dtype)

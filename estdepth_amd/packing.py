@@ -98,20 +98,6 @@ def pack_conv3d(weight, main_idx, extra_idx, out_idx, n_tiles):
     return torch.from_numpy(main), extra
 
 
-def fold_bn(bn, out_idx, eps=None):
-    """BatchNorm3d (eval) -> per-position (scale, shift): y = x*scale + shift
-    (scale = g*rsqrt(var+eps), shift = b - mean*scale; networks/layers_op.py:19,32,38)."""
-    eps = bn.eps if eps is None else eps
-    g = bn.weight.detach().double().cpu()
-    b = bn.bias.detach().double().cpu()
-    m = bn.running_mean.detach().double().cpu()
-    v = bn.running_var.detach().double().cpu()
-    sc = (g / torch.sqrt(v + eps))
-    sh = b - m * sc
-    idx = torch.as_tensor(out_idx, dtype=torch.long)
-    return sc[idx].float(), sh[idx].float()
-
-
 def fold_bn_fp32(bn, out_idx):
     """Same folding done in fp32 exactly like ATen's native_batch_norm (invstd = 1/sqrt(var+eps))."""
     g = bn.weight.detach().float().cpu()

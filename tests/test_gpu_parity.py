@@ -346,3 +346,26 @@ def test_channels_last_2d_backbones_keep_parity(golden_dir):
         mem_costs.append(costs); mem_poses.append(cposes)
         mem_costs, mem_poses = mem_costs[-2:], mem_poses[-2:]
         _cmp_outputs(outputs, g, prefix="w%d|" % w)
+
+
+@pytest.mark.parametrize("cache", [False, True])
+def test_streaming_harness_reproduces_estm_golden(golden_dir, cache):
+    """ESTMStream (eval_hybrid_seq.py protocol as a class, with/without the per-frame PSM feature cache) fed frame by
+    frame must reproduce the windows of the reference's streaming run (G8)."""
+    from estdepth_amd.streaming import ESTMStream
+    g = _g(golden_dir, "g8_estm_stream.npz")
+    m = _stream_model()
+    imgs, poses, intr, sample = S.e2e_inputs(6, S.E2E_HI, S.E2E_WI, seed=1003)
+    imgs, poses, intr = imgs.to(DEV), poses.to(DEV), intr.to(DEV)
+    st = ESTMStream(m, lwindow=3, memory_size=2, cache_features=cache)
+    w = 0
+    for f in range(6):
+        r = st.push(imgs[0, f], poses[0, f], intr[0])
+        if f < 2:
+            assert r is None
+            continue
+        outputs, costs, cposes = r
+        _cmp_outputs(outputs, g, prefix="w%d|" % w)
+        assert np.array_equal(cposes[0].cpu().numpy(), g["w%d|pose" % w])
+        w += 1
+    assert w == 4 and st.windows == 4
