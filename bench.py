@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="joint", choices=["joint", "estm", "cfg1"])
+    ap.add_argument("--workload", default="joint", choices=["joint", "estm", "cfg1", "stream"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
@@ -112,6 +112,32 @@ def cpu_baseline(model, workload):
                       "3D hot path of one step, + 2D networks on torch-CPU %.2f s" % (t_cv, gf_cv, gf_3d / gf_cv, t_2d)}
 
 
+def stream_bench(args, device, rank, world):
+    """Extra (not the headline): frame-by-frame ESTM streaming at cfg3 size through estdepth_amd.streaming.ESTMStream
+    with the per-frame PSM feature cache; one step = one pushed frame = one depth frame."""
+    from estdepth_amd import synth
+    from estdepth_amd.streaming import ESTMStream
+    model = build_model("estm", device)
+    n = args.warmup + args.steps + 2
+    imgs, poses, intr, _ = synth.make_sequence(n, 480, 640, seed=1003 + rank)
+    imgs, poses, intr = imgs.to(device), poses.to(device), intr.to(device)
+    st = ESTMStream(model, cache_features=True)
+    for f in range(args.warmup + 2):
+        st.push(imgs[0, f], poses[0, f], intr[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for f in range(args.warmup + 2, n):
+        st.push(imgs[0, f], poses[0, f], intr[0])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({"metric": "depth frames/sec (ESTM streaming, 480x640, D=64, cached matching features)",
+                          "value": round(args.steps * world / dt, 3), "unit": "depth frames/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "ESTM stream: 1 new frame per step, window 3, memory 2, eager launches"}}), flush=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,6 +157,8 @@ def main():
     torch.backends.cuda.matmul.allow_tf32 = False
 
     from estdepth_amd import ops, parallel
+    if args.workload == "stream":
+        return stream_bench(args, device, rank, world)
     model = build_model(args.workload, device)
     imgs, poses, intr, sample = make_inputs(args.workload, rank, device)
     sub = lambda sl: {k: v[:, sl] for k, v in sample.items()}
