@@ -37,6 +37,9 @@
 #else
 #define ESTD_STATS_ON 1
 #endif
+#ifndef ESTD_STORE_AUX
+#define ESTD_STORE_AUX 0   // buffer-store cache policy bits (2 = nt)
+#endif
 #ifndef ESTD_ABL
 #define ESTD_ABL 0   // timing ablations only (tools/ablate_conv.sh); results are wrong when != 0
 #endif
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
                             if (p.residual) v0 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, eo, so, 0));
                             v0 *= p.out_scale;
                             if (p.accumulate) v0 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_out, eo, so, 0));
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_out, eo, so, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_out, eo, so, ESTD_STORE_AUX);
                         } else {
                             if (p.residual) {
                                 const u32x2 rv = __builtin_amdgcn_raw_buffer_load_b64(rs_res, eo, so, 0);
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
                             }
                             const float2 ov = make_float2(v0, v1);
                             u32x2 od; __builtin_memcpy(&od, &ov, 8);
-                            __builtin_amdgcn_raw_buffer_store_b64(od, rs_out, eo, so, 0);
+                            __builtin_amdgcn_raw_buffer_store_b64(od, rs_out, eo, so, ESTD_STORE_AUX);
                         }
                     }
                 }

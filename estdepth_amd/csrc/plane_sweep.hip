@@ -213,38 +213,57 @@ __global__ __launch_bounds__(256) void mix1x1_kernel(const float* __restrict__ i
     }
 }
 
-// Fused warp + pre0.  8 lanes per voxel, each lane owns one float4 of the 32 channels, so a wave
-// writes 8 consecutive 128-byte voxel records per step and reads 4 x 128-byte source records.
-constexpr int SWEEP_VOX_PER_BLOCK = 32;   // 256 threads / 8
-constexpr int SWEEP_STEPS = 8;            // voxels per lane group per block
+// Fused warp + pre0.  Two phases per 256-voxel block:
+//   1. one thread per voxel evaluates the homography (4 offsets + 4 weights) ONCE and parks them in LDS
+//      (the coordinate math is ~90 VALU ops: doing it in each of the 8 channel lanes made the kernel VALU-bound);
+//   2. 8 lanes per voxel (one float4 of the 32 channels each) fetch the record from LDS (16-byte broadcast reads),
+//      gather the four 128-byte source records from the L2-resident map and write whole 128-byte voxel records.
+constexpr int SWEEP_VOX_PER_BLOCK = 256;
 
 __global__ __launch_bounds__(256) void homo_warp_costvol_kernel(const float* __restrict__ src, const float* __restrict__ ref,
                                                                 const float* __restrict__ P, const float* __restrict__ dvals,
                                                                 float* __restrict__ out, int D, int H, int W)
 {
+    __shared__ __attribute__((aligned(16))) int s_off[SWEEP_VOX_PER_BLOCK][4];
+    __shared__ __attribute__((aligned(16))) float s_w[SWEEP_VOX_PER_BLOCK][4];
     const long long HW = (long long)H * W;
     const long long total = (long long)D * HW;
-    const int sub = threadIdx.x & 7;
-    const int grp = threadIdx.x >> 3;
-    const long long base = (long long)blockIdx.x * (SWEEP_VOX_PER_BLOCK * SWEEP_STEPS);
-#pragma unroll
-    for (int s = 0; s < SWEEP_STEPS; ++s) {
-        const long long idx = base + s * SWEEP_VOX_PER_BLOCK + grp;
-        if (idx >= total) break;
+    const long long base = (long long)blockIdx.x * SWEEP_VOX_PER_BLOCK;
+    {
+        const long long raw = base + threadIdx.x;
+        const long long idx = raw < total ? raw : total - 1;
         const int x = (int)(idx % W);
         const int y = (int)((idx / W) % H);
         const int d = (int)(idx / HW);
         const Bilin b = sweep_coords(P, dvals[d], x, y, H, W);
-        const float4* s4 = reinterpret_cast<const float4*>(src) + sub;
-        const float4 c00 = s4[(long long)b.o00 * 8], c01 = s4[(long long)b.o01 * 8];
-        const float4 c10 = s4[(long long)b.o10 * 8], c11 = s4[(long long)b.o11 * 8];
-        const float4 rf = reinterpret_cast<const float4*>(ref)[((long long)y * W + x) * 8 + sub];
-        float4 o;
-        o.x = rf.x + (c00.x * b.w00 + c01.x * b.w01 + c10.x * b.w10 + c11.x * b.w11);
-        o.y = rf.y + (c00.y * b.w00 + c01.y * b.w01 + c10.y * b.w10 + c11.y * b.w11);
-        o.z = rf.z + (c00.z * b.w00 + c01.z * b.w01 + c10.z * b.w10 + c11.z * b.w11);
-        o.w = rf.w + (c00.w * b.w00 + c01.w * b.w01 + c10.w * b.w10 + c11.w * b.w11);
-        reinterpret_cast<float4*>(out)[idx * 8 + sub] = o;
+        *reinterpret_cast<int4*>(s_off[threadIdx.x]) = make_int4(b.o00, b.o01, b.o10, b.o11);
+        *reinterpret_cast<float4*>(s_w[threadIdx.x]) = make_float4(b.w00, b.w01, b.w10, b.w11);
+    }
+    __syncthreads();
+    const int sub = threadIdx.x & 7;
+    const int grp = threadIdx.x >> 3;
+    const float4* s4 = reinterpret_cast<const float4*>(src) + sub;
+    const float4* r4 = reinterpret_cast<const float4*>(ref) + sub;
+    float4* o4 = reinterpret_cast<float4*>(out) + sub;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int v = s * 32 + grp;
+        const long long idx = base + v;
+        if (idx < total) {
+            const int4 of = *reinterpret_cast<const int4*>(s_off[v]);
+            const float4 w = *reinterpret_cast<const float4*>(s_w[v]);
+            const float4 c00 = s4[(long long)of.x * 8], c01 = s4[(long long)of.y * 8];
+            const float4 c10 = s4[(long long)of.z * 8], c11 = s4[(long long)of.w * 8];
+            const float4 rf = r4[(idx % HW) * 8];
+            float4 o;
+            o.x = rf.x + (c00.x * w.x + c01.x * w.y + c10.x * w.z + c11.x * w.w);
+            o.y = rf.y + (c00.y * w.x + c01.y * w.y + c10.y * w.z + c11.y * w.w);
+            o.z = rf.z + (c00.z * w.x + c01.z * w.y + c10.z * w.z + c11.z * w.w);
+            o.w = rf.w + (c00.w * w.x + c01.w * w.y + c10.w * w.z + c11.w * w.w);
+            typedef float nt_f4 __attribute__((ext_vector_type(4)));
+            nt_f4 ov = {o.x, o.y, o.z, o.w};
+            __builtin_nontemporal_store(ov, reinterpret_cast<nt_f4*>(&o4[idx * 8]));   // streamed once, read later by the conv
+        }
     }
 }
 
@@ -294,7 +313,7 @@ extern "C" int estd_homo_warp_costvol(const float* src, const float* ref, const 
 {
     if (!src || !ref || !P || !dvals || !out || D <= 0 || H <= 0 || W <= 0) return ESTD_ERR_ARG;
     const long long total = (long long)D * H * W;
-    const long long per_block = SWEEP_VOX_PER_BLOCK * SWEEP_STEPS;
+    const long long per_block = SWEEP_VOX_PER_BLOCK;
     hipLaunchKernelGGL(homo_warp_costvol_kernel, dim3((unsigned)((total + per_block - 1) / per_block)), dim3(256), 0,
                        estd_stream(s), src, ref, P, dvals, out, D, H, W);
     return ESTD_LAUNCH_CHECK();
