@@ -24,7 +24,7 @@ class Conv3dDesc(ctypes.Structure):
         ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
         ("act_a", ctypes.c_int), ("act_b", ctypes.c_int), ("act_split", ctypes.c_int),
         ("out_main", ctypes.c_void_p), ("out_stride", ctypes.c_int), ("out_channels", ctypes.c_int),
-        ("residual", ctypes.c_void_p), ("out_scale", ctypes.c_float), ("accumulate", ctypes.c_int),
+        ("residual", ctypes.c_void_p), ("residual2", ctypes.c_void_p), ("out_scale", ctypes.c_float), ("accumulate", ctypes.c_int),
         ("out_extra", ctypes.c_void_p),
         ("head_w", ctypes.c_void_p), ("head_b", ctypes.c_void_p), ("out_head", ctypes.c_void_p),
         ("stats_partials", ctypes.c_void_p),

@@ -195,9 +195,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
         const int ey0 = th0 + row0, ex0 = tw0 + 4 * g;
 
         // output descriptors and per-lane output offsets of this segment (bytes inside one depth plane)
-        __amdgpu_buffer_rsrc_t rs_out = rs_in, rs_res = rs_in;
+        __amdgpu_buffer_rsrc_t rs_out = rs_in, rs_res = rs_in, rs_res2 = rs_in;
         if (p.out_main) rs_out = make_rsrc(p.out_main + (size_t)n * vol * p.out_stride, vol * p.out_stride);
         if (p.residual) rs_res = make_rsrc(p.residual + (size_t)n * vol * p.out_stride, vol * p.out_stride);
+        if (p.residual2) rs_res2 = make_rsrc(p.residual2 + (size_t)n * vol * p.out_stride, vol * p.out_stride);
         const int out_plane_bytes = HW * p.out_stride * 4;
         unsigned eoff[MT][4];
 #pragma unroll
@@ -246,12 +247,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
                         const int so = dd * out_plane_bytes;
                         if (NT == 1) {
                             if (p.residual) v0 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, eo, so, 0));
+                            if (p.residual2) v0 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res2, eo, so, 0));
                             v0 *= p.out_scale;
                             if (p.accumulate) v0 += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_out, eo, so, 0));
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_out, eo, so, ESTD_STORE_AUX);
                         } else {
                             if (p.residual) {
                                 const u32x2 rv = __builtin_amdgcn_raw_buffer_load_b64(rs_res, eo, so, 0);
+                                float2 rr; __builtin_memcpy(&rr, &rv, 8);
+                                v0 += rr.x; v1 += rr.y;
+                            }
+                            if (p.residual2) {
+                                const u32x2 rv = __builtin_amdgcn_raw_buffer_load_b64(rs_res2, eo, so, 0);
                                 float2 rr; __builtin_memcpy(&rr, &rv, 8);
                                 v0 += rr.x; v1 += rr.y;
                             }

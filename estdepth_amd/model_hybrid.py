@@ -48,7 +48,7 @@ class DepthNetHybrid(nn.Module):
             # pre0(cat[ref, warped]) = (sc*W[:, :32]) ref + sh  +  warp((sc*W[:, 32:]) src)      (:93-94)
             return {"w_ref": (sc[:, None] * w0[:, :32]).contiguous().to(dev), "b_ref": sh.contiguous().to(dev),
                     "w_src": (sc[:, None] * w0[:, 32:]).contiguous().to(dev),
-                    "pre1": self.pre1.plan(), "pre2": self.pre2.plan()}
+                    "pre1": self.pre1.plan(), "pre2": self.pre2.plan(), "pre2x2": self.pre2.plan().with_shift_scaled(2)}
         return self._cache.get(self, build)
 
     def _costvolumes(self, ref_mixes, src_mix_pairs, ref_poses, src_pose_pairs, cam_intr, depth_values):
@@ -63,16 +63,29 @@ class DepthNetHybrid(nn.Module):
         dims = (T, D, H, W)
         dev = ref_mixes[0].device
         cost = torch.empty((T, D, H, W, 32), device=dev, dtype=torch.float32)
-        x = torch.empty_like(cost)
         y = torch.empty_like(cost)
         n_src = len(src_mix_pairs[0])
-        for k in range(n_src):
+
+        def sweep(k, x):
             for t in range(T):
                 proj = ops.cam_sweep_proj(ref_poses[t], src_pose_pairs[t][k], cam_intr)          # :74-88 + homo_utils.py:469
                 ops.homo_warp_costvol(src_mix_pairs[t][k], ref_mixes[t], proj, depth_values, D, out=x[t])   # :90-94
-            P["pre1"].run(x, dims, out=y, out_stride=32)                                          # :95
-            P["pre2"].run(y, dims, out=cost, out_stride=32, residual=x,
-                          out_scale=1.0 / n_src, accumulate=(k > 0))                              # :95-99
+
+        if n_src == 2:
+            # pre2 = conv + BN is LINEAR (no activation, :60), so  sum_k pre2(y_k) = conv(sum_k y_k)*s + n*t :
+            # ONE pre2 convolution per target instead of one per source.  cost = (x_0 + x_1 + pre2sum(y_0 + y_1)) / 2.
+            xs = [torch.empty_like(cost), torch.empty_like(cost)]
+            for k in range(2):
+                sweep(k, xs[k])
+                P["pre1"].run(xs[k], dims, out=y, out_stride=32, accumulate=(k > 0))              # y = y_0 + y_1   (:95)
+            P["pre2x2"].run(y, dims, out=cost, out_stride=32, residual=xs[0], residual2=xs[1], out_scale=0.5)   # :95-99
+        else:
+            x = torch.empty_like(cost)
+            for k in range(n_src):
+                sweep(k, x)
+                P["pre1"].run(x, dims, out=y, out_stride=32)                                      # :95
+                P["pre2"].run(y, dims, out=cost, out_stride=32, residual=x,
+                              out_scale=1.0 / n_src, accumulate=(k > 0))                          # :95-99
         return cost
 
     def _costvolume(self, ref_mix, src_mixes, ref_pose, src_poses, cam_intr, depth_values):

@@ -115,8 +115,16 @@ class Conv3dPlan:
         self.head_w = head_w.float().contiguous().to(device) if head_w is not None else None
         self.head_b = head_b.float().contiguous().to(device) if head_b is not None else None
 
+    def with_shift_scaled(self, k):
+        """same packed weights, BN shift multiplied by k: sum of k conv+BN results of a LINEAR layer computed as ONE
+        convolution of the summed inputs (conv is linear, the shift is counted k times)."""
+        import copy
+        other = copy.copy(self)
+        other.shift = (self.shift * float(k)).contiguous()
+        return other
+
     def run(self, x, dims, in_stride=None, in_extra=None, out=None, out_stride=None, out_channels=None,
-            residual=None, out_scale=1.0, accumulate=False, out_extra=None, out_head=None, stats_partials=None):
+            residual=None, residual2=None, out_scale=1.0, accumulate=False, out_extra=None, out_head=None, stats_partials=None):
         """x: channels-last volume(s) [N,D,H,W,in_stride] (or a base view of it); dims = (N,D,H,W)."""
         Nn, D, H, W = dims
         d = N.Conv3dDesc()
@@ -138,6 +146,7 @@ class Conv3dPlan:
         d.out_stride = out_stride if out_stride is not None else (16 * min(self.n_tiles, 2))
         d.out_channels = out_channels if out_channels is not None else 16 * min(self.n_tiles, 2)
         d.residual = residual.data_ptr() if residual is not None else None
+        d.residual2 = residual2.data_ptr() if residual2 is not None else None
         d.out_scale = float(out_scale)
         d.accumulate = 1 if accumulate else 0
         d.out_extra = out_extra.data_ptr() if out_extra is not None else None

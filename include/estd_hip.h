@@ -97,6 +97,7 @@ typedef struct estd_conv3d_desc {
     int out_stride;
     int out_channels;         /* 16 or 32 real channels written to out_main */
     const float* residual;    /* vol with the layout of out_main added after the activation, or NULL */
+    const float* residual2;   /* a second such volume (sum over two source views before the linear pre2), or NULL */
     float out_scale;          /* applied after the residual add (1.0 = none) */
     int accumulate;           /* 1: out_main += result (running sum over source views) */
     float* out_extra;         /* scalar volume receiving output channel 32 (n_tiles == 3), or NULL */
