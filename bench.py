@@ -146,12 +146,18 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
+    if "ESTD_FORCE_DEVICE" in os.environ:          # code-path smoke test of N > 1 on a single-GPU box (with gloo)
+        local_rank = int(os.environ["ESTD_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=device)
+        backend = os.environ.get("ESTD_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
     torch.backends.cudnn.benchmark = True
     torch.backends.cudnn.allow_tf32 = False
     torch.backends.cuda.matmul.allow_tf32 = False

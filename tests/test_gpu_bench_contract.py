@@ -1,0 +1,48 @@
+"""GPU: bench.py contract -- one JSON line with the required keys at N=1, and the N=2 code path (two ranks sharing the
+single test GPU, gloo instead of RCCL) including the memory-bank all-gather and the max-over-ranks timing."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_line():
+    out = subprocess.run([sys.executable, "bench.py", "--workload", "cfg1", "--steps", "3", "--warmup", "1"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=900)
+    d = _last_json(out.stdout)
+    assert REQUIRED <= set(d) and "cpu_baseline" in d
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["workload"].startswith("cfg1")
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+
+
+def test_bench_two_ranks_code_path():
+    env = dict(os.environ, ESTD_FORCE_DEVICE="0", ESTD_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--workload", "cfg1", "--steps", "3", "--warmup", "1"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert "all-gather" in d["config"]["parallelism"]
