@@ -104,3 +104,18 @@ def e2e_inputs(n_views, hi, wi, seed, first_frame=0):
 
 
 E2E_HI, E2E_WI = 128, 160
+
+
+def g10_cases():
+    """G10 depth-error suite (metric.py): (name, pred, gt) float64 maps with out-of-window, zero, NaN and inf pixels."""
+    out = []
+    for i, (h, w, bias) in enumerate(((24, 32, 0.0), (17, 23, 0.4), (8, 8, -0.2))):
+        g = np.random.default_rng(100 + i)
+        gt = g.uniform(0.1, 6.0, size=(h, w))
+        pred = gt * np.exp(g.normal(bias * 0.1, 0.15, size=(h, w))) + bias * 0.05
+        gt[0, :3] = 0.0
+        gt[1, 0], gt[1, 1] = np.nan, np.inf
+        pred[2, 0], pred[2, 1], pred[2, 2] = np.nan, np.inf, -1.0
+        out.append(("m%d" % i, pred, gt))
+    out.append(("empty", np.full((4, 4), 7.0), np.full((4, 4), 7.0)))
+    return out

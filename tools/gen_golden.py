@@ -57,7 +57,33 @@ def checksum(t):
     return np.concatenate([[a.sum().item(), a.abs().sum().item()], a[idx].numpy()])
 
 
+def gen_metrics():
+    """G10: the reference's depth-error suite (metric.py) on seeded maps -> scalar tables."""
+    sys.path.insert(0, REF)
+    import metric as rm
+    out = {}
+    for name, pred, gt in S.g10_cases():
+        with np.errstate(all="ignore"):
+            e = rm.compute_errors(pred.copy(), gt.copy())
+        keys = sorted(e)
+        out[name + "|keys"] = np.array(keys)
+        out[name + "|vals"] = np.array([float(e[k]) for k in keys], dtype=np.float64)
+        m = rm.compute_valid_depth_mask(pred, gt)
+        out[name + "|mask"] = m
+        if m.sum():
+            p, g = pred[m], gt[m]
+            out[name + "|scale"] = np.array([rm.compute_depth_scale_factor(p, g, s) for s in ("abs", "log", "inv")])
+            e0, e1 = rm.evaluate_depth(np.array([0.3, 0.1, 0.2]), gt.copy(), pred.copy(), inverse_gt=False, inverse_pred=False)
+            out[name + "|eval0"] = np.array([float(e0[k]) for k in keys])
+            out[name + "|eval1"] = np.array([float(e1[k]) for k in keys])
+    np.savez(os.path.join(OUT, "g10_metrics.npz"), **out)
+    print("G10 done")
+
+
 def main():
+    if "--metrics-only" in sys.argv:
+        os.makedirs(OUT, exist_ok=True)
+        return gen_metrics()
     torch.set_grad_enabled(False)
     torch.manual_seed(0)
     hu, et, hd, mh = import_reference()
@@ -176,6 +202,7 @@ def main():
         out["c%d|pose" % call] = npy(pre_poses[0])
         out["c%d|value_ck" % call] = checksum(pre_costs["values"][0])
     np.savez(os.path.join(OUT, "g9_joint_carry.npz"), **out)
+    gen_metrics()
     print("done")
 
 
