@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_BF16_MATRIX_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak; the 3xbf16 split spends 6 bf16 FLOPs per fp32 FLOP
 HBM_PEAK_GBS = 8000.0
 
 
@@ -35,6 +36,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--conv3d-arith", default=os.environ.get("ESTD_CONV3D_ARITH", "f32"), choices=["f32", "bf16x3"],
+                    help="products of the plain 32->32 3D convolutions: native fp32 MFMA (default) or the exact 3-way bf16 "
+                         "operand split with six bf16 MFMAs per product block (fp32-level error, opt-in)")
     return ap.parse_args()
 
 
@@ -163,6 +167,7 @@ def main():
     torch.backends.cuda.matmul.allow_tf32 = False
 
     from estdepth_amd import ops, parallel
+    ops.CONV3D_ARITH = args.conv3d_arith
     if args.workload == "stream":
         return stream_bench(args, device, rank, world)
     model = build_model(args.workload, device)
@@ -247,11 +252,12 @@ def main():
         tot_ms = sum(s.elapsed_time(e) for (_, s, e) in prof)
         tot_flop = sum(f for (f, _, _) in prof)
         achieved = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        peak = PEAK_FP32_MATRIX_TFLOPS if args.conv3d_arith == "f32" else PEAK_BF16_MATRIX_TFLOPS / 6.0
         # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE, see
         # profiles/r1_conv3d_pmc.json), scaled to this run's average volumes per launch; null if the file is absent
         traffic = None
         pmc_file = os.path.join(ROOT, "profiles", "r1_conv3d_pmc.json")
-        if os.path.exists(pmc_file) and prof and args.workload != "cfg1":
+        if os.path.exists(pmc_file) and prof and args.workload != "cfg1" and args.conv3d_arith == "f32":
             per_vol = json.load(open(pmc_file))["hbm_bytes_per_volume"]
             vols = tot_flop / (2.0 * 27 * 32 * 32 * 64 * 120 * 160)
             traffic = round(per_vol * vols / len(prof))
@@ -259,18 +265,23 @@ def main():
             "metric": "depth frames/sec (seq_len=5, 480x640, D=64)" if args.workload == "joint" else "depth frames/sec",
             "value": round(value, 3), "unit": "depth frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32" if args.conv3d_arith == "f32" else "f32 (32->32 conv3d products as six bf16 MFMAs of exactly 3-way-split operands, f32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": {"joint": "cfg2: seq_len=5, 480x640, ndepths=64, ResNet-50, Joint mode steady state (carried memory, EST on)",
                                     "estm": "cfg3: ESTM steady-state window (3 frames, memory 2), 480x640, ndepths=64, ResNet-50",
                                     "cfg1": "cfg1: seq_len=3, 128x160, ndepths=16, ResNet-18, EST off"}[args.workload],
                        "depth_frames_per_step": frames, "input_frames_per_step": x_imgs.shape[1],
                        "input_frames_per_s": round(x_imgs.shape[1] * world * args.steps / elapsed, 3),
                        "launch": "eager" if (args.no_graph or state["fwd"] is model) else "hipGraph replay",
+                       "conv3d_arith": args.conv3d_arith,
                        "notes": state["notes"],
                        "parallelism": "1 sequence per GPU" + ("; RCCL all-gather of {K,V,pose} per step, overlapped with the next step" if world > 1 and not args.no_allgather else "")},
-            "roofline": {"bound": "mfma", "kernel": "conv3d_k3_kernel<32,2> (3x3x3 conv 32->32, fp32 MFMA 16x16x4)",
-                         "achieved": round(achieved, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": traffic,
+            "roofline": {"bound": "mfma",
+                         "kernel": "conv3d_k3_kernel<32,2> (3x3x3 conv 32->32, fp32 MFMA 16x16x4)" if args.conv3d_arith == "f32" else
+                                   "conv3d_k3_split_kernel (3x3x3 conv 32->32, 6 x bf16 MFMA 16x16x32 per fp32 product block; peak = bf16 dense / 6)",
+                         "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_conv3d_pmc.json)",
                          "launches": len(prof), "avg_launch_ms": round(tot_ms / max(len(prof), 1), 4)},
         }

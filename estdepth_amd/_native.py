@@ -28,6 +28,7 @@ class Conv3dDesc(ctypes.Structure):
         ("out_extra", ctypes.c_void_p),
         ("head_w", ctypes.c_void_p), ("head_b", ctypes.c_void_p), ("out_head", ctypes.c_void_p),
         ("stats_partials", ctypes.c_void_p),
+        ("w_split", ctypes.c_void_p),
     ]
 
 
@@ -56,6 +57,7 @@ _SIGNATURES = {
     "estd_homo_warp_costvol": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
                                               ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
     "estd_conv3d_k3": (ctypes.c_int, [ctypes.POINTER(Conv3dDesc), c_stream]),
+    "estd_conv3d_k3_split": (ctypes.c_int, [ctypes.POINTER(Conv3dDesc), c_stream]),
     "estd_conv2d_k3": (ctypes.c_int, [ctypes.POINTER(Conv2dDesc), c_stream]),
     "estd_conv3d_k3_grid": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "estd_groupnorm_finalize": (ctypes.c_int, [c_float_p, ctypes.c_int, ctypes.c_double, ctypes.c_float,

@@ -1,0 +1,509 @@
+// conv3d_split_bf16.hip -- the 32->32 3x3x3 convolution with fp32 operands split into three bf16 pieces.
+//
+// Same operator, descriptor and epilogue as conv3d_mfma.hip (networks/layers_op.py:16-39 stacks,
+// transformer/epipolar_transformer.py:21); different arithmetic for the products:
+//
+//     a = a1 + a2 + a3,  b = b1 + b2 + b3      (round-to-nearest bf16 pieces; the split is exact: 3 x 8 >= 24 bits)
+//     a*b ~= a1b3 + a3b1 + a2b2 + a1b2 + a2b1 + a1b1      (dropped terms <= 2^-26 |ab|; fp32 accumulation in the MFMA)
+//
+// i.e. six v_mfma_f32_16x16x32_bf16 (K = 32 = all input channels of one tap, 16 cycles each) replace eight
+// v_mfma_f32_16x16x4_f32 (32 cycles each): 96 instead of 256 matrix-pipe cycles per (16 voxels x 16 channels x tap),
+// and far fewer joules -- the fp32 kernel is DVFS-limited.  The result carries fp32-level error
+// (tests/test_gpu_split_conv.py measures both kernels against an fp64 convolution).
+//
+// Design (CDNA4), differences from the fp32 kernel:
+//   * The operands are needed faster than a wave-private stream from L2 can supply them, so BOTH operands come from
+//     LDS: 512-thread workgroup (8 waves, one per tile row), tile 1 x 8 x 32 voxels, one workgroup per CU.
+//   * Input slices are split into bf16 pieces ONCE, when they enter LDS (9 VALU ops per channel pair per slice
+//     element; every element is then read 27 times).  LDS slice layout [piece][chunk of 8 channels][voxel] x 16 B with
+//     the voxel index rotated by 2*chunk: the A-fragment read (16 consecutive voxels, chunk = k-group) and the fill
+//     (chunk fastest across lanes) are both bank-conflict free.
+//   * 2-slot slice ring: taps kd=0 read slice d-1; once they are done its slot is refilled with slice d+1 (prefetched
+//     into registers during the previous tile) while the kd=1 taps run; kd=2 then reads it.  2 x 66 KB.
+//   * Weights: host-split [tap][piece][n-tile][lane][8] bf16 (6 KB per tap, packing.py::pack_conv3d_split), streamed
+//     L2 -> registers -> a 2-slot LDS buffer one tap ahead; fragments for tap t+1 are read into registers during tap t.
+//     One LDS-only barrier per tap publishes the weight slot, the ring refill and the GroupNorm scratch.
+//   * The body of a tap is ONE basic block (no exec-mask or uniform branches: out-of-range work is redirected to
+//     out-of-bounds buffer offsets / an LDS dump area) so that the issue order can be prescribed: every MFMA is
+//     followed by a few of the tap's other instructions (LDS reads of the next tap, weight hand-over, slice split,
+//     the previous tile's epilogue), which then execute in the shadow of the 16-cycle matrix operation.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "estd_hip.h"
+#include "estd_common.h"
+
+#ifdef ESTD_TIMELINE
+#define ESTD_SPLIT_STATS_ON 0   // debug build: stats_partials receives per-tile time stamps instead of GroupNorm sums
+#else
+#define ESTD_SPLIT_STATS_ON 1
+#endif
+#ifndef ESTD_SABL
+#define ESTD_SABL 0   // timing ablations only (tools/ablate_split.sh); results are wrong when != 0
+#endif
+#ifndef ESTD_SPIPE
+#define ESTD_SPIPE 1  // 1: prescribe the per-tap issue pipeline with sched_group_barrier
+#endif
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((__vector_size__(16)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
+typedef unsigned int u32x2 __attribute__((__vector_size__(8)));
+
+constexpr int TH = 8, TW = 32;
+constexpr int IN_H = TH + 2, IN_W = TW + 2;
+constexpr int SL_VOX = IN_H * IN_W;            // 340 voxels per slice (with halo)
+constexpr int PLANE = 352;                     // 16-byte entries per chunk plane: multiple of 16, >= 340 + 6 (rotation)
+constexpr int CHUNK_BYTES = PLANE * 16;        // 5632
+constexpr int PIECE_BYTES = 4 * CHUNK_BYTES;   // 22528
+constexpr int SLICE_BYTES = 3 * PIECE_BYTES;   // 67584
+constexpr int WTAP_BYTES = 3 * 2 * 64 * 16;    // 6144 bytes of split weights per tap: [piece][n-tile][lane] x 16 B
+constexpr int WSLOT_BYTES = 512 * 16;          // LDS weight slot: every thread hands over 16 B (the last 2 KB are padding)
+constexpr int LDS_W = 2 * SLICE_BYTES;
+constexpr int LDS_DUMP = LDS_W + 2 * WSLOT_BYTES;      // 512 x 16 B: target of the fill writes of threads without an item
+constexpr int LDS_RED = LDS_DUMP + 512 * 16;
+constexpr int LDS_TOTAL = LDS_RED + 8 * 4 * 8;         // 160000 of 163840
+constexpr int FILL_E = SL_VOX * 4;             // (voxel, chunk) items per slice: 1360
+constexpr int FIT = 3;                         // items per thread (512 threads)
+constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;
+
+__device__ __forceinline__ float4 as_float4(u32x4 v)
+{
+    float4 f;
+    __builtin_memcpy(&f, &v, 16);
+    return f;
+}
+
+__device__ __forceinline__ float2 as_float2(u32x2 v)
+{
+    float2 f;
+    __builtin_memcpy(&f, &v, 8);
+    return f;
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, size_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// x0, x1 -> three packed bf16 pairs with x = h + m + l (exact unless x is within 2^-24 of the bf16 range limits)
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& h, unsigned& m, unsigned& l)
+{
+    const bf16x2 hb = {(__bf16)x0, (__bf16)x1};
+    h = __builtin_bit_cast(unsigned, hb);
+    float r0 = x0 - __builtin_bit_cast(float, h << 16);
+    float r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+    const bf16x2 mb = {(__bf16)r0, (__bf16)r1};
+    m = __builtin_bit_cast(unsigned, mb);
+    r0 -= __builtin_bit_cast(float, m << 16);
+    r1 -= __builtin_bit_cast(float, m & 0xffff0000u);
+    const bf16x2 lb = {(__bf16)r0, (__bf16)r1};
+    l = __builtin_bit_cast(unsigned, lb);
+}
+
+// 8 channels (two float4) of one voxel -> LDS, one 16-byte write per piece (o1 - o0 = o2 - o1 = PIECE_BYTES for real items)
+__device__ __forceinline__ void fill_item(char* smem, int o0, int o1, int o2, float4 a, float4 b)
+{
+    u32x4 h, m, l;
+    unsigned th, tm, tl;
+    split2(a.x, a.y, th, tm, tl); h[0] = th; m[0] = tm; l[0] = tl;
+    split2(a.z, a.w, th, tm, tl); h[1] = th; m[1] = tm; l[1] = tl;
+    split2(b.x, b.y, th, tm, tl); h[2] = th; m[2] = tm; l[2] = tl;
+    split2(b.z, b.w, th, tm, tl); h[3] = th; m[3] = tm; l[3] = tl;
+    *reinterpret_cast<u32x4*>(smem + o0) = h;
+    *reinterpret_cast<u32x4*>(smem + o1) = m;
+    *reinterpret_cast<u32x4*>(smem + o2) = l;
+}
+
+// compile-time tap index: a "#pragma unroll" loop gets peeled (some taps are special) and is then no longer fully unrolled
+template <typename F, int... I>
+__device__ __forceinline__ void for_each_tap(F&& f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
+// Issue order of one tap: one MFMA, then a few of the other instructions of the tap (IGroupLP pipeline).
+//   0x008 MFMA   0x100 DS read   0x200 DS write   0x020 VMEM read   0x040 VMEM write   0x002 VALU   0x004 SALU
+template <int TAP>
+__device__ __forceinline__ void tap_pipeline()
+{
+#if ESTD_SPIPE
+#pragma unroll
+    for (int k = 0; k < 24; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (k < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (TAP <= 2 || (TAP >= 8 && TAP <= 10)) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);    // epilogue / slice split
+        if (k >= 12 && k < 16) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        if (k >= 12) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if (TAP >= 1 && TAP <= 2 && k >= 16 && k < 20) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+    }
+#endif
+}
+
+template <bool TANH, bool STATS>
+__global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int total_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // = tile row of this wave
+    const int g = lane >> 4;            // k group (A, B) / row group (D)
+    const int i = lane & 15;            // M row (A) / N column (B, D)
+    const int D = p.D, H = p.H, W = p.W;
+
+    int u, u_end;
+    {
+        const int G = gridDim.x, bid = blockIdx.x;
+        const int r = ((G & 7) == 0) ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;     // XCD x owns a contiguous block of ranges
+        u = (int)((long long)total_tiles * r / G);
+        u_end = (int)((long long)total_tiles * (r + 1) / G);
+    }
+    if (u >= u_end) return;
+
+    const int cbase = 2 * i;            // output channels of this lane: 2i (n-tile 0), 2i+1 (n-tile 1)
+    const float sc0 = p.scale[cbase], sh0 = p.shift[cbase], sc1 = p.scale[cbase + 1], sh1 = p.shift[cbase + 1];
+    const int act0 = cbase < p.act_split ? p.act_a : p.act_b;
+    const float relu_floor = act0 == ESTD_ACT_RELU ? 0.0f : -__builtin_huge_valf();    // max(v, floor): branch-free ReLU / identity
+    const float out_scale = p.out_scale;
+
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w_split, (size_t)27 * WTAP_BYTES);
+    const size_t vol = (size_t)D * H * W;
+    const int HW = H * W;
+    const int tiles_w16 = (W + 15) / 16;                 // GroupNorm partials keep the 8x16-tile numbering of estd_conv3d_k3_grid
+    const int a_lane = g * CHUNK_BYTES + (i + 2 * g) * 16;     // lane part of an A-fragment address
+    const int b_lane = lane * 16;
+    const int w_lane = tid * 16;
+    double* red = reinterpret_cast<double*>(smem + LDS_RED);
+
+    while (u < u_end) {
+        // ---- column segment [u, seg_end): same (n, h-tile, w-tile), consecutive d ----
+        const int col = u / D;
+        int d = u - col * D;
+        const int twi = col % tiles_w, c2 = col / tiles_w;
+        const int thi = c2 % tiles_h, n = c2 / tiles_h;
+        const int tw0 = twi * TW, th0 = thi * TH;
+        const int seg_end = min(u_end, (col + 1) * D);
+
+        // absent optional operands get an EMPTY descriptor: every load returns 0, so the epilogue needs no branches
+        const size_t out_bytes = vol * p.out_stride * 4;
+        const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in_main + (size_t)n * vol * p.in_stride, vol * p.in_stride * 4);
+        const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(p.out_main + (size_t)n * vol * p.out_stride, out_bytes);
+        const __amdgpu_buffer_rsrc_t rs_res = make_rsrc(p.residual ? p.residual + (size_t)n * vol * p.out_stride : p.out_main, p.residual ? out_bytes : 0);
+        const __amdgpu_buffer_rsrc_t rs_res2 = make_rsrc(p.residual2 ? p.residual2 + (size_t)n * vol * p.out_stride : p.out_main, p.residual2 ? out_bytes : 0);
+        const __amdgpu_buffer_rsrc_t rs_acc = make_rsrc(p.out_main + (size_t)n * vol * p.out_stride, p.accumulate ? out_bytes : 0);
+        const int in_slice_bytes = HW * p.in_stride * 4;
+        const int out_plane_bytes = HW * p.out_stride * 4;
+
+        // slice-fill items of this thread: item e = (voxel e/4, chunk e%4): 32 contiguous bytes of the voxel record
+        unsigned voff[FIT];
+        int loff[FIT];
+#pragma unroll
+        for (int it = 0; it < FIT; ++it) {
+            const int e = tid + it * 512;
+            const int vs = e >> 2, c = e & 3;
+            const int zy = vs / IN_W, zx = vs - zy * IN_W;
+            const int gy = th0 - 1 + zy, gx = tw0 - 1 + zx;
+            const bool ok = e < FILL_E && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            voff[it] = ok ? (unsigned)((gy * W + gx) * p.in_stride + c * 8) * 4u : OOB_OFFSET;
+            loff[it] = e < FILL_E ? c * CHUNK_BYTES + (vs + 2 * c) * 16 : -1;
+        }
+        const bool last_item = loff[FIT - 1] >= 0;       // items 0..FIT-2 exist for every thread
+        auto fill = [&](int slot_bytes, int it, float4 a, float4 b) {
+            const bool real = it < FIT - 1 || last_item;
+            const int o0 = real ? slot_bytes + loff[it] : LDS_DUMP + w_lane;
+            const int st = real ? PIECE_BYTES : 0;
+            fill_item(smem, o0, o0 + st, o0 + 2 * st, a, b);
+        };
+
+        // epilogue lane offsets: this wave owns tile row `wave`; M tile m covers columns 16m..16m+15; lane rows 4g..4g+3
+        const int ey = th0 + wave;
+        unsigned eoff[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int x = tw0 + 16 * m + 4 * g + r;
+                eoff[m][r] = (ey < H && x < W) ? (unsigned)((ey * W + x) * p.out_stride + cbase) * 4u : OOB_OFFSET;
+            }
+
+        // ---- epilogue of one M tile, in two halves so that its loads are a tap ahead of their use ----
+        struct EpiLoads { u32x2 r1[4], r2[4], ac[4]; };
+        auto epi_load = [&](EpiLoads& L, int m, int dd, bool live) {
+            const int so = dd * out_plane_bytes;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned eo = live ? eoff[m][r] : OOB_OFFSET;
+                L.r1[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_res, eo, so, 0);
+                L.r2[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_res2, eo, so, 0);
+                L.ac[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_acc, eo, so, 0);
+            }
+        };
+        double s_sum = 0.0, s_sq = 0.0;
+        auto epi_finish = [&](const EpiLoads& L, const f32x4 (&a)[2][2], int m, int dd, bool live) {
+            const int so = dd * out_plane_bytes;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned eo = live ? eoff[m][r] : OOB_OFFSET;
+                float v0 = a[m][0][r] * sc0 + sh0;
+                float v1 = a[m][1][r] * sc1 + sh1;
+                if (STATS) {
+                    const double w = eo != OOB_OFFSET ? 1.0 : 0.0;
+                    s_sum += w * ((double)v0 + (double)v1);
+                    s_sq += w * ((double)v0 * (double)v0 + (double)v1 * (double)v1);
+                }
+                if (TANH) {
+                    if (act0 == ESTD_ACT_TANH) { v0 = tanhf(v0); v1 = tanhf(v1); }
+                }
+                v0 = fmaxf(v0, relu_floor); v1 = fmaxf(v1, relu_floor);
+                const float2 q1 = as_float2(L.r1[r]), q2 = as_float2(L.r2[r]), qa = as_float2(L.ac[r]);
+                v0 = (v0 + q1.x + q2.x) * out_scale + qa.x;
+                v1 = (v1 + q1.y + q2.y) * out_scale + qa.y;
+                const float2 ov = make_float2(v0, v1);
+                u32x2 od; __builtin_memcpy(&od, &ov, 8);
+                __builtin_amdgcn_raw_buffer_store_b64(od, rs_out, eo, so, 0);
+            }
+        };
+        // GroupNorm partials of one tile: lane sums -> wave sums -> LDS scratch (published by the next barrier)
+        auto stats_to_lds = [&]() {
+            const int grp = (cbase >= 16) ? 1 : 0;
+            double a0 = grp == 0 ? s_sum : 0.0, q0 = grp == 0 ? s_sq : 0.0;
+            double a1 = grp == 1 ? s_sum : 0.0, q1 = grp == 1 ? s_sq : 0.0;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                a0 += __shfl_xor(a0, o); q0 += __shfl_xor(q0, o);
+                a1 += __shfl_xor(a1, o); q1 += __shfl_xor(q1, o);
+            }
+            if (lane == 0) { red[wave * 4 + 0] = a0; red[wave * 4 + 1] = q0; red[wave * 4 + 2] = a1; red[wave * 4 + 3] = q1; }
+            s_sum = 0.0; s_sq = 0.0;
+        };
+        auto stats_store = [&](int dd, bool live) {
+            if (tid < 4 && live) {
+                double tot = 0.0;
+#pragma unroll
+                for (int w8 = 0; w8 < 8; ++w8) tot += red[w8 * 4 + tid];
+                const size_t t16 = (((size_t)n * D + dd) * tiles_h + thi) * tiles_w16 + 2 * twi;
+                p.stats_partials[t16 * 4 + tid] = tot;
+                if (2 * twi + 1 < tiles_w16) p.stats_partials[(t16 + 1) * 4 + tid] = 0.0;
+            }
+        };
+
+        // ---- prologue: prime ring (slot 0 = slice d-1, slot 1 = slice d), weights of taps 0 and 1, prefetch slice d+1 ----
+        lds_barrier();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int sd = d - 1 + s;
+            const bool sv = (unsigned)sd < (unsigned)D;
+            float4 t0[FIT], t1[FIT];
+#pragma unroll
+            for (int it = 0; it < FIT; ++it) {
+                const unsigned vo = sv ? voff[it] : OOB_OFFSET;
+                t0[it] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, sd * in_slice_bytes, 0));
+                t1[it] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, sd * in_slice_bytes + 16, 0));
+            }
+#pragma unroll
+            for (int it = 0; it < FIT; ++it) fill(s * SLICE_BYTES, it, t0[it], t1[it]);
+        }
+        float4 pf[2 * FIT];
+        {
+            const int sd = d + 1;
+#pragma unroll
+            for (int it = 0; it < FIT; ++it) {
+                const unsigned vo = sd < D ? voff[it] : OOB_OFFSET;
+                pf[2 * it] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, sd * in_slice_bytes, 0));
+                pf[2 * it + 1] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, sd * in_slice_bytes + 16, 0));
+            }
+        }
+        u32x4 wreg;
+        {
+            // threads 384..511 hand over bytes beyond the tap (next tap / zeros): they land in the slot padding
+            const u32x4 w0 = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, 0, 0);
+            const u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, WTAP_BYTES, 0);
+            wreg = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, 2 * WTAP_BYTES, 0);
+            *reinterpret_cast<u32x4*>(smem + LDS_W + w_lane) = w0;
+            *reinterpret_cast<u32x4*>(smem + LDS_W + WSLOT_BYTES + w_lane) = w1;
+        }
+        lds_barrier();
+        bf16x8 acur[2][3], bcur[3][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+                acur[m][pc] = *reinterpret_cast<const bf16x8*>(smem + pc * PIECE_BYTES + a_lane + (wave * IN_W + 16 * m) * 16);
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn)
+                bcur[pc][nn] = *reinterpret_cast<const bf16x8*>(smem + LDS_W + (pc * 2 + nn) * 1024 + b_lane);
+        lds_barrier();      // nobody overwrites weight slot 0 (tap 2) before every wave has its tap-0 fragments
+
+        int q = 0;          // ring parity: slot q holds slice d-1 (later d+1), slot q^1 holds slice d
+        int wsel = 1;       // weight slot holding tap t+1 at the start of tap t
+        f32x4 pend[2][2] = {};
+        int pend_d = 0;
+        bool have_pend = false;
+        EpiLoads el;
+
+        for (; u < seg_end; ++u, ++d) {
+            const int sb_even = q * SLICE_BYTES, sb_odd = (q ^ 1) * SLICE_BYTES;
+            const bool fetch = (u + 1 < seg_end) && (d + 2 < D);     // slice d+2 exists and is ours to use
+            const int next_soff = (d + 2) * in_slice_bytes;
+
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn) acc[m][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef ESTD_TIMELINE
+            if (tid == 0 && p.stats_partials) {
+                const size_t t16 = (((size_t)n * D + d) * tiles_h + thi) * tiles_w16 + 2 * twi;
+                p.stats_partials[t16 * 4 + 0] = (double)__builtin_amdgcn_s_memtime();
+                p.stats_partials[t16 * 4 + 1] = (double)blockIdx.x;
+                p.stats_partials[t16 * 4 + 2] = (double)wall_clock64();
+            }
+#endif
+
+            for_each_tap([&](auto tap_c) __attribute__((always_inline)) {
+                constexpr int tap = decltype(tap_c)::value;
+                constexpr int nt = tap == 26 ? 0 : tap + 1;
+                constexpr int nkd = nt / 9, nkh = (nt / 3) % 3, nkw = nt % 3;
+                // slot of the NEXT tap's slice: kd 0/2 -> even slot, kd 1 -> odd slot; tap 0 of the next tile -> its even slot = our odd
+                const int nsb = (tap == 26) ? sb_odd : (nkd == 1 ? sb_odd : sb_even);
+                const int wrd = LDS_W + wsel * WSLOT_BYTES, wwr = LDS_W + (wsel ^ 1) * WSLOT_BYTES;
+
+                // 1. fragments of the next tap
+                bf16x8 anext[2][3], bnext[3][2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) {
+                        if (ESTD_SABL & 2) { anext[m][pc] = acur[m][pc]; asm volatile("" : "+v"(anext[m][pc])); } else
+                        anext[m][pc] = *reinterpret_cast<const bf16x8*>(smem + nsb + pc * PIECE_BYTES + a_lane + ((wave + nkh) * IN_W + nkw + 16 * m) * 16);
+                    }
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+                    for (int nn = 0; nn < 2; ++nn) {
+                        if (ESTD_SABL & 4) { bnext[pc][nn] = bcur[pc][nn]; asm volatile("" : "+v"(bnext[pc][nn])); } else
+                        bnext[pc][nn] = *reinterpret_cast<const bf16x8*>(smem + wrd + (pc * 2 + nn) * 1024 + b_lane);
+                    }
+                // 2. weights of tap+2 -> the free weight slot; 3. weights of tap+3 -> registers
+                if (!(ESTD_SABL & 8)) {
+                    *reinterpret_cast<u32x4*>(smem + wwr + w_lane) = wreg;
+                    wreg = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, ((tap + 3) % 27) * WTAP_BYTES, 0);
+                }
+                // 4. ring: refill the even slot with slice d+1 (taps 8..10), then prefetch slice d+2 (taps 11..16)
+                if constexpr (tap >= 8 && tap < 8 + FIT) {
+                    if (!(ESTD_SABL & 16)) fill(sb_even, tap - 8, pf[2 * (tap - 8)], pf[2 * (tap - 8) + 1]);
+                }
+                if constexpr (tap >= 11 && tap < 11 + 2 * FIT) {
+                    constexpr int k = tap - 11;
+                    if (!(ESTD_SABL & 16))
+                        pf[k] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, fetch ? voff[k >> 1] : OOB_OFFSET, next_soff + (k & 1) * 16, 0));
+                }
+                // 5. deferred epilogue of the previous tile (all stores are dropped while there is none)
+                if (!(ESTD_SABL & 32)) {
+                    if constexpr (tap == 0) epi_load(el, 0, pend_d, have_pend);
+                    if constexpr (tap == 1) { epi_finish(el, pend, 0, pend_d, have_pend); epi_load(el, 1, pend_d, have_pend); }
+                    if constexpr (tap == 2) { epi_finish(el, pend, 1, pend_d, have_pend); if (STATS && ESTD_SPLIT_STATS_ON) stats_to_lds(); }
+                    if constexpr (tap == 3) { if (STATS && ESTD_SPLIT_STATS_ON) stats_store(pend_d, have_pend); }
+                }
+                // 6. this tap's products, smallest terms first; the four accumulator chains are interleaved
+                {
+                    constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+                    for (int t = 0; t < 6; ++t)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+#pragma unroll
+                            for (int nn = 0; nn < 2; ++nn)
+                                acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(acur[m][PA[t]], bcur[PB[t]][nn], acc[m][nn], 0, 0, 0);
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) acur[m][pc] = anext[m][pc];
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+                    for (int nn = 0; nn < 2; ++nn) bcur[pc][nn] = bnext[pc][nn];
+                wsel ^= 1;
+                tap_pipeline<tap>();
+                __builtin_amdgcn_sched_barrier(0);       // nothing of this tap moves past the barrier (asm volatile does not order register-only ops)
+                if (ESTD_SABL & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else
+                lds_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }, std::make_integer_sequence<int, 27>{});
+
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int nn = 0; nn < 2; ++nn) pend[m][nn] = acc[m][nn];
+            pend_d = d;
+            have_pend = true;
+            q ^= 1;
+        }
+        if (have_pend) {       // last tile of the segment
+            epi_load(el, 0, pend_d, true);
+            epi_finish(el, pend, 0, pend_d, true);
+            epi_load(el, 1, pend_d, true);
+            epi_finish(el, pend, 1, pend_d, true);
+            if (STATS && ESTD_SPLIT_STATS_ON) {
+                stats_to_lds();
+                __syncthreads();
+                stats_store(pend_d, true);
+            }
+        }
+    }
+}
+
+template <bool TANH, bool STATS>
+int launch(const estd_conv3d_desc& d, hipStream_t stream, int tiles_w, int tiles_h, int total)
+{
+    int grid = total < 256 ? total : 256;       // one workgroup per CU (LDS-limited)
+    if (grid >= 8) grid &= ~7;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_split_kernel<TANH, STATS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3d_k3_split_kernel<TANH, STATS>), dim3(grid), dim3(512), LDS_TOTAL, stream, d, tiles_w, tiles_h, total);
+    return hipGetLastError() == hipSuccess ? ESTD_OK : ESTD_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int estd_conv3d_k3_split(const estd_conv3d_desc* dp, estd_stream_t s)
+{
+    if (!dp) return ESTD_ERR_ARG;
+    const estd_conv3d_desc& d = *dp;
+    hipStream_t stream = static_cast<hipStream_t>(s);
+    if (d.N <= 0 || d.D <= 0 || d.H <= 0 || d.W <= 0) return ESTD_ERR_ARG;
+    if (!d.in_main || !d.w_split || !d.scale || !d.shift || !d.out_main) return ESTD_ERR_ARG;
+    if (d.cin_main != 32 || d.n_tiles != 2 || d.in_extra || d.head_w || d.out_extra) return ESTD_ERR_UNSUPPORTED;
+    if (d.in_stride < 32 || (d.in_stride & 3) || d.out_stride < 32 || (d.out_stride & 1) || (d.act_split & 1)) return ESTD_ERR_ARG;
+    const int tiles_w = (d.W + TW - 1) / TW, tiles_h = (d.H + TH - 1) / TH;
+    const long long total = (long long)d.N * d.D * tiles_h * tiles_w;
+    if (total > 0x7fffffffLL) return ESTD_ERR_ARG;
+    {
+        const long long vox = (long long)d.D * d.H * d.W;
+        const int widest = d.in_stride > d.out_stride ? d.in_stride : d.out_stride;
+        if (vox * widest * 4 >= 0x7fffff00LL) return ESTD_ERR_UNSUPPORTED;
+    }
+    const bool tanh_used = (d.act_split > 0 && d.act_a == ESTD_ACT_TANH) || d.act_b == ESTD_ACT_TANH;
+    const bool stats = d.stats_partials != nullptr;
+    if (tanh_used) return stats ? launch<true, true>(d, stream, tiles_w, tiles_h, (int)total) : launch<true, false>(d, stream, tiles_w, tiles_h, (int)total);
+    return stats ? launch<false, true>(d, stream, tiles_w, tiles_h, (int)total) : launch<false, false>(d, stream, tiles_w, tiles_h, (int)total);
+}

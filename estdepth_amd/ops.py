@@ -3,6 +3,7 @@ the arithmetic is libestd_hip.so's).  Every function enqueues on the current HIP
 returns tensors owned by the caching allocator.  CUDA(ROCm)-only: CPU tensors raise RuntimeError.
 """
 import ctypes
+import os
 
 import torch
 
@@ -14,6 +15,10 @@ ACT = {"none": 0, "relu": 1, "tanh": 2}
 # bench.py sets this to a list to collect (flops, start_event, end_event) around every launch of the
 # dominant kernel (3x3x3 conv 32->32 without extra channel) on the stream it is launched on.
 PROFILE = None
+
+# Arithmetic of the plain 32->32 3x3x3 convolutions: "f32" = v_mfma_f32_16x16x4_f32 (csrc/conv3d_mfma.hip),
+# "bf16x3" = exact 3-way bf16 operand split, six bf16 MFMAs per product block (csrc/conv3d_split_bf16.hip).
+CONV3D_ARITH = os.environ.get("ESTD_CONV3D_ARITH", "f32")
 
 
 def _stream():
@@ -105,6 +110,8 @@ class Conv3dPlan:
         self.cin_main = len(main_idx)
         self.n_tiles = n_tiles
         self.n_out = len(out_idx)
+        splittable = len(main_idx) == 32 and n_tiles == 2 and extra_idx is None and head_w is None
+        self.w_split = packing.pack_conv3d_split(weight, main_idx, out_idx).to(device) if splittable else None
         self.w_main = wm.to(device)
         self.w_extra = wx.to(device) if wx is not None else None
         self.scale = scale.float().contiguous().to(device)
@@ -159,7 +166,13 @@ class Conv3dPlan:
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream())
-        N.check(N.lib().estd_conv3d_k3(ctypes.byref(d), _stream()), "estd_conv3d_k3")
+        if CONV3D_ARITH == "bf16x3" and self.w_split is not None and out is not None:
+            d.w_split = self.w_split.data_ptr()
+            N.check(N.lib().estd_conv3d_k3_split(ctypes.byref(d), _stream()), "estd_conv3d_k3_split")
+        elif CONV3D_ARITH not in ("f32", "bf16x3"):
+            raise RuntimeError("ESTD_CONV3D_ARITH must be f32 or bf16x3, got %r" % (CONV3D_ARITH,))
+        else:
+            N.check(N.lib().estd_conv3d_k3(ctypes.byref(d), _stream()), "estd_conv3d_k3")
         if prof:
             e1.record(torch.cuda.current_stream())
             PROFILE.append((2.0 * 27 * 32 * 32 * Nn * D * H * W, e0, e1))

@@ -135,3 +135,37 @@ def pack_conv2d(weight, group_tiles):
                     # value[tap, lane] = w[co[lane], c*32 + ci[lane], tap]
                     out[grp, c, :9, idx // 4, :, idx % 4] = w[co, c * 32 + ci_in_chunk, :].T
     return torch.from_numpy(out)
+
+
+def bf16_split3(x):
+    """float32 array -> three uint16 arrays (bf16 bit patterns, round-to-nearest-even) with x == p0 + p1 + p2 exactly
+    for every finite x whose pieces stay normal (3 x 8 significand bits cover fp32's 24)."""
+    def rne(v):
+        u = v.astype(np.float32).view(np.uint32).astype(np.uint64)
+        u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+        return u.astype(np.uint32).view(np.float32)
+    r = np.ascontiguousarray(x, dtype=np.float32)
+    pieces = []
+    for _ in range(3):
+        p = rne(r)
+        pieces.append((p.view(np.uint32) >> 16).astype(np.uint16))
+        r = (r - p).astype(np.float32)
+    return pieces
+
+
+def pack_conv3d_split(weight, main_idx, out_idx):
+    """32->32 weights for csrc/conv3d_split_bf16.hip: uint16 [27 taps][3 pieces][2 n-tiles][64 lanes][8] (bf16 bits).
+    v_mfma_f32_16x16x32_bf16 B operand: lane l holds column j = l & 15 and k = 8*(l >> 4) .. +7; k = position of the
+    input channel in memory order (main_idx), output channel position of (tile n, column j) = 2j + n."""
+    w = weight.detach().float().cpu().numpy().reshape(weight.shape[0], weight.shape[1], 27)
+    assert len(main_idx) == 32 and len(out_idx) >= 32
+    sel = np.zeros((27, 2, 64, 8), np.float32)
+    for lane in range(64):
+        kg, j = lane >> 4, lane & 15
+        for n in range(2):
+            co = out_idx[2 * j + n]
+            for e in range(8):
+                sel[:, n, lane, e] = w[co, main_idx[8 * kg + e], :]
+    pieces = bf16_split3(sel)
+    out = np.stack(pieces, axis=1)            # [27][3][2][64][8]
+    return torch.from_numpy(out.view(np.int16).copy())

@@ -108,9 +108,17 @@ typedef struct estd_conv3d_desc {
     /* GroupNorm(1 group) statistics of the raw outputs, per 16-channel group: partial sums per block,
      * double[grid][2 groups][2] = {sum, sumsq}; finalised by estd_groupnorm_finalize. */
     double* stats_partials;   /* or NULL */
+    /* estd_conv3d_k3_split only: the 32->32 weights split into three bf16 pieces,
+     * uint16 [27 taps][3 pieces][2 n-tiles][64 lanes][8] (packing.py::pack_conv3d_split), else NULL */
+    const void* w_split;
 } estd_conv3d_desc;
 
 int estd_conv3d_k3(const estd_conv3d_desc* desc, estd_stream_t stream);
+/* Same operator for the plain 32->32 case (cin_main = 32, n_tiles = 2, no extra channel / head / 33rd output), with
+ * every fp32 product evaluated as six bf16 MFMA products of exactly split operands (a = a1+a2+a3, b = b1+b2+b3,
+ * fp32 accumulation; dropped terms <= 2^-26 |ab|): fp32-level error at 96 instead of 256 matrix-pipe cycles per
+ * 16x16x32 block.  Reads w_split instead of w_main.  ESTD_ERR_UNSUPPORTED for any other shape. */
+int estd_conv3d_k3_split(const estd_conv3d_desc* desc, estd_stream_t stream);
 /* number of thread blocks estd_conv3d_k3 launches for a volume (size of stats_partials / 4 doubles) */
 int estd_conv3d_k3_grid(int N, int D, int H, int W);
 
