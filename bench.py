@@ -54,6 +54,8 @@ def build_model(workload, device):
         m.use_channels_last_2d()                      # NHWC MIOpen kernels for the 2D backbones
         if os.environ.get("ESTD_PSM", "hip") == "hip":
             m.use_hip_psm()                           # PSM 3x3 convs on the MFMA conv2d kernel
+        if os.environ.get("ESTD_FUSE_BN", "1") == "1":
+            m.fuse_bn_2d()                            # BN(+add)(+ReLU) after the library convs in one NHWC pass
         if os.environ.get("ESTD_OVERLAP", "1") == "1":
             m.overlap_semantic_branch()               # semantic branch on a second stream
     return m

@@ -74,6 +74,7 @@ _SIGNATURES = {
     "estd_gru_reset_apply": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
                                             ctypes.c_int64, c_stream]),
     "estd_gru_blend": (ctypes.c_int, [c_float_p] * 10 + [ctypes.c_int, ctypes.c_int64, c_stream]),
+    "estd_bn_act_nhwc": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_stream]),
     "estd_cdhw_to_vol": (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, c_stream]),
     "estd_vol_to_cdhw": (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, c_stream]),
 }

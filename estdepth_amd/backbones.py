@@ -22,6 +22,45 @@ def conv_bn2d(cin, cout, k, stride, pad, dilation):
         nn.BatchNorm2d(cout))
 
 
+def _folded(bn):
+    """(scale, shift) of an eval BatchNorm2d on its device, cached on the module until a parameter changes."""
+    from . import packing
+    key = (bn.weight.device, bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+           bn.weight.data_ptr())
+    c = bn.__dict__.get("_estd_fold")
+    if c is None or c[0] != key:
+        sc, sh = packing.fold_bn_fp32(bn, list(range(bn.num_features)))
+        c = (key, sc.to(bn.weight.device), sh.to(bn.weight.device))
+        bn.__dict__["_estd_fold"] = c
+    return c[1], c[2]
+
+
+def fused_on(mod, x):
+    """the fused BatchNorm/ReLU/residual epilogue (estd_bn_act_nhwc) applies: opted in, inference, on the GPU."""
+    return mod.__dict__.get("_fuse_bn", False) and x.is_cuda and not mod.training
+
+
+def conv_bn_act(conv, bn, x, relu, residual=None):
+    """library convolution, then ONE in-place NHWC pass for BatchNorm2d(eval) [+ residual] [+ ReLU]."""
+    from . import ops
+    y = conv(x)
+    if not y.is_contiguous(memory_format=torch.channels_last):
+        y = y.contiguous(memory_format=torch.channels_last)
+    if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
+        residual = residual.contiguous(memory_format=torch.channels_last)
+    sc, sh = _folded(bn)
+    return ops.bn_act_nhwc_(y, sc, sh, relu, residual)
+
+
+def enable_fused_bn(root, enable=True):
+    """Opt-in for every 2D block under ``root``: BatchNorm2d -> (add) -> ReLU after a library convolution become
+    one estd_bn_act_nhwc launch.  Needs channels_last activations (DepthNetHybrid.use_channels_last_2d)."""
+    for m in root.modules():
+        if isinstance(m, (_PSMBlock, PSMFeatures, _Basic, _Bottleneck, SemanticEncoder, UpBlock)):
+            m.__dict__["_fuse_bn"] = bool(enable)
+    return root
+
+
 class _PSMBlock(nn.Module):
     def __init__(self, cin, cout, stride, downsample, pad, dilation):
         super().__init__()
@@ -29,7 +68,21 @@ class _PSMBlock(nn.Module):
         self.conv2 = conv_bn2d(cout, cout, 3, 1, pad, dilation)
         self.downsample = downsample
 
+    def shortcut(self, x):
+        if self.downsample is None:
+            return x
+        if fused_on(self, x):
+            return conv_bn_act(self.downsample[0], self.downsample[1], x, relu=False)
+        return self.downsample(x)
+
+    def first(self, x):
+        if fused_on(self, x):
+            return conv_bn_act(self.conv1[0][0], self.conv1[0][1], x, relu=True)
+        return self.conv1(x)
+
     def forward(self, x):
+        if fused_on(self, x):
+            return conv_bn_act(self.conv2[0], self.conv2[1], self.first(x), relu=False, residual=self.shortcut(x))
         y = self.conv2(self.conv1(x))
         return y + (x if self.downsample is None else self.downsample(x))
 
@@ -103,26 +156,33 @@ class PSMFeatures(nn.Module):
     def _forward_hip(self, x):
         P = self._plans()
         fc = self.firstconv
-        x = fc[1](fc[0](x.contiguous(memory_format=torch.channels_last)))      # 3->32 stride 2: MIOpen
+        x = x.contiguous(memory_format=torch.channels_last)
+        x = conv_bn_act(fc[0][0], fc[0][1], x, relu=True) if fused_on(self, x) else fc[1](fc[0](x))      # 3->32 stride 2: MIOpen
         x = P["first2"].run(P["first1"].run(self._nhwc(x)))
         for lname in ("layer1", "layer2", "layer3", "layer4"):
             for bi, blk in enumerate(getattr(self, lname)):
                 if (lname, bi, 1) in P:
                     y = P[(lname, bi, 1)].run(x)
                 else:                                                             # stride-2 conv1 (layer2.0): MIOpen
-                    y = self._nhwc(blk.conv1(self._nchw(x)))
-                res = x if blk.downsample is None else self._nhwc(blk.downsample(self._nchw(x)))
+                    y = self._nhwc(blk.first(self._nchw(x)))
+                res = x if blk.downsample is None else self._nhwc(blk.shortcut(self._nchw(x)))
                 x = P[(lname, bi, 2)].run(y, residual=res)
             if lname == "layer2":
                 raw = x
         skip = x
         skip_nchw = self._nchw(skip)
         size = skip_nchw.shape[2:]
-        ups = [F.interpolate(getattr(self, "branch%d" % i)(skip_nchw), size=size, mode="bilinear", align_corners=False)
-               for i in (4, 3, 2, 1)]
+        ups = [F.interpolate(self._branch(i, skip_nchw), size=size, mode="bilinear", align_corners=False) for i in (4, 3, 2, 1)]
         cat = torch.cat([self._nchw(raw), skip_nchw] + ups, 1)
         y = P["last"].run(self._nhwc(cat))
         return self.lastconv[2](self._nchw(y))
+
+    def _branch(self, i, skip):
+        """SPP branch: AvgPool -> 1x1 conv -> BN -> ReLU (psm_submodule.py:100-110)."""
+        br = getattr(self, "branch%d" % i)
+        if fused_on(self, skip):
+            return conv_bn_act(br[1][0], br[1][1], br[0](skip), relu=True)
+        return br(skip)
 
     def forward(self, x):
         if getattr(self, "_hip", False) and x.is_cuda and not self.training:
@@ -152,6 +212,10 @@ class _Basic(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        if fused_on(self, x):
+            sc = x if self.downsample is None else conv_bn_act(self.downsample[0], self.downsample[1], x, relu=False)
+            y = conv_bn_act(self.conv1, self.bn1, x, relu=True)
+            return conv_bn_act(self.conv2, self.bn2, y, relu=True, residual=sc)
         y = self.relu(self.bn1(self.conv1(x)))
         y = self.bn2(self.conv2(y))
         return self.relu(y + (x if self.downsample is None else self.downsample(x)))
@@ -172,6 +236,11 @@ class _Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        if fused_on(self, x):
+            sc = x if self.downsample is None else conv_bn_act(self.downsample[0], self.downsample[1], x, relu=False)
+            y = conv_bn_act(self.conv1, self.bn1, x, relu=True)
+            y = conv_bn_act(self.conv2, self.bn2, y, relu=True)
+            return conv_bn_act(self.conv3, self.bn3, y, relu=True, residual=sc)
         y = self.relu(self.bn1(self.conv1(x)))
         y = self.relu(self.bn2(self.conv2(y)))
         y = self.bn3(self.conv3(y))
@@ -225,7 +294,7 @@ class SemanticEncoder(nn.Module):
 
     def forward(self, x):
         e = self.encoder
-        f0 = e.relu(e.bn1(e.conv1(x)))
+        f0 = conv_bn_act(e.conv1, e.bn1, x, relu=True) if fused_on(self, x) else e.relu(e.bn1(e.conv1(x)))
         f1 = e.layer1(e.maxpool(f0))
         f2 = e.layer2(f1)
         f3 = e.layer3(f2)
@@ -253,6 +322,8 @@ class UpBlock(nn.Module):
                     self._plan = (key, ops.Conv2dPlan(conv, self.conv[1], relu_before=True))
                 y = self._plan[1].run(x.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1))
                 return y.permute(0, 3, 1, 2)
+        if fused_on(self, x):
+            return conv_bn_act(self.conv[0], self.conv[1], x, relu=True)
         return self.nonlin(self.conv(x))
 
 

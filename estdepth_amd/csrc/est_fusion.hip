@@ -498,3 +498,36 @@ extern "C" const char* estd_status_string(int st)
         default: return "unknown status";
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// fused BatchNorm2d(eval) (+ residual) (+ ReLU), NHWC, in place: one pass instead of BN -> add -> clamp
+namespace {
+__global__ __launch_bounds__(256) void bn_act_nhwc_kernel(float4* __restrict__ x, const float4* __restrict__ scale,
+                                                          const float4* __restrict__ shift, const float4* __restrict__ residual,
+                                                          int relu, long long n4, int c4)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += stride) {
+        const int c = (int)(e % c4);
+        float4 v = x[e];
+        const float4 s = scale[c], t = shift[c];
+        v.x = v.x * s.x + t.x; v.y = v.y * s.y + t.y; v.z = v.z * s.z + t.z; v.w = v.w * s.w + t.w;
+        if (residual) { const float4 r = residual[e]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        x[e] = v;
+    }
+}
+}  // namespace
+
+extern "C" int estd_bn_act_nhwc(float* x, const float* scale, const float* shift, const float* residual, int relu,
+                                int64_t n_pix, int C, estd_stream_t stream)
+{
+    if (!x || !scale || !shift || n_pix <= 0 || C <= 0 || (C & 3)) return ESTD_ERR_ARG;
+    const long long n4 = (long long)n_pix * (C / 4);
+    long long blocks = (n4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(bn_act_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, estd_stream(stream),
+                       reinterpret_cast<float4*>(x), reinterpret_cast<const float4*>(scale), reinterpret_cast<const float4*>(shift),
+                       reinterpret_cast<const float4*>(residual), relu, n4, C / 4);
+    return ESTD_LAUNCH_CHECK();
+}

@@ -130,6 +130,15 @@ class DepthNetHybrid(nn.Module):
                 child.to(memory_format=fmt)
         return self
 
+    def fuse_bn_2d(self, enable=True):
+        """Opt-in: BatchNorm2d -> (residual add) -> ReLU after the library convolutions of the 2D backbones as ONE
+        in-place NHWC pass (estd_bn_act_nhwc) instead of two or three MIOpen/ATen launches.  Implies NHWC backbones."""
+        from .backbones import enable_fused_bn
+        self.use_channels_last_2d(True)
+        for mod in (self.matchingFeature, self.semanticFeature, self.CostRegNet):
+            enable_fused_bn(mod, enable)
+        return self
+
     def normalise_images(self, imgs):
         """2*(imgs/255)-1 (model_hybrid.py:119), exposed for callers that cache per-frame matching features."""
         return 2 * (imgs / 255.) - 1.

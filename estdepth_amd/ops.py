@@ -286,6 +286,19 @@ def gru_blend(xh, ru, o_raw, stats_ru, stats_o, gamma_u, beta_u, gamma_o, beta_o
                                    _p(gamma_o), _p(beta_o), _p(out_value), out_stride, n_vox, _stream()), "estd_gru_blend")
 
 
+# ---------------------------------------------------------------------------------- 2D backbone epilogues
+def bn_act_nhwc_(x, scale, shift, relu, residual=None):
+    """in place on an NCHW-shaped tensor in channels_last memory: x = act(x*scale[c] + shift[c] (+ residual))."""
+    if not x.is_cuda or x.dtype != torch.float32 or not x.is_contiguous(memory_format=torch.channels_last):
+        raise RuntimeError("bn_act_nhwc_: expected a float32 CUDA tensor in channels_last memory (no CPU path)")
+    n, c, h, w = x.shape
+    if residual is not None and (residual.shape != x.shape or not residual.is_contiguous(memory_format=torch.channels_last)):
+        raise RuntimeError("bn_act_nhwc_: residual must match x (shape, channels_last)")
+    N.check(N.lib().estd_bn_act_nhwc(_p(x), _p(scale), _p(shift), _p(residual) if residual is not None else None,
+                                     1 if relu else 0, n * h * w, c, _stream()), "estd_bn_act_nhwc")
+    return x
+
+
 # ---------------------------------------------------------------------------------- layout converters
 def cdhw_to_vol(src, dst, dst_stride, dst_off):
     """src [C,D,H,W] contiguous -> channels dst_off.. of the channels-last records of dst."""

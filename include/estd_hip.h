@@ -197,6 +197,13 @@ int estd_cdhw_to_vol(const float* src_cdhw, float* dst, int C, int64_t S, int ds
 int estd_vol_to_cdhw(const float* src, float* dst_cdhw, int C, int64_t S, int src_stride, int src_off,
                      estd_stream_t stream);
 
+/* ---- fused inference BatchNorm2d (+ residual add) (+ ReLU) on NHWC maps, in place --------------------------------
+ * x[p][c] = act(x[p][c] * scale[c] + shift[c] + residual[p][c]); replaces the BatchNorm2d -> (add) -> ReLU launches that
+ * follow the library convolutions of the 2D backbones (resnet_encoder.py:43-49, psm_submodule.py:14-37,
+ * hybrid_depth_decoder.py:17-30).  C multiple of 4; residual may be NULL. */
+int estd_bn_act_nhwc(float* x, const float* scale, const float* shift, const float* residual, int relu,
+                     int64_t n_pix, int C, estd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

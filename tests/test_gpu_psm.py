@@ -72,7 +72,7 @@ def test_e2e_golden_with_hip_psm(golden_dir):
 
 
 def test_overlapped_semantic_branch_and_all_accelerators_match_plain_path():
-    """use_hip_psm + overlap_semantic_branch + hipGraph replay (what bench.py runs) == plain eager forward."""
+    """use_hip_psm + fuse_bn_2d + overlap_semantic_branch + hipGraph replay (what bench.py runs) == plain eager forward."""
     import fixtures_spec as S
     from estdepth_amd import synth, DepthNetHybrid
     from estdepth_amd.graph import GraphedForward
@@ -80,7 +80,7 @@ def test_overlapped_semantic_branch_and_all_accelerators_match_plain_path():
         m = DepthNetHybrid(ndepths=64, depth_min=0.1, depth_max=10.0, resnet=18, IF_EST_transformer=True).eval()
         synth.fill_state_dict(m, seed=2, head_gain=1.0)
         return m.to(DEV)
-    plain, fast = make(), make().use_hip_psm().overlap_semantic_branch()
+    plain, fast = make(), make().use_hip_psm().fuse_bn_2d().overlap_semantic_branch()
     gf = GraphedForward(fast)
     imgs, poses, intr, sample = S.e2e_inputs(8, S.E2E_HI, S.E2E_WI, seed=1004)
     imgs, poses, intr = imgs.to(DEV), poses.to(DEV), intr.to(DEV)
@@ -96,3 +96,50 @@ def test_overlapped_semantic_branch_and_all_accelerators_match_plain_path():
             # the graph's outputs are static buffers: detach the memory we carry to the next call
             pc_b = {"keys": [cb["keys"][0].contiguous().clone()], "values": [cb["values"][0].contiguous().clone()]}
             pp_b = [pb[0].clone()]
+
+
+@pytest.mark.parametrize("shape,relu,res", [((2, 64, 13, 21), True, True), ((1, 32, 5, 7), False, False), ((3, 256, 8, 8), True, False)])
+def test_bn_act_nhwc_matches_torch(shape, relu, res):
+    from estdepth_amd import ops, synth
+    from estdepth_amd.backbones import _folded
+    bn = torch.nn.BatchNorm2d(shape[1]).eval()
+    synth.fill_state_dict(bn, seed=shape[1])
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(*shape, generator=g)
+    r = torch.randn(*shape, generator=g) if res else None
+    with torch.no_grad():
+        ref = bn.double()(x.double())
+        if res:
+            ref = ref + r.double()
+        if relu:
+            ref = torch.relu(ref)
+    bn = bn.float().to(DEV)
+    sc, sh = _folded(bn)
+    y = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    out = ops.bn_act_nhwc_(y, sc, sh, relu, r.to(DEV).contiguous(memory_format=torch.channels_last) if res else None)
+    assert out.data_ptr() == y.data_ptr()
+    assert (out.double().cpu() - ref).abs().max().item() < 1e-5
+    with pytest.raises(RuntimeError, match="channels_last"):
+        ops.bn_act_nhwc_(x.to(DEV), sc, sh, relu)
+
+
+def test_e2e_golden_with_fused_bn(golden_dir):
+    """cfg1 golden (R18, EST off) and the Joint carry golden (R18, EST on) with fuse_bn_2d + use_hip_psm: depth within 1e-4."""
+    import os
+    import fixtures_spec as S
+    from estdepth_amd import synth, DepthNetHybrid
+    g = np.load(os.path.join(golden_dir, "g9_joint_carry.npz"))
+    m = DepthNetHybrid(ndepths=64, depth_min=0.1, depth_max=10.0, resnet=18, IF_EST_transformer=True).eval()
+    synth.fill_state_dict(m, seed=2, head_gain=1.0)
+    m = m.to(DEV).use_hip_psm().fuse_bn_2d()
+    imgs, poses, intr, sample = S.e2e_inputs(8, S.E2E_HI, S.E2E_WI, seed=1004)
+    imgs, poses, intr = imgs.to(DEV), poses.to(DEV), intr.to(DEV)
+    pc = pp = None
+    for call in range(2):
+        sl = slice(3 * call, 3 * call + 5)
+        with torch.no_grad():
+            outputs, pc, pp = m(imgs[:, sl], poses[:, sl], intr, {k: v[:, sl] for k, v in sample.items()}, pc, pp, mode="val")
+        for k, v in outputs.items():
+            name = "c%d|" % call + "|".join(map(str, k))
+            if name in g.files:
+                assert np.abs(v.cpu().numpy() - g[name]).max() < 1e-4, name
