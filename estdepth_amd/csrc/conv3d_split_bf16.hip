@@ -23,6 +23,10 @@
 //   * Weights: host-split [tap][piece][n-tile][lane][8] bf16 (6 KB per tap, packing.py::pack_conv3d_split), streamed
 //     L2 -> registers -> a 2-slot LDS buffer one tap ahead; fragments for tap t+1 are read into registers during tap t.
 //     One LDS-only barrier per tap publishes the weight slot, the ring refill and the GroupNorm scratch.
+//   * 33rd INPUT channel (dres2, key|value convs): its 27 taps are one more K = 32 block ("tap 27"): the A fragment is
+//     gathered from a 3-slot LDS ring of the scalar slices and split in registers; its weights are record 27.
+//   * 33rd OUTPUT channel (dres2): a third N tile whose only live column is 0; its B fragment (64 B per piece) rides in
+//     the padding of the 8 KB weight record, lanes of the other columns read a zero block.
 //   * The body of a tap is ONE basic block (no exec-mask or uniform branches: out-of-range work is redirected to
 //     out-of-bounds buffer offsets / an LDS dump area) so that the issue order can be prescribed: every MFMA is
 //     followed by a few of the tap's other instructions (LDS reads of the next tap, weight hand-over, slice split,
@@ -63,12 +67,17 @@ constexpr int PLANE = 352;                     // 16-byte entries per chunk plan
 constexpr int CHUNK_BYTES = PLANE * 16;        // 5632
 constexpr int PIECE_BYTES = 4 * CHUNK_BYTES;   // 22528
 constexpr int SLICE_BYTES = 3 * PIECE_BYTES;   // 67584
-constexpr int WTAP_BYTES = 3 * 2 * 64 * 16;    // 6144 bytes of split weights per tap: [piece][n-tile][lane] x 16 B
-constexpr int WSLOT_BYTES = 512 * 16;          // LDS weight slot: every thread hands over 16 B (the last 2 KB are padding)
+constexpr int WMAIN_BYTES = 3 * 2 * 64 * 16;   // 6144 bytes of split weights per tap: [piece][n-tile][lane] x 16 B
+constexpr int WTAP_BYTES = 512 * 16;           // weight record of one tap, global and LDS: every thread hands over 16 B;
+                                               // bytes 6144..6335 = column of the 33rd output channel [piece][k-group] x 16 B, rest zero
+constexpr int WX_OFF = WMAIN_BYTES;            // 33rd-output column inside a record
+constexpr int WZERO_OFF = WMAIN_BYTES + 256;   // 16 zero bytes inside every record
 constexpr int LDS_W = 2 * SLICE_BYTES;
-constexpr int LDS_DUMP = LDS_W + 2 * WSLOT_BYTES;      // 512 x 16 B: target of the fill writes of threads without an item
-constexpr int LDS_RED = LDS_DUMP + 512 * 16;
-constexpr int LDS_TOTAL = LDS_RED + 8 * 4 * 8;         // 160000 of 163840
+constexpr int LDS_DUMP = LDS_W + 2 * WTAP_BYTES;       // 176 x 16 B: target of the writes of threads without an item
+constexpr int XSLICE_BYTES = SL_VOX * 4;               // scalar (33rd input channel) slice, fp32
+constexpr int LDS_XRING = LDS_DUMP + 176 * 16;         // 3 slots
+constexpr int LDS_RED = LDS_XRING + 4096;
+constexpr int LDS_TOTAL = LDS_RED + 8 * 4 * 8;         // 158720 of 163840
 constexpr int FILL_E = SL_VOX * 4;             // (voxel, chunk) items per slice: 1360
 constexpr int FIT = 3;                         // items per thread (512 threads)
 constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;
@@ -135,25 +144,30 @@ __device__ __forceinline__ void for_each_tap(F&& f, std::integer_sequence<int, I
 
 // Issue order of one tap: one MFMA, then a few of the other instructions of the tap (IGroupLP pipeline).
 //   0x008 MFMA   0x100 DS read   0x200 DS write   0x020 VMEM read   0x040 VMEM write   0x002 VALU   0x004 SALU
-template <int TAP>
+template <int TAP, int NT, bool EXTRA>
 __device__ __forceinline__ void tap_pipeline()
 {
 #if ESTD_SPIPE
+    constexpr int NM = 12 * NT;                     // MFMAs of the tap
+    constexpr int NR = 6 + 3 * NT;                  // LDS fragment reads of the next tap
+    constexpr bool VALU_HEAVY = TAP <= 2 || (TAP >= 8 && TAP <= 10) || (EXTRA && TAP == 26);
 #pragma unroll
-    for (int k = 0; k < 24; ++k) {
+    for (int k = 0; k < NM; ++k) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (k < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        if (TAP <= 2 || (TAP >= 8 && TAP <= 10)) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);    // epilogue / slice split
-        if (k >= 12 && k < 16) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        if (k >= 12) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        if (TAP >= 1 && TAP <= 2 && k >= 16 && k < 20) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+        if (k < NR + (EXTRA && TAP == 26 ? 4 : 0)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (VALU_HEAVY) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);    // epilogue / slice split / extra-channel split
+        if (k >= NR && k < NR + 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        if (k >= NR) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if (TAP >= 1 && TAP <= 2 && k >= NR + 4 && k < NR + 8) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
     }
 #endif
 }
 
-template <bool TANH, bool STATS>
+// NT: 16-channel output tiles on the MFMA (2 = 32 channels; 3 = 32 channels + the 33rd in column 0 of a third tile)
+template <int NT, bool EXTRA, bool TANH, bool STATS>
 __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int total_tiles)
 {
+    constexpr int NTAPS = EXTRA ? 28 : 27;          // tap 27 = the scalar input channel's 27 taps as one K = 32 block
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -177,15 +191,31 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
     const int act0 = cbase < p.act_split ? p.act_a : p.act_b;
     const float relu_floor = act0 == ESTD_ACT_RELU ? 0.0f : -__builtin_huge_valf();    // max(v, floor): branch-free ReLU / identity
     const float out_scale = p.out_scale;
+    float sc2 = 0.f, sh2 = 0.f, relu_floor2 = 0.f;
+    if (NT == 3) { sc2 = p.scale[32]; sh2 = p.shift[32]; relu_floor2 = p.act_b == ESTD_ACT_RELU ? 0.0f : -__builtin_huge_valf(); }
 
-    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w_split, (size_t)27 * WTAP_BYTES);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w_split, (size_t)NTAPS * WTAP_BYTES);
     const size_t vol = (size_t)D * H * W;
     const int HW = H * W;
     const int tiles_w16 = (W + 15) / 16;                 // GroupNorm partials keep the 8x16-tile numbering of estd_conv3d_k3_grid
     const int a_lane = g * CHUNK_BYTES + (i + 2 * g) * 16;     // lane part of an A-fragment address
     const int b_lane = lane * 16;
+    const int bx_lane = i == 0 ? WX_OFF + g * 16 : WZERO_OFF;  // third N tile: only column 0 is live
     const int w_lane = tid * 16;
+    const int dump16 = LDS_DUMP + (tid >= 336 ? tid - 336 : 0) * 16;
     double* red = reinterpret_cast<double*>(smem + LDS_RED);
+
+    // extra (scalar) input channel: lane (i, g) contracts taps 8g..8g+7 of "tap 27"; taps >= 27 are padding
+    int xo[8], xkd[8];
+    if (EXTRA) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int tp = 8 * g + j;
+            const int tq = tp > 26 ? 26 : tp;
+            xkd[j] = tp > 26 ? -1 : tq / 9;
+            xo[j] = (((tq / 3) % 3) * IN_W + tq % 3) * 4;
+        }
+    }
 
     while (u < u_end) {
         // ---- column segment [u, seg_end): same (n, h-tile, w-tile), consecutive d ----
@@ -199,7 +229,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
         // absent optional operands get an EMPTY descriptor: every load returns 0, so the epilogue needs no branches
         const size_t out_bytes = vol * p.out_stride * 4;
         const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in_main + (size_t)n * vol * p.in_stride, vol * p.in_stride * 4);
+        const __amdgpu_buffer_rsrc_t rs_ex = make_rsrc(EXTRA ? p.in_extra + (size_t)n * vol : p.in_main, EXTRA ? vol * 4 : 0);
         const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(p.out_main + (size_t)n * vol * p.out_stride, out_bytes);
+        const __amdgpu_buffer_rsrc_t rs_xout = make_rsrc(NT == 3 ? p.out_extra + (size_t)n * vol : p.out_main, NT == 3 ? vol * 4 : 0);
         const __amdgpu_buffer_rsrc_t rs_res = make_rsrc(p.residual ? p.residual + (size_t)n * vol * p.out_stride : p.out_main, p.residual ? out_bytes : 0);
         const __amdgpu_buffer_rsrc_t rs_res2 = make_rsrc(p.residual2 ? p.residual2 + (size_t)n * vol * p.out_stride : p.out_main, p.residual2 ? out_bytes : 0);
         const __amdgpu_buffer_rsrc_t rs_acc = make_rsrc(p.out_main + (size_t)n * vol * p.out_stride, p.accumulate ? out_bytes : 0);
@@ -222,20 +254,34 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
         const bool last_item = loff[FIT - 1] >= 0;       // items 0..FIT-2 exist for every thread
         auto fill = [&](int slot_bytes, int it, float4 a, float4 b) {
             const bool real = it < FIT - 1 || last_item;
-            const int o0 = real ? slot_bytes + loff[it] : LDS_DUMP + w_lane;
+            const int o0 = real ? slot_bytes + loff[it] : dump16;
             const int st = real ? PIECE_BYTES : 0;
             fill_item(smem, o0, o0 + st, o0 + 2 * st, a, b);
+        };
+        // scalar-channel slice element of this thread (threads >= 340 have none)
+        unsigned voffx = OOB_OFFSET;
+        if (EXTRA) {
+            const int zy = tid / IN_W, zx = tid - zy * IN_W;
+            const int gy = th0 - 1 + zy, gx = tw0 - 1 + zx;
+            if (tid < SL_VOX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) voffx = (unsigned)(gy * W + gx) * 4u;
+        }
+        auto xslot = [&](int sd) { return LDS_XRING + ((sd + 3) % 3) * XSLICE_BYTES; };     // slice number -> ring slot (sd >= -1)
+        auto xstore = [&](int sd, float v) {
+            const int o = tid < SL_VOX ? xslot(sd) + tid * 4 : dump16;
+            *reinterpret_cast<float*>(smem + o) = v;
         };
 
         // epilogue lane offsets: this wave owns tile row `wave`; M tile m covers columns 16m..16m+15; lane rows 4g..4g+3
         const int ey = th0 + wave;
-        unsigned eoff[2][4];
+        unsigned eoff[2][4], eoffx[2][4];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int x = tw0 + 16 * m + 4 * g + r;
-                eoff[m][r] = (ey < H && x < W) ? (unsigned)((ey * W + x) * p.out_stride + cbase) * 4u : OOB_OFFSET;
+                const bool ok = ey < H && x < W;
+                eoff[m][r] = ok ? (unsigned)((ey * W + x) * p.out_stride + cbase) * 4u : OOB_OFFSET;
+                eoffx[m][r] = (NT == 3 && ok && i == 0) ? (unsigned)(ey * W + x) * 4u : OOB_OFFSET;
             }
 
         // ---- epilogue of one M tile, in two halves so that its loads are a tap ahead of their use ----
@@ -251,7 +297,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
             }
         };
         double s_sum = 0.0, s_sq = 0.0;
-        auto epi_finish = [&](const EpiLoads& L, const f32x4 (&a)[2][2], int m, int dd, bool live) {
+        auto epi_finish = [&](const EpiLoads& L, const f32x4 (&a)[2][NT], int m, int dd, bool live) {
             const int so = dd * out_plane_bytes;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -273,6 +319,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
                 const float2 ov = make_float2(v0, v1);
                 u32x2 od; __builtin_memcpy(&od, &ov, 8);
                 __builtin_amdgcn_raw_buffer_store_b64(od, rs_out, eo, so, 0);
+                if (NT == 3) {      // 33rd output channel: column 0 of the third N tile
+                    const float v2 = fmaxf(a[m][NT - 1][r] * sc2 + sh2, relu_floor2);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v2), rs_xout, live ? eoffx[m][r] : OOB_OFFSET, dd * HW * 4, 0);
+                }
             }
         };
         // GroupNorm partials of one tile: lane sums -> wave sums -> LDS scratch (published by the next barrier)
@@ -315,6 +365,14 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
 #pragma unroll
             for (int it = 0; it < FIT; ++it) fill(s * SLICE_BYTES, it, t0[it], t1[it]);
         }
+        if (EXTRA) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int sd = d - 1 + s;
+                const unsigned vo = (unsigned)sd < (unsigned)D ? voffx : OOB_OFFSET;
+                xstore(sd, __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ex, vo, sd * HW * 4, 0)));
+            }
+        }
         float4 pf[2 * FIT];
         {
             const int sd = d + 1;
@@ -325,32 +383,34 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
                 pf[2 * it + 1] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, sd * in_slice_bytes + 16, 0));
             }
         }
+        float pfx = 0.f;
         u32x4 wreg;
         {
-            // threads 384..511 hand over bytes beyond the tap (next tap / zeros): they land in the slot padding
             const u32x4 w0 = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, 0, 0);
             const u32x4 w1 = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, WTAP_BYTES, 0);
             wreg = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, 2 * WTAP_BYTES, 0);
             *reinterpret_cast<u32x4*>(smem + LDS_W + w_lane) = w0;
-            *reinterpret_cast<u32x4*>(smem + LDS_W + WSLOT_BYTES + w_lane) = w1;
+            *reinterpret_cast<u32x4*>(smem + LDS_W + WTAP_BYTES + w_lane) = w1;
         }
         lds_barrier();
-        bf16x8 acur[2][3], bcur[3][2];
+        bf16x8 acur[2][3], bcur[3][NT];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc)
                 acur[m][pc] = *reinterpret_cast<const bf16x8*>(smem + pc * PIECE_BYTES + a_lane + (wave * IN_W + 16 * m) * 16);
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
+        for (int pc = 0; pc < 3; ++pc) {
 #pragma unroll
             for (int nn = 0; nn < 2; ++nn)
                 bcur[pc][nn] = *reinterpret_cast<const bf16x8*>(smem + LDS_W + (pc * 2 + nn) * 1024 + b_lane);
+            if (NT == 3) bcur[pc][NT - 1] = *reinterpret_cast<const bf16x8*>(smem + LDS_W + pc * 64 + bx_lane);
+        }
         lds_barrier();      // nobody overwrites weight slot 0 (tap 2) before every wave has its tap-0 fragments
 
         int q = 0;          // ring parity: slot q holds slice d-1 (later d+1), slot q^1 holds slice d
         int wsel = 1;       // weight slot holding tap t+1 at the start of tap t
-        f32x4 pend[2][2] = {};
+        f32x4 pend[2][NT] = {};
         int pend_d = 0;
         bool have_pend = false;
         EpiLoads el;
@@ -360,11 +420,11 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
             const bool fetch = (u + 1 < seg_end) && (d + 2 < D);     // slice d+2 exists and is ours to use
             const int next_soff = (d + 2) * in_slice_bytes;
 
-            f32x4 acc[2][2];
+            f32x4 acc[2][NT];
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int nn = 0; nn < 2; ++nn) acc[m][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int nn = 0; nn < NT; ++nn) acc[m][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #ifdef ESTD_TIMELINE
             if (tid == 0 && p.stats_partials) {
                 const size_t t16 = (((size_t)n * D + d) * tiles_h + thi) * tiles_w16 + 2 * twi;
@@ -376,32 +436,59 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
 
             for_each_tap([&](auto tap_c) __attribute__((always_inline)) {
                 constexpr int tap = decltype(tap_c)::value;
-                constexpr int nt = tap == 26 ? 0 : tap + 1;
+                constexpr int nt = tap == NTAPS - 1 ? 0 : tap + 1;
+                constexpr bool next_is_extra = EXTRA && nt == 27;
                 constexpr int nkd = nt / 9, nkh = (nt / 3) % 3, nkw = nt % 3;
                 // slot of the NEXT tap's slice: kd 0/2 -> even slot, kd 1 -> odd slot; tap 0 of the next tile -> its even slot = our odd
-                const int nsb = (tap == 26) ? sb_odd : (nkd == 1 ? sb_odd : sb_even);
-                const int wrd = LDS_W + wsel * WSLOT_BYTES, wwr = LDS_W + (wsel ^ 1) * WSLOT_BYTES;
+                const int nsb = (nt == 0) ? sb_odd : (nkd == 1 ? sb_odd : sb_even);
+                const int wrd = LDS_W + wsel * WTAP_BYTES, wwr = LDS_W + (wsel ^ 1) * WTAP_BYTES;
 
                 // 1. fragments of the next tap
-                bf16x8 anext[2][3], bnext[3][2];
+                bf16x8 anext[2][3], bnext[3][NT];
+                if constexpr (next_is_extra) {
+                    // gather the 8 taps of this lane's k group from the scalar ring and split them in registers
+                    const int xs0 = xslot(d - 1), xs1 = xslot(d), xs2 = xslot(d + 1);
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                    for (int m = 0; m < 2; ++m) {
+                        float xv[8];
 #pragma unroll
-                    for (int pc = 0; pc < 3; ++pc) {
-                        if (ESTD_SABL & 2) { anext[m][pc] = acur[m][pc]; asm volatile("" : "+v"(anext[m][pc])); } else
-                        anext[m][pc] = *reinterpret_cast<const bf16x8*>(smem + nsb + pc * PIECE_BYTES + a_lane + ((wave + nkh) * IN_W + nkw + 16 * m) * 16);
+                        for (int j = 0; j < 8; ++j) {
+                            const int base = xkd[j] <= 0 ? xs0 : (xkd[j] == 1 ? xs1 : xs2);
+                            const float v = *reinterpret_cast<const float*>(smem + base + xo[j] + (wave * IN_W + 16 * m + i) * 4);
+                            xv[j] = xkd[j] < 0 ? 0.f : v;
+                        }
+                        u32x4 h, md, l;
+                        unsigned th, tm, tl;
+                        split2(xv[0], xv[1], th, tm, tl); h[0] = th; md[0] = tm; l[0] = tl;
+                        split2(xv[2], xv[3], th, tm, tl); h[1] = th; md[1] = tm; l[1] = tl;
+                        split2(xv[4], xv[5], th, tm, tl); h[2] = th; md[2] = tm; l[2] = tl;
+                        split2(xv[6], xv[7], th, tm, tl); h[3] = th; md[3] = tm; l[3] = tl;
+                        __builtin_memcpy(&anext[m][0], &h, 16);
+                        __builtin_memcpy(&anext[m][1], &md, 16);
+                        __builtin_memcpy(&anext[m][2], &l, 16);
                     }
+                } else {
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc) {
+                            if (ESTD_SABL & 2) { anext[m][pc] = acur[m][pc]; asm volatile("" : "+v"(anext[m][pc])); } else
+                            anext[m][pc] = *reinterpret_cast<const bf16x8*>(smem + nsb + pc * PIECE_BYTES + a_lane + ((wave + nkh) * IN_W + nkw + 16 * m) * 16);
+                        }
+                }
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
 #pragma unroll
                     for (int nn = 0; nn < 2; ++nn) {
                         if (ESTD_SABL & 4) { bnext[pc][nn] = bcur[pc][nn]; asm volatile("" : "+v"(bnext[pc][nn])); } else
                         bnext[pc][nn] = *reinterpret_cast<const bf16x8*>(smem + wrd + (pc * 2 + nn) * 1024 + b_lane);
                     }
+                    if (NT == 3) bnext[pc][NT - 1] = *reinterpret_cast<const bf16x8*>(smem + wrd + pc * 64 + bx_lane);
+                }
                 // 2. weights of tap+2 -> the free weight slot; 3. weights of tap+3 -> registers
                 if (!(ESTD_SABL & 8)) {
                     *reinterpret_cast<u32x4*>(smem + wwr + w_lane) = wreg;
-                    wreg = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, ((tap + 3) % 27) * WTAP_BYTES, 0);
+                    wreg = __builtin_amdgcn_raw_buffer_load_b128(rs_w, w_lane, ((tap + 3) % NTAPS) * WTAP_BYTES, 0);
                 }
                 // 4. ring: refill the even slot with slice d+1 (taps 8..10), then prefetch slice d+2 (taps 11..16)
                 if constexpr (tap >= 8 && tap < 8 + FIT) {
@@ -412,6 +499,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
                     if (!(ESTD_SABL & 16))
                         pf[k] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, fetch ? voff[k >> 1] : OOB_OFFSET, next_soff + (k & 1) * 16, 0));
                 }
+                if constexpr (EXTRA && tap == 17)      // scalar channel: slice d+2 -> register, stored once tap 27's gather (issued in tap 26) is done
+                    pfx = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ex, fetch ? voffx : OOB_OFFSET, (d + 2) * HW * 4, 0));
+                if constexpr (EXTRA && tap == 27) xstore(d + 2, pfx);
                 // 5. deferred epilogue of the previous tile (all stores are dropped while there is none)
                 if (!(ESTD_SABL & 32)) {
                     if constexpr (tap == 0) epi_load(el, 0, pend_d, have_pend);
@@ -419,7 +509,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
                     if constexpr (tap == 2) { epi_finish(el, pend, 1, pend_d, have_pend); if (STATS && ESTD_SPLIT_STATS_ON) stats_to_lds(); }
                     if constexpr (tap == 3) { if (STATS && ESTD_SPLIT_STATS_ON) stats_store(pend_d, have_pend); }
                 }
-                // 6. this tap's products, smallest terms first; the four accumulator chains are interleaved
+                // 6. this tap's products, smallest terms first; the accumulator chains are interleaved
                 {
                     constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
@@ -427,7 +517,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
 #pragma unroll
                         for (int m = 0; m < 2; ++m)
 #pragma unroll
-                            for (int nn = 0; nn < 2; ++nn)
+                            for (int nn = 0; nn < NT; ++nn)
                                 acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(acur[m][PA[t]], bcur[PB[t]][nn], acc[m][nn], 0, 0, 0);
                 }
 #pragma unroll
@@ -437,19 +527,19 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
-                    for (int nn = 0; nn < 2; ++nn) bcur[pc][nn] = bnext[pc][nn];
+                    for (int nn = 0; nn < NT; ++nn) bcur[pc][nn] = bnext[pc][nn];
                 wsel ^= 1;
-                tap_pipeline<tap>();
+                tap_pipeline<tap, NT, EXTRA>();
                 __builtin_amdgcn_sched_barrier(0);       // nothing of this tap moves past the barrier (asm volatile does not order register-only ops)
                 if (ESTD_SABL & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else
                 lds_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-            }, std::make_integer_sequence<int, 27>{});
+            }, std::make_integer_sequence<int, NTAPS>{});
 
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int nn = 0; nn < 2; ++nn) pend[m][nn] = acc[m][nn];
+                for (int nn = 0; nn < NT; ++nn) pend[m][nn] = acc[m][nn];
             pend_d = d;
             have_pend = true;
             q ^= 1;
@@ -468,18 +558,18 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
     }
 }
 
-template <bool TANH, bool STATS>
+template <int NT, bool EXTRA, bool TANH, bool STATS>
 int launch(const estd_conv3d_desc& d, hipStream_t stream, int tiles_w, int tiles_h, int total)
 {
     int grid = total < 256 ? total : 256;       // one workgroup per CU (LDS-limited)
     if (grid >= 8) grid &= ~7;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_split_kernel<TANH, STATS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_split_kernel<NT, EXTRA, TANH, STATS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3d_k3_split_kernel<TANH, STATS>), dim3(grid), dim3(512), LDS_TOTAL, stream, d, tiles_w, tiles_h, total);
+    hipLaunchKernelGGL((conv3d_k3_split_kernel<NT, EXTRA, TANH, STATS>), dim3(grid), dim3(512), LDS_TOTAL, stream, d, tiles_w, tiles_h, total);
     return hipGetLastError() == hipSuccess ? ESTD_OK : ESTD_ERR_LAUNCH;
 }
 
@@ -492,7 +582,9 @@ extern "C" int estd_conv3d_k3_split(const estd_conv3d_desc* dp, estd_stream_t s)
     hipStream_t stream = static_cast<hipStream_t>(s);
     if (d.N <= 0 || d.D <= 0 || d.H <= 0 || d.W <= 0) return ESTD_ERR_ARG;
     if (!d.in_main || !d.w_split || !d.scale || !d.shift || !d.out_main) return ESTD_ERR_ARG;
-    if (d.cin_main != 32 || d.n_tiles != 2 || d.in_extra || d.head_w || d.out_extra) return ESTD_ERR_UNSUPPORTED;
+    if (d.cin_main != 32 || (d.n_tiles != 2 && d.n_tiles != 3) || d.head_w) return ESTD_ERR_UNSUPPORTED;
+    if (d.n_tiles == 3 && (!d.out_extra || !d.in_extra)) return ESTD_ERR_ARG;
+    if (d.n_tiles == 2 && d.out_extra) return ESTD_ERR_ARG;
     if (d.in_stride < 32 || (d.in_stride & 3) || d.out_stride < 32 || (d.out_stride & 1) || (d.act_split & 1)) return ESTD_ERR_ARG;
     const int tiles_w = (d.W + TW - 1) / TW, tiles_h = (d.H + TH - 1) / TH;
     const long long total = (long long)d.N * d.D * tiles_h * tiles_w;
@@ -504,6 +596,11 @@ extern "C" int estd_conv3d_k3_split(const estd_conv3d_desc* dp, estd_stream_t s)
     }
     const bool tanh_used = (d.act_split > 0 && d.act_a == ESTD_ACT_TANH) || d.act_b == ESTD_ACT_TANH;
     const bool stats = d.stats_partials != nullptr;
-    if (tanh_used) return stats ? launch<true, true>(d, stream, tiles_w, tiles_h, (int)total) : launch<true, false>(d, stream, tiles_w, tiles_h, (int)total);
-    return stats ? launch<false, true>(d, stream, tiles_w, tiles_h, (int)total) : launch<false, false>(d, stream, tiles_w, tiles_h, (int)total);
+    const bool extra = d.in_extra != nullptr;
+    const int t = (int)total;
+    // instantiated combinations = the ones the decoder / transformer use (hybrid_depth_decoder.py:84-112, epipolar_transformer.py:21)
+    if (d.n_tiles == 3) return (!tanh_used && !stats) ? launch<3, true, false, false>(d, stream, tiles_w, tiles_h, t) : ESTD_ERR_UNSUPPORTED;
+    if (extra) return stats ? ESTD_ERR_UNSUPPORTED : launch<2, true, true, false>(d, stream, tiles_w, tiles_h, t);
+    if (tanh_used) return ESTD_ERR_UNSUPPORTED;
+    return stats ? launch<2, false, false, true>(d, stream, tiles_w, tiles_h, t) : launch<2, false, false, false>(d, stream, tiles_w, tiles_h, t);
 }

@@ -110,8 +110,8 @@ class Conv3dPlan:
         self.cin_main = len(main_idx)
         self.n_tiles = n_tiles
         self.n_out = len(out_idx)
-        splittable = len(main_idx) == 32 and n_tiles == 2 and extra_idx is None and head_w is None
-        self.w_split = packing.pack_conv3d_split(weight, main_idx, out_idx).to(device) if splittable else None
+        splittable = len(main_idx) == 32 and head_w is None and (n_tiles == 2 or (n_tiles == 3 and extra_idx is not None))
+        self.w_split = packing.pack_conv3d_split(weight, main_idx, out_idx, extra_idx, n_tiles).to(device) if splittable else None
         self.w_main = wm.to(device)
         self.w_extra = wx.to(device) if wx is not None else None
         self.scale = scale.float().contiguous().to(device)
@@ -166,7 +166,16 @@ class Conv3dPlan:
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream())
-        if CONV3D_ARITH == "bf16x3" and self.w_split is not None and out is not None:
+        # instances of the split kernel (csrc/conv3d_split_bf16.hip dispatch): plain [+stats], extra input [tanh|relu], 33 -> 33
+        tanh = ACT["tanh"] in ((self.act_a if self.act_split > 0 else self.act_b), self.act_b)
+        if self.n_tiles == 3:
+            inst = not tanh and stats_partials is None
+        elif self.w_extra is not None:
+            inst = stats_partials is None
+        else:
+            inst = not tanh
+        split_ok = self.w_split is not None and out is not None and inst
+        if CONV3D_ARITH == "bf16x3" and split_ok:
             d.w_split = self.w_split.data_ptr()
             N.check(N.lib().estd_conv3d_k3_split(ctypes.byref(d), _stream()), "estd_conv3d_k3_split")
         elif CONV3D_ARITH not in ("f32", "bf16x3"):

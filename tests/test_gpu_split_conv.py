@@ -75,10 +75,10 @@ def test_split_error_is_fp32_level(dims, scale):
 
 @pytest.mark.parametrize("dims", [(1, 4, 8, 32), (3, 5, 13, 50), (1, 2, 120, 160), (2, 1, 9, 33), (1, 70, 8, 32)])
 def test_split_matches_fp32_kernel_all_epilogues(dims):
-    """residual, second residual, 1/n scale, running accumulation, ReLU|tanh split, GroupNorm partials, strided I/O."""
+    """residual, second residual, 1/n scale, running accumulation, none|ReLU split, GroupNorm partials, strided I/O."""
     from estdepth_amd import ops
     mod, plan = _plan(21)
-    plan.act_a, plan.act_b, plan.act_split = ops.ACT["tanh"], ops.ACT["relu"], 16
+    plan.act_a, plan.act_b, plan.act_split = ops.ACT["none"], ops.ACT["relu"], 16
     N, D, H, W = dims
     g = torch.Generator(device=DEV).manual_seed(3)
     x = torch.randn(N, D, H, W, 40, device=DEV, generator=g)           # in_stride 40 > 32
@@ -158,3 +158,62 @@ def test_joint_carry_golden_with_split_arithmetic(golden_dir, split_arith):
             assert err < 1e-4, (name, err)                     # north_star tolerance
         assert checksum_close(checksum(pre_costs["values"][0].cpu().numpy()), g["c%d|value_ck" % call])
     print("joint carry with bf16x3 arithmetic: worst |depth - reference| = %.3g" % worst)
+
+
+@pytest.mark.parametrize("dims", [(1, 4, 8, 32), (2, 5, 13, 50), (1, 66, 9, 33), (3, 1, 24, 32)])
+def test_split_extra_input_and_33rd_output_match_fp32_kernel(dims):
+    """dres2 (33 -> 33: scalar extra input channel + 33rd output channel) and the fused value|key conv (33 -> 32, tanh|relu)
+    on both arithmetics (hybrid_depth_decoder.py:95-97)."""
+    from estdepth_amd import ops, synth
+    from estdepth_amd.layers_op import ConvBN3d
+    N, D, H, W = dims
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.randn(N, D, H, W, 32, device=DEV, generator=g)
+    xe = torch.randn(N, D, H, W, device=DEV, generator=g)
+    d2 = ConvBN3d(33, 33, 3, 1, 1, "relu").eval()
+    synth.fill_state_dict(d2, seed=33)
+    p2 = d2.to(DEV).plan(main_idx=list(range(1, 33)), extra_idx=0, out_idx=list(range(33)), n_tiles=3)
+    vl, kl = ConvBN3d(33, 16, 3, 1, 1, "tanh").eval(), ConvBN3d(33, 16, 3, 1, 1, "relu").eval()
+    synth.fill_state_dict(vl, seed=34); synth.fill_state_dict(kl, seed=35)
+    vl, kl = vl.to(DEV), kl.to(DEV)
+    sv, hv = vl.folded(); sk, hk = kl.folded()
+    pkv = ops.Conv3dPlan(torch.cat([vl[0].weight.detach(), kl[0].weight.detach()], 0), list(range(32)), 32, list(range(32)), 2,
+                         torch.cat([sv, sk]), torch.cat([hv, hk]), act_a="tanh", act_b="relu", act_split=16, device=DEV)
+    assert p2.w_split is not None and pkv.w_split is not None
+    res = {}
+    for arith in ("f32", "bf16x3"):
+        ops.CONV3D_ARITH = arith
+        try:
+            a = torch.empty_like(x); ex = torch.full_like(xe, float("nan"))
+            p2.run(x, dims, in_extra=xe, out=a, out_stride=32, out_extra=ex)
+            kv = torch.empty_like(x)
+            pkv.run(a, dims, in_extra=ex, out=kv, out_stride=32)
+            torch.cuda.synchronize()
+        finally:
+            ops.CONV3D_ARITH = "f32"
+        res[arith] = (a, ex, kv)
+    for k, name in enumerate(("dres2 main", "dres2 33rd", "value|key")):
+        a, b = res["f32"][k], res["bf16x3"][k]
+        assert torch.isfinite(b).all(), name
+        assert (a - b).abs().max().item() < 3e-6 * max(1.0, a.abs().max().item()), (name, (a - b).abs().max().item())
+
+
+def test_decoder_golden_with_split_arithmetic(golden_dir, split_arith):
+    """G6 (decoder, R18, one memory volume: transformer branch) with every eligible conv on the split kernel."""
+    from estdepth_amd import DepthHybridDecoder, synth
+    import os
+    g = np.load(os.path.join(golden_dir, "g6_decoder_r18_mem1.npz"))
+    ch = np.array([64, 64, 128, 256, 512])
+    dec = DepthHybridDecoder(ch, ndepths=64, depth_max=10.0, IF_EST_transformer=True).eval()
+    synth.fill_state_dict(dec, seed=6)
+    dec = dec.to(DEV)
+    cvs, sem, cposes, K, dv, dmin, dint = S.g6_inputs(18, 2)
+    pre_costs, pre_poses = S.g6_memory(1)
+    to = lambda t: t.to(DEV)
+    pre_costs = {k: [to(t) for t in v] for k, v in pre_costs.items()}
+    with torch.no_grad():
+        outputs, costs, rposes = dec([to(c) for c in cvs], [to(s_) for s_ in sem], [to(p_) for p_ in cposes], to(K), to(dv), dmin, dint,
+                                     pre_costs, [to(p_) for p_ in pre_poses], mode="val")
+    for k, v in outputs.items():
+        name = "|".join(map(str, k))
+        assert np.abs(v.cpu().numpy() - g[name]).max() < 1e-4, name
