@@ -133,6 +133,19 @@ def test_split_linearity_full_size():
     assert (o32 - ox).abs().max().item() < 2e-6 * o32.abs().max().item()
 
 
+def test_split_cfg5_volume_matches_fp32_kernel():
+    """BASELINE configs[4] volume (128x240x320x32 = 1.26 GB): the two arithmetics agree on the whole tensor, with a
+    residual and the 1/2 scale of the cost-volume mean in the epilogue."""
+    mod, plan = _plan(55)
+    dims = (1, 128, 240, 320)
+    g = torch.Generator(device=DEV).manual_seed(2)
+    x = torch.randn(*dims, 32, device=DEV, generator=g)
+    a = _run(plan, "f32", x, dims, residual=x, out_scale=0.5)
+    b = _run(plan, "bf16x3", x, dims, residual=x, out_scale=0.5)
+    assert bool(torch.isfinite(b).all())
+    assert (a - b).abs().max().item() < 2e-6 * a.abs().max().item()
+
+
 def test_joint_carry_golden_with_split_arithmetic(golden_dir, split_arith):
     """configs[1] protocol (two chained Joint calls, EST transformer on the second) vs the reference's golden depth maps."""
     from estdepth_amd import DepthNetHybrid, synth

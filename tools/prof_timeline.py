@@ -62,3 +62,22 @@ qs = defaultdict(int)
 for s, e, n, q, st in region:
     qs[(q, st)] += e - s
 print("per (queue, stream) busy ms/step:", {k: round(v / 1e6 / steps, 2) for k, v in qs.items()})
+
+# ---- per-queue gaps of the LAST step: where does each stream wait? ----
+if "--gaps" in sys.argv:
+    step_len = span // steps
+    s0 = t1 - step_len
+    last = [r for r in region if r[0] >= s0]
+    byq = defaultdict(list)
+    for s, e, n, q, st in last:
+        byq[q].append((s, e, n))
+    for q, ks in byq.items():
+        ks.sort()
+        busy = sum(e - s for s, e, _ in ks)
+        print("queue %s: %d kernels, busy %.2f ms, first start +%.2f ms, last end +%.2f ms" % (q, len(ks), busy / 1e6, (ks[0][0] - s0) / 1e6, (ks[-1][1] - s0) / 1e6))
+        prev_e, prev_n = ks[0][1], ks[0][2]
+        for s, e, n in ks[1:]:
+            if s - prev_e > 100000:
+                print("    gap %.2f ms at +%.2f ms: after %s -> before %s" % ((s - prev_e) / 1e6, (prev_e - s0) / 1e6, prev_n[:60], n[:60]))
+            if e > prev_e:
+                prev_e, prev_n = e, n
