@@ -19,6 +19,7 @@ PROFILE = None
 # Arithmetic of the plain 32->32 3x3x3 convolutions: "f32" = v_mfma_f32_16x16x4_f32 (csrc/conv3d_mfma.hip),
 # "bf16x3" = exact 3-way bf16 operand split, six bf16 MFMAs per product block (csrc/conv3d_split_bf16.hip).
 CONV3D_ARITH = os.environ.get("ESTD_CONV3D_ARITH", "f32")
+CONV2D_ARITH = os.environ.get("ESTD_CONV2D_ARITH", "f32")     # same choice for the 3x3 / dilation-1 NHWC convolutions
 
 
 def _stream():
@@ -202,6 +203,7 @@ class Conv2dPlan:
         self.cin, self.cout, self.dil = conv.in_channels, conv.out_channels, conv.dilation[0]
         self.nt = 4 if self.cout % 64 == 0 else 2
         self.w = packing.pack_conv2d(conv.weight, self.nt).to(dev)
+        self.w_split = packing.pack_conv2d_split(conv.weight).to(dev) if self.dil == 1 else None
         sc, sh = packing.fold_bn_fp32(bn, list(range(self.cout)))
         self.scale, self.shift = sc.to(dev), sh.to(dev)
         self.relu_before, self.relu_after = int(relu_before), int(relu_after)
@@ -221,7 +223,13 @@ class Conv2dPlan:
             raise RuntimeError("Conv2dPlan.run: residual must be contiguous NHWC of the output shape")
         d.residual = residual.data_ptr() if residual is not None else None
         d.out = out.data_ptr()
-        N.check(N.lib().estd_conv2d_k3(ctypes.byref(d), _stream()), "estd_conv2d_k3")
+        if CONV2D_ARITH == "bf16x3" and self.w_split is not None:
+            d.w_split = self.w_split.data_ptr()
+            N.check(N.lib().estd_conv2d_k3_split(ctypes.byref(d), _stream()), "estd_conv2d_k3_split")
+        elif CONV2D_ARITH not in ("f32", "bf16x3"):
+            raise RuntimeError("ESTD_CONV2D_ARITH must be f32 or bf16x3, got %r" % (CONV2D_ARITH,))
+        else:
+            N.check(N.lib().estd_conv2d_k3(ctypes.byref(d), _stream()), "estd_conv2d_k3")
         return out
 
 

@@ -185,3 +185,18 @@ def pack_conv3d_split(weight, main_idx, out_idx, extra_idx=None, n_tiles=2):
     rec[:, :3072] = np.stack(bf16_split3(main), axis=1).reshape(ntaps, 3072)
     rec[:, 3072:3072 + 96] = np.stack(bf16_split3(xcol), axis=1).reshape(ntaps, 96)
     return torch.from_numpy(rec.view(np.int16).copy())
+
+
+def pack_conv2d_split(weight):
+    """3x3 Conv2d weight [Cout, Cin, 3, 3] (multiples of 32) for csrc/conv2d_split_bf16.hip: int16
+    [Cout/32 groups][Cin/32 chunks][9 taps][4096]: per record bytes 0..6143 = [3 pieces][2 n-tiles][64 lanes][8] bf16
+    (lane l = column j = l & 15, k = 8*(l >> 4) .. +7 inside the chunk; output channel = 32*group + 2j + n-tile), rest zero."""
+    w = weight.detach().float().cpu().numpy()
+    cout, cin = w.shape[:2]
+    assert cout % 32 == 0 and cin % 32 == 0 and w.shape[2:] == (3, 3)
+    w = w.reshape(cout // 32, 16, 2, cin // 32, 4, 8, 9)            # [grp][j][n][chunk][kg][e][tap]
+    sel = np.ascontiguousarray(w.transpose(0, 3, 6, 2, 4, 1, 5))    # [grp][chunk][tap][n][kg][j][e]
+    sel = sel.reshape(cout // 32, cin // 32, 9, 2, 64, 8)           # lane = kg*16 + j
+    rec = np.zeros((cout // 32, cin // 32, 9, 4096), np.uint16)
+    rec[..., :3072] = np.stack(bf16_split3(sel), axis=3).reshape(cout // 32, cin // 32, 9, 3072)
+    return torch.from_numpy(rec.view(np.int16).copy())

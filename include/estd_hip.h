@@ -139,9 +139,14 @@ typedef struct estd_conv2d_desc {
     int relu_after_residual;  /* relu(conv-bn + residual) */
     const float* residual;    /* [N][H][W][cout] or NULL */
     float* out;               /* [N][H][W][cout] */
+    /* estd_conv2d_k3_split only: int16 [cout/32][cin/32][9 taps][4096] bf16 split weights (packing.py::pack_conv2d_split) */
+    const void* w_split;
 } estd_conv2d_desc;
 
 int estd_conv2d_k3(const estd_conv2d_desc* desc, estd_stream_t stream);
+/* Same operator (dilation 1 only; group_tiles ignored: 32 output channels per work item) with every fp32 product as six
+ * bf16 MFMA products of exactly 3-way split operands, fp32 accumulation (see estd_conv3d_k3_split). */
+int estd_conv2d_k3_split(const estd_conv2d_desc* desc, estd_stream_t stream);
 
 /* mean/rstd from the partials: stats_out = {mean_g0, rstd_g0, mean_g1, rstd_g1}; count = 16*D*H*W per group
  * (transformer/epipolar_transformer.py:22-23,:27 GroupNorm(1, 16, eps=1e-5)). */

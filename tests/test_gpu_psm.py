@@ -143,3 +143,70 @@ def test_e2e_golden_with_fused_bn(golden_dir):
             name = "c%d|" % call + "|".join(map(str, k))
             if name in g.files:
                 assert np.abs(v.cpu().numpy() - g[name]).max() < 1e-4, name
+
+
+@pytest.mark.parametrize("cin,cout,dims,relu,res", [(32, 32, (2, 13, 21), True, False), (64, 64, (1, 24, 32), False, True),
+                                                    (96, 64, (1, 8, 16), False, False), (320, 128, (1, 9, 40), True, False),
+                                                    (64, 64, (5, 120, 160), False, True)])
+def test_conv2d_split_vs_fp64_and_fp32_kernel(cin, cout, dims, relu, res):
+    """3xbf16 split conv2d: fp32-level error against an fp64 convolution, agreement with the fp32 MFMA kernel."""
+    from estdepth_amd import synth, ops
+    from estdepth_amd.backbones import conv_bn2d
+    N, H, W = dims
+    mod = conv_bn2d(cin, cout, 3, 1, 1, 1).eval()
+    synth.fill_state_dict(mod, seed=cin + cout)
+    g = torch.Generator().manual_seed(cin * 3 + cout)
+    x = torch.randn(N, cin, H, W, generator=g)
+    r = torch.randn(N, cout, H, W, generator=g) if res else None
+    mod = mod.to(DEV)
+    plan = ops.Conv2dPlan(mod[0], mod[1], relu_before=relu, relu_after=res)
+    xin = x.to(DEV).permute(0, 2, 3, 1).contiguous()
+    rin = r.to(DEV).permute(0, 2, 3, 1).contiguous() if res else None
+    outs = {}
+    for arith in ("f32", "bf16x3"):
+        ops.CONV2D_ARITH = arith
+        try:
+            outs[arith] = plan.run(xin, residual=rin)
+            torch.cuda.synchronize()
+        finally:
+            ops.CONV2D_ARITH = "f32"
+    a, b = outs["f32"], outs["bf16x3"]
+    mag = max(1.0, a.abs().max().item())
+    assert (a - b).abs().max().item() < 3e-6 * mag
+    if N * H * W <= 4096:
+        with torch.no_grad():
+            ref = mod.double().cpu()(x.double())
+            if relu:
+                ref = torch.relu(ref)
+            if res:
+                ref = torch.relu(ref + r.double())
+        ref = ref.permute(0, 2, 3, 1)
+        e32 = (a.double().cpu() - ref).abs().max().item()
+        esp = (b.double().cpu() - ref).abs().max().item()
+        assert esp <= 2.0 * e32 + 1e-7 * mag, (esp, e32)
+
+
+def test_e2e_golden_with_all_split_arithmetic(golden_dir):
+    """Joint carry golden with conv3d AND the PSM conv2d kernels on the split arithmetic: depth within 1e-4."""
+    import os
+    import fixtures_spec as S
+    from estdepth_amd import synth, DepthNetHybrid, ops
+    g = np.load(os.path.join(golden_dir, "g9_joint_carry.npz"))
+    m = DepthNetHybrid(ndepths=64, depth_min=0.1, depth_max=10.0, resnet=18, IF_EST_transformer=True).eval()
+    synth.fill_state_dict(m, seed=2, head_gain=1.0)
+    m = m.to(DEV).use_hip_psm().fuse_bn_2d()
+    imgs, poses, intr, sample = S.e2e_inputs(8, S.E2E_HI, S.E2E_WI, seed=1004)
+    imgs, poses, intr = imgs.to(DEV), poses.to(DEV), intr.to(DEV)
+    ops.CONV2D_ARITH = ops.CONV3D_ARITH = "bf16x3"
+    try:
+        pc = pp = None
+        for call in range(2):
+            sl = slice(3 * call, 3 * call + 5)
+            with torch.no_grad():
+                outputs, pc, pp = m(imgs[:, sl], poses[:, sl], intr, {k: v[:, sl] for k, v in sample.items()}, pc, pp, mode="val")
+            for k, v in outputs.items():
+                name = "c%d|" % call + "|".join(map(str, k))
+                if name in g.files:
+                    assert np.abs(v.cpu().numpy() - g[name]).max() < 1e-4, name
+    finally:
+        ops.CONV2D_ARITH = ops.CONV3D_ARITH = "f32"

@@ -1,0 +1,25 @@
+"""Time the PSM 3x3 convolutions (5 images, cfg2) on both arithmetics.  python tools/conv2d_bench.py"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from estdepth_amd import ops
+dev = "cuda"
+for (h, w, cin, cout) in [(240, 320, 32, 32), (120, 160, 64, 64), (120, 160, 128, 128), (120, 160, 320, 128)]:
+    conv = torch.nn.Conv2d(cin, cout, 3, 1, 1, bias=False).to(dev)
+    bn = torch.nn.BatchNorm2d(cout).to(dev).eval()
+    plan = ops.Conv2dPlan(conv, bn, relu_before=True)
+    x = torch.randn(5, h, w, cin, device=dev)
+    gf = 2.0 * 9 * 5 * h * w * cin * cout / 1e9
+    line = "%3dx%-3d %3d->%-3d" % (h, w, cin, cout)
+    for arith in ("f32", "bf16x3"):
+        ops.CONV2D_ARITH = arith
+        for _ in range(3): plan.run(x)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): plan.run(x)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        line += "   %s %.4f ms (%.1f TF/s)" % (arith, ms, gf / ms)
+    print(line)
