@@ -36,6 +36,8 @@ def test_bench_single_gpu_line():
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["workload"].startswith("cfg1")
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    assert d["dtype"] == "f32" and d["config"]["conv3d_arith"] == "f32"          # the headline is native fp32 MFMA
+    assert d["alt_arith"]["conv3d_arith"] == "bf16x3" and d["alt_arith"]["value"] > 0
 
 
 def test_bench_two_ranks_code_path():
