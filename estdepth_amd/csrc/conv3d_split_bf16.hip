@@ -148,8 +148,8 @@ template <int TAP, int NT, bool EXTRA>
 __device__ __forceinline__ void tap_pipeline()
 {
 #if ESTD_SPIPE
-    constexpr int NM = 12 * NT;                     // MFMAs of the tap
-    constexpr int NR = 6 + 3 * NT;                  // LDS fragment reads of the next tap
+    constexpr int NM = NT == 3 ? 30 : 24;           // MFMAs of the tap (third N tile: 3 per M tile)
+    constexpr int NR = NT == 3 ? 13 : 12;           // LDS fragment reads of the next tap
     constexpr bool VALU_HEAVY = TAP <= 2 || (TAP >= 8 && TAP <= 10) || (EXTRA && TAP == 26);
 #pragma unroll
     for (int k = 0; k < NM; ++k) {
@@ -200,7 +200,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
     const int tiles_w16 = (W + 15) / 16;                 // GroupNorm partials keep the 8x16-tile numbering of estd_conv3d_k3_grid
     const int a_lane = g * CHUNK_BYTES + (i + 2 * g) * 16;     // lane part of an A-fragment address
     const int b_lane = lane * 16;
-    const int bx_lane = i == 0 ? WX_OFF + g * 16 : WZERO_OFF;  // third N tile: only column 0 is live
+    // third N tile: column j < 3 holds PIECE j of the 33rd output channel's weights, so one MFMA per A piece puts
+    // a_p*b_1, a_p*b_2, a_p*b_3 into columns 0..2: 3 MFMAs give all nine products, summed over the columns in the epilogue
+    const int bx_lane = i < 3 ? WX_OFF + i * 64 + g * 16 : WZERO_OFF;
     const int w_lane = tid * 16;
     const int dump16 = LDS_DUMP + (tid >= 336 ? tid - 336 : 0) * 16;
     double* red = reinterpret_cast<double*>(smem + LDS_RED);
@@ -319,8 +321,10 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
                 const float2 ov = make_float2(v0, v1);
                 u32x2 od; __builtin_memcpy(&od, &ov, 8);
                 __builtin_amdgcn_raw_buffer_store_b64(od, rs_out, eo, so, 0);
-                if (NT == 3) {      // 33rd output channel: column 0 of the third N tile
-                    const float v2 = fmaxf(a[m][NT - 1][r] * sc2 + sh2, relu_floor2);
+                if (NT == 3) {      // 33rd output channel: columns 0..2 of the third N tile hold the b1/b2/b3 partial sums
+                    float x2 = a[m][NT - 1][r];
+                    x2 += __shfl_down(x2, 1, 16) + __shfl_down(x2, 2, 16);     // lane i = 0 of each 16-lane row gets c0 + c1 + c2
+                    const float v2 = fmaxf(x2 * sc2 + sh2, relu_floor2);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v2), rs_xout, live ? eoffx[m][r] : OOB_OFFSET, dd * HW * 4, 0);
                 }
             }
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
             *reinterpret_cast<u32x4*>(smem + LDS_W + WTAP_BYTES + w_lane) = w1;
         }
         lds_barrier();
-        bf16x8 acur[2][3], bcur[3][NT];
+        bf16x8 acur[2][3], bcur[3][2], bxcur;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -404,8 +408,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
 #pragma unroll
             for (int nn = 0; nn < 2; ++nn)
                 bcur[pc][nn] = *reinterpret_cast<const bf16x8*>(smem + LDS_W + (pc * 2 + nn) * 1024 + b_lane);
-            if (NT == 3) bcur[pc][NT - 1] = *reinterpret_cast<const bf16x8*>(smem + LDS_W + pc * 64 + bx_lane);
         }
+        bxcur = *reinterpret_cast<const bf16x8*>(smem + LDS_W + bx_lane);
         lds_barrier();      // nobody overwrites weight slot 0 (tap 2) before every wave has its tap-0 fragments
 
         int q = 0;          // ring parity: slot q holds slice d-1 (later d+1), slot q^1 holds slice d
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
                 const int wrd = LDS_W + wsel * WTAP_BYTES, wwr = LDS_W + (wsel ^ 1) * WTAP_BYTES;
 
                 // 1. fragments of the next tap
-                bf16x8 anext[2][3], bnext[3][NT];
+                bf16x8 anext[2][3], bnext[3][2], bxnext;
                 if constexpr (next_is_extra) {
                     // gather the 8 taps of this lane's k group from the scalar ring and split them in registers
                     const int xs0 = xslot(d - 1), xs1 = xslot(d), xs2 = xslot(d + 1);
@@ -483,8 +487,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
                         if (ESTD_SABL & 4) { bnext[pc][nn] = bcur[pc][nn]; asm volatile("" : "+v"(bnext[pc][nn])); } else
                         bnext[pc][nn] = *reinterpret_cast<const bf16x8*>(smem + wrd + (pc * 2 + nn) * 1024 + b_lane);
                     }
-                    if (NT == 3) bnext[pc][NT - 1] = *reinterpret_cast<const bf16x8*>(smem + wrd + pc * 64 + bx_lane);
                 }
+                bxnext = bxcur;
+                if (NT == 3) bxnext = *reinterpret_cast<const bf16x8*>(smem + wrd + bx_lane);
                 // 2. weights of tap+2 -> the free weight slot; 3. weights of tap+3 -> registers
                 if (!(ESTD_SABL & 8)) {
                     *reinterpret_cast<u32x4*>(smem + wwr + w_lane) = wreg;
@@ -517,8 +522,15 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
 #pragma unroll
                         for (int m = 0; m < 2; ++m)
 #pragma unroll
-                            for (int nn = 0; nn < NT; ++nn)
+                            for (int nn = 0; nn < 2; ++nn)
                                 acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(acur[m][PA[t]], bcur[PB[t]][nn], acc[m][nn], 0, 0, 0);
+                    if (NT == 3) {
+#pragma unroll
+                        for (int pc = 2; pc >= 0; --pc)
+#pragma unroll
+                            for (int m = 0; m < 2; ++m)
+                                acc[m][NT - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(acur[m][pc], bxcur, acc[m][NT - 1], 0, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
@@ -527,7 +539,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
-                    for (int nn = 0; nn < NT; ++nn) bcur[pc][nn] = bnext[pc][nn];
+                    for (int nn = 0; nn < 2; ++nn) bcur[pc][nn] = bnext[pc][nn];
+                bxcur = bxnext;
                 wsel ^= 1;
                 tap_pipeline<tap, NT, EXTRA>();
                 __builtin_amdgcn_sched_barrier(0);       // nothing of this tap moves past the barrier (asm volatile does not order register-only ops)
