@@ -195,17 +195,24 @@ class PSMFeatures(nn.Module):
         skip = x
         skip_nchw = self._nchw(skip)
         size = skip_nchw.shape[2:]
-        ups = [F.interpolate(self._branch(i, skip_nchw), size=size, mode="bilinear", align_corners=False) for i in (4, 3, 2, 1)]
+        pooled = None
+        if fused_on(self, skip_nchw):
+            # SPP pyramid (windows 4, 8, 16, 32; psm_submodule.py:100-110) from ONE pass over the map: the coarser windows are
+            # aligned unions of 4x4 cells, so their means are means of cell means (ATen's NHWC avg_pool2d walks the 49 MB map
+            # once per branch and takes up to 290 us for the 32x32 windows)
+            p4 = F.avg_pool2d(skip_nchw, 4, 4)
+            pooled = {4: p4, 3: F.avg_pool2d(p4, 2, 2), 2: F.avg_pool2d(p4, 4, 4), 1: F.avg_pool2d(p4, 8, 8)}
+        ups = [F.interpolate(self._branch(i, skip_nchw, pooled), size=size, mode="bilinear", align_corners=False) for i in (4, 3, 2, 1)]
         cat = torch.cat([self._nchw(raw), skip_nchw] + ups, 1)
         y = P["last"].run(self._nhwc(cat))
         last = self.lastconv[2]                                                   # 1x1, 128 -> 32, no BN
         return conv1x1_gemm(last, self._nchw(y)) if fused_on(self, y) else last(self._nchw(y))
 
-    def _branch(self, i, skip):
+    def _branch(self, i, skip, pooled=None):
         """SPP branch: AvgPool -> 1x1 conv -> BN -> ReLU (psm_submodule.py:100-110)."""
         br = getattr(self, "branch%d" % i)
         if fused_on(self, skip):
-            return conv_bn_act(br[1][0], br[1][1], br[0](skip), relu=True)
+            return conv_bn_act(br[1][0], br[1][1], br[0](skip) if pooled is None else pooled[i], relu=True)
         return br(skip)
 
     def forward(self, x):
