@@ -9,6 +9,8 @@ unchanged (parameter names must match the reference's state dict):
     torchvision-layout ResNet (keys ``semanticFeature.encoder.*`` incl. the unused ``fc``)
   * ``conv_bn2d`` / ``UpBlock`` <-> networks/layers_op.py:10-27, hybrid_depth_decoder.py:17-30
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -202,9 +204,14 @@ class PSMFeatures(nn.Module):
             # once per branch and takes up to 290 us for the 32x32 windows)
             p4 = F.avg_pool2d(skip_nchw, 4, 4)
             pooled = {4: p4, 3: F.avg_pool2d(p4, 2, 2), 2: F.avg_pool2d(p4, 4, 4), 1: F.avg_pool2d(p4, 8, 8)}
-        ups = [F.interpolate(self._branch(i, skip_nchw, pooled), size=size, mode="bilinear", align_corners=False) for i in (4, 3, 2, 1)]
-        cat = torch.cat([self._nchw(raw), skip_nchw] + ups, 1)
-        y = P["last"].run(self._nhwc(cat))
+        if pooled is not None and os.environ.get("ESTD_SPP_FUSED", "1") == "1":
+            from . import ops
+            brs = [self._nhwc(self._branch(i, skip_nchw, pooled)) for i in (4, 3, 2, 1)]
+            cat_nhwc = ops.spp_upsample_cat(raw.contiguous(), skip.contiguous(), [b.contiguous() for b in brs])     # upsample x4 + cat, one pass
+        else:
+            ups = [F.interpolate(self._branch(i, skip_nchw, pooled), size=size, mode="bilinear", align_corners=False) for i in (4, 3, 2, 1)]
+            cat_nhwc = self._nhwc(torch.cat([self._nchw(raw), skip_nchw] + ups, 1))
+        y = P["last"].run(cat_nhwc)
         last = self.lastconv[2]                                                   # 1x1, 128 -> 32, no BN
         return conv1x1_gemm(last, self._nchw(y)) if fused_on(self, y) else last(self._nchw(y))
 

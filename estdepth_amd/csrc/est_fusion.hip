@@ -531,3 +531,63 @@ extern "C" int estd_bn_act_nhwc(float* x, const float* scale, const float* shift
                        reinterpret_cast<const float4*>(residual), relu, n4, C / 4);
     return ESTD_LAUNCH_CHECK();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// PSM SPP tail: bilinear upsampling of the (tiny) pooled branch maps fused with the channel concatenation
+namespace {
+struct SppArgs { const float* b[4]; int bh[4], bw[4]; };
+
+__global__ __launch_bounds__(256) void spp_upsample_cat_kernel(const float4* __restrict__ raw, int raw4, const float4* __restrict__ skip, int skip4,
+                                                               SppArgs a, int nb, int cb4, float4* __restrict__ out, int N, int H, int W)
+{
+    const int out4 = raw4 + skip4 + nb * cb4;
+    const long long total = (long long)N * H * W * out4;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int c = (int)(e % out4);
+        const long long pix = e / out4;
+        float4 v;
+        if (c < raw4) v = raw[pix * raw4 + c];
+        else if (c < raw4 + skip4) v = skip[pix * skip4 + (c - raw4)];
+        else {
+            const int k = (c - raw4 - skip4) / cb4, cc = (c - raw4 - skip4) - k * cb4;
+            const int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((long long)W * H));
+            const int bh = a.bh[k], bw = a.bw[k];
+            // ATen area_pixel_compute_source_index, align_corners = False: src = scale * (dst + 0.5) - 0.5, clamped at 0
+            const float sy = fmaxf(((float)bh / (float)H) * ((float)y + 0.5f) - 0.5f, 0.0f);
+            const float sx = fmaxf(((float)bw / (float)W) * ((float)x + 0.5f) - 0.5f, 0.0f);
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int y1 = y0 + (y0 < bh - 1 ? 1 : 0), x1 = x0 + (x0 < bw - 1 ? 1 : 0);
+            const float ly = sy - (float)y0, lx = sx - (float)x0;
+            const float hy = 1.0f - ly, hx = 1.0f - lx;
+            const float4* src = reinterpret_cast<const float4*>(a.b[k]) + (long long)n * bh * bw * cb4 + cc;
+            const float4 v00 = src[((long long)y0 * bw + x0) * cb4], v01 = src[((long long)y0 * bw + x1) * cb4];
+            const float4 v10 = src[((long long)y1 * bw + x0) * cb4], v11 = src[((long long)y1 * bw + x1) * cb4];
+            v.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+            v.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+            v.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+            v.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+        }
+        out[e] = v;
+    }
+}
+}  // namespace
+
+extern "C" int estd_spp_upsample_cat(const float* raw, int c_raw, const float* skip, int c_skip, const float* const* branches,
+                                     const int* bh, const int* bw, int nb, int c_b, float* out, int N, int H, int W, estd_stream_t stream)
+{
+    if (!raw || !skip || !branches || !bh || !bw || !out || nb < 1 || nb > 4 || N <= 0 || H <= 0 || W <= 0) return ESTD_ERR_ARG;
+    if (c_raw <= 0 || c_skip <= 0 || c_b <= 0 || ((c_raw | c_skip | c_b) & 3)) return ESTD_ERR_ARG;
+    SppArgs a;
+    for (int k = 0; k < 4; ++k) {
+        a.b[k] = branches[k < nb ? k : 0]; a.bh[k] = bh[k < nb ? k : 0]; a.bw[k] = bw[k < nb ? k : 0];
+        if (k < nb && (!a.b[k] || a.bh[k] <= 0 || a.bw[k] <= 0)) return ESTD_ERR_ARG;
+    }
+    const long long total = (long long)N * H * W * ((c_raw + c_skip + nb * c_b) / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(spp_upsample_cat_kernel, dim3((unsigned)blocks), dim3(256), 0, estd_stream(stream),
+                       reinterpret_cast<const float4*>(raw), c_raw / 4, reinterpret_cast<const float4*>(skip), c_skip / 4, a, nb, c_b / 4,
+                       reinterpret_cast<float4*>(out), N, H, W);
+    return ESTD_LAUNCH_CHECK();
+}

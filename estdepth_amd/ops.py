@@ -316,6 +316,23 @@ def bn_act_nhwc_(x, scale, shift, relu, residual=None):
     return x
 
 
+def spp_upsample_cat(raw, skip, branches):
+    """NHWC tensors: raw [N,H,W,Cr], skip [N,H,W,Cs], branches [N,hk,wk,Cb] -> [N,H,W,Cr+Cs+nb*Cb] =
+    cat(raw, skip, bilinear_up(branches...)) in one pass (psm_submodule.py:100-116)."""
+    n, h, w, cr = raw.shape
+    cs, cb, nb = skip.shape[3], branches[0].shape[3], len(branches)
+    for t in [raw, skip] + list(branches):
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError("spp_upsample_cat: contiguous float32 NHWC CUDA tensors expected (no CPU path)")
+    out = torch.empty((n, h, w, cr + cs + nb * cb), device=raw.device, dtype=torch.float32)
+    arr = (ctypes.c_void_p * nb)(*[b.data_ptr() for b in branches])
+    bh = (ctypes.c_int * nb)(*[b.shape[1] for b in branches])
+    bw = (ctypes.c_int * nb)(*[b.shape[2] for b in branches])
+    N.check(N.lib().estd_spp_upsample_cat(_p(raw), cr, _p(skip), cs, arr, bh, bw, nb, cb, _p(out), n, h, w, _stream()),
+            "estd_spp_upsample_cat")
+    return out
+
+
 # ---------------------------------------------------------------------------------- layout converters
 def cdhw_to_vol(src, dst, dst_stride, dst_off):
     """src [C,D,H,W] contiguous -> channels dst_off.. of the channels-last records of dst."""

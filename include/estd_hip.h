@@ -209,6 +209,14 @@ int estd_vol_to_cdhw(const float* src, float* dst_cdhw, int C, int64_t S, int sr
 int estd_bn_act_nhwc(float* x, const float* scale, const float* shift, const float* residual, int relu,
                      int64_t n_pix, int C, estd_stream_t stream);
 
+/* ---- PSMNet SPP tail (networks/psm_submodule.py:100-116): out[n][y][x] = cat(raw, skip, up(b[0]), .. up(b[nb-1])) ----------
+ * raw [N][H][W][c_raw], skip [N][H][W][c_skip], b[k] [N][bh[k]][bw[k]][c_b] (NHWC), up = bilinear resize to HxW with
+ * align_corners = False (F.upsample in the reference's torch version = F.interpolate(..., align_corners=False)).
+ * One pass instead of nb upsample kernels + a 123 MB concatenation.  Channel counts multiples of 4, nb <= 4. */
+int estd_spp_upsample_cat(const float* raw, int c_raw, const float* skip, int c_skip, const float* const* branches,
+                          const int* bh, const int* bw, int nb, int c_b, float* out, int N, int H, int W,
+                          estd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -210,3 +210,19 @@ def test_e2e_golden_with_all_split_arithmetic(golden_dir):
                     assert np.abs(v.cpu().numpy() - g[name]).max() < 1e-4, name
     finally:
         ops.CONV2D_ARITH = ops.CONV3D_ARITH = "f32"
+
+
+def test_spp_upsample_cat_matches_torch():
+    """fused bilinear-upsample x4 + concat of the PSM SPP tail vs F.interpolate(align_corners=False) + torch.cat."""
+    from estdepth_amd import ops
+    g = torch.Generator().manual_seed(0)
+    n, h, w = 2, 120, 160
+    raw = torch.randn(n, h, w, 64, generator=g).to(DEV)
+    skip = torch.randn(n, h, w, 128, generator=g).to(DEV)
+    brs = [torch.randn(n, bh, bw, 32, generator=g).to(DEV) for bh, bw in ((30, 40), (15, 20), (7, 10), (3, 5))]
+    out = ops.spp_upsample_cat(raw, skip, brs)
+    ups = [torch.nn.functional.interpolate(b.permute(0, 3, 1, 2), size=(h, w), mode="bilinear", align_corners=False).permute(0, 2, 3, 1) for b in brs]
+    ref = torch.cat([raw, skip] + ups, 3)
+    assert out.shape == ref.shape
+    assert torch.equal(out[..., :192], ref[..., :192])
+    assert (out - ref).abs().max().item() < 2e-6
