@@ -93,6 +93,13 @@ __global__ __launch_bounds__(256) void warp_volume_kernel(const float* __restric
 
 // Fused warp(K_j), warp(V_j) + attention.  4 lanes per target voxel; lane c owns float4 chunk c of
 // the 16 value channels and chunk c of the 16 key channels (kv record = [V(16) | K(16)] = 128 B).
+#ifndef WA_TD
+#define WA_TD 2      // target brick of one 256-thread workgroup (64 voxels x 4 lanes): depth x rows x columns
+#define WA_TY 4
+#define WA_TX 8
+#endif
+static_assert(WA_TD * WA_TY * WA_TX == 64, "a workgroup owns 64 target voxels");
+
 struct WarpAttnArgs {
     const float* kv_src[8];
 };
@@ -105,13 +112,20 @@ __global__ __launch_bounds__(256) void warp_attention_kernel(const float* __rest
 {
     // NS = compile-time source count (1..4) or 8 = generic loop bounded by n_src: registers follow the real count,
     // which keeps occupancy up for this gather-latency-bound kernel.
-    const long long HW = (long long)H * W, S = (long long)D * HW;
+    const long long HW = (long long)H * W;
     const int sub = threadIdx.x & 3;
-    const long long idx = (long long)blockIdx.x * 64 + (threadIdx.x >> 2);
-    if (idx >= S) return;    // whole 4-lane groups exit together
-    const int x = (int)(idx % W);
-    const int y = (int)((idx / W) % H);
-    const int d = (int)(idx / HW);
+    // A workgroup owns a compact 2 x 4 x 8 (d, y, x) brick of target voxels: the gathered source footprint of a brick is
+    // ~135 records per source instead of ~260 for 64 voxels along x, and bricks are numbered x-fastest inside a contiguous
+    // eighth of the volume per XCD, so neighbouring bricks (which gather the same source lines) share one private L2.
+    // (rocprofv3 PMC: the linear mapping fetched 2.95x the algorithmic bytes.)
+    unsigned bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int tx_n = (W + WA_TX - 1) / WA_TX, ty_n = (H + WA_TY - 1) / WA_TY;
+    const int bx = (int)(bid % tx_n), by = (int)((bid / tx_n) % ty_n), bd = (int)(bid / ((unsigned)tx_n * ty_n));
+    const int v = threadIdx.x >> 2;                       // voxel inside the brick: x fastest
+    const int x = bx * WA_TX + (v % WA_TX), y = by * WA_TY + ((v / WA_TX) % WA_TY), d = bd * WA_TD + v / (WA_TX * WA_TY);
+    if (x >= W || y >= H || d >= D) return;               // whole 4-lane groups exit together
+    const long long idx = (long long)d * HW + (long long)y * W + x;
     const float dep = dvals[d];
 
     const float4* t4 = reinterpret_cast<const float4*>(kv_t) + idx * 8;
@@ -395,8 +409,7 @@ extern "C" int estd_warp_attention(const float* kv_target, const float* const* k
     WarpAttnArgs a;
     for (int j = 0; j < 8; ++j) a.kv_src[j] = j < n_src ? kv_src[j] : kv_src[0];
     for (int j = 0; j < n_src; ++j) if (!kv_src[j]) return ESTD_ERR_ARG;
-    const long long S = (long long)D * H * W;
-    const dim3 grid((unsigned)((S + 63) / 64));
+    const dim3 grid((unsigned)(((D + WA_TD - 1) / WA_TD) * ((H + WA_TY - 1) / WA_TY) * ((W + WA_TX - 1) / WA_TX)));   // one workgroup per brick
 #define ESTD_WA_LAUNCH(NS) hipLaunchKernelGGL(warp_attention_kernel<NS>, grid, dim3(256), 0, estd_stream(s), kv_target, a, \
                                               mats_dev, n_src, dvals, depth_min, depth_interval, xh_out, D, H, W)
     switch (n_src) {
