@@ -24,7 +24,8 @@ class GraphedForward:
 
     def _signature(self, imgs, pre_costs, mode):
         n_mem = 0 if pre_costs is None else len(pre_costs["keys"])
-        return (tuple(imgs.shape), n_mem, mode)
+        from . import ops
+        return (tuple(imgs.shape), n_mem, mode, ops.CONV3D_ARITH, ops.CONV2D_ARITH)     # a captured graph bakes the kernel choice in
 
     def _capture(self, key, imgs, cam_poses, cam_intr, sample, pre_costs, pre_cam_poses, mode):
         m = self.model
