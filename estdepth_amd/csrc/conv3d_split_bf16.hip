@@ -148,8 +148,8 @@ template <int TAP, int NT, bool EXTRA>
 __device__ __forceinline__ void tap_pipeline()
 {
 #if ESTD_SPIPE
-    constexpr int NM = NT == 3 ? 30 : 24;           // MFMAs of the tap (third N tile: 3 per M tile)
-    constexpr int NR = NT == 3 ? 13 : 12;           // LDS fragment reads of the next tap
+    constexpr int NM = NT == 3 ? 30 : 12 * NT;      // MFMAs of the tap (third N tile: 3 per M tile)
+    constexpr int NR = NT == 3 ? 13 : 6 + 3 * NT;   // LDS fragment reads of the next tap
     constexpr bool VALU_HEAVY = TAP <= 2 || (TAP >= 8 && TAP <= 10) || (EXTRA && TAP == 26);
 #pragma unroll
     for (int k = 0; k < NM; ++k) {
@@ -163,11 +163,12 @@ __device__ __forceinline__ void tap_pipeline()
 #endif
 }
 
-// NT: 16-channel output tiles on the MFMA (2 = 32 channels; 3 = 32 channels + the 33rd in column 0 of a third tile)
+// NT: 16-channel output tiles on the MFMA (1 = 16 channels; 2 = 32 channels; 3 = 32 channels + the 33rd in a third tile)
 template <int NT, bool EXTRA, bool TANH, bool STATS>
 __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int total_tiles)
 {
     constexpr int NTAPS = EXTRA ? 28 : 27;          // tap 27 = the scalar input channel's 27 taps as one K = 32 block
+    constexpr int NB = NT == 1 ? 1 : 2;             // full N tiles (the third tile of NT == 3 is handled apart)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -186,8 +187,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
     }
     if (u >= u_end) return;
 
-    const int cbase = 2 * i;            // output channels of this lane: 2i (n-tile 0), 2i+1 (n-tile 1)
-    const float sc0 = p.scale[cbase], sh0 = p.shift[cbase], sc1 = p.scale[cbase + 1], sh1 = p.shift[cbase + 1];
+    const int cbase = NB * i;           // output channels of this lane: 2i (n-tile 0), 2i+1 (n-tile 1); NT == 1: channel i
+    const float sc0 = p.scale[cbase], sh0 = p.shift[cbase], sc1 = p.scale[cbase + NB - 1], sh1 = p.shift[cbase + NB - 1];
     const int act0 = cbase < p.act_split ? p.act_a : p.act_b;
     const float relu_floor = act0 == ESTD_ACT_RELU ? 0.0f : -__builtin_huge_valf();    // max(v, floor): branch-free ReLU / identity
     const float out_scale = p.out_scale;
@@ -293,9 +294,15 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const unsigned eo = live ? eoff[m][r] : OOB_OFFSET;
-                L.r1[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_res, eo, so, 0);
-                L.r2[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_res2, eo, so, 0);
-                L.ac[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_acc, eo, so, 0);
+                if (NB == 2) {
+                    L.r1[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_res, eo, so, 0);
+                    L.r2[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_res2, eo, so, 0);
+                    L.ac[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_acc, eo, so, 0);
+                } else {
+                    L.r1[r] = (u32x2){__builtin_amdgcn_raw_buffer_load_b32(rs_res, eo, so, 0), 0u};
+                    L.r2[r] = (u32x2){__builtin_amdgcn_raw_buffer_load_b32(rs_res2, eo, so, 0), 0u};
+                    L.ac[r] = (u32x2){__builtin_amdgcn_raw_buffer_load_b32(rs_acc, eo, so, 0), 0u};
+                }
             }
         };
         double s_sum = 0.0, s_sq = 0.0;
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
             for (int r = 0; r < 4; ++r) {
                 const unsigned eo = live ? eoff[m][r] : OOB_OFFSET;
                 float v0 = a[m][0][r] * sc0 + sh0;
-                float v1 = a[m][1][r] * sc1 + sh1;
+                float v1 = NB == 2 ? a[m][NB - 1][r] * sc1 + sh1 : 0.0f;
                 if (STATS) {
                     const double w = eo != OOB_OFFSET ? 1.0 : 0.0;
                     s_sum += w * ((double)v0 + (double)v1);
@@ -318,9 +325,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
                 const float2 q1 = as_float2(L.r1[r]), q2 = as_float2(L.r2[r]), qa = as_float2(L.ac[r]);
                 v0 = (v0 + q1.x + q2.x) * out_scale + qa.x;
                 v1 = (v1 + q1.y + q2.y) * out_scale + qa.y;
-                const float2 ov = make_float2(v0, v1);
-                u32x2 od; __builtin_memcpy(&od, &ov, 8);
-                __builtin_amdgcn_raw_buffer_store_b64(od, rs_out, eo, so, 0);
+                if (NB == 2) {
+                    const float2 ov = make_float2(v0, v1);
+                    u32x2 od; __builtin_memcpy(&od, &ov, 8);
+                    __builtin_amdgcn_raw_buffer_store_b64(od, rs_out, eo, so, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), rs_out, eo, so, 0);
+                }
                 if (NT == 3) {      // 33rd output channel: columns 0..2 of the third N tile hold the b1/b2/b3 partial sums
                     float x2 = a[m][NT - 1][r];
                     x2 += __shfl_down(x2, 1, 16) + __shfl_down(x2, 2, 16);     // lane i = 0 of each 16-lane row gets c0 + c1 + c2
@@ -397,7 +408,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
             *reinterpret_cast<u32x4*>(smem + LDS_W + WTAP_BYTES + w_lane) = w1;
         }
         lds_barrier();
-        bf16x8 acur[2][3], bcur[3][2], bxcur;
+        bf16x8 acur[2][3], bcur[3][NB], bxcur;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -406,8 +417,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) {
 #pragma unroll
-            for (int nn = 0; nn < 2; ++nn)
-                bcur[pc][nn] = *reinterpret_cast<const bf16x8*>(smem + LDS_W + (pc * 2 + nn) * 1024 + b_lane);
+            for (int nn = 0; nn < NB; ++nn)
+                bcur[pc][nn] = *reinterpret_cast<const bf16x8*>(smem + LDS_W + (pc * NB + nn) * 1024 + b_lane);
         }
         bxcur = *reinterpret_cast<const bf16x8*>(smem + LDS_W + bx_lane);
         lds_barrier();      // nobody overwrites weight slot 0 (tap 2) before every wave has its tap-0 fragments
@@ -448,7 +459,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
                 const int wrd = LDS_W + wsel * WTAP_BYTES, wwr = LDS_W + (wsel ^ 1) * WTAP_BYTES;
 
                 // 1. fragments of the next tap
-                bf16x8 anext[2][3], bnext[3][2], bxnext;
+                bf16x8 anext[2][3], bnext[3][NB], bxnext;
                 if constexpr (next_is_extra) {
                     // gather the 8 taps of this lane's k group from the scalar ring and split them in registers
                     const int xs0 = xslot(d - 1), xs1 = xslot(d), xs2 = xslot(d + 1);
@@ -483,9 +494,9 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) {
 #pragma unroll
-                    for (int nn = 0; nn < 2; ++nn) {
+                    for (int nn = 0; nn < NB; ++nn) {
                         if (ESTD_SABL & 4) { bnext[pc][nn] = bcur[pc][nn]; asm volatile("" : "+v"(bnext[pc][nn])); } else
-                        bnext[pc][nn] = *reinterpret_cast<const bf16x8*>(smem + wrd + (pc * 2 + nn) * 1024 + b_lane);
+                        bnext[pc][nn] = *reinterpret_cast<const bf16x8*>(smem + wrd + (pc * NB + nn) * 1024 + b_lane);
                     }
                 }
                 bxnext = bxcur;
@@ -522,7 +533,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
 #pragma unroll
                         for (int m = 0; m < 2; ++m)
 #pragma unroll
-                            for (int nn = 0; nn < 2; ++nn)
+                            for (int nn = 0; nn < NB; ++nn)
                                 acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(acur[m][PA[t]], bcur[PB[t]][nn], acc[m][nn], 0, 0, 0);
                     if (NT == 3) {
 #pragma unroll
@@ -539,7 +550,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
-                    for (int nn = 0; nn < 2; ++nn) bcur[pc][nn] = bnext[pc][nn];
+                    for (int nn = 0; nn < NB; ++nn) bcur[pc][nn] = bnext[pc][nn];
                 bxcur = bxnext;
                 wsel ^= 1;
                 tap_pipeline<tap, NT, EXTRA>();
@@ -595,10 +606,11 @@ extern "C" int estd_conv3d_k3_split(const estd_conv3d_desc* dp, estd_stream_t s)
     hipStream_t stream = static_cast<hipStream_t>(s);
     if (d.N <= 0 || d.D <= 0 || d.H <= 0 || d.W <= 0) return ESTD_ERR_ARG;
     if (!d.in_main || !d.w_split || !d.scale || !d.shift || !d.out_main) return ESTD_ERR_ARG;
-    if (d.cin_main != 32 || (d.n_tiles != 2 && d.n_tiles != 3) || d.head_w) return ESTD_ERR_UNSUPPORTED;
+    if (d.cin_main != 32 || d.n_tiles < 1 || d.n_tiles > 3 || d.head_w) return ESTD_ERR_UNSUPPORTED;
     if (d.n_tiles == 3 && (!d.out_extra || !d.in_extra)) return ESTD_ERR_ARG;
-    if (d.n_tiles == 2 && d.out_extra) return ESTD_ERR_ARG;
-    if (d.in_stride < 32 || (d.in_stride & 3) || d.out_stride < 32 || (d.out_stride & 1) || (d.act_split & 1)) return ESTD_ERR_ARG;
+    if (d.n_tiles < 3 && d.out_extra) return ESTD_ERR_ARG;
+    if (d.in_stride < 32 || (d.in_stride & 3) || d.out_stride < (d.n_tiles == 1 ? 16 : 32) || (d.act_split & 1)) return ESTD_ERR_ARG;
+    if (d.n_tiles >= 2 && (d.out_stride & 1)) return ESTD_ERR_ARG;
     const int tiles_w = (d.W + TW - 1) / TW, tiles_h = (d.H + TH - 1) / TH;
     const long long total = (long long)d.N * d.D * tiles_h * tiles_w;
     if (total > 0x7fffffffLL) return ESTD_ERR_ARG;
@@ -613,6 +625,10 @@ extern "C" int estd_conv3d_k3_split(const estd_conv3d_desc* dp, estd_stream_t s)
     const int t = (int)total;
     // instantiated combinations = the ones the decoder / transformer use (hybrid_depth_decoder.py:84-112, epipolar_transformer.py:21)
     if (d.n_tiles == 3) return (!tanh_used && !stats) ? launch<3, true, false, false>(d, stream, tiles_w, tiles_h, t) : ESTD_ERR_UNSUPPORTED;
+    if (d.n_tiles == 1) {        // 32 -> 16 (GRU output convolution)
+        if (extra || tanh_used) return ESTD_ERR_UNSUPPORTED;
+        return stats ? launch<1, false, false, true>(d, stream, tiles_w, tiles_h, t) : launch<1, false, false, false>(d, stream, tiles_w, tiles_h, t);
+    }
     if (extra) return stats ? ESTD_ERR_UNSUPPORTED : launch<2, true, true, false>(d, stream, tiles_w, tiles_h, t);
     if (tanh_used) return ESTD_ERR_UNSUPPORTED;
     return stats ? launch<2, false, false, true>(d, stream, tiles_w, tiles_h, t) : launch<2, false, false, false>(d, stream, tiles_w, tiles_h, t);

@@ -111,7 +111,8 @@ class Conv3dPlan:
         self.cin_main = len(main_idx)
         self.n_tiles = n_tiles
         self.n_out = len(out_idx)
-        splittable = len(main_idx) == 32 and head_w is None and (n_tiles == 2 or (n_tiles == 3 and extra_idx is not None))
+        splittable = len(main_idx) == 32 and head_w is None and \
+            (n_tiles == 2 or (n_tiles == 3 and extra_idx is not None) or (n_tiles == 1 and extra_idx is None))
         self.w_split = packing.pack_conv3d_split(weight, main_idx, out_idx, extra_idx, n_tiles).to(device) if splittable else None
         self.w_main = wm.to(device)
         self.w_extra = wx.to(device) if wx is not None else None
@@ -171,6 +172,8 @@ class Conv3dPlan:
         tanh = ACT["tanh"] in ((self.act_a if self.act_split > 0 else self.act_b), self.act_b)
         if self.n_tiles == 3:
             inst = not tanh and stats_partials is None
+        elif self.n_tiles == 1:
+            inst = not tanh and self.w_extra is None
         elif self.w_extra is not None:
             inst = stats_partials is None
         else:

@@ -155,21 +155,22 @@ def bf16_split3(x):
 
 def pack_conv3d_split(weight, main_idx, out_idx, extra_idx=None, n_tiles=2):
     """Split weights for csrc/conv3d_split_bf16.hip: int16 [27|28 records][4096] (bf16 bit patterns), 8192 bytes per tap:
-      bytes    0..6143  [3 pieces][2 n-tiles][64 lanes][8]: v_mfma_f32_16x16x32_bf16 B operand, lane l = column j = l & 15,
-                        k = 8*(l >> 4) .. +7 = position of the input channel in memory order (main_idx); output channel
-                        position of (tile n, column j) = 2j + n;
+      bytes    0..6143  [3 pieces][NB n-tiles][64 lanes][8] (NB = 1 for n_tiles == 1, else 2): v_mfma_f32_16x16x32_bf16 B
+                        operand, lane l = column j = l & 15, k = 8*(l >> 4) .. +7 = position of the input channel in memory
+                        order (main_idx); output channel position of (tile n, column j) = NB*j + n;
       bytes 6144..6335  [3 pieces][4 k-groups][8]: the same k order for output channel out_idx[32] (n_tiles == 3), else 0;
       rest              zero (the kernel reads a zero block at byte 6400).
     With ``extra_idx`` a 28th record holds the scalar input channel: k = tap index 0..26 (27..31 zero)."""
     w = weight.detach().float().cpu().numpy().reshape(weight.shape[0], weight.shape[1], 27)
-    assert len(main_idx) == 32 and len(out_idx) >= 32 and n_tiles in (2, 3)
+    assert len(main_idx) == 32 and n_tiles in (1, 2, 3) and len(out_idx) >= (16 if n_tiles == 1 else 32)
+    nb = 1 if n_tiles == 1 else 2
     ntaps = 27 if extra_idx is None else 28
-    main = np.zeros((ntaps, 2, 64, 8), np.float32)
+    main = np.zeros((ntaps, nb, 64, 8), np.float32)
     xcol = np.zeros((ntaps, 4, 8), np.float32)
     for lane in range(64):
         kg, j = lane >> 4, lane & 15
-        for n in range(2):
-            co = out_idx[2 * j + n]
+        for n in range(nb):
+            co = out_idx[nb * j + n]
             for e in range(8):
                 main[:27, n, lane, e] = w[co, main_idx[8 * kg + e], :]
                 if extra_idx is not None and 8 * kg + e < 27:
@@ -182,7 +183,7 @@ def pack_conv3d_split(weight, main_idx, out_idx, extra_idx=None, n_tiles=2):
                 if extra_idx is not None and 8 * kg + e < 27:
                     xcol[27, kg, e] = w[co, extra_idx, 8 * kg + e]
     rec = np.zeros((ntaps, 4096), np.uint16)
-    rec[:, :3072] = np.stack(bf16_split3(main), axis=1).reshape(ntaps, 3072)
+    rec[:, :1536 * nb] = np.stack(bf16_split3(main), axis=1).reshape(ntaps, 1536 * nb)
     rec[:, 3072:3072 + 96] = np.stack(bf16_split3(xcol), axis=1).reshape(ntaps, 96)
     return torch.from_numpy(rec.view(np.int16).copy())
 

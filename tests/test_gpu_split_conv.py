@@ -230,3 +230,27 @@ def test_decoder_golden_with_split_arithmetic(golden_dir, split_arith):
     for k, v in outputs.items():
         name = "|".join(map(str, k))
         assert np.abs(v.cpu().numpy() - g[name]).max() < 1e-4, name
+
+
+@pytest.mark.parametrize("dims,stats", [((1, 4, 8, 32), True), ((2, 5, 13, 50), False), ((1, 64, 120, 160), True)])
+def test_split_32_to_16_matches_fp32_kernel(dims, stats):
+    """the GRU output convolution shape (32 -> 16, bias, optional GroupNorm partials; epipolar_transformer.py:26)."""
+    from estdepth_amd import ops
+    g = torch.Generator().manual_seed(4)
+    w = torch.randn(16, 32, 3, 3, 3, generator=g) * 0.05
+    bias = torch.randn(16, generator=g)
+    plan = ops.Conv3dPlan(w, list(range(32)), None, list(range(16)), 1, torch.ones(16), bias, device=DEV)
+    assert plan.w_split is not None
+    N, D, H, W = dims
+    x = torch.randn(N, D, H, W, 32, generator=torch.Generator().manual_seed(5)).to(DEV)
+    nblk = ops.conv3d_grid(N, D, H, W)
+    res = {}
+    for arith in ("f32", "bf16x3"):
+        part = torch.full((nblk * 4,), float("nan"), device=DEV, dtype=torch.float64) if stats else None
+        out = _run(plan, arith, x, dims, out=torch.empty(N, D, H, W, 16, device=DEV), out_stride=16, stats_partials=part)
+        st = ops.groupnorm_finalize(part, nblk, 16.0 * N * D * H * W, 1e-5) if stats else None
+        res[arith] = (out, st)
+    a, b = res["f32"][0], res["bf16x3"][0]
+    assert (a - b).abs().max().item() < 3e-6 * max(1.0, a.abs().max().item())
+    if stats:
+        np.testing.assert_allclose(res["bf16x3"][1].cpu().numpy()[:2], res["f32"][1].cpu().numpy()[:2], rtol=2e-5, atol=1e-6)
