@@ -204,12 +204,23 @@ class Conv2dPlan:
             raise RuntimeError("Conv2dPlan: channel counts must be multiples of 32")
         dev = conv.weight.device
         self.cin, self.cout, self.dil = conv.in_channels, conv.out_channels, conv.dilation[0]
-        self.nt = 4 if self.cout % 64 == 0 else 2
-        self.w = packing.pack_conv2d(conv.weight, self.nt).to(dev)
+        # output channels per work item: 64 (NT = 4: the input brick feeds twice the MFMAs) unless that leaves the 512 resident
+        # workgroups badly balanced (e.g. 64 -> 64 on 5 x 120x160: 750 items = 1.46 rounds, 87 TFLOP/s; NT = 2: 1500 items, 103)
+        self.w_nt = {2: packing.pack_conv2d(conv.weight, 2).to(dev)}
+        if self.cout % 64 == 0:
+            self.w_nt[4] = packing.pack_conv2d(conv.weight, 4).to(dev)
         self.w_split = packing.pack_conv2d_split(conv.weight).to(dev) if self.dil == 1 else None
         sc, sh = packing.fold_bn_fp32(bn, list(range(self.cout)))
         self.scale, self.shift = sc.to(dev), sh.to(dev)
         self.relu_before, self.relu_after = int(relu_before), int(relu_after)
+
+    def _pick_nt(self, n, h, w):
+        if 4 not in self.w_nt:
+            return 2
+        tiles = n * ((h + 7) // 8) * ((w + 15) // 16)
+        def balance(items):                       # fraction of the persistent grid's rounds that does useful work
+            return items / (512.0 * ((items + 511) // 512))
+        return 2 if 0.93 * balance(tiles * (self.cout // 32)) > balance(tiles * (self.cout // 64)) else 4
 
     def run(self, x_nhwc, residual=None):
         """x_nhwc [N,H,W,Cin] contiguous -> [N,H,W,Cout]."""
@@ -218,9 +229,10 @@ class Conv2dPlan:
             raise RuntimeError("Conv2dPlan.run: expected contiguous NHWC input with %d channels" % self.cin)
         out = torch.empty((Nn, H, W, self.cout), device=x_nhwc.device, dtype=torch.float32)
         d = N.Conv2dDesc()
-        d.N, d.H, d.W, d.cin, d.cout, d.dilation, d.group_tiles = Nn, H, W, self.cin, self.cout, self.dil, self.nt
+        nt = self._pick_nt(Nn, H, W)
+        d.N, d.H, d.W, d.cin, d.cout, d.dilation, d.group_tiles = Nn, H, W, self.cin, self.cout, self.dil, nt
         d.in_ = x_nhwc.data_ptr()
-        d.w, d.scale, d.shift = self.w.data_ptr(), self.scale.data_ptr(), self.shift.data_ptr()
+        d.w, d.scale, d.shift = self.w_nt[nt].data_ptr(), self.scale.data_ptr(), self.shift.data_ptr()
         d.relu_before_residual, d.relu_after_residual = self.relu_before, self.relu_after
         if residual is not None and (tuple(residual.shape) != tuple(out.shape) or not residual.is_contiguous()):
             raise RuntimeError("Conv2dPlan.run: residual must be contiguous NHWC of the output shape")
