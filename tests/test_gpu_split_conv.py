@@ -254,3 +254,34 @@ def test_split_32_to_16_matches_fp32_kernel(dims, stats):
     assert (a - b).abs().max().item() < 3e-6 * max(1.0, a.abs().max().item())
     if stats:
         np.testing.assert_allclose(res["bf16x3"][1].cpu().numpy()[:2], res["f32"][1].cpu().numpy()[:2], rtol=2e-5, atol=1e-6)
+
+
+def test_split_kernels_are_deterministic_at_full_size():
+    """race detector: the LDS pipelines (ring refill, weight hand-over, per-tap barriers) must give bit-identical results on
+    repeated launches of the cfg2-size problem (a missing barrier shows up as run-to-run differences)."""
+    from estdepth_amd import ops, synth
+    from estdepth_amd.backbones import conv_bn2d
+    mod, plan = _plan(91)
+    dims = (3, 64, 120, 160)
+    x = torch.randn(*dims, 32, device=DEV, generator=torch.Generator(device=DEV).manual_seed(8))
+    nblk = ops.conv3d_grid(*dims)
+    ref, ref_st = None, None
+    for _ in range(6):
+        part = torch.zeros(nblk * 4, device=DEV, dtype=torch.float64)
+        out = _run(plan, "bf16x3", x, dims, residual=x, stats_partials=part)
+        if ref is None:
+            ref, ref_st = out.clone(), part.clone()
+        else:
+            assert torch.equal(out, ref) and torch.equal(part, ref_st)
+    c2 = conv_bn2d(64, 64, 3, 1, 1, 1).eval()
+    synth.fill_state_dict(c2, seed=3)
+    c2 = c2.to(DEV)
+    p2 = ops.Conv2dPlan(c2[0], c2[1], relu_before=True)
+    x2 = torch.randn(5, 120, 160, 64, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9))
+    ops.CONV2D_ARITH = "bf16x3"
+    try:
+        outs = [p2.run(x2).clone() for _ in range(6)]
+        torch.cuda.synchronize()
+    finally:
+        ops.CONV2D_ARITH = "f32"
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
