@@ -1,10 +1,11 @@
-// conv2d_split_bf16.hip -- the 3x3 / stride 1 / dilation 1 NHWC convolution of conv2d_mfma.hip with every fp32 product
+// conv2d_split_bf16.hip -- the 3x3 / stride 1 / dilation 1|2 NHWC convolution of conv2d_mfma.hip with every fp32 product
 // evaluated as six bf16 MFMA products of exactly 3-way split operands (see conv3d_split_bf16.hip for the arithmetic and
 // the error bound).  Same descriptor and epilogue (folded BatchNorm, ReLU before/after the residual add) as
 // estd_conv2d_k3 (networks/layers_op.py:10-27, psm_submodule.py:14-37); reads ``w_split`` instead of ``w``.
 //
 // Structure = the 3D split kernel with "input-channel chunk" in the role of "depth slice":
-//   * 512-thread workgroup, one per CU; work item = (32 output channels, image, 8 x 32-pixel tile); wave = tile row.
+//   * 512-thread workgroup, one per CU; work item = (32 output channels, image, 8 x 32-pixel tile); wave = tile row
+//     (dilation 2: 8 x 16-pixel tiles, one M tile per wave, so that two 12 x 20-pixel brick slots fit LDS).
 //   * The haloed 10 x 34-pixel brick of one 32-channel chunk is split into bf16 pieces when it enters LDS
 //     ([piece][8-channel chunk][pixel] x 16 B, pixel index rotated by 2*chunk: conflict-free fill and fragment reads);
 //     two brick slots: while chunk step s computes its 9 taps, the brick of step s+1 is written (taps 0..2, from
@@ -31,20 +32,28 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
 typedef unsigned int u32x2 __attribute__((__vector_size__(8)));
 
-constexpr int TH = 8, TW = 32;
-constexpr int IN_H = TH + 2, IN_W = TW + 2;
-constexpr int NPIX = IN_H * IN_W;              // 340 pixels per brick (with halo)
-constexpr int PLANE = 352;
-constexpr int CHUNK_BYTES = PLANE * 16;
-constexpr int PIECE_BYTES = 4 * CHUNK_BYTES;
-constexpr int SLOT_BYTES = 3 * PIECE_BYTES;    // 67584
+constexpr int TH = 8;
 constexpr int WREC_BYTES = 512 * 16;           // weight record of one (group, chunk, tap); 6144 used
-constexpr int LDS_W = 2 * SLOT_BYTES;
-constexpr int LDS_DUMP = LDS_W + 2 * WREC_BYTES;
-constexpr int LDS_TOTAL = LDS_DUMP + 176 * 16;
-constexpr int FILL_E = NPIX * 4;
-constexpr int FIT = 3;
 constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;
+
+// Geometry of one instance: dilation 1 -> 8 x 32-pixel tiles (two 16-pixel M tiles per wave), brick 10 x 34;
+//                           dilation 2 -> 8 x 16-pixel tiles (one M tile per wave), brick 12 x 20 (two brick slots must fit LDS)
+template <int DIL> struct Geo {
+    static constexpr int MT = DIL == 1 ? 2 : 1;
+    static constexpr int TW = 16 * MT;
+    static constexpr int IN_H = TH + 2 * DIL, IN_W = TW + 2 * DIL;
+    static constexpr int NPIX = IN_H * IN_W;                       // 340 / 240 pixels per brick (with halo)
+    static constexpr int PLANE = (NPIX + 6 + 15) / 16 * 16;        // 352 / 256
+    static constexpr int CHUNK_BYTES = PLANE * 16;
+    static constexpr int PIECE_BYTES = 4 * CHUNK_BYTES;
+    static constexpr int SLOT_BYTES = 3 * PIECE_BYTES;             // 67584 / 49152
+    static constexpr int FILL_E = NPIX * 4;
+    static constexpr int FIT = (FILL_E + 511) / 512;               // 3 / 2
+    static constexpr int LAST_FULL = FILL_E - 512 * (FIT - 1);     // threads below this own a last item
+    static constexpr int LDS_W = 2 * SLOT_BYTES;
+    static constexpr int LDS_DUMP = LDS_W + 2 * WREC_BYTES;
+    static constexpr int LDS_TOTAL = LDS_DUMP + (512 - LAST_FULL) * 16;
+};
 
 __device__ __forceinline__ float4 as_float4(u32x4 v) { float4 f; __builtin_memcpy(&f, &v, 16); return f; }
 __device__ __forceinline__ float2 as_float2(u32x2 v) { float2 f; __builtin_memcpy(&f, &v, 8); return f; }
@@ -89,24 +98,30 @@ __device__ __forceinline__ void for_each_tap(F&& f, std::integer_sequence<int, I
     (f(std::integral_constant<int, I>{}), ...);
 }
 
-template <int TAP>
+template <int TAP, int MT>
 __device__ __forceinline__ void tap_pipeline()
 {
+    constexpr int NM = 12 * MT, NR = 3 * MT + 6;
 #pragma unroll
-    for (int k = 0; k < 24; ++k) {
+    for (int k = 0; k < NM; ++k) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // MFMA
-        if (k < 12) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // DS read
+        if (k < NR - NM / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // DS reads (more reads than early MFMA slots when MT = 1)
+        else if (k < NM / 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         if (TAP <= 2) __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);        // VALU: slice split + epilogue
-        if (k >= 12 && k < 16) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
-        if (k >= 12) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);         // VMEM read
-        if (TAP >= 1 && TAP <= 2 && k >= 16 && k < 20) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);   // VMEM write
+        if (k >= NM / 2 && k < NM / 2 + 4) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // DS write
+        if (k >= NM / 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
+        if (TAP >= 1 && TAP <= 2 && k >= NM - 4) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);   // VMEM write
     }
 }
 
 struct Step { int grp, n, th0, tw0, c; bool valid; };
 
+template <int DIL>
 __global__ __launch_bounds__(512, 1) void conv2d_k3_split_kernel(const estd_conv2d_desc p, int tiles_w, int tiles_h, int total_items)
 {
+    typedef Geo<DIL> G_;
+    constexpr int MT = G_::MT, TW = G_::TW, IN_W = G_::IN_W, CHUNK_BYTES = G_::CHUNK_BYTES, PIECE_BYTES = G_::PIECE_BYTES;
+    constexpr int SLOT_BYTES = G_::SLOT_BYTES, FILL_E = G_::FILL_E, FIT = G_::FIT, LDS_W = G_::LDS_W, LDS_DUMP = G_::LDS_DUMP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -138,7 +153,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_k3_split_kernel(const estd_conv
     const int a_lane = g * CHUNK_BYTES + (i + 2 * g) * 16;
     const int b_lane = lane * 16;
     const int w_lane = tid * 16;
-    const int dump16 = LDS_DUMP + (tid >= 336 ? tid - 336 : 0) * 16;
+    const int dump16 = LDS_DUMP + (tid >= G_::LAST_FULL ? tid - G_::LAST_FULL : 0) * 16;
 
     // ---- the WG's sequence of chunk steps: step s = (item u0 + s / nchunks, chunk s % nchunks) ----
     auto decode_step = [&](int s) {
@@ -168,7 +183,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_k3_split_kernel(const estd_conv
             const int e = tid + it * 512;
             const int vs = e >> 2, c4 = e & 3;
             const int zy = vs / IN_W, zx = vs - zy * IN_W;
-            const int gy = st.th0 - 1 + zy, gx = st.tw0 - 1 + zx;
+            const int gy = st.th0 - DIL + zy, gx = st.tw0 - DIL + zx;
             const bool ok = st.valid && e < FILL_E && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
             v[it] = ok ? (unsigned)(((st.n * H + gy) * W + gx) * Cin + st.c * 32 + c4 * 8) * 4u : OOB_OFFSET;
         }
@@ -212,9 +227,9 @@ __global__ __launch_bounds__(512, 1) void conv2d_k3_split_kernel(const estd_conv
         *reinterpret_cast<u32x4*>(smem + LDS_W + WREC_BYTES + w_lane) = w1;
     }
     lds_barrier();
-    bf16x8 acur[2][3], bcur[3][2];
+    bf16x8 acur[MT][3], bcur[3][2];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc)
             acur[m][pc] = *reinterpret_cast<const bf16x8*>(smem + pc * PIECE_BYTES + a_lane + (wave * IN_W + 16 * m) * 16);
@@ -226,12 +241,12 @@ __global__ __launch_bounds__(512, 1) void conv2d_k3_split_kernel(const estd_conv
     lds_barrier();
 
     int wsel = 1;
-    f32x4 acc[2][2], pend[2][2] = {};
-    unsigned eoff_p[2][4];              // output offsets of the pending (finished) item
+    f32x4 acc[MT][2], pend[MT][2] = {};
+    unsigned eoff_p[MT][4];             // output offsets of the pending (finished) item
     float psc0 = 0.f, psh0 = 0.f, psc1 = 0.f, psh1 = 0.f;
     bool pend_live = false;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) eoff_p[m][r] = OOB_OFFSET;
     struct EpiLoads { u32x2 r1[4]; } el;
@@ -259,7 +274,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_k3_split_kernel(const estd_conv
         const int sb = (s & 1) * SLOT_BYTES, sbn = ((s + 1) & 1) * SLOT_BYTES;
         if (cur.c == 0) {
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int nn = 0; nn < 2; ++nn) acc[m][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
@@ -274,12 +289,12 @@ __global__ __launch_bounds__(512, 1) void conv2d_k3_split_kernel(const estd_conv
             const int nsb = tap == 8 ? sbn : sb;
             const int wrd = LDS_W + wsel * WREC_BYTES, wwr = LDS_W + (wsel ^ 1) * WREC_BYTES;
 
-            bf16x8 anext[2][3], bnext[3][2];
+            bf16x8 anext[MT][3], bnext[3][2];
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc)
-                    anext[m][pc] = *reinterpret_cast<const bf16x8*>(smem + nsb + pc * PIECE_BYTES + a_lane + ((wave + nkh) * IN_W + nkw + 16 * m) * 16);
+                    anext[m][pc] = *reinterpret_cast<const bf16x8*>(smem + nsb + pc * PIECE_BYTES + a_lane + ((wave + nkh * DIL) * IN_W + nkw * DIL + 16 * m) * 16);
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
@@ -296,20 +311,20 @@ __global__ __launch_bounds__(512, 1) void conv2d_k3_split_kernel(const estd_conv
             }
             // deferred epilogue of the item that finished with the previous step
             if constexpr (tap == 0) epi_load(0);
-            if constexpr (tap == 1) { epi_finish(0); epi_load(1); }
-            if constexpr (tap == 2) epi_finish(1);
+            if constexpr (tap == 1) { epi_finish(0); if (MT == 2) epi_load(MT - 1); }
+            if constexpr (tap == 2) { if (MT == 2) epi_finish(MT - 1); }
             {
                 constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
                 for (int t = 0; t < 6; ++t)
 #pragma unroll
-                    for (int m = 0; m < 2; ++m)
+                    for (int m = 0; m < MT; ++m)
 #pragma unroll
                         for (int nn = 0; nn < 2; ++nn)
                             acc[m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(acur[m][PA[t]], bcur[PB[t]][nn], acc[m][nn], 0, 0, 0);
             }
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) acur[m][pc] = anext[m][pc];
 #pragma unroll
@@ -317,7 +332,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_k3_split_kernel(const estd_conv
 #pragma unroll
                 for (int nn = 0; nn < 2; ++nn) bcur[pc][nn] = bnext[pc][nn];
             wsel ^= 1;
-            tap_pipeline<tap>();
+            tap_pipeline<tap, MT>();
             __builtin_amdgcn_sched_barrier(0);
             lds_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -326,14 +341,14 @@ __global__ __launch_bounds__(512, 1) void conv2d_k3_split_kernel(const estd_conv
         pend_live = false;                       // the pending item (if any) was written during taps 0..2
         if (cur.c == nchunks - 1) {              // item finished: hand its accumulators to the deferred epilogue
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int nn = 0; nn < 2; ++nn) pend[m][nn] = acc[m][nn];
             const int cb = cur.grp * 32 + 2 * i;
             psc0 = p.scale[cb]; psh0 = p.shift[cb]; psc1 = p.scale[cb + 1]; psh1 = p.shift[cb + 1];
             const int y = cur.th0 + wave;
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int x = cur.tw0 + 16 * m + 4 * g + r;
@@ -346,8 +361,26 @@ __global__ __launch_bounds__(512, 1) void conv2d_k3_split_kernel(const estd_conv
     }
     if (pend_live) {
         epi_load(0); epi_finish(0);
-        epi_load(1); epi_finish(1);
+        if (MT == 2) { epi_load(MT - 1); epi_finish(MT - 1); }
     }
+}
+
+template <int DIL>
+int launch_split2d(const estd_conv2d_desc& d, hipStream_t stream)
+{
+    typedef Geo<DIL> G_;
+    const int tiles_w = (d.W + G_::TW - 1) / G_::TW, tiles_h = (d.H + TH - 1) / TH;
+    const long long total = (long long)(d.cout >> 5) * d.N * tiles_h * tiles_w;
+    if (total > 0x7fffffffLL) return ESTD_ERR_ARG;
+    int grid = total < 256 ? (int)total : 256;
+    if (grid >= 8) grid &= ~7;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_k3_split_kernel<DIL>), hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS_TOTAL);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv2d_k3_split_kernel<DIL>), dim3(grid), dim3(512), G_::LDS_TOTAL, stream, d, tiles_w, tiles_h, (int)total);
+    return hipGetLastError() == hipSuccess ? ESTD_OK : ESTD_ERR_LAUNCH;
 }
 
 }  // namespace
@@ -358,20 +391,10 @@ extern "C" int estd_conv2d_k3_split(const estd_conv2d_desc* dp, estd_stream_t s)
     const estd_conv2d_desc& d = *dp;
     if (d.N <= 0 || d.H <= 0 || d.W <= 0 || !d.in || !d.w_split || !d.scale || !d.shift || !d.out) return ESTD_ERR_ARG;
     if (d.cin < 32 || (d.cin & 31) || d.cout < 32 || (d.cout & 31)) return ESTD_ERR_ARG;
-    if (d.dilation != 1) return ESTD_ERR_UNSUPPORTED;
+    if (d.dilation != 1 && d.dilation != 2) return ESTD_ERR_UNSUPPORTED;
     const long long widest = (long long)d.N * d.H * d.W * (d.cin > d.cout ? d.cin : d.cout) * 4;
     if (widest >= 0x7fffff00LL) return ESTD_ERR_UNSUPPORTED;          // one descriptor spans the whole batch
     if ((long long)(d.cout >> 5) * (d.cin >> 5) * 9 * WREC_BYTES >= 0x7fffff00LL) return ESTD_ERR_UNSUPPORTED;
-    const int tiles_w = (d.W + TW - 1) / TW, tiles_h = (d.H + TH - 1) / TH;
-    const long long total = (long long)(d.cout >> 5) * d.N * tiles_h * tiles_w;
-    if (total > 0x7fffffffLL) return ESTD_ERR_ARG;
-    int grid = total < 256 ? (int)total : 256;
-    if (grid >= 8) grid &= ~7;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_k3_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(conv2d_k3_split_kernel, dim3(grid), dim3(512), LDS_TOTAL, static_cast<hipStream_t>(s), d, tiles_w, tiles_h, (int)total);
-    return hipGetLastError() == hipSuccess ? ESTD_OK : ESTD_ERR_LAUNCH;
+    hipStream_t stream = static_cast<hipStream_t>(s);
+    return d.dilation == 1 ? launch_split2d<1>(d, stream) : launch_split2d<2>(d, stream);
 }

@@ -209,7 +209,7 @@ class Conv2dPlan:
         self.w_nt = {2: packing.pack_conv2d(conv.weight, 2).to(dev)}
         if self.cout % 64 == 0:
             self.w_nt[4] = packing.pack_conv2d(conv.weight, 4).to(dev)
-        self.w_split = packing.pack_conv2d_split(conv.weight).to(dev) if self.dil == 1 else None
+        self.w_split = packing.pack_conv2d_split(conv.weight).to(dev)
         sc, sh = packing.fold_bn_fp32(bn, list(range(self.cout)))
         self.scale, self.shift = sc.to(dev), sh.to(dev)
         self.relu_before, self.relu_after = int(relu_before), int(relu_after)

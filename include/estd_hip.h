@@ -144,7 +144,7 @@ typedef struct estd_conv2d_desc {
 } estd_conv2d_desc;
 
 int estd_conv2d_k3(const estd_conv2d_desc* desc, estd_stream_t stream);
-/* Same operator (dilation 1 only; group_tiles ignored: 32 output channels per work item) with every fp32 product as six
+/* Same operator (group_tiles ignored: 32 output channels per work item) with every fp32 product as six
  * bf16 MFMA products of exactly 3-way split operands, fp32 accumulation (see estd_conv3d_k3_split). */
 int estd_conv2d_k3_split(const estd_conv2d_desc* desc, estd_stream_t stream);
 

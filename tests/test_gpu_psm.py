@@ -145,15 +145,16 @@ def test_e2e_golden_with_fused_bn(golden_dir):
                 assert np.abs(v.cpu().numpy() - g[name]).max() < 1e-4, name
 
 
-@pytest.mark.parametrize("cin,cout,dims,relu,res", [(32, 32, (2, 13, 21), True, False), (64, 64, (1, 24, 32), False, True),
-                                                    (96, 64, (1, 8, 16), False, False), (320, 128, (1, 9, 40), True, False),
-                                                    (64, 64, (5, 120, 160), False, True)])
-def test_conv2d_split_vs_fp64_and_fp32_kernel(cin, cout, dims, relu, res):
+@pytest.mark.parametrize("cin,cout,dims,relu,res,dil", [(32, 32, (2, 13, 21), True, False, 1), (64, 64, (1, 24, 32), False, True, 1),
+                                                        (96, 64, (1, 8, 16), False, False, 1), (320, 128, (1, 9, 40), True, False, 1),
+                                                        (64, 64, (5, 120, 160), False, True, 1), (128, 128, (1, 17, 35), True, False, 2),
+                                                        (32, 64, (2, 8, 16), False, True, 2), (128, 128, (5, 120, 160), True, False, 2)])
+def test_conv2d_split_vs_fp64_and_fp32_kernel(cin, cout, dims, relu, res, dil):
     """3xbf16 split conv2d: fp32-level error against an fp64 convolution, agreement with the fp32 MFMA kernel."""
     from estdepth_amd import synth, ops
     from estdepth_amd.backbones import conv_bn2d
     N, H, W = dims
-    mod = conv_bn2d(cin, cout, 3, 1, 1, 1).eval()
+    mod = conv_bn2d(cin, cout, 3, 1, dil, dil).eval()
     synth.fill_state_dict(mod, seed=cin + cout)
     g = torch.Generator().manual_seed(cin * 3 + cout)
     x = torch.randn(N, cin, H, W, generator=g)

@@ -5,13 +5,13 @@ sys.path.insert(0, ROOT)
 import torch
 from estdepth_amd import ops
 dev = "cuda"
-for (h, w, cin, cout) in [(240, 320, 32, 32), (120, 160, 64, 64), (120, 160, 128, 128), (120, 160, 320, 128)]:
-    conv = torch.nn.Conv2d(cin, cout, 3, 1, 1, bias=False).to(dev)
+for (h, w, cin, cout, dil) in [(240, 320, 32, 32, 1), (120, 160, 64, 64, 1), (120, 160, 128, 128, 1), (120, 160, 320, 128, 1), (120, 160, 128, 128, 2)]:
+    conv = torch.nn.Conv2d(cin, cout, 3, 1, dil, dil, bias=False).to(dev)
     bn = torch.nn.BatchNorm2d(cout).to(dev).eval()
     plan = ops.Conv2dPlan(conv, bn, relu_before=True)
     x = torch.randn(5, h, w, cin, device=dev)
     gf = 2.0 * 9 * 5 * h * w * cin * cout / 1e9
-    line = "%3dx%-3d %3d->%-3d" % (h, w, cin, cout)
+    line = "%3dx%-3d %3d->%-3d dil %d" % (h, w, cin, cout, dil)
     for arith in ("f32", "bf16x3"):
         ops.CONV2D_ARITH = arith
         for _ in range(3): plan.run(x)
