@@ -164,7 +164,8 @@ __device__ __forceinline__ void tap_pipeline()
 }
 
 // NT: 16-channel output tiles on the MFMA (1 = 16 channels; 2 = 32 channels; 3 = 32 channels + the 33rd in a third tile)
-template <int NT, bool EXTRA, bool TANH, bool STATS>
+// RES: some of residual / residual2 / accumulate is present (otherwise the epilogue issues no loads at all)
+template <int NT, bool EXTRA, bool TANH, bool STATS, bool RES>
 __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int total_tiles)
 {
     constexpr int NTAPS = EXTRA ? 28 : 27;          // tap 27 = the scalar input channel's 27 taps as one K = 32 block
@@ -290,6 +291,7 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
         // ---- epilogue of one M tile, in two halves so that its loads are a tap ahead of their use ----
         struct EpiLoads { u32x2 r1[4], r2[4], ac[4]; };
         auto epi_load = [&](EpiLoads& L, int m, int dd, bool live) {
+            if (!RES) return;
             const int so = dd * out_plane_bytes;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -322,9 +324,13 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
                     if (act0 == ESTD_ACT_TANH) { v0 = tanhf(v0); v1 = tanhf(v1); }
                 }
                 v0 = fmaxf(v0, relu_floor); v1 = fmaxf(v1, relu_floor);
-                const float2 q1 = as_float2(L.r1[r]), q2 = as_float2(L.r2[r]), qa = as_float2(L.ac[r]);
-                v0 = (v0 + q1.x + q2.x) * out_scale + qa.x;
-                v1 = (v1 + q1.y + q2.y) * out_scale + qa.y;
+                if (RES) {
+                    const float2 q1 = as_float2(L.r1[r]), q2 = as_float2(L.r2[r]), qa = as_float2(L.ac[r]);
+                    v0 = (v0 + q1.x + q2.x) * out_scale + qa.x;
+                    v1 = (v1 + q1.y + q2.y) * out_scale + qa.y;
+                } else {
+                    v0 *= out_scale; v1 *= out_scale;
+                }
                 if (NB == 2) {
                     const float2 ov = make_float2(v0, v1);
                     u32x2 od; __builtin_memcpy(&od, &ov, 8);
@@ -582,19 +588,28 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
     }
 }
 
-template <int NT, bool EXTRA, bool TANH, bool STATS>
-int launch(const estd_conv3d_desc& d, hipStream_t stream, int tiles_w, int tiles_h, int total)
+template <int NT, bool EXTRA, bool TANH, bool STATS, bool RES>
+int launch_inst(const estd_conv3d_desc& d, hipStream_t stream, int tiles_w, int tiles_h, int total)
 {
     int grid = total < 256 ? total : 256;       // one workgroup per CU (LDS-limited)
     if (grid >= 8) grid &= ~7;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_split_kernel<NT, EXTRA, TANH, STATS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_split_kernel<NT, EXTRA, TANH, STATS, RES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv3d_k3_split_kernel<NT, EXTRA, TANH, STATS>), dim3(grid), dim3(512), LDS_TOTAL, stream, d, tiles_w, tiles_h, total);
+    hipLaunchKernelGGL((conv3d_k3_split_kernel<NT, EXTRA, TANH, STATS, RES>), dim3(grid), dim3(512), LDS_TOTAL, stream, d, tiles_w, tiles_h, total);
     return hipGetLastError() == hipSuccess ? ESTD_OK : ESTD_ERR_LAUNCH;
+}
+
+template <int NT, bool EXTRA, bool TANH, bool STATS>
+int launch(const estd_conv3d_desc& d, hipStream_t stream, int tiles_w, int tiles_h, int total)
+{
+    // the plain 32 -> 32 convolutions dominate: they get an instance without epilogue loads; the rarer shapes always use RES
+    if (NT == 2 && !EXTRA && !d.residual && !d.residual2 && !d.accumulate)
+        return launch_inst<NT, EXTRA, TANH, STATS, false>(d, stream, tiles_w, tiles_h, total);
+    return launch_inst<NT, EXTRA, TANH, STATS, true>(d, stream, tiles_w, tiles_h, total);
 }
 
 }  // namespace
