@@ -116,7 +116,7 @@ __device__ __forceinline__ void tap_pipeline()
 
 struct Step { int grp, n, th0, tw0, c; bool valid; };
 
-template <int DIL>
+template <int DIL, bool RES>
 __global__ __launch_bounds__(512, 1) void conv2d_k3_split_kernel(const estd_conv2d_desc p, int tiles_w, int tiles_h, int total_items)
 {
     typedef Geo<DIL> G_;
@@ -252,6 +252,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_k3_split_kernel(const estd_conv
     struct EpiLoads { u32x2 r1[4]; } el;
 
     auto epi_load = [&](int m) {
+        if (!RES) return;
 #pragma unroll
         for (int r = 0; r < 4; ++r) el.r1[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_res, pend_live ? eoff_p[m][r] : OOB_OFFSET, 0, 0);
     };
@@ -261,9 +262,12 @@ __global__ __launch_bounds__(512, 1) void conv2d_k3_split_kernel(const estd_conv
             const unsigned eo = pend_live ? eoff_p[m][r] : OOB_OFFSET;
             float v0 = fmaxf(pend[m][0][r] * psc0 + psh0, floor_before);
             float v1 = fmaxf(pend[m][1][r] * psc1 + psh1, floor_before);
-            const float2 q = as_float2(el.r1[r]);
-            v0 = fmaxf(v0 + q.x, floor_after);
-            v1 = fmaxf(v1 + q.y, floor_after);
+            if (RES) {
+                const float2 q = as_float2(el.r1[r]);
+                v0 += q.x; v1 += q.y;
+            }
+            v0 = fmaxf(v0, floor_after);
+            v1 = fmaxf(v1, floor_after);
             const float2 ov = make_float2(v0, v1);
             u32x2 od; __builtin_memcpy(&od, &ov, 8);
             __builtin_amdgcn_raw_buffer_store_b64(od, rs_out, eo, 0, 0);
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(512, 1) void conv2d_k3_split_kernel(const estd_conv
     }
 }
 
-template <int DIL>
+template <int DIL, bool RES>
 int launch_split2d(const estd_conv2d_desc& d, hipStream_t stream)
 {
     typedef Geo<DIL> G_;
@@ -376,10 +380,10 @@ int launch_split2d(const estd_conv2d_desc& d, hipStream_t stream)
     if (grid >= 8) grid &= ~7;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_k3_split_kernel<DIL>), hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS_TOTAL);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_k3_split_kernel<DIL, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS_TOTAL);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv2d_k3_split_kernel<DIL>), dim3(grid), dim3(512), G_::LDS_TOTAL, stream, d, tiles_w, tiles_h, (int)total);
+    hipLaunchKernelGGL((conv2d_k3_split_kernel<DIL, RES>), dim3(grid), dim3(512), G_::LDS_TOTAL, stream, d, tiles_w, tiles_h, (int)total);
     return hipGetLastError() == hipSuccess ? ESTD_OK : ESTD_ERR_LAUNCH;
 }
 
@@ -396,5 +400,6 @@ extern "C" int estd_conv2d_k3_split(const estd_conv2d_desc* dp, estd_stream_t s)
     if (widest >= 0x7fffff00LL) return ESTD_ERR_UNSUPPORTED;          // one descriptor spans the whole batch
     if ((long long)(d.cout >> 5) * (d.cin >> 5) * 9 * WREC_BYTES >= 0x7fffff00LL) return ESTD_ERR_UNSUPPORTED;
     hipStream_t stream = static_cast<hipStream_t>(s);
-    return d.dilation == 1 ? launch_split2d<1>(d, stream) : launch_split2d<2>(d, stream);
+    if (d.residual) return d.dilation == 1 ? launch_split2d<1, true>(d, stream) : launch_split2d<2, true>(d, stream);
+    return d.dilation == 1 ? launch_split2d<1, false>(d, stream) : launch_split2d<2, false>(d, stream);
 }
