@@ -267,8 +267,15 @@ def main():
                 step()
             barrier()
             alt_elapsed = time.perf_counter() - ta
+            # how far apart are the two arithmetics on this very input?  (eager forwards of both; all depth outputs, metres)
+            with torch.no_grad():
+                o_alt = model(x_imgs, x_poses, intr, x_sample, pre_costs, list(pre_poses) if pre_poses else None, mode="val")[0]
+                ops.CONV3D_ARITH, ops.CONV2D_ARITH = args.conv3d_arith, args.conv2d_arith
+                o_ref = model(x_imgs, x_poses, intr, x_sample, pre_costs, list(pre_poses) if pre_poses else None, mode="val")[0]
+            ddiff = max(float((o_alt[k] - o_ref[k]).abs().max()) for k in o_ref if k[0] == "depth")
             alt = {"conv3d_arith": "bf16x3", "conv2d_arith": "bf16x3", "value": round(frames * args.steps / alt_elapsed, 3),
                    "ms_per_step": round(1e3 * alt_elapsed / args.steps, 3),
+                   "max_abs_depth_diff_vs_headline_arith_m": float("%.3g" % ddiff),
                    "note": "opt-in (--conv3d-arith/--conv2d-arith bf16x3): every fp32 product as six bf16 MFMA products of exactly "
                            "3-way-split operands, fp32 accumulation; same 1e-4 parity tests, conv error vs fp64 equal to the fp32 MFMA kernel's"}
         except Exception as e:
