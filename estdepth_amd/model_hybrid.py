@@ -159,6 +159,7 @@ class DepthNetHybrid(nn.Module):
                 child._hip = bool(enable)
         return self
 
+    @torch.no_grad()        # inference-only implementation: the HIP operators do not record autograd graphs
     def forward(self, imgs, cam_poses, cam_intr, sample, pre_costs=None, pre_cam_poses=None, mode='train',
                 matching_features=None):
         """model_hybrid.py:110-184 (``matching_features`` is an optional extension used by estdepth_amd.streaming:
