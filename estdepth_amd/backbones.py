@@ -17,6 +17,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+SPP_FUSED = os.environ.get("ESTD_SPP_FUSED", "1") == "1"      # A/B switch for the fused upsample+concat of the PSM SPP tail
+
+
 def conv_bn2d(cin, cout, k, stride, pad, dilation):
     """Conv2d(bias=False)+BatchNorm2d; padding = dilation when dilation > 1 (layers_op.py:10-13)."""
     return nn.Sequential(
@@ -204,7 +207,7 @@ class PSMFeatures(nn.Module):
             # once per branch and takes up to 290 us for the 32x32 windows)
             p4 = F.avg_pool2d(skip_nchw, 4, 4)
             pooled = {4: p4, 3: F.avg_pool2d(p4, 2, 2), 2: F.avg_pool2d(p4, 4, 4), 1: F.avg_pool2d(p4, 8, 8)}
-        if pooled is not None and os.environ.get("ESTD_SPP_FUSED", "1") == "1":
+        if pooled is not None and SPP_FUSED:
             from . import ops
             brs = [self._nhwc(self._branch(i, skip_nchw, pooled)) for i in (4, 3, 2, 1)]
             cat_nhwc = ops.spp_upsample_cat(raw.contiguous(), skip.contiguous(), [b.contiguous() for b in brs])     # upsample x4 + cat, one pass
