@@ -1,30 +1,42 @@
-"""Benchmark of the ESTDepth hot path on MI355X (contract: see the task statement / DESIGN.md §Measurement).
+"""Benchmark of the ESTDepth hot path on MI355X (contract: see the task statement / DESIGN.md §5 Measurement).
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload joint|estm|cfg1] [--no-cpu-baseline]
+    python bench.py [--gpus N --steps K --warmup W] [--workload joint|estm|cfg5|cfg1|stream] [--no-cpu-baseline]
 
 A "step" is one ``DepthNetHybrid.forward`` over one synthetic sequence resident in HBM:
   * joint (default, BASELINE.json configs[1]): seq_len=5, 480x640, D=64, ResNet-50, Joint-mode steady state
     (memory carried from the previous call => EST transformer on, 3 depth frames per step);
-  * estm  (configs[2]): steady-state ESTM window (3 frames, 2 memory volumes, 1 depth frame per step).
-For N > 1 one process per GPU (launched by torch.distributed.run) runs its own sequence (weak scaling);
-after every step the ranks all-gather their memory bank {K, V_fused, pose} over RCCL so any
-rank could continue any stream; ``value`` = depth frames of all ranks / max-over-ranks time.
-Rank 0 prints ONE JSON line.
+  * estm  (configs[2]): steady-state ESTM window (3 frames, 2 memory volumes, 1 depth frame per step);
+  * cfg5  (configs[4]): the same ESTM steady-state window at 960x1280, D=128 (HBM-bound stress);
+  * cfg1  (configs[0]): seq_len=3, 128x160, D=16, ResNet-18, EST off;
+  * stream: frame-by-frame ESTM streaming with the per-frame matching-feature cache (extra, not a BASELINE config).
+``--gpus N`` with N > 1 (BASELINE.json configs[3]): if the process was not started by a launcher (no WORLD_SIZE in the
+environment) bench.py re-executes ITSELF under ``python -m torch.distributed.run --nproc-per-node N`` -- one rank per
+GPU over RCCL -- so ``python bench.py --gpus 8`` and the explicit torchrun command line are the same job.  Every rank
+runs its own sequence (weak scaling, no data-path collective); after every step the ranks all-gather their memory bank
+{K, V_fused, pose} over RCCL, overlapped with the next step; ``value`` = depth frames of all ranks /
+max-over-ranks time.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_BF16_MATRIX_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak; the 3xbf16 split spends 6 bf16 FLOPs per fp32 FLOP
-HBM_PEAK_GBS = 8000.0
+HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E spec peak (about 6.3 TB/s is achievable by a copy)
+
+#            name:  (views, Hi,  Wi,   D,  resnet, EST,   description)
+WORKLOADS = {
+    "cfg1": (3, 128, 160, 16, 18, False, "cfg1: seq_len=3, 128x160, ndepths=16, ResNet-18, EST off"),
+    "joint": (8, 480, 640, 64, 50, True, "cfg2: seq_len=5, 480x640, ndepths=64, ResNet-50, Joint mode steady state (carried memory, EST on)"),
+    "estm": (5, 480, 640, 64, 50, True, "cfg3: ESTM steady-state window (3 frames, memory 2), 480x640, ndepths=64, ResNet-50"),
+    "cfg5": (5, 960, 1280, 128, 50, True, "cfg5: ESTM steady-state window (3 frames, memory 2), 960x1280, ndepths=128, ResNet-50"),
+}
 
 
 def parse():
@@ -32,8 +44,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="joint", choices=["joint", "estm", "cfg1", "stream"])
+    ap.add_argument("--workload", default="joint", choices=["joint", "estm", "cfg5", "cfg1", "stream"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the cpu_baseline leg (0 = every core of the box)")
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--conv3d-arith", default=os.environ.get("ESTD_CONV3D_ARITH", "f32"), choices=["f32", "bf16x3"],
@@ -45,12 +58,37 @@ def parse():
     return ap.parse_args()
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch_if_needed(args):
+    """``python bench.py --gpus N`` (N > 1) without a launcher: become N ranks (one per GPU) under torch.distributed.run.
+    On a box with fewer than N GPUs (the 1-GPU test box) the ranks share the devices round-robin and use gloo instead of
+    RCCL (RCCL refuses two ranks on one device): a code-path check, flagged as such in the JSON line."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import torch
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus:
+        env["ESTD_OVERSUBSCRIBED"] = str(max(ndev, 1))
+        env.setdefault("ESTD_DIST_BACKEND", "gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
+
+
 def build_model(workload, device):
     from estdepth_amd import DepthNetHybrid, synth
-    if workload == "cfg1":
-        m = DepthNetHybrid(ndepths=16, depth_min=0.1, depth_max=10.0, resnet=18, IF_EST_transformer=False)
-    else:
-        m = DepthNetHybrid(ndepths=64, depth_min=0.1, depth_max=10.0, resnet=50, IF_EST_transformer=True)
+    _, _, _, D, resnet, est, _ = WORKLOADS[workload]
+    m = DepthNetHybrid(ndepths=D, depth_min=0.1, depth_max=10.0, resnet=resnet, IF_EST_transformer=est)
     synth.fill_state_dict(m, seed=0, head_gain=1.0)
     m = m.eval().to(device)
     if str(device) != "cpu" and os.environ.get("ESTD_NCHW_2D", "0") != "1":
@@ -66,76 +104,98 @@ def build_model(workload, device):
 
 def make_inputs(workload, rank, device):
     from estdepth_amd import synth
-    if workload == "cfg1":
-        v, hi, wi = 3, 128, 160
-    elif workload == "joint":
-        v, hi, wi = 8, 480, 640      # two consecutive 5-frame calls with stride seq_len-2 (general_eval.py:52)
-    else:
-        v, hi, wi = 5, 480, 640      # three sliding windows of 3
+    v, hi, wi = WORKLOADS[workload][:3]
     imgs, poses, intr, sample = synth.make_sequence(v, hi, wi, seed=1000 + rank)
     to = lambda t: t.to(device)
     return to(imgs), to(poses), to(intr), {k: to(t) for k, t in sample.items()}
 
 
-def cpu_baseline(model, workload):
-    """Oracle (C port, OpenMP) timed on the host cores on a bounded sample: ONE get_costvolume at the
-    workload's size (2 plane sweeps + pre0 + 2x(pre1,pre2): 281.8 GF of the 2496 GF 3D hot path of a
-    Joint sequence), scaled by the FLOP ratio, plus the 2D networks timed with torch on the same cores."""
-    import numpy as np
-    from oracle import ref_model as M, ref_ops as O
-    from estdepth_amd import synth
-    cores = O.num_threads()
-    P = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items() if k.startswith("pre")}
-    D = model.ndepths
-    H, W = (32, 40) if workload == "cfg1" else (120, 160)
-    rng = np.random.RandomState(0)
-    feats = [rng.randn(1, 32, H, W).astype(np.float32) for _ in range(3)]
-    poses = np.stack([synth.camera_pose(v) for v in range(3)])[None]
-    K = synth.intrinsics(H * 4, W * 4).copy()
-    K[:2] *= 0.25
-    dv = model.depth_cands.view(1, D, 1, 1).numpy()
-    t0 = time.time()
-    M.get_costvolume(P, feats, poses, K[None], dv, D)
-    t_cv = time.time() - t0
-    # 2D networks on the same cores (torch CPU): PSM on V images, ResNet + 2D decoder on T images
-    cpu_model = build_model(workload, "cpu")
-    V, T = (3, 1) if workload != "joint" else (5, 3)
-    hi, wi = H * 4, W * 4
+def steady_state(model, workload, imgs, poses, intr, sample):
+    """Untimed calls that establish the memory bank of the timed step.  Returns (frame slice, depth frames per step,
+    pre_costs, pre_poses)."""
+    import torch
+    sub = lambda sl: {k: v[:, sl] for k, v in sample.items()}
     with torch.no_grad():
-        x = torch.randn(V, 3, hi, wi)
-        t0 = time.time()
-        cpu_model.matchingFeature(x)
-        sem = cpu_model.semanticFeature(x[:T])
-        sv = cpu_model.CostRegNet._semantic_vs(sem)
-        cpu_model.CostRegNet._refine(sv, torch.randn(T, D, H, W), sem)
-        t_2d = time.time() - t0
-    vox = D * H * W
-    gf_cv = (2 * 2 * 27 * 32 * 32 * 2 + 2 * 2 * 64 * 32) * vox / 1e9                   # one get_costvolume
-    conv = lambda ci, co: 2 * 27 * ci * co * vox / 1e9
-    per_target = gf_cv + 4 * conv(32, 32) + conv(33, 33) + 2 * conv(33, 16) + 2 * conv(16, 16)
-    est = conv(32, 32) + conv(32, 16) if workload != "cfg1" else 0.0
-    gf_3d = T * (per_target + est)
-    t_seq = t_cv * gf_3d / gf_cv + t_2d
-    return {"value": round(T / t_seq, 4), "unit": "depth frames/s", "cores": cores, "kind": "port",
-            "sample": "oracle (C/OpenMP) get_costvolume for 1 target at full size: %.2f s for %.1f GF, scaled x%.2f to the "
-                      "3D hot path of one step, + 2D networks on torch-CPU %.2f s" % (t_cv, gf_cv, gf_3d / gf_cv, t_2d)}
+        if workload == "joint":       # two consecutive 5-frame calls with stride seq_len-2 (general_eval.py:52); call 2 is timed
+            _, pre_costs, pre_poses = model(imgs[:, 0:5], poses[:, 0:5], intr, sub(slice(0, 5)), None, None, mode="val")
+            return slice(3, 8), 3, pre_costs, pre_poses
+        if workload in ("estm", "cfg5"):   # three sliding windows of 3 (eval_hybrid_seq.py:160-193); window 3 is timed
+            _, c0, p0 = model(imgs[:, 0:3], poses[:, 0:3], intr, sub(slice(0, 3)), None, None, mode="val")
+            _, c1, p1 = model(imgs[:, 1:4], poses[:, 1:4], intr, sub(slice(1, 4)),
+                              {"keys": [c0["keys"][0]], "values": [c0["values"][0]]}, [p0[0]], mode="val")
+            pre_costs = {"keys": [c0["keys"][0], c1["keys"][0]], "values": [c0["values"][0], c1["values"][0]]}
+            return slice(2, 5), 1, pre_costs, [p0[0], p1[0]]
+    return slice(0, 3), 1, None, None
+
+
+def _cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses, gpu_outputs, frames):
+    """The CPU oracle (C/OpenMP restatement of the reference + the product's plain 2D nn.Modules on torch-CPU = a
+    "port") timed on ONE full step of the same workload on the box's host cores: the whole DepthNetHybrid.forward of the
+    timed step -- PSM, ResNet, plane sweeps, every 3D convolution, the 2N volume warps + attention + ConvGRU per target,
+    soft-argmin, 2D refinement -- on the very inputs (and carried memory) of the GPU step.  Nothing is extrapolated.
+    The same call doubles as the full-size parity check of the benchmarked configuration (max |depth_gpu - depth_oracle|)."""
+    import numpy as np
+    import torch
+    from oracle import ref_model as M, ref_ops as O
+    from oracle.nets2d import Nets2D, sd_numpy
+    ncores = os.cpu_count() or 1
+    threads = ncores if threads <= 0 else min(threads, ncores)
+    O.set_num_threads(threads)
+    torch.set_num_threads(threads)
+    D = WORKLOADS[workload][3]
+    cpu_model = build_model(workload, "cpu")
+    P = sd_numpy(cpu_model)
+    nets = Nets2D(model=cpu_model)
+    np_ = lambda t: t.detach().float().cpu().contiguous().numpy()
+    pc, pp = None, None
+    if pre_costs is not None:
+        pc = {"keys": [np_(k) for k in pre_costs["keys"]], "values": [np_(v) for v in pre_costs["values"]]}
+        pp = [np_(p) for p in pre_poses]
+    a_imgs, a_poses, a_intr = np_(x_imgs), np_(x_poses), np_(intr)
+    t0 = time.time()
+    ref, _, _ = M.model_forward(P, a_imgs, a_poses, a_intr, pc, pp, nets, ndepths=D, depth_min=0.1, depth_max=10.0,
+                                IF_EST_transformer=WORKLOADS[workload][5])
+    dt = time.time() - t0
+    worst = {}
+    for k, v in gpu_outputs.items():
+        if k[0] == "depth":
+            worst[k[2]] = max(worst.get(k[2], 0.0), float(np.abs(np_(v) - ref[k]).max()))
+    base = {"value": round(frames / dt, 4), "unit": "depth frames/s", "cores": threads, "kind": "port",
+            "cpu": "%s (%d hardware threads on the box)" % (_cpu_model_name(), ncores),
+            "sample": "ONE full step of this workload (%d depth frames: 2D networks on torch-CPU + C/OpenMP oracle for the whole 3D "
+                      "hot path incl. volume warps, attention, ConvGRU), %.1f s wall, %d threads" % (frames, dt, threads)}
+    parity = {"max_abs_depth_diff_vs_oracle_m": {"scale%d" % s: float("%.3g" % w) for s, w in sorted(worst.items())},
+              "tolerance_m": 1e-4, "within_tolerance": bool(max(worst.values()) <= 1e-4),
+              "what": "hipGraph/eager HIP path of THIS benchmark configuration vs the CPU oracle on the same inputs, all depth outputs"}
+    return base, parity
 
 
 def stream_bench(args, device, rank, world):
     """Extra (not the headline): frame-by-frame ESTM streaming at cfg3 size through estdepth_amd.streaming.ESTMStream
     with the per-frame PSM feature cache; one step = one pushed frame = one depth frame."""
+    import torch
     from estdepth_amd import synth
     from estdepth_amd.streaming import ESTMStream
     model = build_model("estm", device)
-    n = args.warmup + args.steps + 2
+    n = args.warmup + args.steps + 4
     imgs, poses, intr, _ = synth.make_sequence(n, 480, 640, seed=1003 + rank)
     imgs, poses, intr = imgs.to(device), poses.to(device), intr.to(device)
-    st = ESTMStream(model, cache_features=True)
-    for f in range(args.warmup + 2):
+    st = ESTMStream(model, cache_features=True, graph=not args.no_graph)
+    for f in range(args.warmup + 4):          # fills the window, the memory (graphs for 0, 1, 2 memories are captured here)
         st.push(imgs[0, f], poses[0, f], intr[0])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for f in range(args.warmup + 2, n):
+    for f in range(args.warmup + 4, n):
         st.push(imgs[0, f], poses[0, f], intr[0])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -144,22 +204,53 @@ def stream_bench(args, device, rank, world):
                           "value": round(args.steps * world / dt, 3), "unit": "depth frames/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": "ESTM stream: 1 new frame per step, window 3, memory 2, eager launches"}}), flush=True)
+                          "config": {"workload": "ESTM stream: 1 new frame per step, window 3, memory 2, %s"
+                                                 % ("eager launches" if args.no_graph else "hipGraph replay (PSM per frame + window forward)")}}),
+              flush=True)
+
+
+def summarize(prof, peak_tf):
+    """ops.PROFILE entries -> per-group averages.  FLOP groups ("conv3d:*") against the MFMA peak, byte groups against HBM."""
+    groups = {}
+    for group, amount, e0, e1 in prof:
+        g = groups.setdefault(group, [0, 0.0, 0.0])
+        g[0] += 1
+        g[1] += amount
+        g[2] += e0.elapsed_time(e1)
+    mfma, hbm = {}, {}
+    for name, (n, amount, ms) in sorted(groups.items()):
+        if ms <= 0:
+            continue
+        if name.startswith("conv3d:"):
+            tf = amount / (ms * 1e-3) / 1e12
+            mfma[name] = {"launches": n, "avg_launch_ms": round(ms / n, 4), "gflop_per_launch": round(amount / n / 1e9, 2),
+                          "achieved_tflops": round(tf, 2), "frac": round(tf / peak_tf, 4)}
+        else:
+            gbs = amount / (ms * 1e-3) / 1e9
+            hbm[name] = {"launches": n, "avg_launch_us": round(1e3 * ms / n, 1), "algorithmic_mb_per_launch": round(amount / n / 1e6, 2),
+                         "achieved_gbs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    return mfma, hbm
 
 
 def main():
     args = parse()
+    self_launch_if_needed(args)
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
-    if "ESTD_FORCE_DEVICE" in os.environ:          # code-path smoke test of N > 1 on a single-GPU box (with gloo)
+    oversub = int(os.environ.get("ESTD_OVERSUBSCRIBED", "0"))
+    if oversub:                                     # fewer GPUs than ranks (1-GPU test box): share devices, gloo collectives
+        local_rank = local_rank % oversub
+    if "ESTD_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["ESTD_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
+    backend = None
     if world > 1:
         import torch.distributed as dist
         # The only collective is the per-step memory-bank all-gather (157 MB per rank, ~37 GB/s of ingress at N = 8): a few RCCL
@@ -178,31 +269,23 @@ def main():
     ops.CONV3D_ARITH = args.conv3d_arith
     ops.CONV2D_ARITH = args.conv2d_arith
     if args.workload == "stream":
-        return stream_bench(args, device, rank, world)
+        stream_bench(args, device, rank, world)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     model = build_model(args.workload, device)
     imgs, poses, intr, sample = make_inputs(args.workload, rank, device)
-    sub = lambda sl: {k: v[:, sl] for k, v in sample.items()}
-
-    # ---- establish the steady state (untimed): memory bank from the preceding call(s) ----
-    with torch.no_grad():
-        if args.workload == "joint":
-            _, pre_costs, pre_poses = model(imgs[:, 0:5], poses[:, 0:5], intr, sub(slice(0, 5)), None, None, mode="val")
-            sl, frames = slice(3, 8), 3
-        elif args.workload == "estm":
-            _, c0, p0 = model(imgs[:, 0:3], poses[:, 0:3], intr, sub(slice(0, 3)), None, None, mode="val")
-            _, c1, p1 = model(imgs[:, 1:4], poses[:, 1:4], intr, sub(slice(1, 4)),
-                              {"keys": [c0["keys"][0]], "values": [c0["values"][0]]}, [p0[0]], mode="val")
-            pre_costs = {"keys": [c0["keys"][0], c1["keys"][0]], "values": [c0["values"][0], c1["values"][0]]}
-            pre_poses = [p0[0], p1[0]]
-            sl, frames = slice(2, 5), 1
-        else:
-            pre_costs, pre_poses, sl, frames = None, None, slice(0, 3), 1
-    x_imgs, x_poses, x_sample = imgs[:, sl].contiguous(), poses[:, sl].contiguous(), sub(sl)
+    sl, frames, pre_costs, pre_poses = steady_state(model, args.workload, imgs, poses, intr, sample)
+    x_imgs, x_poses = imgs[:, sl].contiguous(), poses[:, sl].contiguous()
+    x_sample = {k: v[:, sl] for k, v in sample.items()}
 
     from estdepth_amd.graph import GraphedForward
     fwd = model if args.no_graph else GraphedForward(model)     # hipGraph replay of the same forward (same kernels)
 
     state = {"pending": None, "fwd": fwd, "allgather": world > 1 and not args.no_allgather, "notes": []}
+    if oversub:
+        state["notes"].append("%d ranks share %d GPU(s), gloo collectives: code-path check, not a scaling measurement" % (world, oversub))
 
     def drain():
         if state["pending"] is not None:
@@ -217,7 +300,7 @@ def main():
             except Exception as e:                       # graph capture refused on this stack: keep measuring, eagerly
                 if f is model:
                     raise
-                state["notes"].append("hipGraph capture failed (%s): eager launches" % type(e).__name__)
+                state["notes"].append("hipGraph capture failed (%s: %s): eager launches" % (type(e).__name__, str(e)[:80]))
                 state["fwd"] = model
                 torch.cuda.synchronize()
                 out, costs, cposes = model(x_imgs, x_poses, intr, x_sample, pre_costs, list(pre_poses) if pre_poses else None, mode="val")
@@ -229,7 +312,7 @@ def main():
                 except Exception as e:                   # same failure on every rank (collective): keep the shards running
                     state["notes"].append("memory-bank all-gather failed (%s: %s): disabled" % (type(e).__name__, str(e)[:80]))
                     state["allgather"], state["pending"] = False, None
-        return out
+        return out, costs, cposes
 
     def barrier():
         if world > 1:
@@ -242,19 +325,41 @@ def main():
     ops.profile_mark(0)                    # estd_mark_kernel brackets the timed region in a rocprofv3 trace
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        last = step()
     drain()                                # the last window's all-gather is inside the timed region
     ops.profile_mark(1)
     barrier()
     elapsed = time.perf_counter() - t0
-    # Roofline of the dominant kernel: the same steps once more, launched eagerly, with a HIP-event pair around
-    # every launch of that kernel on its launch stream (events cannot bracket nodes inside a graph replay).
-    ops.PROFILE = []
+    gathered = state["allgather"]
+    gpu_outputs = {k: v.clone() for k, v in last[0].items()}        # outputs of the timed configuration (for the parity report)
+
+    # ---- the collective alone (N > 1): bytes per rank and achieved bus bandwidth ----
+    ag = None
+    if world > 1 and gathered:
+        with torch.no_grad():
+            reps = 5
+            parallel.allgather_memory_bank_async(last[1], last[2]).wait()
+            barrier()
+            ta = time.perf_counter()
+            for _ in range(reps):
+                parallel.allgather_memory_bank_async(last[1], last[2]).wait()
+            barrier()
+            t_ag = (time.perf_counter() - ta) / reps
+        nbytes = 4 * (last[1]["keys"][0].numel() + last[1]["values"][0].numel() + 16)
+        ag = {"bytes_sent_per_rank": nbytes, "ms_alone": round(1e3 * t_ag, 3),
+              "bus_gbs_per_rank": round((world - 1) * nbytes / t_ag / 1e9, 2),
+              "backend": "RCCL (nccl)" if backend == "nccl" else backend}
     state["allgather"] = False
-    for _ in range(args.steps):
-        step(model)
-    barrier()
-    prof, ops.PROFILE = ops.PROFILE, None
+
+    # Rooflines: the same steps once more, launched eagerly, with a HIP-event pair around every hot-path launch on its
+    # launch stream (events cannot bracket nodes inside a graph replay).  Rank 0 only.
+    prof = []
+    if rank == 0:
+        ops.PROFILE = []
+        for _ in range(args.steps):
+            step(model)
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
     # Second opinion, reported beside (never instead of) the headline: the same K steps with the 3x3x3 / 3x3 convolutions
     # on the exact 3-way bf16 operand split (fp32-level error, tests/test_gpu_split_conv.py), N = 1 only.
     alt = None
@@ -267,15 +372,10 @@ def main():
             barrier()
             ta = time.perf_counter()
             for _ in range(args.steps):
-                step()
+                o_alt = step()[0]
             barrier()
             alt_elapsed = time.perf_counter() - ta
-            # how far apart are the two arithmetics on this very input?  (eager forwards of both; all depth outputs, metres)
-            with torch.no_grad():
-                o_alt = model(x_imgs, x_poses, intr, x_sample, pre_costs, list(pre_poses) if pre_poses else None, mode="val")[0]
-                ops.CONV3D_ARITH, ops.CONV2D_ARITH = args.conv3d_arith, args.conv2d_arith
-                o_ref = model(x_imgs, x_poses, intr, x_sample, pre_costs, list(pre_poses) if pre_poses else None, mode="val")[0]
-            ddiff = max(float((o_alt[k] - o_ref[k]).abs().max()) for k in o_ref if k[0] == "depth")
+            ddiff = max(float((o_alt[k] - gpu_outputs[k]).abs().max()) for k in gpu_outputs if k[0] == "depth")
             alt = {"conv3d_arith": "bf16x3", "conv2d_arith": "bf16x3", "value": round(frames * args.steps / alt_elapsed, 3),
                    "ms_per_step": round(1e3 * alt_elapsed / args.steps, 3),
                    "max_abs_depth_diff_vs_headline_arith_m": float("%.3g" % ddiff),
@@ -285,25 +385,30 @@ def main():
             alt = {"error": "%s: %s" % (type(e).__name__, str(e)[:120])}
         finally:
             ops.CONV3D_ARITH, ops.CONV2D_ARITH = args.conv3d_arith, args.conv2d_arith
+    per_rank_ms = [1e3 * elapsed / args.steps]
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        per_rank_ms = [round(1e3 * float(t.item()) / args.steps, 3) for t in allt]
+        elapsed = max(float(t.item()) for t in allt)
 
     if rank == 0:
         value = frames * world * args.steps / elapsed
-        tot_ms = sum(s.elapsed_time(e) for (_, s, e) in prof)
-        tot_flop = sum(f for (f, _, _) in prof)
-        achieved = tot_flop / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
         peak = PEAK_FP32_MATRIX_TFLOPS if args.conv3d_arith == "f32" else PEAK_BF16_MATRIX_TFLOPS / 6.0
-        # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE, see
-        # profiles/r1_conv3d_pmc.json), scaled to this run's average volumes per launch; null if the file is absent
-        traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r1_conv3d_pmc.json")
-        if os.path.exists(pmc_file) and prof and args.workload != "cfg1" and args.conv3d_arith == "f32":
-            per_vol = json.load(open(pmc_file))["hbm_bytes_per_volume"]
-            vols = tot_flop / (2.0 * 27 * 32 * 32 * 64 * 120 * 160)
-            traffic = round(per_vol * vols / len(prof))
+        mfma, hbm = summarize(prof, peak)
+        dom = mfma.get("conv3d:32->32", {"launches": 0, "avg_launch_ms": 0.0, "achieved_tflops": 0.0, "frac": 0.0, "gflop_per_launch": 0.0})
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 correction +
+        # WRITE_SIZE, tools/pmc_collect.sh), scaled to this run's average volumes per launch; null if the file is absent
+        traffic, traffic_src = None, None
+        vox = WORKLOADS[args.workload][3] * (WORKLOADS[args.workload][1] // 4) * (WORKLOADS[args.workload][2] // 4)
+        for name in ("r2_conv3d_pmc.json", "r1_conv3d_pmc.json"):
+            pmc_file = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pmc_file) and dom["launches"] and args.workload in ("joint", "estm") and args.conv3d_arith == "f32":
+                per_vol = json.load(open(pmc_file))["hbm_bytes_per_volume"]
+                vols = dom["gflop_per_launch"] * 1e9 / (2.0 * 27 * 32 * 32 * vox)
+                traffic, traffic_src = round(per_vol * vols), "profiles/" + name
+                break
         line = {
             "metric": "depth frames/sec (seq_len=5, 480x640, D=64)" if args.workload == "joint" else "depth frames/sec",
             "value": round(value, 3), "unit": "depth frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -311,27 +416,35 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if args.conv3d_arith == "f32" else "f32 (32->32 conv3d products as six bf16 MFMAs of exactly 3-way-split operands, f32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": {"joint": "cfg2: seq_len=5, 480x640, ndepths=64, ResNet-50, Joint mode steady state (carried memory, EST on)",
-                                    "estm": "cfg3: ESTM steady-state window (3 frames, memory 2), 480x640, ndepths=64, ResNet-50",
-                                    "cfg1": "cfg1: seq_len=3, 128x160, ndepths=16, ResNet-18, EST off"}[args.workload],
+            "config": {"workload": WORKLOADS[args.workload][6],
                        "depth_frames_per_step": frames, "input_frames_per_step": x_imgs.shape[1],
                        "input_frames_per_s": round(x_imgs.shape[1] * world * args.steps / elapsed, 3),
                        "launch": "eager" if (args.no_graph or state["fwd"] is model) else "hipGraph replay",
                        "conv3d_arith": args.conv3d_arith, "conv2d_arith": args.conv2d_arith,
                        "notes": state["notes"],
-                       "parallelism": "1 sequence per GPU" + ("; RCCL all-gather of {K,V,pose} per step, overlapped with the next step" if world > 1 and not args.no_allgather else "")},
+                       "per_rank_ms_per_step": per_rank_ms,
+                       "parallelism": "1 sequence per GPU" + ("; RCCL all-gather of {K,V,pose} per step, overlapped with the next step" if gathered else "")},
             "roofline": {"bound": "mfma",
                          "kernel": "conv3d_k3_kernel<32,2> (3x3x3 conv 32->32, fp32 MFMA 16x16x4)" if args.conv3d_arith == "f32" else
                                    "conv3d_k3_split_kernel (3x3x3 conv 32->32, 6 x bf16 MFMA 16x16x32 per fp32 product block; peak = bf16 dense / 6)",
-                         "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r1_conv3d_pmc.json)",
-                         "launches": len(prof), "avg_launch_ms": round(tot_ms / max(len(prof), 1), 4)},
+                         "achieved": dom["achieved_tflops"], "peak": round(peak, 1), "unit": "TFLOP/s",
+                         "frac": dom["frac"], "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, %s)" % traffic_src,
+                         "launches": dom["launches"], "avg_launch_ms": dom["avg_launch_ms"],
+                         "how": "HIP events around every launch in %d eager steps after the timed loop (same streams / overlap as the timed step)" % args.steps,
+                         "mfma_kernels": mfma,                     # every 3x3x3 convolution instance: TFLOP/s and fraction of the fp32 MFMA peak
+                         "hbm_kernels": hbm},                      # warp / volume build / attention / GRU tail / soft-argmin: GB/s of ALGORITHMIC bytes, fraction of 8 TB/s
         }
+        if ag is not None:
+            line["config"]["allgather"] = ag
         if alt is not None:
             line["alt_arith"] = alt
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(model.cpu(), args.workload)
+            del model, fwd
+            state["fwd"] = None
+            base, parity = cpu_baseline(args.workload, args.cpu_threads, x_imgs, x_poses, intr, pre_costs, pre_poses, gpu_outputs, frames)
+            line["cpu_baseline"] = base
+            line["parity"] = parity
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

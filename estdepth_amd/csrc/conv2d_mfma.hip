@@ -253,11 +253,7 @@ int launch2d(const estd_conv2d_desc& d, hipStream_t stream)
     const size_t lds = (size_t)2 * IN_H * IN_W * 128;
     int grid = total < 512 ? total : 512;
     if (grid >= 8) grid &= ~7;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_k3_kernel<NT, DIL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    estd_allow_dynamic_lds<conv2d_k3_kernel<NT, DIL>>((int)lds);
     hipLaunchKernelGGL((conv2d_k3_kernel<NT, DIL>), dim3(grid), dim3(256), lds, stream, d, tiles_w, tiles_h, total);
     return hipGetLastError() == hipSuccess ? ESTD_OK : ESTD_ERR_LAUNCH;
 }

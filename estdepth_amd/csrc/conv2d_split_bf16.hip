@@ -378,11 +378,7 @@ int launch_split2d(const estd_conv2d_desc& d, hipStream_t stream)
     if (total > 0x7fffffffLL) return ESTD_ERR_ARG;
     int grid = total < 256 ? (int)total : 256;
     if (grid >= 8) grid &= ~7;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv2d_k3_split_kernel<DIL, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, G_::LDS_TOTAL);
-        attr_set = true;
-    }
+    estd_allow_dynamic_lds<conv2d_k3_split_kernel<DIL, RES>>((int)G_::LDS_TOTAL);
     hipLaunchKernelGGL((conv2d_k3_split_kernel<DIL, RES>), dim3(grid), dim3(512), G_::LDS_TOTAL, stream, d, tiles_w, tiles_h, (int)total);
     return hipGetLastError() == hipSuccess ? ESTD_OK : ESTD_ERR_LAUNCH;
 }

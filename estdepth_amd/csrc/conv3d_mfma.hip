@@ -514,12 +514,7 @@ int launch(const estd_conv3d_desc& d, hipStream_t stream)
     int grid = total < PERSISTENT_WGS ? total : PERSISTENT_WGS;
     if (grid >= 8) grid &= ~7;
     const size_t lds = (size_t)3 * SL_VOX * CM * 4 + (EXTRA ? 3 * SL_VOX * 4 : 0) + 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_kernel<CM, NT, EXTRA, XOUT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    estd_allow_dynamic_lds<conv3d_k3_kernel<CM, NT, EXTRA, XOUT>>((int)lds);
     hipLaunchKernelGGL((conv3d_k3_kernel<CM, NT, EXTRA, XOUT>), dim3(grid), dim3(256), lds, stream, d, tiles_w, tiles_h, total);
     return hipGetLastError() == hipSuccess ? ESTD_OK : ESTD_ERR_LAUNCH;
 }

@@ -593,12 +593,7 @@ int launch_inst(const estd_conv3d_desc& d, hipStream_t stream, int tiles_w, int 
 {
     int grid = total < 256 ? total : 256;       // one workgroup per CU (LDS-limited)
     if (grid >= 8) grid &= ~7;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_split_kernel<NT, EXTRA, TANH, STATS, RES>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
-        attr_set = true;
-    }
+    estd_allow_dynamic_lds<conv3d_k3_split_kernel<NT, EXTRA, TANH, STATS, RES>>((int)LDS_TOTAL);
     hipLaunchKernelGGL((conv3d_k3_split_kernel<NT, EXTRA, TANH, STATS, RES>), dim3(grid), dim3(512), LDS_TOTAL, stream, d, tiles_w, tiles_h, total);
     return hipGetLastError() == hipSuccess ? ESTD_OK : ESTD_ERR_LAUNCH;
 }

@@ -12,4 +12,21 @@ static inline hipStream_t estd_stream(estd_stream_t s) { return static_cast<hipS
 
 static inline int estd_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (function, device): raise it once per device ordinal and
+// kernel instantiation.  One atomic bit mask per instantiation -- thread-safe, and correct when a process drives
+// several devices (launches under graph capture find the bit already set by the warm-up launch).
+#include <atomic>
+template <auto Kernel>
+static inline void estd_allow_dynamic_lds(int bytes)
+{
+    static std::atomic<unsigned long long> done{0ull};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        done.fetch_or(bit, std::memory_order_release);
+    }
+}
+
 #endif

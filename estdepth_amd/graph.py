@@ -1,19 +1,28 @@
 """HIP-graph replay of ``DepthNetHybrid.forward`` (opt-in accelerator; same kernels, same results).
 
-A forward pass is ~500 kernel launches (MIOpen 2D backbones + our HIP kernels) with static shapes; launched
+A forward pass is ~330 kernel launches (MIOpen 2D backbones + our HIP kernels) with static shapes; launched
 eagerly the GPU idles ~12 % of the step between launches (profiles/).  ``GraphedForward`` captures one forward
-per (input shape, number of memory volumes) into a hipGraph on first use and replays it afterwards.
+per call signature into a hipGraph on first use and replays it afterwards.  It is a drop-in for the model in
+every inference call site of the reference (``eval_hybrid.py:229-243``, ``eval_hybrid_seq.py:160-193``) and in
+``estdepth_amd.streaming.ESTMStream`` (attribute access falls through to the wrapped model).
 
 Contract differences from the eager call (documented, not hidden):
-  * returned tensors are the graph's static output buffers: they are overwritten by the next call with the
-    same signature -- consume or clone them first (eval loops of the reference copy results to the host
-    right after each call, eval_hybrid_seq.py:210-236);
-  * memory volumes handed in as ``pre_costs`` are copied into static input buffers (one 157 MB device copy
-    per volume at cfg2 size), so they may alias the previous call's outputs.
+  * the tensors of the returned ``outputs`` dict are the graph's static output buffers: they are overwritten by
+    the next call with the same signature -- consume or clone them first (the reference's eval loops copy results
+    to the host right after each call, eval_hybrid_seq.py:210-236);
+  * the returned memory ``(costs, cam_poses)`` ARE fresh tensors (one 157 MB device copy at cfg2 size): callers
+    keep them across calls (memory_size = 2 windows in the ESTM protocol), so they must not alias each other;
+  * memory volumes handed in as ``pre_costs`` are copied into static input buffers (one device copy per volume);
+  * ``mode='test'`` (metrics on boolean-masked ground truth) synchronises with the host and cannot be captured:
+    it raises.  Run ``mode='val'`` through the graph and evaluate the metrics on the outputs.
+A capture is keyed by (input shape, number of memory volumes, matching-features given?, mode, convolution arithmetic,
+weights epoch of the model): ``load_state_dict`` / ``.to()`` bump the epoch and force a re-capture; call
+``invalidate()`` after editing parameters in place.
 """
 import torch
 
 from .hybrid_depth_decoder import kv_from_pair, kv_views
+from .layers_op import PlanCache
 
 
 class GraphedForward:
@@ -22,15 +31,26 @@ class GraphedForward:
         self.warmup = warmup
         self._graphs = {}
 
-    def _signature(self, imgs, pre_costs, mode):
+    def __getattr__(self, name):                 # normalise_images, matchingFeature, ndepths, ... of the wrapped model
+        if name in ("model", "warmup", "_graphs"):
+            raise AttributeError(name)
+        return getattr(self.model, name)
+
+    def invalidate(self):
+        """drop every captured graph (after in-place edits of parameters, which no epoch counter can see)."""
+        self._graphs.clear()
+
+    def _signature(self, imgs, pre_costs, mode, matching_features):
         n_mem = 0 if pre_costs is None else len(pre_costs["keys"])
         from . import ops
-        return (tuple(imgs.shape), n_mem, mode, ops.CONV3D_ARITH, ops.CONV2D_ARITH)     # a captured graph bakes the kernel choice in
+        return (tuple(imgs.shape), n_mem, matching_features is not None, mode, ops.CONV3D_ARITH, ops.CONV2D_ARITH,
+                getattr(self.model, "_estd_weights_epoch", 0))     # a captured graph bakes kernel choice and weight buffers in
 
-    def _capture(self, key, imgs, cam_poses, cam_intr, sample, pre_costs, pre_cam_poses, mode):
+    def _capture(self, key, imgs, cam_poses, cam_intr, sample, pre_costs, pre_cam_poses, mode, matching_features):
         m = self.model
         st = {"imgs": imgs.clone(), "poses": cam_poses.clone(), "intr": cam_intr.clone(),
-              "sample": {k: v.clone() for k, v in sample.items()}}
+              "sample": {k: v.clone() for k, v in sample.items()},
+              "feats": matching_features.clone() if matching_features is not None else None}
         if pre_costs is not None:
             st["kv"] = [kv_from_pair(k, v).clone() for k, v in zip(pre_costs["keys"], pre_costs["values"])]
             st["mem_poses"] = [p.clone() for p in pre_cam_poses]
@@ -41,7 +61,7 @@ class GraphedForward:
                 pairs = [kv_views(kv) for kv in st["kv"]]
                 pc = {"keys": [k for k, _ in pairs], "values": [v for _, v in pairs]}
                 pp = list(st["mem_poses"])
-            return m(st["imgs"], st["poses"], st["intr"], st["sample"], pc, pp, mode=mode)
+            return m(st["imgs"], st["poses"], st["intr"], st["sample"], pc, pp, mode=mode, matching_features=st["feats"])
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -55,17 +75,30 @@ class GraphedForward:
         with torch.no_grad(), torch.cuda.graph(g, capture_error_mode="thread_local"):
             out = run()
         st["graph"], st["out"] = g, out
+        # the replay reads the packed-weight buffers that existed at capture time: keep them alive even if a PlanCache
+        # is rebuilt later (stale-but-valid until the epoch check re-captures), never a use-after-free
+        st["keepalive"] = [c._plans for c in (getattr(mod, "_cache", None) for mod in m.modules()) if isinstance(c, PlanCache)]
+        for k in [k for k in self._graphs if k[:-1] == key[:-1]]:      # same call shape, older weights epoch
+            del self._graphs[k]
         self._graphs[key] = st
         return st
 
-    def __call__(self, imgs, cam_poses, cam_intr, sample, pre_costs=None, pre_cam_poses=None, mode="val"):
-        key = self._signature(imgs, pre_costs, mode)
+    def __call__(self, imgs, cam_poses, cam_intr, sample, pre_costs=None, pre_cam_poses=None, mode="val",
+                 matching_features=None):
+        if mode != "val":
+            raise RuntimeError("GraphedForward replays mode='val' only: mode=%r needs host-side masking/metrics "
+                               "(call the model eagerly, or evaluate the metrics on the returned outputs)" % (mode,))
+        key = self._signature(imgs, pre_costs, mode, matching_features)
         st = self._graphs.get(key)
         if st is None:
-            st = self._capture(key, imgs, cam_poses, cam_intr, sample, pre_costs, pre_cam_poses, mode)
+            st = self._capture(key, imgs, cam_poses, cam_intr, sample, pre_costs, pre_cam_poses, mode, matching_features)
         st["imgs"].copy_(imgs)
         st["poses"].copy_(cam_poses)
         st["intr"].copy_(cam_intr)
+        for k, v in sample.items():           # unused by mode='val' arithmetic, refreshed anyway so the buffers never go stale
+            st["sample"][k].copy_(v)
+        if matching_features is not None:
+            st["feats"].copy_(matching_features)
         if pre_costs is not None:
             for dst, k, v in zip(st["kv"], pre_costs["keys"], pre_costs["values"]):
                 src = kv_from_pair(k, v)
@@ -74,4 +107,43 @@ class GraphedForward:
             for dst, p in zip(st["mem_poses"], pre_cam_poses):
                 dst.copy_(p)
         st["graph"].replay()
-        return st["out"]
+        outputs, costs, cposes = st["out"]
+        # memory handed back to the caller: fresh tensors (they outlive the next replay)
+        key_t, value_t = costs["keys"][0], costs["values"][0]
+        kv = getattr(value_t, "_estd_kv", None)
+        if kv is not None and getattr(key_t, "_estd_kv", None) is kv:
+            k2, v2 = kv_views(kv.clone())
+        else:
+            k2, v2 = key_t.clone(), value_t.clone()
+        return outputs, {"keys": [k2], "values": [v2]}, [p.clone() for p in cposes]
+
+
+class GraphedModule:
+    """hipGraph replay of a single-tensor-in / single-tensor-out module call with a static input shape (used for the
+    per-frame PSM matching-feature extraction of the streaming harness).  The returned tensor is a fresh clone."""
+
+    def __init__(self, fn, warmup=2):
+        self.fn = fn
+        self.warmup = warmup
+        self._graphs = {}
+
+    def __call__(self, x):
+        key = (tuple(x.shape), x.is_contiguous(memory_format=torch.channels_last))
+        st = self._graphs.get(key)
+        if st is None:
+            st = {"x": x.clone(memory_format=torch.preserve_format)}
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(self.warmup):
+                    self.fn(st["x"])
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(g, capture_error_mode="thread_local"):
+                st["y"] = self.fn(st["x"])
+            st["graph"] = g
+            self._graphs[key] = st
+        st["x"].copy_(x)
+        st["graph"].replay()
+        return st["y"].clone()

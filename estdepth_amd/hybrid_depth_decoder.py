@@ -103,30 +103,6 @@ class DepthHybridDecoder(nn.Module):
             nn.Conv3d(base_channels // 2, 1, kernel_size=1, padding=0, stride=1, bias=True))
         self._cache = PlanCache()
 
-    # ------------------------------------------------------------------------------ helpers kept for parity
-    def scale_cam_intr(self, cam_intr, scale):
-        cam_intr_new = cam_intr.clone()
-        cam_intr_new[:, :2, :] *= scale
-        return cam_intr_new
-
-    def collapse_num(self, x):
-        if len(x.shape) == 5:
-            B, NUM, C, H, W = x.shape
-            x = x.reshape(B * NUM, C, H, W)
-        elif len(x.shape) == 6:
-            B, NUM, C, D, H, W = x.shape
-            x = x.reshape(B * NUM, C, D, H, W)
-        return x
-
-    def expand_num(self, x, NUM):
-        if len(x.shape) == 4:
-            B_NUM, C, H, W = x.shape
-            x = x.view(-1, NUM, C, H, W)
-        elif len(x.shape) == 5:
-            B_NUM, C, D, H, W = x.shape
-            x = x.view(-1, NUM, C, D, H, W)
-        return x
-
     # ------------------------------------------------------------------------------ packed weights
     def _plans(self):
         def build():
@@ -147,7 +123,8 @@ class DepthHybridDecoder(nn.Module):
             p["head0"] = self.stereo_head0[0].plan(head=self.stereo_head0[1])
             p["head1"] = self.stereo_head1[0].plan(head=self.stereo_head1[1])
             return p
-        return self._cache.get(self, build)
+        hot = (self.dres0, self.dres1, self.dres2, self.value_layer, self.key_layer, self.stereo_head0, self.stereo_head1)
+        return self._cache.get(hot, build)       # the 3D layers the plans are packed from (not the 2D decoder)
 
     # ------------------------------------------------------------------------------ 2D decoder pieces
     def _semantic_vs(self, semantic_features):

@@ -38,6 +38,18 @@ class DepthNetHybrid(nn.Module):
         self.pre1 = convbnrelu_3d(32, 32, 3, 1, 1)
         self.pre2 = convbn_3d(32, 32, 3, 1, 1)
         self._cache = PlanCache()
+        # weights epoch: bumped whenever parameters are replaced wholesale (load_state_dict, .to()/.cuda()); captured
+        # hipGraphs (estdepth_amd.graph) bake packed-weight addresses in and re-capture when it changes
+        self._estd_weights_epoch = 0
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._bump_weights_epoch())
+
+    def _bump_weights_epoch(self):
+        self._estd_weights_epoch += 1
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._estd_weights_epoch = getattr(self, "_estd_weights_epoch", 0) + 1
+        return out
 
     # ------------------------------------------------------------------------------ packed weights
     def _plans(self):
@@ -49,14 +61,14 @@ class DepthNetHybrid(nn.Module):
             return {"w_ref": (sc[:, None] * w0[:, :32]).contiguous().to(dev), "b_ref": sh.contiguous().to(dev),
                     "w_src": (sc[:, None] * w0[:, 32:]).contiguous().to(dev),
                     "pre1": self.pre1.plan(), "pre2": self.pre2.plan(), "pre2x2": self.pre2.plan().with_shift_scaled(2)}
-        return self._cache.get(self, build)
+        return self._cache.get((self.pre0, self.pre1, self.pre2), build)      # only these three layers feed the plans
 
-    def _costvolumes(self, ref_mixes, src_mix_pairs, ref_poses, src_pose_pairs, cam_intr, depth_values):
+    def _costvolumes(self, ref_mixes, src_mix_pairs, ref_poses, src_pose_pairs, cam_intr, depth_values, P=None):
         """Fused get_costvolume for T targets at once on pre-mixed 2D features (model_hybrid.py:76-99).
         ref_mixes: T tensors [H,W,32]; src_mix_pairs: T lists of source mixes; returns [T,D,H,W,32].
         The k-th sources of all targets share one batched convolution launch (N = T), and the running mean
         over sources is the second launch's accumulate epilogue -- no race, same arithmetic as :97-99."""
-        P = self._plans()
+        P = self._plans() if P is None else P
         T = len(ref_mixes)
         H, W, _ = ref_mixes[0].shape
         D = self.ndepths
@@ -91,8 +103,8 @@ class DepthNetHybrid(nn.Module):
     def _costvolume(self, ref_mix, src_mixes, ref_pose, src_poses, cam_intr, depth_values):
         return self._costvolumes([ref_mix], [src_mixes], [ref_pose], [src_poses], cam_intr, depth_values)[0]
 
-    def _mix(self, feature_chw, which):
-        P = self._plans()
+    def _mix(self, feature_chw, which, P=None):
+        P = self._plans() if P is None else P
         if which == "ref":
             return ops.mix1x1(feature_chw, P["w_ref"], P["b_ref"])
         return ops.mix1x1(feature_chw, P["w_src"], None)
@@ -114,9 +126,10 @@ class DepthNetHybrid(nn.Module):
         return cost.permute(3, 0, 1, 2).unsqueeze(0)
 
     def scale_cam_intr(self, cam_intr, scale):
-        cam_intr_new = cam_intr.clone()
-        cam_intr_new[:, :2, :] *= scale
-        return cam_intr_new
+        """intrinsics of a down-scaled image: focal lengths and principal point (rows 0,1) times ``scale`` (model_hybrid.py:104-108)."""
+        k = cam_intr.clone()
+        k[:, 0:2] = k[:, 0:2] * scale
+        return k
 
     def use_channels_last_2d(self, enable=True):
         """Opt-in: run the 2D backbones (PSM, ResNet, 2D decoder -- MIOpen, outside the hot path) in NHWC.
@@ -207,28 +220,48 @@ class DepthNetHybrid(nn.Module):
         poses = cam_poses[0].contiguous().float()
 
         # every view is a source for up to two targets: mix each 2D feature once (pre0 pushed in front of the warp)
-        src_mix = [self._mix(matching[v].contiguous(), "src") for v in range(views_num)]
-        ref_mix = [self._mix(matching[t + 1].contiguous(), "ref") for t in range(target_num)]
+        P = self._plans()                                   # one cache-key check per forward
+        src_mix = [self._mix(matching[v].contiguous(), "src", P) for v in range(views_num)]
+        ref_mix = [self._mix(matching[t + 1].contiguous(), "ref", P) for t in range(target_num)]
         costs = self._costvolumes(ref_mix, [[src_mix[t], src_mix[t + 2]] for t in range(target_num)],
                                   [poses[t + 1] for t in range(target_num)],
-                                  [[poses[t], poses[t + 2]] for t in range(target_num)], intr, dv)      # :152-156
+                                  [[poses[t], poses[t + 2]] for t in range(target_num)], intr, dv, P)   # :152-156
         cost_volumes = [costs[t].permute(3, 0, 1, 2).unsqueeze(0) for t in range(target_num)]
         target_cam_poses = [cam_poses[:, t + 1, :, :] for t in range(target_num)]                            # :161
 
         outputs, cur_costs, cur_cam_poses = self.CostRegNet(cost_volumes, semantic_features, target_cam_poses,
                                                             cam_intr_stage1, depth_values, self.depth_min,
                                                             self.depth_interval, pre_costs, pre_cam_poses, mode)   # :166
-        if mode == 'test':
-            metrics = {}
-            for s in (0, 2):
-                vals = []
-                for t in range(target_num):
-                    gt = sample["dmaps"][:, t + 1]
-                    mask = sample["dmasks"][:, t + 1]
-                    vals.append(abs_rel(outputs[("depth", t, s)][mask], gt[mask]))
-                metrics["abs_rel_{}".format(s)] = torch.stack(vals).mean()
-            return outputs, metrics
+        if mode == 'test':                                                                                   # :179-181
+            gts = [sample["dmaps"][:, t + 1] for t in range(target_num)]
+            masks = [sample["dmasks"][:, t + 1] for t in range(target_num)]
+            return outputs, self.depth_metrics(outputs, [0, 2], gts, masks, target_num)
         return outputs, cur_costs, cur_cam_poses
+
+    METRIC_NAMES = ("a1", "a2", "a3", "abs_diff", "abs_rel", "sq_rel", "rmse", "rmse_log")
+
+    def metrics(self, gt, pred):
+        """the eight depth-error figures of model_hybrid.py:305-320 on flat (masked) tensors, in METRIC_NAMES order."""
+        ratio = torch.max(gt / pred, pred / gt)
+        within = [(ratio < 1.25 ** k).float().mean() for k in (1, 2, 3)]
+        err = gt - pred
+        log_err = torch.log(gt) - torch.log(pred)
+        return (*within, err.abs().mean(), (err.abs() / gt).mean(), (err ** 2 / gt).mean(),
+                (err ** 2).mean().sqrt(), (log_err ** 2).mean().sqrt())
+
+    def depth_metrics(self, outputs, scales, depth_gt_ms, gt_masks, target_num):
+        """model_hybrid.py:264-303: per scale, the mean over targets of every figure, keys '<name>_<scale>';
+        accumulated as 0 + sum_t value_t / target_num in target order like the reference."""
+        out = {}
+        for scale in scales:
+            acc = [torch.zeros((), dtype=torch.float32, device=depth_gt_ms[0].device) for _ in self.METRIC_NAMES]
+            for t in range(target_num):
+                pred, gt, mask = outputs[("depth", t, scale)], depth_gt_ms[t], gt_masks[t]
+                for a, v in zip(acc, self.metrics(gt[mask], pred[mask])):
+                    a += v / target_num
+            for name, a in zip(self.METRIC_NAMES, acc):
+                out["{}_{}".format(name, scale)] = a
+        return out
 
 
 def abs_rel(pred, gt):

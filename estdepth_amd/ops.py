@@ -12,9 +12,31 @@ from . import packing
 
 ACT = {"none": 0, "relu": 1, "tanh": 2}
 
-# bench.py sets this to a list to collect (flops, start_event, end_event) around every launch of the
-# dominant kernel (3x3x3 conv 32->32 without extra channel) on the stream it is launched on.
+# bench.py sets this to a list to collect (group, amount, start_event, end_event) around every launch of the hot-path
+# kernels on the stream they are launched on: amount = algorithmic FLOPs (groups "conv3d:<Cin>-><Cout>[+x]") or
+# algorithmic bytes (SURVEY §8d figures; groups "homo_warp_costvol", "warp_attention", "gru_elementwise", "softargmin").
 PROFILE = None
+
+
+class _Prof:
+    """HIP-event pair around one launch (events are recorded on torch's CURRENT stream = the launch stream)."""
+    __slots__ = ("group", "amount", "e0")
+
+    def __init__(self, group, amount):
+        self.group, self.amount, self.e0 = group, amount, None
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream())
+        return self
+
+    def __exit__(self, *exc):
+        if self.e0 is not None and PROFILE is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(torch.cuda.current_stream())
+            PROFILE.append((self.group, float(self.amount), self.e0, e1))
+        return False
 
 # Arithmetic of the plain 32->32 3x3x3 convolutions: "f32" = v_mfma_f32_16x16x4_f32 (csrc/conv3d_mfma.hip),
 # "bf16x3" = exact 3-way bf16 operand split, six bf16 MFMAs per product block (csrc/conv3d_split_bf16.hip).
@@ -94,9 +116,10 @@ def homo_warp_costvol(src_mix, ref_mix, proj12, depth_values, D, out=None):
     H, W, _ = src_mix.shape
     if out is None:
         out = torch.empty((D, H, W, 32), device=src_mix.device, dtype=torch.float32)
-    N.check(N.lib().estd_homo_warp_costvol(_p(_chk(src_mix, "src_mix")), _p(_chk(ref_mix, "ref_mix")), _p(proj12),
-                                           _p(_chk(depth_values, "depth_values")), _p(out), D, H, W, _stream()),
-            "estd_homo_warp_costvol")
+    with _Prof("homo_warp_costvol", 4.0 * 32 * H * W * (2 + D)):          # src map + ref map + one volume
+        N.check(N.lib().estd_homo_warp_costvol(_p(_chk(src_mix, "src_mix")), _p(_chk(ref_mix, "ref_mix")), _p(proj12),
+                                               _p(_chk(depth_values, "depth_values")), _p(out), D, H, W, _stream()),
+                "estd_homo_warp_costvol")
     return out
 
 
@@ -163,11 +186,9 @@ class Conv3dPlan:
         d.head_b = self.head_b.data_ptr() if (self.head_b is not None and out_head is not None) else None
         d.out_head = out_head.data_ptr() if out_head is not None else None
         d.stats_partials = stats_partials.data_ptr() if stats_partials is not None else None
-        prof = PROFILE is not None and self.cin_main == 32 and self.n_tiles == 2 and self.w_extra is None
-        if prof:
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(torch.cuda.current_stream())
+        cin = self.cin_main + (1 if self.w_extra is not None else 0)
+        prof = _Prof("conv3d:%d->%d" % (cin, self.n_out), 2.0 * 27 * cin * self.n_out * Nn * D * H * W)
+        prof.__enter__()
         # instances of the split kernel (csrc/conv3d_split_bf16.hip dispatch): plain [+stats], extra input [tanh|relu], 33 -> 33
         tanh = ACT["tanh"] in ((self.act_a if self.act_split > 0 else self.act_b), self.act_b)
         if self.n_tiles == 3:
@@ -186,9 +207,7 @@ class Conv3dPlan:
             raise RuntimeError("ESTD_CONV3D_ARITH must be f32 or bf16x3, got %r" % (CONV3D_ARITH,))
         else:
             N.check(N.lib().estd_conv3d_k3(ctypes.byref(d), _stream()), "estd_conv3d_k3")
-        if prof:
-            e1.record(torch.cuda.current_stream())
-            PROFILE.append((2.0 * 27 * 32 * 32 * Nn * D * H * W, e0, e1))
+        prof.__exit__()
 
 
 class Conv2dPlan:
@@ -268,8 +287,9 @@ def softargmin_up(logits, depth_values, scale=4):
     Nn, D, H, W = logits.shape
     depth = torch.empty((Nn, 1, H * scale, W * scale), device=logits.device, dtype=torch.float32)
     prob = torch.empty_like(depth)
-    N.check(N.lib().estd_softargmin_up(_p(_chk(logits, "logits")), _p(_chk(depth_values, "depth_values")), _p(depth), _p(prob),
-                                       Nn, D, H, W, scale, _stream()), "estd_softargmin_up")
+    with _Prof("softargmin", 4.0 * Nn * H * W * (D + 2 * scale * scale)):       # logits in, depth + prob maps out
+        N.check(N.lib().estd_softargmin_up(_p(_chk(logits, "logits")), _p(_chk(depth_values, "depth_values")), _p(depth), _p(prob),
+                                           Nn, D, H, W, scale, _stream()), "estd_softargmin_up")
     return depth, prob
 
 
@@ -289,9 +309,10 @@ def warp_attention(kv_target, kv_sources, mats, depth_values, depth_min, depth_i
     n = len(kv_sources)
     arr = (ctypes.c_void_p * n)(*[_chk(k, "kv source").data_ptr() for k in kv_sources])
     xh = torch.empty((D, H, W, 32), device=kv_target.device, dtype=torch.float32)
-    N.check(N.lib().estd_warp_attention(_p(_chk(kv_target, "kv target")), arr, _p(_chk(mats, "mats")), n,
-                                        _p(_chk(depth_values, "depth_values")), float(depth_min), float(depth_interval),
-                                        _p(xh), D, H, W, _stream()), "estd_warp_attention")
+    with _Prof("warp_attention", 4.0 * 16 * D * H * W * (2 + 2 * n)):          # K_t, h out, K_j and V_j of every source
+        N.check(N.lib().estd_warp_attention(_p(_chk(kv_target, "kv target")), arr, _p(_chk(mats, "mats")), n,
+                                            _p(_chk(depth_values, "depth_values")), float(depth_min), float(depth_interval),
+                                            _p(xh), D, H, W, _stream()), "estd_warp_attention")
     return xh
 
 
@@ -307,15 +328,17 @@ def attention_prewarped(kv_target, kv_sources):
 def gru_reset_apply(xh, ru, stats4, gamma_r, beta_r):
     xrh = torch.empty_like(xh)
     n_vox = xh.numel() // 32
-    N.check(N.lib().estd_gru_reset_apply(_p(xh), _p(ru), _p(stats4), _p(gamma_r), _p(beta_r), _p(xrh), n_vox, _stream()),
-            "estd_gru_reset_apply")
+    with _Prof("gru_elementwise", 4.0 * 16 * n_vox * 2):       # SURVEY §8d K11+K13 = 5 x 16 channels per voxel: r, h here
+        N.check(N.lib().estd_gru_reset_apply(_p(xh), _p(ru), _p(stats4), _p(gamma_r), _p(beta_r), _p(xrh), n_vox, _stream()),
+                "estd_gru_reset_apply")
     return xrh
 
 
 def gru_blend(xh, ru, o_raw, stats_ru, stats_o, gamma_u, beta_u, gamma_o, beta_o, out_value, out_stride):
     n_vox = xh.numel() // 32
-    N.check(N.lib().estd_gru_blend(_p(xh), _p(ru), _p(o_raw), _p(stats_ru), _p(stats_o), _p(gamma_u), _p(beta_u),
-                                   _p(gamma_o), _p(beta_o), _p(out_value), out_stride, n_vox, _stream()), "estd_gru_blend")
+    with _Prof("gru_elementwise", 4.0 * 16 * n_vox * 3):       # ... u, o_raw, out here (h counted once, in the reset pass)
+        N.check(N.lib().estd_gru_blend(_p(xh), _p(ru), _p(o_raw), _p(stats_ru), _p(stats_o), _p(gamma_u), _p(beta_u),
+                                       _p(gamma_o), _p(beta_o), _p(out_value), out_stride, n_vox, _stream()), "estd_gru_blend")
 
 
 # ---------------------------------------------------------------------------------- 2D backbone epilogues

@@ -13,9 +13,18 @@ import torch
 
 
 class ESTMStream:
-    def __init__(self, model, lwindow=3, memory_size=2, cache_features=True):
+    def __init__(self, model, lwindow=3, memory_size=2, cache_features=True, graph=False):
+        """``graph=True``: replay captured hipGraphs instead of ~330 eager launches per window -- one graph per number of
+        memory volumes (0, 1, ..memory_size) for the window forward and one for the per-frame PSM extraction
+        (estdepth_amd.graph); same kernels, same results, returned ``outputs`` live until the next push."""
         if lwindow < 3:
             raise RuntimeError("a window needs at least 3 frames (model_hybrid.py:123)")
+        self._psm = None                     # None = model.matchingFeature, looked up at call time
+        if graph:
+            from .graph import GraphedForward, GraphedModule
+            if not isinstance(model, GraphedForward):
+                model = GraphedForward(model)
+            self._psm = GraphedModule(model.matchingFeature)
         self.model = model
         self.lwindow = lwindow
         self.memory_size = memory_size
@@ -44,7 +53,7 @@ class ESTMStream:
             x = self.model.normalise_images(img)
             if getattr(self.model, "_channels_last_2d", False):
                 x = x.contiguous(memory_format=torch.channels_last)
-            fr["feat"] = self.model.matchingFeature(x)                      # [1,32,H/4,W/4], once per frame
+            fr["feat"] = (self._psm or self.model.matchingFeature)(x)                                       # [1,32,H/4,W/4], once per frame
         self._frames.append(fr)
         if len(self._frames) < self.lwindow:
             return None

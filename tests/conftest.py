@@ -15,6 +15,23 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """gpu-marked tests need a ROCm device AND the built HIP library: skip them (with the reason) on any other box
+    instead of failing with RuntimeErrors when `-m "not gpu"` is forgotten."""
+    import torch
+    from estdepth_amd import _native
+    reason = None
+    if not torch.cuda.is_available():
+        reason = "no ROCm device visible"
+    elif not os.path.exists(_native.LIB_PATH):
+        reason = "libestd_hip.so not built (python -m estdepth_amd.build)"
+    if reason:
+        skip = pytest.mark.skip(reason=reason)
+        for item in items:
+            if "gpu" in item.keywords:
+                item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

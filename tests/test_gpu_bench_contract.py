@@ -36,15 +36,35 @@ def test_bench_single_gpu_line():
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["workload"].startswith("cfg1")
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    assert d["parity"]["within_tolerance"] and max(d["parity"]["max_abs_depth_diff_vs_oracle_m"].values()) <= 1e-4
+    assert {"homo_warp_costvol", "softargmin"} <= set(d["roofline"]["hbm_kernels"])
+    assert "conv3d:32->32" in d["roofline"]["mfma_kernels"]
     assert d["dtype"] == "f32" and d["config"]["conv3d_arith"] == "f32"          # the headline is native fp32 MFMA
     assert d["alt_arith"]["conv3d_arith"] == "bf16x3" and d["alt_arith"]["value"] > 0
 
 
-def test_bench_two_ranks_code_path():
+def _check_two_ranks(d):
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert "all-gather" in d["config"]["parallelism"]
+    assert len(d["config"]["per_rank_ms_per_step"]) == 2
+    ag = d["config"]["allgather"]
+    assert ag["bytes_sent_per_rank"] == 4 * (2 * 16 * 16 * 32 * 40 + 16) and ag["bus_gbs_per_rank"] > 0
+
+
+def test_bench_gpus_flag_launches_the_ranks_itself():
+    """the driver's command line: `python bench.py --gpus N` with NO launcher and no WORLD_SIZE -> bench.py re-executes
+    itself under torch.distributed.run with N ranks (here: 2 ranks sharing the single test GPU, gloo instead of RCCL)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--workload", "cfg1", "--steps", "3", "--warmup", "1"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    d = _last_json(out.stdout)
+    _check_two_ranks(d)
+    assert any("share" in n for n in d["config"]["notes"])          # flagged as a code-path check on a 1-GPU box
+
+
+def test_bench_two_ranks_under_an_external_launcher():
     env = dict(os.environ, ESTD_FORCE_DEVICE="0", ESTD_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--workload", "cfg1", "--steps", "3", "--warmup", "1"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    d = _last_json(out.stdout)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert "all-gather" in d["config"]["parallelism"]
+    _check_two_ranks(_last_json(out.stdout))

@@ -73,7 +73,7 @@ def main():
                             scannet_layout=args.layout == "scannet")
     stream = ESTMStream(model, lwindow=args.lwindow, memory_size=args.memory_size,
                         cache_features=not args.no_feature_cache)
-    errs, times, window = RunningErrors(), [], []
+    errs, times, window, resized = RunningErrors(), [], [], 0
     for idx in range(len(reader)):
         s = reader[idx]
         window.append(s)
@@ -91,10 +91,18 @@ def main():
         save_window_outputs(outputs, args.out, target["img_path"])
         pred = outputs[("depth", 0, 0)][0, 0].cpu().numpy().astype(np.float64)
         gt = target["dmap"][0, 0].numpy().astype(np.float64)
-        if gt.shape == pred.shape:
-            errs.add(pred, gt)
+        if gt.shape != pred.shape:
+            # the ground-truth depth stays at native resolution (general_eval_seq.py:191) while the network runs at
+            # --image-size: bring the PREDICTION to the ground-truth grid (nearest neighbour on pixel centres, no new
+            # depth values are invented) instead of silently skipping the frame
+            ys = np.minimum(((np.arange(gt.shape[0]) + 0.5) * pred.shape[0] / gt.shape[0]).astype(np.int64), pred.shape[0] - 1)
+            xs = np.minimum(((np.arange(gt.shape[1]) + 0.5) * pred.shape[1] / gt.shape[1]).astype(np.int64), pred.shape[1] - 1)
+            pred = pred[ys][:, xs]
+            resized += 1
+        errs.add(pred, gt)
     report = {"scene": scene_dir, "frames": len(reader), "windows": stream.windows,
-              "mean_window_ms": 1e3 * float(np.mean(times[1:] or times or [0.0])), "errors": errs.mean()}
+              "mean_window_ms": 1e3 * float(np.mean(times[1:] or times or [0.0])), "errors": errs.mean(),
+              "predictions_resized_to_gt_grid": resized}
     os.makedirs(args.out, exist_ok=True)
     with open(os.path.join(args.out, "metrics.json"), "w") as f:
         json.dump(report, f, indent=1)
