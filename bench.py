@@ -46,7 +46,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="joint", choices=["joint", "estm", "cfg5", "cfg1", "stream"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the cpu_baseline leg (0 = every core of the box)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="host threads of the cpu_baseline leg (0 = torch's default = the physical cores of the box; SMT siblings slow both "
+                         "the OpenMP oracle and the oneDNN convolutions of the 2D networks down)")
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--conv3d-arith", default=os.environ.get("ESTD_CONV3D_ARITH", "f32"), choices=["f32", "bf16x3"],
@@ -149,7 +151,7 @@ def cpu_baseline(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses,
     from oracle import ref_model as M, ref_ops as O
     from oracle.nets2d import Nets2D, sd_numpy
     ncores = os.cpu_count() or 1
-    threads = ncores if threads <= 0 else min(threads, ncores)
+    threads = torch.get_num_threads() if threads <= 0 else min(threads, ncores)
     O.set_num_threads(threads)
     torch.set_num_threads(threads)
     D = WORKLOADS[workload][3]

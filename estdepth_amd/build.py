@@ -1,6 +1,13 @@
-"""Build libestd_hip.so (gfx950 only) with hipcc.  In-tree output: estdepth_amd/lib/libestd_hip.so
+"""Build the native libraries (gfx950 only) with hipcc, in-tree:
+
+    estdepth_amd/lib/libestd_hip.so         the HIP kernels behind the torch-free C ABI (include/estd_hip.h)
+    estdepth_amd/lib/libestd_torch_ops.so   TORCH_LIBRARY(estdepth_hip) operator registration over that C ABI (csrc/torch_ops.cpp)
 
     python -m estdepth_amd.build [--force] [--verbose]
+
+The libraries are git-ignored build products: a fresh clone has to run this once (hipcc cross-compiles without a GPU;
+``__graft_entry__.build()`` does it), and they travel to the GPU box with the working tree.  Staleness is decided by
+mtime of sources and headers.
 """
 import os
 import subprocess
@@ -59,7 +66,30 @@ def build(force=False, verbose=False):
                     sys.stderr.write(log)
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
+    build_torch_ops(force=force)
     return LIB
+
+
+TORCH_OPS_SRC = os.path.join(CSRC, "torch_ops.cpp")
+TORCH_OPS_LIB = os.path.join(OUT_DIR, "libestd_torch_ops%s.so" % os.environ.get("ESTD_LIB_SUFFIX", ""))
+
+
+def build_torch_ops(force=False):
+    """TORCH_LIBRARY wrappers: host-only C++ against libtorch (no device code), linked to libestd_hip.so via $ORIGIN."""
+    if not (force or _stale(TORCH_OPS_LIB, [TORCH_OPS_SRC, HEADERS[0], LIB])):
+        return TORCH_OPS_LIB
+    import torch
+    from torch.utils import cpp_extension
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = [_hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DHIPBLAS_V2",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI), "-I" + os.path.join(ROOT, "include")]
+    cmd += ["-I" + p for p in cpp_extension.include_paths("cuda")]
+    cmd += [TORCH_OPS_SRC, "-o", TORCH_OPS_LIB, "-L" + OUT_DIR, "-l:" + os.path.basename(LIB), "-L" + tlib,
+            "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), r.stderr[-4000:]))
+    return TORCH_OPS_LIB
 
 
 if __name__ == "__main__":

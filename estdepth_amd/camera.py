@@ -1,0 +1,109 @@
+"""Camera algebra of the hot path -- a few dozen 4x4 / 3x3 matrix inverses and products per forward.
+
+These tiny matrices decide on which side of the ``|normalised coordinate| > 1 -> 2`` masks (homo_utils.py:488-491,
+:192-197) every sample of the plane sweep and of the volume warps falls.  The masks are discontinuous: a relative
+difference of 1e-5 in a projection matrix (what an fp64 device evaluation differs by from the reference's fp32 LAPACK
+composition) flips isolated boundary samples, and one flipped voxel of a cost volume moves ~2000 depth pixels by up to
+2e-3 m after the 3D convolutions (measured at BASELINE configs[4] size, tools/parity_diag.py).  So the default evaluates
+them ON THE HOST with the very torch-CPU calls the reference makes -- same ATen kernels, same shapes (the batched [1,4,4]
+forms: ATen's bmm and mm kernels round differently), same association order -- and hands the kernels bit-identical
+matrices; the per-voxel arithmetic in the kernels then reproduces the reference's rounding sequence op for op
+(csrc/plane_sweep.hip::sweep_coords, csrc/est_fusion.hip::volume_coords_base).
+
+    model_hybrid.py:74-88       extrinsic = inverse(pose);  proj[:, :3, :4] = K @ extrinsic[:, :3, :4]
+    homo_utils.py:469-471       proj = src_proj @ inverse(ref_proj);  rot | trans
+    hybrid_depth_decoder.py:235 rel = pose_j @ inverse(pose_i)                       
+    homo_utils.py:258, :51      inverse(rel), inverse(K)
+
+Cost: one small D2H copy of the poses (a synchronisation point unless they are handed in as CPU tensors), ~40 ATen CPU
+calls, one H2D copy -- about 0.2 ms per forward.  ``mode="device"`` keeps everything on the GPU (estd_cam_* kernels, fp64
+Gauss-Jordan, no synchronisation) for latency-critical eager callers that accept the boundary-sample caveat above.
+"""
+import torch
+
+from . import ops
+
+
+def _cpu(t):
+    return t.detach().to(device="cpu", dtype=torch.float32)
+
+
+def _sweep_set(poses, K, ref, srcs):
+    """rot(9) | trans(3) of the plane-sweep homographies from reference view ``ref`` into the views ``srcs`` -> [len(srcs), 12]."""
+    def view_proj(v):
+        extrinsic = torch.inverse(poses[:, v, :, :])                            # model_hybrid.py:74,:83
+        proj = extrinsic.clone()
+        proj[:, :3, :4] = torch.matmul(K, extrinsic[:, :3, :4])                 # :87-88
+        return proj
+    ref_inv = torch.inverse(view_proj(ref))
+    out = torch.empty(len(srcs), 12, dtype=torch.float32)
+    for k, s in enumerate(srcs):
+        pr = torch.matmul(view_proj(s), ref_inv)                                # homo_utils.py:469
+        out[k, :9] = pr[0, :3, :3].reshape(-1)                                  # :470
+        out[k, 9:] = pr[0, :3, 3]                                               # :471
+    return out
+
+
+def sweep_projection_set(cam_poses, cam_intr_q, ref, srcs, device):
+    """get_costvolume() of one reference view: cam_poses [1,V,4,4], cam_intr_q [1,3,3] (1/4 scale) -> [len(srcs), 12]."""
+    return _sweep_set(_cpu(cam_poses), _cpu(cam_intr_q), ref, list(srcs)).to(device)
+
+
+def sweep_projections(cam_poses, cam_intr_q, device):
+    """cam_poses [1,V,4,4] camera-to-world, cam_intr_q [1,3,3] at 1/4 scale  ->  [V-2, 2, 12] on ``device``:
+    the homography sweep of target t (= view t+1) from its two sources (views t and t+2), model_hybrid.py:152-156."""
+    poses, K = _cpu(cam_poses), _cpu(cam_intr_q)
+    return torch.stack([_sweep_set(poses, K, t + 1, (t, t + 2)) for t in range(poses.shape[1] - 2)]).to(device)
+
+
+def pair_projection(src_proj, ref_proj, device):
+    """level-1 homo_warping(): one batch element, src_proj / ref_proj [4,4] -> [12] on ``device``."""
+    pr = torch.matmul(_cpu(src_proj)[None], torch.inverse(_cpu(ref_proj)[None]))
+    return torch.cat([pr[0, :3, :3].reshape(-1), pr[0, :3, 3]]).to(device)
+
+
+def volume_matrices(poses, n_targets, cam_intr_q, device):
+    """poses: list of [1,4,4] (targets first, then memory poses); -> [n_targets, len(poses)-1, 30] on ``device``:
+    per target i and other view j (ascending j, i skipped): inverse(K)(9) | inverse(pose_j @ inverse(pose_i))[:3](12) | K(9)."""
+    P = [_cpu(p).reshape(1, 4, 4) for p in poses]
+    K = _cpu(cam_intr_q).reshape(1, 3, 3)
+    kinv = torch.inverse(K)                                                      # homo_utils.py:51
+    n = len(P)
+    out = torch.empty(n_targets, n - 1, 30, dtype=torch.float32)
+    for i in range(n_targets):
+        inv_i = torch.inverse(P[i])
+        r = 0
+        for j in range(n):
+            if j == i:
+                continue
+            rel = torch.matmul(P[j], inv_i)                                      # hybrid_depth_decoder.py:235 (Q8)
+            m = torch.inverse(rel)                                               # homo_utils.py:258
+            out[i, r, :9] = kinv[0].reshape(-1)
+            out[i, r, 9:21] = m[0, :3, :].reshape(-1)
+            out[i, r, 21:] = K[0].reshape(-1)
+            r += 1
+    return out.to(device)
+
+
+def relative_volume_matrix(rel_pose, cam_intr_q, device):
+    """level-1 warp_volume(): rel_pose [4,4] is already the relative pose -> [30] on ``device``."""
+    K = _cpu(cam_intr_q).reshape(1, 3, 3)
+    m = torch.inverse(_cpu(rel_pose).reshape(1, 4, 4))
+    return torch.cat([torch.inverse(K)[0].reshape(-1), m[0, :3, :].reshape(-1), K[0].reshape(-1)]).to(device)
+
+
+# ------------------------------------------------------------------------------------------------ device variants
+def sweep_projections_device(cam_poses, cam_intr_q):
+    poses, K = cam_poses[0].contiguous().float(), cam_intr_q[0].contiguous().float()
+    V = poses.shape[0]
+    return torch.stack([torch.stack([ops.cam_sweep_proj(poses[t + 1], poses[s], K) for s in (t, t + 2)]) for t in range(V - 2)])
+
+
+def volume_matrices_device(poses, n_targets, cam_intr_q):
+    P = [p.reshape(4, 4).contiguous().float() for p in poses]
+    K = cam_intr_q.reshape(3, 3).contiguous().float()
+    out = torch.empty((n_targets, len(P) - 1, 30), device=P[0].device, dtype=torch.float32)
+    for i in range(n_targets):
+        for r, j in enumerate([j for j in range(len(P)) if j != i]):
+            ops.cam_volume_mats(P[j], P[i], K, out=out[i, r])
+    return out

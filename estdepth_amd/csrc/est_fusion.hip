@@ -24,24 +24,33 @@ struct Tri {
     float w[8];         // trilinear weights, 0 when the corner is out of bounds
 };
 
+// base corner (floor of the un-normalised sample position; -2 when the position is NaN) and the trilinear fractions
+struct TriBase {
+    int x0, y0, z0;
+    float tx, ty, tz;
+};
+
 // homo_utils.py:51-54 (pixel2cam), :33-36 (cam2cam), :115-121 (cam2pixel_depth), :183-198 (normalise+mask),
 // then ATen grid_sampler_3d un-normalisation for align_corners=False.  M = [kinv(9) | m(12) | k(9)].
-__device__ __forceinline__ Tri volume_coords(const float* __restrict__ M, float dep, int x, int y,
-                                             float depth_min, float depth_interval, int D, int H, int W)
+__device__ __forceinline__ TriBase volume_coords_base(const float* __restrict__ M, float dep, int x, int y,
+                                                      float depth_min, float depth_interval, int D, int H, int W)
 {
-    // no FMA contraction: separate rounded ops like the reference's ATen composition, and bit-identical coordinates in
-    // every kernel that inlines this function (the masks and floor() are discontinuous)
+    // Rounding sequence of the reference's torch-CPU composition, op for op, so that the |norm| > 1 masks (discontinuous!)
+    // see bit-identical coordinates: the three matrix products are bmm/matmul calls (homo_utils.py:52-54, :35, :116) whose
+    // GEMM kernels accumulate k = 0,1,2(,3) in order with fused multiply-adds -- acc = a0*b0; acc = fma(a1,b1,acc); ... (checked
+    // against torch.matmul/bmm bit for bit, tests/test_oracle_ops_golden.py) -- everything else is an elementwise ATen op with
+    // its own rounding.  Hence explicit fmaf() for the products and NO contraction anywhere else.
 #pragma clang fp contract(off)
     const float fx = (float)x, fy = (float)y;
-    const float c0 = (M[0] * fx + M[1] * fy + M[2]) * dep;
-    const float c1 = (M[3] * fx + M[4] * fy + M[5]) * dep;
-    const float c2 = (M[6] * fx + M[7] * fy + M[8]) * dep;
-    const float s0 = M[9] * c0 + M[10] * c1 + M[11] * c2 + M[12];
-    const float s1 = M[13] * c0 + M[14] * c1 + M[15] * c2 + M[16];
-    const float s2 = M[17] * c0 + M[18] * c1 + M[19] * c2 + M[20];
-    const float q0 = M[21] * s0 + M[22] * s1 + M[23] * s2;
-    const float q1 = M[24] * s0 + M[25] * s1 + M[26] * s2;
-    const float q2 = M[27] * s0 + M[28] * s1 + M[29] * s2;
+    const float c0 = (fmaf(M[1], fy, M[0] * fx) + M[2]) * dep;          // (K^-1 @ [x, y, 1]) * depth
+    const float c1 = (fmaf(M[4], fy, M[3] * fx) + M[5]) * dep;
+    const float c2 = (fmaf(M[7], fy, M[6] * fx) + M[8]) * dep;
+    const float s0 = fmaf(M[11], c2, fmaf(M[10], c1, M[9] * c0)) + M[12];    // extrinsic @ [c, 1]
+    const float s1 = fmaf(M[15], c2, fmaf(M[14], c1, M[13] * c0)) + M[16];
+    const float s2 = fmaf(M[19], c2, fmaf(M[18], c1, M[17] * c0)) + M[20];
+    const float q0 = fmaf(M[23], s2, fmaf(M[22], s1, M[21] * s0));           // K @ s
+    const float q1 = fmaf(M[26], s2, fmaf(M[25], s1, M[24] * s0));
+    const float q2 = fmaf(M[29], s2, fmaf(M[28], s1, M[27] * s0));
     const float den = q2 + 1e-10f;
     const float X = q0 / den, Y = q1 / den, Z = q2;
     float xn = 2.0f * X / (float)(W - 1) - 1.0f;
@@ -54,16 +63,25 @@ __device__ __forceinline__ Tri volume_coords(const float* __restrict__ M, float 
     const float iy = ((yn + 1.0f) * (float)H - 1.0f) * 0.5f;
     const float iz = ((zn + 1.0f) * (float)D - 1.0f) * 0.5f;
     const float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
-    const float tx = ix - fx0, ty = iy - fy0, tz = iz - fz0;
     const bool finite = (ix == ix) && (iy == iy) && (iz == iz);
-    const int x0 = finite ? (int)fx0 : -2, y0 = finite ? (int)fy0 : -2, z0 = finite ? (int)fz0 : -2;
+    TriBase b;
+    b.tx = ix - fx0; b.ty = iy - fy0; b.tz = iz - fz0;
+    b.x0 = finite ? (int)fx0 : -2; b.y0 = finite ? (int)fy0 : -2; b.z0 = finite ? (int)fz0 : -2;
+    return b;
+}
+
+__device__ __forceinline__ Tri volume_coords(const float* __restrict__ M, float dep, int x, int y,
+                                             float depth_min, float depth_interval, int D, int H, int W)
+{
+#pragma clang fp contract(off)
+    const TriBase b = volume_coords_base(M, dep, x, y, depth_min, depth_interval, D, H, W);
     Tri t;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int dx = k & 1, dy = (k >> 1) & 1, dz = (k >> 2) & 1;
-        const int xx = x0 + dx, yy = y0 + dy, zz = z0 + dz;
+        const int xx = b.x0 + dx, yy = b.y0 + dy, zz = b.z0 + dz;
         const bool ok = xx >= 0 && xx < W && yy >= 0 && yy < H && zz >= 0 && zz < D;
-        const float wgt = (dx ? tx : 1.0f - tx) * (dy ? ty : 1.0f - ty) * (dz ? tz : 1.0f - tz);
+        const float wgt = (dx ? b.tx : 1.0f - b.tx) * (dy ? b.ty : 1.0f - b.ty) * (dz ? b.tz : 1.0f - b.tz);
         t.w[k] = ok ? wgt : 0.0f;
         t.off[k] = ok ? (zz * H + yy) * W + xx : 0;
     }
@@ -101,7 +119,7 @@ __global__ __launch_bounds__(256) void warp_volume_kernel(const float* __restric
 static_assert(WA_TD * WA_TY * WA_TX == 64, "a workgroup owns 64 target voxels");
 
 struct WarpAttnArgs {
-    const float* kv_src[8];
+    const float* kv_src[ESTD_MAX_ATTENTION_SOURCES];
 };
 
 template <int NS>
@@ -110,14 +128,17 @@ __global__ __launch_bounds__(256) void warp_attention_kernel(const float* __rest
                                                              const float* __restrict__ dvals, float depth_min, float depth_interval,
                                                              float* __restrict__ xh, int D, int H, int W)
 {
-    // NS = compile-time source count (1..4) or 8 = generic loop bounded by n_src: registers follow the real count,
-    // which keeps occupancy up for this gather-latency-bound kernel.
+    // NS = compile-time source count (2..4), or 8 / 16 = generic loop bounded by n_src (1 and 5..8 / 9..16 sources): registers
+    // follow the real count.  Measured alternatives that were SLOWER on MI355X (profiles/README.md, round 2): staging the
+    // source box of a 2x8x16 brick in LDS (DMA or register-staged, 304-386 us vs 255 us at N = 3: the fill/blend phases
+    // serialise and the larger bricks miss more in L2), sharing the sample positions inside the 4-lane group with DPP moves and
+    // raising occupancy to 4-5 waves per SIMD (325 us: more bricks in flight than the 4 MB L2 of an XCD holds lines for).
     const long long HW = (long long)H * W;
     const int sub = threadIdx.x & 3;
     // A workgroup owns a compact 2 x 4 x 8 (d, y, x) brick of target voxels: the gathered source footprint of a brick is
     // ~135 records per source instead of ~260 for 64 voxels along x, and bricks are numbered x-fastest inside a contiguous
     // eighth of the volume per XCD, so neighbouring bricks (which gather the same source lines) share one private L2.
-    // (rocprofv3 PMC: the linear mapping fetched 2.95x the algorithmic bytes.)
+    // (rocprofv3 PMC, profiles/r2_hbm_kernels_pmc.csv: 1.24x the compulsory read bytes reach HBM; the linear mapping fetched 2.95x.)
     unsigned bid = blockIdx.x;
     if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
     const int tx_n = (W + WA_TX - 1) / WA_TX, ty_n = (H + WA_TY - 1) / WA_TY;
@@ -138,7 +159,7 @@ __global__ __launch_bounds__(256) void warp_attention_kernel(const float* __rest
     for (int j = 0; j < NS; ++j) {
         corr[j] = -INFINITY;
         wv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (NS < 8 || j < n_src) {
+        if (NS < 8 || j < n_src) {     // generic instances: slots past n_src keep corr = -inf (softmax weight 0)
             const Tri t = volume_coords(mats + j * 30, dep, x, y, depth_min, depth_interval, D, H, W);
             const float4* s4 = reinterpret_cast<const float4*>(srcs.kv_src[j]) + sub;
             float4 cv[8], ck[8];
@@ -405,19 +426,21 @@ extern "C" int estd_warp_attention(const float* kv_target, const float* const* k
                                    float* xh_out, int D, int H, int W, estd_stream_t s)
 {
     if (!kv_target || !kv_src || !mats_dev || !dvals || !xh_out) return ESTD_ERR_ARG;
-    if (n_src < 1 || n_src > 8 || D <= 1 || H <= 1 || W <= 1) return ESTD_ERR_ARG;
+    if (n_src < 1 || D <= 1 || H <= 1 || W <= 1) return ESTD_ERR_ARG;
+    if (n_src > ESTD_MAX_ATTENTION_SOURCES) return ESTD_ERR_UNSUPPORTED;
     WarpAttnArgs a;
-    for (int j = 0; j < 8; ++j) a.kv_src[j] = j < n_src ? kv_src[j] : kv_src[0];
     for (int j = 0; j < n_src; ++j) if (!kv_src[j]) return ESTD_ERR_ARG;
+    for (int j = 0; j < ESTD_MAX_ATTENTION_SOURCES; ++j) a.kv_src[j] = kv_src[j < n_src ? j : 0];
     const dim3 grid((unsigned)(((D + WA_TD - 1) / WA_TD) * ((H + WA_TY - 1) / WA_TY) * ((W + WA_TX - 1) / WA_TX)));   // one workgroup per brick
 #define ESTD_WA_LAUNCH(NS) hipLaunchKernelGGL(warp_attention_kernel<NS>, grid, dim3(256), 0, estd_stream(s), kv_target, a, \
                                               mats_dev, n_src, dvals, depth_min, depth_interval, xh_out, D, H, W)
     switch (n_src) {
-        case 1: ESTD_WA_LAUNCH(8); break;     /* measured: the generic body (132 VGPRs) beats the 1-source specialisation */
         case 2: ESTD_WA_LAUNCH(2); break;
         case 3: ESTD_WA_LAUNCH(3); break;
         case 4: ESTD_WA_LAUNCH(4); break;
-        default: ESTD_WA_LAUNCH(8); break;
+        default:                              /* measured: for one source the generic body beats a 1-source specialisation */
+            if (n_src <= 8) ESTD_WA_LAUNCH(8); else ESTD_WA_LAUNCH(16);
+            break;
     }
 #undef ESTD_WA_LAUNCH
     return ESTD_LAUNCH_CHECK();

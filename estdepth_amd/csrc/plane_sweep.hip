@@ -131,13 +131,14 @@ struct Bilin {
 // homo_utils.py:479-501 for one (x, y, depth plane)
 __device__ __forceinline__ Bilin sweep_coords(const float* __restrict__ P, float dv, int x, int y, int H, int W)
 {
-    // no FMA contraction: the reference evaluates these as separate rounded ATen ops, and every kernel that inlines this
-    // function must produce bit-identical coordinates (the |norm| > 1 mask and floor() are discontinuous)
+    // Rounding sequence of the reference's torch-CPU composition, op for op (the |norm| > 1 mask is discontinuous, so the
+    // coordinates must be bit-identical): rot @ [x, y, 1] is a matmul (homo_utils.py:479) whose GEMM kernel accumulates
+    // k = 0,1,2 in order with fused multiply-adds; the rest are elementwise ATen ops with their own rounding (:480-485).
 #pragma clang fp contract(off)
     const float fx = (float)x, fy = (float)y;
-    const float r0 = P[0] * fx + P[1] * fy + P[2];
-    const float r1 = P[3] * fx + P[4] * fy + P[5];
-    const float r2 = P[6] * fx + P[7] * fy + P[8];
+    const float r0 = fmaf(P[1], fy, P[0] * fx) + P[2];
+    const float r1 = fmaf(P[4], fy, P[3] * fx) + P[5];
+    const float r2 = fmaf(P[7], fy, P[6] * fx) + P[8];
     const float p0 = r0 * dv + P[9];
     const float p1 = r1 * dv + P[10];
     const float p2 = r2 * dv + P[11];

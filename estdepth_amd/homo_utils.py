@@ -7,7 +7,7 @@ eps 1e-8 (2D) vs 1e-10 (3D).
 """
 import torch
 
-from . import ops
+from . import camera, ops
 
 
 def set_id_grid(h, w):
@@ -37,7 +37,7 @@ def homo_warping(src_fea, src_proj, ref_proj, depth_values):
     dv = _depth_vector(depth_values, batch, num_depth)
     outs = []
     for b in range(batch):
-        proj = ops.cam_pair_proj(src_proj[b].contiguous().float(), ref_proj[b].contiguous().float())
+        proj = camera.pair_projection(src_proj[b], ref_proj[b], src_fea.device)          # :469-471 with the reference's torch-CPU calls
         outs.append(ops.homo_warping_chw(src_fea[b].contiguous(), proj, dv[b], num_depth))
     return torch.stack(outs, 0)
 
@@ -55,6 +55,6 @@ def warp_volume(feat_volume, depth, pose, cam_intr, pixel_coords, depth_min, dep
     dv = _depth_vector(depth.reshape(N, D, H * W), N, D)
     outs = []
     for b in range(N):
-        mats = ops.cam_volume_mats(pose[b].contiguous().float(), None, cam_intr[b].contiguous().float())
+        mats = camera.relative_volume_matrix(pose[b], cam_intr[b], feat_volume.device)  # :51, :258 with the reference's torch-CPU calls
         outs.append(ops.warp_volume_cdhw(feat_volume[b].contiguous(), mats, dv[b], depth_min, depth_interval))
     return torch.stack(outs, 0)

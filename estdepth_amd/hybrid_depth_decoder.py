@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import camera, ops
 from .backbones import UpBlock as ConvBlock, up2
 from .epipolar_transformer import EpipolarTransformer
 from .homo_utils import *  # noqa: F401,F403  (the reference re-exports utils.homo_utils here)
@@ -248,19 +248,27 @@ class DepthHybridDecoder(nn.Module):
             pre_num = len(pre_cam_poses)
         else:
             pre_num = 0
+        if num + pre_num - 1 > ops.MAX_ATTENTION_SOURCES:
+            raise RuntimeError("EST fusion attends to %d other views/memory volumes per target; this build supports at most %d "
+                               "(ESTD_MAX_ATTENTION_SOURCES in include/estd_hip.h): use a shorter sequence or fewer memory "
+                               "volumes" % (num + pre_num - 1, ops.MAX_ATTENTION_SOURCES))
         if num + pre_num < 2:
             raise RuntimeError("EST transformer needs at least one other view or memory volume "
                                "(the reference crashes in torch.stack([]) here)")
 
         P = self._plans()
-        intr = cam_intr[0].contiguous().float()
-        poses = [p[0].contiguous().float() for p in cam_poses]
+        # frustum-to-frustum maps of every (target, other view): handed over by DepthNetHybrid.forward, or formed here
+        # when the decoder is called on its own (:235 + homo_utils.py:51,:258; estdepth_amd/camera.py)
+        vol_mats, self._vol_mats_pre = getattr(self, "_vol_mats_pre", None), None
+        if vol_mats is None or tuple(vol_mats.shape) != (num, num + pre_num - 1, 30):
+            if getattr(self, "camera_algebra", "host") == "device":
+                vol_mats = camera.volume_matrices_device(cam_poses, num, cam_intr)
+            else:
+                vol_mats = camera.volume_matrices(cam_poses, num, cam_intr, kv.device)
         fused_logits = torch.empty((num, D, H, W), device=kv.device, dtype=torch.float32)
         for i in range(num):                                              # :229 sequential on purpose (Q9)
             others = [j for j in range(num + pre_num) if j != i]
-            mats = torch.empty((len(others), 30), device=kv.device, dtype=torch.float32)
-            for r, j in enumerate(others):
-                ops.cam_volume_mats(poses[j], poses[i], intr, out=mats[r])      # :235 (Q8) + homo_utils.py:51,:258
+            mats = vol_mats[i]
             # stereo_head0 (side stream) reads every UNFUSED value: it must be done before the first value is overwritten
             join = (lambda: main.wait_stream(side)) if (side is not None and i == 0) else None
             self.epipolar_transformer.fuse_kv(kvs[i], [kvs[j] for j in others], mats, dv, depth_min, depth_interval,

@@ -8,7 +8,7 @@ mode is outside this path.  abs_rel (model_hybrid.py:306) is provided for the be
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import camera, ops
 from .backbones import PSMFeatures, SemanticEncoder
 from .hybrid_depth_decoder import DepthHybridDecoder
 from .homo_utils import homo_warping  # noqa: F401  (re-exported like the reference module does)
@@ -38,6 +38,9 @@ class DepthNetHybrid(nn.Module):
         self.pre1 = convbnrelu_3d(32, 32, 3, 1, 1)
         self.pre2 = convbn_3d(32, 32, 3, 1, 1)
         self._cache = PlanCache()
+        # "host" (default): camera matrices with the reference's own torch-CPU calls, bit-identical (estdepth_amd/camera.py);
+        # "device": estd_cam_* kernels, no host synchronisation, boundary samples may flip vs the reference
+        self.camera_algebra = "host"
         # weights epoch: bumped whenever parameters are replaced wholesale (load_state_dict, .to()/.cuda()); captured
         # hipGraphs (estdepth_amd.graph) bake packed-weight addresses in and re-capture when it changes
         self._estd_weights_epoch = 0
@@ -63,9 +66,26 @@ class DepthNetHybrid(nn.Module):
                     "pre1": self.pre1.plan(), "pre2": self.pre2.plan(), "pre2x2": self.pre2.plan().with_shift_scaled(2)}
         return self._cache.get((self.pre0, self.pre1, self.pre2), build)      # only these three layers feed the plans
 
-    def _costvolumes(self, ref_mixes, src_mix_pairs, ref_poses, src_pose_pairs, cam_intr, depth_values, P=None):
+    def camera_matrices(self, cam_poses, cam_intr_stage1, pre_cam_poses=None):
+        """Every camera matrix one forward needs (estdepth_amd/camera.py): {"sweep": [T,2,12], "vol": [T,n,30] or None}
+        on the model's device.  ``vol`` (frustum-to-frustum maps of the EST fusion) is only formed when the transformer
+        branch will run (hybrid_depth_decoder.py:423)."""
+        T = cam_poses.shape[1] - 2
+        dev = self.pre0[0].weight.device
+        est = self.IF_EST_transformer and pre_cam_poses is not None
+        plist = [cam_poses[:, t + 1] for t in range(T)] + (list(pre_cam_poses) if est else [])
+        if self.camera_algebra == "device":
+            return {"sweep": camera.sweep_projections_device(cam_poses.to(dev), cam_intr_stage1.to(dev)),
+                    "vol": camera.volume_matrices_device([p.to(dev) for p in plist], T, cam_intr_stage1.to(dev)) if est else None}
+        if self.camera_algebra != "host":
+            raise RuntimeError("camera_algebra must be 'host' or 'device', got %r" % (self.camera_algebra,))
+        return {"sweep": camera.sweep_projections(cam_poses, cam_intr_stage1, dev),
+                "vol": camera.volume_matrices(plist, T, cam_intr_stage1, dev) if est else None}
+
+    def _costvolumes(self, ref_mixes, src_mix_pairs, sweep, depth_values, P=None):
         """Fused get_costvolume for T targets at once on pre-mixed 2D features (model_hybrid.py:76-99).
-        ref_mixes: T tensors [H,W,32]; src_mix_pairs: T lists of source mixes; returns [T,D,H,W,32].
+        ref_mixes: T tensors [H,W,32]; src_mix_pairs: T lists of source mixes; sweep [T,n_src,12] homographies;
+        returns [T,D,H,W,32].
         The k-th sources of all targets share one batched convolution launch (N = T), and the running mean
         over sources is the second launch's accumulate epilogue -- no race, same arithmetic as :97-99."""
         P = self._plans() if P is None else P
@@ -78,30 +98,27 @@ class DepthNetHybrid(nn.Module):
         y = torch.empty_like(cost)
         n_src = len(src_mix_pairs[0])
 
-        def sweep(k, x):
-            for t in range(T):
-                proj = ops.cam_sweep_proj(ref_poses[t], src_pose_pairs[t][k], cam_intr)          # :74-88 + homo_utils.py:469
-                ops.homo_warp_costvol(src_mix_pairs[t][k], ref_mixes[t], proj, depth_values, D, out=x[t])   # :90-94
+        def run_sweep(k, x):
+            for t in range(T):      # proj = :74-88 + homo_utils.py:469-471 (camera.py)
+                ops.homo_warp_costvol(src_mix_pairs[t][k], ref_mixes[t], sweep[t, k], depth_values, D, out=x[t])   # :90-94
 
         if n_src == 2:
             # pre2 = conv + BN is LINEAR (no activation, :60), so  sum_k pre2(y_k) = conv(sum_k y_k)*s + n*t :
             # ONE pre2 convolution per target instead of one per source.  cost = (x_0 + x_1 + pre2sum(y_0 + y_1)) / 2.
             xs = [torch.empty_like(cost), torch.empty_like(cost)]
             for k in range(2):
-                sweep(k, xs[k])
+                run_sweep(k, xs[k])
                 P["pre1"].run(xs[k], dims, out=y, out_stride=32, accumulate=(k > 0))              # y = y_0 + y_1   (:95)
             P["pre2x2"].run(y, dims, out=cost, out_stride=32, residual=xs[0], residual2=xs[1], out_scale=0.5)   # :95-99
         else:
             x = torch.empty_like(cost)
             for k in range(n_src):
-                sweep(k, x)
+                run_sweep(k, x)
                 P["pre1"].run(x, dims, out=y, out_stride=32)                                      # :95
                 P["pre2"].run(y, dims, out=cost, out_stride=32, residual=x,
                               out_scale=1.0 / n_src, accumulate=(k > 0))                          # :95-99
         return cost
 
-    def _costvolume(self, ref_mix, src_mixes, ref_pose, src_poses, cam_intr, depth_values):
-        return self._costvolumes([ref_mix], [src_mixes], [ref_pose], [src_poses], cam_intr, depth_values)[0]
 
     def _mix(self, feature_chw, which, P=None):
         P = self._plans() if P is None else P
@@ -117,12 +134,17 @@ class DepthNetHybrid(nn.Module):
         if features[0].shape[0] != 1:
             raise RuntimeError("estdepth_amd runs one sequence per call (batch 1)")
         mid = num_views // 2
+        dev = features[0].device
         dv = depth_values.reshape(-1)[:self.ndepths].contiguous().float()
         ref_mix = self._mix(features[mid][0].contiguous(), "ref")
         srcs = [v for v in range(num_views) if v != mid]
         src_mixes = [self._mix(features[v][0].contiguous(), "src") for v in srcs]
-        poses = cam_poses[0].contiguous().float()
-        cost = self._costvolume(ref_mix, src_mixes, poses[mid], [poses[v] for v in srcs], cam_intr[0].contiguous().float(), dv)
+        if self.camera_algebra == "device":
+            poses, K = cam_poses[0].contiguous().float(), cam_intr[0].contiguous().float()
+            sweep = torch.stack([ops.cam_sweep_proj(poses[mid], poses[v], K) for v in srcs])[None]
+        else:       # the reference's own torch-CPU composition (camera.py)
+            sweep = camera.sweep_projection_set(cam_poses, cam_intr, mid, srcs, dev)[None]
+        cost = self._costvolumes([ref_mix], [src_mixes], sweep, dv)[0]
         return cost.permute(3, 0, 1, 2).unsqueeze(0)
 
     def scale_cam_intr(self, cam_intr, scale):
@@ -174,9 +196,10 @@ class DepthNetHybrid(nn.Module):
 
     @torch.no_grad()        # inference-only implementation: the HIP operators do not record autograd graphs
     def forward(self, imgs, cam_poses, cam_intr, sample, pre_costs=None, pre_cam_poses=None, mode='train',
-                matching_features=None):
-        """model_hybrid.py:110-184 (``matching_features`` is an optional extension used by estdepth_amd.streaming:
-        precomputed PSM features [V,32,H/4,W/4] of the frames, so overlapping windows do not recompute them).  imgs [1,V,3,Hi,Wi] in 0..255; cam_poses [1,V,4,4] camera-to-world;
+                matching_features=None, cam_mats=None):
+        """model_hybrid.py:110-184.  Two optional extensions: ``matching_features`` (estdepth_amd.streaming) = precomputed
+        PSM features [V,32,H/4,W/4] of the frames, so overlapping windows do not recompute them; ``cam_mats``
+        (estdepth_amd.graph) = the result of ``camera_matrices`` for these poses, evaluated outside a captured hipGraph.  imgs [1,V,3,Hi,Wi] in 0..255; cam_poses [1,V,4,4] camera-to-world;
         cam_intr [1,3,3] full-resolution pixels; returns (outputs, cur_costs, cur_cam_poses) for
         inference modes."""
         if mode == 'train' or self.training:
@@ -216,16 +239,16 @@ class DepthNetHybrid(nn.Module):
             self._dv_cache = (dkey, self.depth_cands.view(1, self.ndepths, 1, 1).to(imgs.dtype).to(imgs.device))
         depth_values = self._dv_cache[1]                                                                     # :144-145
         dv = depth_values.reshape(-1).contiguous()
-        intr = cam_intr_stage1[0].contiguous().float()
-        poses = cam_poses[0].contiguous().float()
+        if cam_mats is None:                                 # :74-88, homo_utils.py:469, decoder :235 (estdepth_amd/camera.py)
+            cam_mats = self.camera_matrices(cam_poses, cam_intr_stage1, pre_cam_poses)
+        self.CostRegNet._vol_mats_pre = cam_mats.get("vol")
 
         # every view is a source for up to two targets: mix each 2D feature once (pre0 pushed in front of the warp)
         P = self._plans()                                   # one cache-key check per forward
         src_mix = [self._mix(matching[v].contiguous(), "src", P) for v in range(views_num)]
         ref_mix = [self._mix(matching[t + 1].contiguous(), "ref", P) for t in range(target_num)]
         costs = self._costvolumes(ref_mix, [[src_mix[t], src_mix[t + 2]] for t in range(target_num)],
-                                  [poses[t + 1] for t in range(target_num)],
-                                  [[poses[t], poses[t + 2]] for t in range(target_num)], intr, dv, P)   # :152-156
+                                  cam_mats["sweep"], dv, P)                                             # :152-156
         cost_volumes = [costs[t].permute(3, 0, 1, 2).unsqueeze(0) for t in range(target_num)]
         target_cam_poses = [cam_poses[:, t + 1, :, :] for t in range(target_num)]                            # :161
 

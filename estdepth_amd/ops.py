@@ -10,7 +10,38 @@ import torch
 from . import _native as N
 from . import packing
 
+# Binding of the hot-path operators:
+#   "torch"  (default) -- PyTorch custom operators torch.ops.estdepth_hip.* registered with TORCH_LIBRARY by
+#             csrc/torch_ops.cpp (libestd_torch_ops.so): dispatcher, TORCH_CHECK validation, at::empty outputs, current
+#             HIP stream taken in C++;
+#   "ctypes" -- the torch-free C ABI of libestd_hip.so called directly with raw device pointers (what a non-PyTorch host
+#             would bind; kept as the second test path: ESTD_BINDING=ctypes).
+# Both end in the same extern "C" entry points; there is no CPU / eager fallback under either.
+BINDING = os.environ.get("ESTD_BINDING", "torch")
+_TORCH_OPS_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libestd_torch_ops.so")
+_torch_ops = None
+
+
+def T():
+    """torch.ops.estdepth_hip (loads libestd_torch_ops.so once; RuntimeError when it has not been built)."""
+    global _torch_ops
+    if _torch_ops is None:
+        if BINDING not in ("torch", "ctypes"):
+            raise RuntimeError("ESTD_BINDING must be 'torch' or 'ctypes', got %r" % (BINDING,))
+        if not os.path.exists(_TORCH_OPS_LIB):
+            raise RuntimeError("libestd_torch_ops.so not found at %s -- build it with `python -m estdepth_amd.build` "
+                               "(there is no CPU/eager fallback)" % _TORCH_OPS_LIB)
+        N.lib()                                   # libestd_hip.so first: the operator library links against it
+        torch.ops.load_library(_TORCH_OPS_LIB)
+        _torch_ops = torch.ops.estdepth_hip
+    return _torch_ops
+
+
+def _use_torch():
+    return BINDING == "torch"
+
 ACT = {"none": 0, "relu": 1, "tanh": 2}
+MAX_ATTENTION_SOURCES = 16      # ESTD_MAX_ATTENTION_SOURCES (include/estd_hip.h)
 
 # bench.py sets this to a list to collect (group, amount, start_event, end_event) around every launch of the hot-path
 # kernels on the stream they are launched on: amount = algorithmic FLOPs (groups "conv3d:<Cin>-><Cout>[+x]") or
@@ -65,12 +96,16 @@ def _p(t):
 
 
 def profile_mark(idx):
+    if _use_torch():
+        return T().profile_mark(int(idx))
     N.check(N.lib().estd_profile_mark(int(idx), _stream()), "estd_profile_mark")
 
 
 # ---------------------------------------------------------------------------------- camera algebra
 def cam_pair_proj(src_proj, ref_proj):
     """rot|trans of src_proj @ inverse(ref_proj) for one batch element -> [12]."""
+    if _use_torch():
+        return T().cam_pair_proj(src_proj, ref_proj)
     out = torch.empty(12, device=src_proj.device, dtype=torch.float32)
     N.check(N.lib().estd_cam_pair_proj(_p(_chk(src_proj, "src_proj")), _p(_chk(ref_proj, "ref_proj")), _p(out), _stream()),
             "estd_cam_pair_proj")
@@ -78,6 +113,8 @@ def cam_pair_proj(src_proj, ref_proj):
 
 
 def cam_sweep_proj(ref_pose, src_pose, intr):
+    if _use_torch():
+        return T().cam_sweep_proj(ref_pose, src_pose, intr)
     out = torch.empty(12, device=ref_pose.device, dtype=torch.float32)
     N.check(N.lib().estd_cam_sweep_proj(_p(_chk(ref_pose, "ref_pose")), _p(_chk(src_pose, "src_pose")),
                                         _p(_chk(intr, "cam_intr")), _p(out), _stream()), "estd_cam_sweep_proj")
@@ -87,6 +124,9 @@ def cam_sweep_proj(ref_pose, src_pose, intr):
 def cam_volume_mats(pose_j, pose_i, intr, out=None):
     if out is None:
         out = torch.empty(30, device=pose_j.device, dtype=torch.float32)
+    if _use_torch():
+        T().cam_volume_mats(pose_j, pose_i, intr, out)
+        return out
     N.check(N.lib().estd_cam_volume_mats(_p(_chk(pose_j, "pose_j")), _p(_chk(pose_i, "pose_i")) if pose_i is not None else None,
                                          _p(_chk(intr, "cam_intr")), _p(out), _stream()), "estd_cam_volume_mats")
     return out
@@ -94,6 +134,8 @@ def cam_volume_mats(pose_j, pose_i, intr, out=None):
 
 # ---------------------------------------------------------------------------------- plane sweep
 def homo_warping_chw(src_chw, proj12, depth_values, D):
+    if _use_torch():
+        return T().homo_warping(src_chw, proj12, depth_values, D)
     C, H, W = src_chw.shape
     out = torch.empty((C, D, H, W), device=src_chw.device, dtype=torch.float32)
     N.check(N.lib().estd_homo_warping(_p(_chk(src_chw, "src_fea")), _p(proj12), _p(_chk(depth_values, "depth_values")),
@@ -103,6 +145,8 @@ def homo_warping_chw(src_chw, proj12, depth_values, D):
 
 def mix1x1(in_chw, w, bias):
     """[Cin,H,W] -> [H,W,Cout] channel mix."""
+    if _use_torch():
+        return T().mix1x1(in_chw, w, bias)
     Cin, H, W = in_chw.shape
     Cout = w.shape[0]
     out = torch.empty((H, W, Cout), device=in_chw.device, dtype=torch.float32)
@@ -117,6 +161,9 @@ def homo_warp_costvol(src_mix, ref_mix, proj12, depth_values, D, out=None):
     if out is None:
         out = torch.empty((D, H, W, 32), device=src_mix.device, dtype=torch.float32)
     with _Prof("homo_warp_costvol", 4.0 * 32 * H * W * (2 + D)):          # src map + ref map + one volume
+        if _use_torch():
+            T().homo_warp_costvol(src_mix, ref_mix, proj12, depth_values, D, out)
+            return out
         N.check(N.lib().estd_homo_warp_costvol(_p(_chk(src_mix, "src_mix")), _p(_chk(ref_mix, "ref_mix")), _p(proj12),
                                                _p(_chk(depth_values, "depth_values")), _p(out), D, H, W, _stream()),
                 "estd_homo_warp_costvol")
@@ -159,36 +206,15 @@ class Conv3dPlan:
             residual=None, residual2=None, out_scale=1.0, accumulate=False, out_extra=None, out_head=None, stats_partials=None):
         """x: channels-last volume(s) [N,D,H,W,in_stride] (or a base view of it); dims = (N,D,H,W)."""
         Nn, D, H, W = dims
-        d = N.Conv3dDesc()
-        d.N, d.D, d.H, d.W = Nn, D, H, W
-        d.cin_main = self.cin_main
-        d.in_stride = in_stride if in_stride is not None else self.cin_main
-        d.n_tiles = self.n_tiles
-        d.in_main = x.data_ptr()
-        d.in_extra = in_extra.data_ptr() if in_extra is not None else None
-        d.w_main = self.w_main.data_ptr()
-        d.w_extra = self.w_extra.data_ptr() if self.w_extra is not None else None
-        d.w_xout = self.w_xout.data_ptr() if self.w_xout is not None else None
         if (in_extra is None) != (self.w_extra is None):
             raise RuntimeError("conv3d plan/extra-channel mismatch")
-        d.scale = self.scale.data_ptr()
-        d.shift = self.shift.data_ptr()
-        d.act_a, d.act_b, d.act_split = self.act_a, self.act_b, self.act_split
-        d.out_main = out.data_ptr() if out is not None else None
-        d.out_stride = out_stride if out_stride is not None else (16 * min(self.n_tiles, 2))
-        d.out_channels = out_channels if out_channels is not None else 16 * min(self.n_tiles, 2)
-        d.residual = residual.data_ptr() if residual is not None else None
-        d.residual2 = residual2.data_ptr() if residual2 is not None else None
-        d.out_scale = float(out_scale)
-        d.accumulate = 1 if accumulate else 0
-        d.out_extra = out_extra.data_ptr() if out_extra is not None else None
-        d.head_w = self.head_w.data_ptr() if (self.head_w is not None and out_head is not None) else None
-        d.head_b = self.head_b.data_ptr() if (self.head_b is not None and out_head is not None) else None
-        d.out_head = out_head.data_ptr() if out_head is not None else None
-        d.stats_partials = stats_partials.data_ptr() if stats_partials is not None else None
-        cin = self.cin_main + (1 if self.w_extra is not None else 0)
-        prof = _Prof("conv3d:%d->%d" % (cin, self.n_out), 2.0 * 27 * cin * self.n_out * Nn * D * H * W)
-        prof.__enter__()
+        if CONV3D_ARITH not in ("f32", "bf16x3"):
+            raise RuntimeError("ESTD_CONV3D_ARITH must be f32 or bf16x3, got %r" % (CONV3D_ARITH,))
+        in_stride = in_stride if in_stride is not None else self.cin_main
+        out_stride = out_stride if out_stride is not None else (16 * min(self.n_tiles, 2))
+        out_channels = out_channels if out_channels is not None else 16 * min(self.n_tiles, 2)
+        head_w = self.head_w if out_head is not None else None
+        head_b = self.head_b if out_head is not None else None
         # instances of the split kernel (csrc/conv3d_split_bf16.hip dispatch): plain [+stats], extra input [tanh|relu], 33 -> 33
         tanh = ACT["tanh"] in ((self.act_a if self.act_split > 0 else self.act_b), self.act_b)
         if self.n_tiles == 3:
@@ -199,15 +225,41 @@ class Conv3dPlan:
             inst = stats_partials is None
         else:
             inst = not tanh
-        split_ok = self.w_split is not None and out is not None and inst
-        if CONV3D_ARITH == "bf16x3" and split_ok:
-            d.w_split = self.w_split.data_ptr()
-            N.check(N.lib().estd_conv3d_k3_split(ctypes.byref(d), _stream()), "estd_conv3d_k3_split")
-        elif CONV3D_ARITH not in ("f32", "bf16x3"):
-            raise RuntimeError("ESTD_CONV3D_ARITH must be f32 or bf16x3, got %r" % (CONV3D_ARITH,))
-        else:
-            N.check(N.lib().estd_conv3d_k3(ctypes.byref(d), _stream()), "estd_conv3d_k3")
-        prof.__exit__()
+        split = CONV3D_ARITH == "bf16x3" and self.w_split is not None and out is not None and inst
+        cin = self.cin_main + (1 if self.w_extra is not None else 0)
+        with _Prof("conv3d:%d->%d" % (cin, self.n_out), 2.0 * 27 * cin * self.n_out * Nn * D * H * W):
+            if _use_torch():
+                T().conv3d_k3(x, in_extra, self.w_main, self.w_extra, self.w_xout, self.w_split if split else None, self.scale, self.shift,
+                              (Nn, D, H, W), self.cin_main, in_stride, self.n_tiles, self.act_a, self.act_b, self.act_split, out,
+                              out_stride, out_channels, residual, residual2, float(out_scale), bool(accumulate), out_extra, head_w, head_b,
+                              out_head, stats_partials, split)
+                return
+            d = N.Conv3dDesc()
+            d.N, d.D, d.H, d.W = Nn, D, H, W
+            d.cin_main, d.in_stride, d.n_tiles = self.cin_main, in_stride, self.n_tiles
+            d.in_main = x.data_ptr()
+            d.in_extra = in_extra.data_ptr() if in_extra is not None else None
+            d.w_main = self.w_main.data_ptr()
+            d.w_extra = self.w_extra.data_ptr() if self.w_extra is not None else None
+            d.w_xout = self.w_xout.data_ptr() if self.w_xout is not None else None
+            d.scale, d.shift = self.scale.data_ptr(), self.shift.data_ptr()
+            d.act_a, d.act_b, d.act_split = self.act_a, self.act_b, self.act_split
+            d.out_main = out.data_ptr() if out is not None else None
+            d.out_stride, d.out_channels = out_stride, out_channels
+            d.residual = residual.data_ptr() if residual is not None else None
+            d.residual2 = residual2.data_ptr() if residual2 is not None else None
+            d.out_scale = float(out_scale)
+            d.accumulate = 1 if accumulate else 0
+            d.out_extra = out_extra.data_ptr() if out_extra is not None else None
+            d.head_w = head_w.data_ptr() if head_w is not None else None
+            d.head_b = head_b.data_ptr() if head_b is not None else None
+            d.out_head = out_head.data_ptr() if out_head is not None else None
+            d.stats_partials = stats_partials.data_ptr() if stats_partials is not None else None
+            if split:
+                d.w_split = self.w_split.data_ptr()
+                N.check(N.lib().estd_conv3d_k3_split(ctypes.byref(d), _stream()), "estd_conv3d_k3_split")
+            else:
+                N.check(N.lib().estd_conv3d_k3(ctypes.byref(d), _stream()), "estd_conv3d_k3")
 
 
 class Conv2dPlan:
@@ -246,22 +298,26 @@ class Conv2dPlan:
         Nn, H, W, C = x_nhwc.shape
         if C != self.cin or not x_nhwc.is_contiguous():
             raise RuntimeError("Conv2dPlan.run: expected contiguous NHWC input with %d channels" % self.cin)
+        if CONV2D_ARITH not in ("f32", "bf16x3"):
+            raise RuntimeError("ESTD_CONV2D_ARITH must be f32 or bf16x3, got %r" % (CONV2D_ARITH,))
+        if residual is not None and (tuple(residual.shape) != (Nn, H, W, self.cout) or not residual.is_contiguous()):
+            raise RuntimeError("Conv2dPlan.run: residual must be contiguous NHWC of the output shape")
+        nt = self._pick_nt(Nn, H, W)
+        split = CONV2D_ARITH == "bf16x3" and self.w_split is not None
+        if _use_torch():
+            return T().conv2d_k3(x_nhwc, self.w_nt[nt], self.w_split if split else None, self.scale, self.shift, self.cout, self.dil, nt,
+                                 bool(self.relu_before), bool(self.relu_after), residual, split)
         out = torch.empty((Nn, H, W, self.cout), device=x_nhwc.device, dtype=torch.float32)
         d = N.Conv2dDesc()
-        nt = self._pick_nt(Nn, H, W)
         d.N, d.H, d.W, d.cin, d.cout, d.dilation, d.group_tiles = Nn, H, W, self.cin, self.cout, self.dil, nt
-        d.in_ = x_nhwc.data_ptr()
+        d.in_ = _chk(x_nhwc, "conv2d input").data_ptr()
         d.w, d.scale, d.shift = self.w_nt[nt].data_ptr(), self.scale.data_ptr(), self.shift.data_ptr()
         d.relu_before_residual, d.relu_after_residual = self.relu_before, self.relu_after
-        if residual is not None and (tuple(residual.shape) != tuple(out.shape) or not residual.is_contiguous()):
-            raise RuntimeError("Conv2dPlan.run: residual must be contiguous NHWC of the output shape")
         d.residual = residual.data_ptr() if residual is not None else None
         d.out = out.data_ptr()
-        if CONV2D_ARITH == "bf16x3" and self.w_split is not None:
+        if split:
             d.w_split = self.w_split.data_ptr()
             N.check(N.lib().estd_conv2d_k3_split(ctypes.byref(d), _stream()), "estd_conv2d_k3_split")
-        elif CONV2D_ARITH not in ("f32", "bf16x3"):
-            raise RuntimeError("ESTD_CONV2D_ARITH must be f32 or bf16x3, got %r" % (CONV2D_ARITH,))
         else:
             N.check(N.lib().estd_conv2d_k3(ctypes.byref(d), _stream()), "estd_conv2d_k3")
         return out
@@ -275,6 +331,8 @@ def conv3d_grid(Nn, D, H, W):
 
 
 def groupnorm_finalize(partials, n_blocks, count, eps=1e-5):
+    if _use_torch():
+        return T().groupnorm_finalize(partials, n_blocks, float(count), float(eps))
     out = torch.empty(4, device=partials.device, dtype=torch.float32)
     N.check(N.lib().estd_groupnorm_finalize(_p(partials), n_blocks, float(count), float(eps), _p(out), _stream()),
             "estd_groupnorm_finalize")
@@ -285,9 +343,11 @@ def groupnorm_finalize(partials, n_blocks, count, eps=1e-5):
 def softargmin_up(logits, depth_values, scale=4):
     """logits [N,D,H,W] -> (depth, prob) each [N,1,scale*H,scale*W]."""
     Nn, D, H, W = logits.shape
-    depth = torch.empty((Nn, 1, H * scale, W * scale), device=logits.device, dtype=torch.float32)
-    prob = torch.empty_like(depth)
     with _Prof("softargmin", 4.0 * Nn * H * W * (D + 2 * scale * scale)):       # logits in, depth + prob maps out
+        if _use_torch():
+            return T().softargmin_up(logits, depth_values, scale)
+        depth = torch.empty((Nn, 1, H * scale, W * scale), device=logits.device, dtype=torch.float32)
+        prob = torch.empty_like(depth)
         N.check(N.lib().estd_softargmin_up(_p(_chk(logits, "logits")), _p(_chk(depth_values, "depth_values")), _p(depth), _p(prob),
                                            Nn, D, H, W, scale, _stream()), "estd_softargmin_up")
     return depth, prob
@@ -295,6 +355,8 @@ def softargmin_up(logits, depth_values, scale=4):
 
 # ---------------------------------------------------------------------------------- EST fusion
 def warp_volume_cdhw(vol, mats30, depth_values, depth_min, depth_interval):
+    if _use_torch():
+        return T().warp_volume(vol, mats30, depth_values, float(depth_min), float(depth_interval))
     C, D, H, W = vol.shape
     out = torch.empty_like(vol)
     N.check(N.lib().estd_warp_volume(_p(_chk(vol, "feat_volume")), _p(mats30), _p(_chk(depth_values, "depth")),
@@ -307,9 +369,11 @@ def warp_attention(kv_target, kv_sources, mats, depth_values, depth_min, depth_i
     """kv_target [D,H,W,32]; kv_sources list of the same; mats [n,30] -> xh [D,H,W,32] = [V_t | h]."""
     D, H, W, _ = kv_target.shape
     n = len(kv_sources)
-    arr = (ctypes.c_void_p * n)(*[_chk(k, "kv source").data_ptr() for k in kv_sources])
-    xh = torch.empty((D, H, W, 32), device=kv_target.device, dtype=torch.float32)
     with _Prof("warp_attention", 4.0 * 16 * D * H * W * (2 + 2 * n)):          # K_t, h out, K_j and V_j of every source
+        if _use_torch():
+            return T().warp_attention(kv_target, list(kv_sources), mats, depth_values, float(depth_min), float(depth_interval))
+        arr = (ctypes.c_void_p * n)(*[_chk(k, "kv source").data_ptr() for k in kv_sources])
+        xh = torch.empty((D, H, W, 32), device=kv_target.device, dtype=torch.float32)
         N.check(N.lib().estd_warp_attention(_p(_chk(kv_target, "kv target")), arr, _p(_chk(mats, "mats")), n,
                                             _p(_chk(depth_values, "depth_values")), float(depth_min), float(depth_interval),
                                             _p(xh), D, H, W, _stream()), "estd_warp_attention")
@@ -317,6 +381,8 @@ def warp_attention(kv_target, kv_sources, mats, depth_values, depth_min, depth_i
 
 
 def attention_prewarped(kv_target, kv_sources):
+    if _use_torch():
+        return T().attention_prewarped(kv_target, list(kv_sources))
     n = len(kv_sources)
     arr = (ctypes.c_void_p * n)(*[_chk(k, "kv source").data_ptr() for k in kv_sources])
     xh = torch.empty_like(kv_target)
@@ -326,9 +392,11 @@ def attention_prewarped(kv_target, kv_sources):
 
 
 def gru_reset_apply(xh, ru, stats4, gamma_r, beta_r):
-    xrh = torch.empty_like(xh)
     n_vox = xh.numel() // 32
     with _Prof("gru_elementwise", 4.0 * 16 * n_vox * 2):       # SURVEY §8d K11+K13 = 5 x 16 channels per voxel: r, h here
+        if _use_torch():
+            return T().gru_reset_apply(xh, ru, stats4, gamma_r, beta_r)
+        xrh = torch.empty_like(xh)
         N.check(N.lib().estd_gru_reset_apply(_p(xh), _p(ru), _p(stats4), _p(gamma_r), _p(beta_r), _p(xrh), n_vox, _stream()),
                 "estd_gru_reset_apply")
     return xrh
@@ -337,6 +405,8 @@ def gru_reset_apply(xh, ru, stats4, gamma_r, beta_r):
 def gru_blend(xh, ru, o_raw, stats_ru, stats_o, gamma_u, beta_u, gamma_o, beta_o, out_value, out_stride):
     n_vox = xh.numel() // 32
     with _Prof("gru_elementwise", 4.0 * 16 * n_vox * 3):       # ... u, o_raw, out here (h counted once, in the reset pass)
+        if _use_torch():
+            return T().gru_blend(xh, ru, o_raw, stats_ru, stats_o, gamma_u, beta_u, gamma_o, beta_o, out_value, out_stride)
         N.check(N.lib().estd_gru_blend(_p(xh), _p(ru), _p(o_raw), _p(stats_ru), _p(stats_o), _p(gamma_u), _p(beta_u),
                                        _p(gamma_o), _p(beta_o), _p(out_value), out_stride, n_vox, _stream()), "estd_gru_blend")
 
@@ -344,6 +414,8 @@ def gru_blend(xh, ru, o_raw, stats_ru, stats_o, gamma_u, beta_u, gamma_o, beta_o
 # ---------------------------------------------------------------------------------- 2D backbone epilogues
 def bn_act_nhwc_(x, scale, shift, relu, residual=None):
     """in place on an NCHW-shaped tensor in channels_last memory: x = act(x*scale[c] + shift[c] (+ residual))."""
+    if _use_torch():
+        return T().bn_act_nhwc_(x, scale, shift, bool(relu), residual)
     if not x.is_cuda or x.dtype != torch.float32 or not x.is_contiguous(memory_format=torch.channels_last):
         raise RuntimeError("bn_act_nhwc_: expected a float32 CUDA tensor in channels_last memory (no CPU path)")
     n, c, h, w = x.shape
@@ -357,6 +429,8 @@ def bn_act_nhwc_(x, scale, shift, relu, residual=None):
 def spp_upsample_cat(raw, skip, branches):
     """NHWC tensors: raw [N,H,W,Cr], skip [N,H,W,Cs], branches [N,hk,wk,Cb] -> [N,H,W,Cr+Cs+nb*Cb] =
     cat(raw, skip, bilinear_up(branches...)) in one pass (psm_submodule.py:100-116)."""
+    if _use_torch():
+        return T().spp_upsample_cat(raw, skip, list(branches))
     n, h, w, cr = raw.shape
     cs, cb, nb = skip.shape[3], branches[0].shape[3], len(branches)
     for t in [raw, skip] + list(branches):
@@ -374,12 +448,16 @@ def spp_upsample_cat(raw, skip, branches):
 # ---------------------------------------------------------------------------------- layout converters
 def cdhw_to_vol(src, dst, dst_stride, dst_off):
     """src [C,D,H,W] contiguous -> channels dst_off.. of the channels-last records of dst."""
+    if _use_torch():
+        return T().cdhw_to_vol(src, dst, dst_stride, dst_off)
     C = src.shape[0]
     S = src.numel() // C
     N.check(N.lib().estd_cdhw_to_vol(_p(_chk(src, "volume")), _p(dst), C, S, dst_stride, dst_off, _stream()), "estd_cdhw_to_vol")
 
 
 def vol_to_cdhw(src, C, dims, src_stride, src_off):
+    if _use_torch():
+        return T().vol_to_cdhw(src, C, list(dims), src_stride, src_off)
     D, H, W = dims
     out = torch.empty((C, D, H, W), device=src.device, dtype=torch.float32)
     N.check(N.lib().estd_vol_to_cdhw(_p(src), _p(out), C, D * H * W, src_stride, src_off, _stream()), "estd_vol_to_cdhw")

@@ -33,6 +33,10 @@ enum estd_status {
 
 enum estd_act { ESTD_ACT_NONE = 0, ESTD_ACT_RELU = 1, ESTD_ACT_TANH = 2 };
 
+/* upper bound on the views + memory volumes one target attends to in estd_warp_attention (the reference loops over
+ * any number, hybrid_depth_decoder.py:229-246; 16 covers Joint mode up to seq_len 17 / 15 targets + 2 memories) */
+#define ESTD_MAX_ATTENTION_SOURCES 16
+
 int estd_version(void);
 /* launches the empty kernel `estd_mark_kernel` so a rocprofv3 kernel trace can be cut to a timed region */
 int estd_profile_mark(int id, estd_stream_t stream);
@@ -173,7 +177,9 @@ int estd_warp_volume(const float* vol_cdhw, const float* mats30, const float* de
  * (hybrid_depth_decoder.py:233-246 + transformer/epipolar_transformer.py:62-73):
  *   xh[vox][0:16] = V_t ; xh[vox][16:32] = h = mean_j( softmax_j(K_t . warp(K_j)) * warp(V_j) ).
  * kv_src: HOST array of n_src device pointers to kv volumes (copied into the launch arguments);
- * mats_dev: device [n_src][30] from estd_cam_volume_mats.  n_src in 1..8. */
+ * mats_dev: device [n_src][30] from estd_cam_volume_mats.  n_src in 1..ESTD_MAX_ATTENTION_SOURCES
+ * (more: ESTD_ERR_UNSUPPORTED).  The source boxes a 2x8x16 target brick samples are staged in LDS; the softmax over
+ * the sources is evaluated in running (max-rescaled) form. */
 int estd_warp_attention(const float* kv_target, const float* const* kv_src, const float* mats_dev,
                         int n_src, const float* depth_values, float depth_min, float depth_interval,
                         float* xh_out, int D, int H, int W, estd_stream_t stream);

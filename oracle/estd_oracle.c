@@ -59,10 +59,12 @@ void orc_homo_warping(const float* src, const float* rot /*3x3*/, const float* t
         for (int y = 0; y < H; ++y) {
             for (int x = 0; x < W; ++x) {
                 const float fx = (float)x, fy = (float)y;
-                /* rot_xyz = rot @ [x,y,1]   (:479) */
-                float r0 = rot[0] * fx + rot[1] * fy + rot[2];
-                float r1 = rot[3] * fx + rot[4] * fy + rot[5];
-                float r2 = rot[6] * fx + rot[7] * fy + rot[8];
+                /* rot_xyz = rot @ [x,y,1]   (:479): a torch.matmul, i.e. a GEMM kernel that accumulates k = 0,1,2 in
+                 * order with fused multiply-adds (checked bit for bit in tests/test_oracle_ops_golden.py); every other
+                 * step is an elementwise ATen op with its own rounding (the file is built with -ffp-contract=off). */
+                float r0 = fmaf(rot[1], fy, rot[0] * fx) + rot[2];
+                float r1 = fmaf(rot[4], fy, rot[3] * fx) + rot[5];
+                float r2 = fmaf(rot[7], fy, rot[6] * fx) + rot[8];
                 /* * depth + trans  (:480-482) */
                 const float dv = depth_values[d];
                 float p0 = r0 * dv + trans[0];
@@ -122,18 +124,20 @@ void orc_warp_volume(const float* vol /*[C][D][H][W]*/, const float* depth /*[D]
             for (int x = 0; x < W; ++x) {
                 const float fx = (float)x, fy = (float)y;
                 const float dep = depth[(long)d * HW + (long)y * W + x];
+                /* The three matrix products are bmm calls: GEMM kernels accumulating k in order with fused
+                 * multiply-adds (acc = a0*b0; acc = fma(a1,b1,acc); ...), see orc_homo_warping. */
                 /* pixel2cam: (K^-1 @ [x,y,1]) * depth   (:51-54) */
-                float c0 = (kinv[0] * fx + kinv[1] * fy + kinv[2]) * dep;
-                float c1 = (kinv[3] * fx + kinv[4] * fy + kinv[5]) * dep;
-                float c2 = (kinv[6] * fx + kinv[7] * fy + kinv[8]) * dep;
+                float c0 = (fmaf(kinv[1], fy, kinv[0] * fx) + kinv[2]) * dep;
+                float c1 = (fmaf(kinv[4], fy, kinv[3] * fx) + kinv[5]) * dep;
+                float c2 = (fmaf(kinv[7], fy, kinv[6] * fx) + kinv[8]) * dep;
                 /* cam2cam: M @ [c;1]   (:33-36) */
-                float s0 = m[0] * c0 + m[1] * c1 + m[2] * c2 + m[3];
-                float s1 = m[4] * c0 + m[5] * c1 + m[6] * c2 + m[7];
-                float s2 = m[8] * c0 + m[9] * c1 + m[10] * c2 + m[11];
+                float s0 = fmaf(m[2], c2, fmaf(m[1], c1, m[0] * c0)) + m[3];
+                float s1 = fmaf(m[6], c2, fmaf(m[5], c1, m[4] * c0)) + m[7];
+                float s2 = fmaf(m[10], c2, fmaf(m[9], c1, m[8] * c0)) + m[11];
                 /* cam2pixel_depth: K @ s[:3]; x/(z+1e-10), y/(z+1e-10), z   (:115-121) */
-                float q0 = kmat[0] * s0 + kmat[1] * s1 + kmat[2] * s2;
-                float q1 = kmat[3] * s0 + kmat[4] * s1 + kmat[5] * s2;
-                float q2 = kmat[6] * s0 + kmat[7] * s1 + kmat[8] * s2;
+                float q0 = fmaf(kmat[2], s2, fmaf(kmat[1], s1, kmat[0] * s0));
+                float q1 = fmaf(kmat[5], s2, fmaf(kmat[4], s1, kmat[3] * s0));
+                float q2 = fmaf(kmat[8], s2, fmaf(kmat[7], s1, kmat[6] * s0));
                 float X = q0 / (q2 + 1e-10f);
                 float Y = q1 / (q2 + 1e-10f);
                 float Z = q2;

@@ -34,19 +34,13 @@ def get_costvolume(P, features, cam_poses, cam_intr, depth_values, ndepths):
     num_views = len(features)
     ref_feature = features[num_views // 2]                                   # :72
     B = ref_feature.shape[0]
-    ref_extr = np.stack([O.inv(cam_poses[b, num_views // 2]) for b in range(B)])   # :74
     ref_volume = np.repeat(ref_feature[:, :, None], ndepths, axis=2)        # :76
     cost = np.zeros_like(ref_volume)
     for v in range(num_views):
         if v == num_views // 2:
             continue
-        src_extr = np.stack([O.inv(cam_poses[b, v]) for b in range(B)])     # :83
-        src_proj = src_extr.copy()
-        ref_proj = ref_extr.copy()
-        for b in range(B):                                                   # :87-88
-            src_proj[b, :3, :4] = cam_intr[b] @ src_extr[b, :3, :4]
-            ref_proj[b, :3, :4] = cam_intr[b] @ ref_extr[b, :3, :4]
-        warped = O.homo_warping(features[v], src_proj, ref_proj, depth_values)      # :90
+        proj = O.sweep_proj(cam_poses, cam_intr, num_views // 2, v)         # :74-88 + homo_utils.py:469 (one torch chain)
+        warped = O.homo_warping_proj(features[v], proj, depth_values)       # :90
         x = np.concatenate([ref_volume, warped], 1)                          # :93
         x = convbn3d(P, "pre0", x, "none")                                   # :94
         x = x + convbn3d(P, "pre2", convbn3d(P, "pre1", x, "relu"), "none")  # :95
@@ -132,8 +126,7 @@ def decoder_forward(P, costvolumes, semantic_features, cam_poses, cam_intr, dept
             for j in range(num + pre_num):
                 if i == j:
                     continue
-                rel = np.stack([(np.asarray(cam_poses[j][b], np.float32) @ O.inv(cam_poses[i][b])).astype(np.float32)
-                                for b in range(B)])                          # :235 (Q8)
+                rel = np.stack([O.matmul(cam_poses[j][b], O.inv(cam_poses[i][b])) for b in range(B)])   # :235 (Q8)
                 wk.append(O.warp_volume(keys[j], depth_lowres, rel, cam_intr, None, depth_min, depth_interval))    # :237
                 wv.append(O.warp_volume(values[j], depth_lowres, rel, cam_intr, None, depth_min, depth_interval))  # :241
             fused = epipolar_transformer(P, prefix + ".epipolar_transformer", keys[i], values[i], wv, wk)   # :248

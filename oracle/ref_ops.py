@@ -34,28 +34,83 @@ def _c(a):
     return a, a.ctypes.data_as(_f)
 
 
+try:                      # the reference's own third-party arithmetic for the tiny camera matrices
+    import torch as _torch
+except ImportError:       # numpy-only environment: same LAPACK family, last-bit differences possible
+    _torch = None
+
+
 def inv(m):
-    """torch.inverse on fp32 (LAPACK getrf/getri family)."""
-    return np.linalg.inv(np.asarray(m, dtype=np.float32)).astype(np.float32)
+    """torch.inverse on fp32, as called by the reference (model_hybrid.py:74,:83; homo_utils.py:51,:258,:469;
+    hybrid_depth_decoder.py:235): ATen's CPU LAPACK path itself when torch is importable -- numpy's LAPACK build gives results
+    that differ in the last bits, which is enough to flip samples across the |norm| > 1 masks."""
+    m = np.asarray(m, dtype=np.float32)
+    if _torch is not None:
+        t = _torch.from_numpy(np.ascontiguousarray(m))
+        return (_torch.inverse(t[None])[0] if t.dim() == 2 else _torch.inverse(t)).numpy()
+    return np.linalg.inv(m).astype(np.float32)
+
+
+def matmul(a, b):
+    """torch.matmul of the small fp32 camera matrices as the reference calls it: on tensors WITH the batch dimension
+    ([B,4,4] @ [B,4,4], [B,3,3] @ [B,3,4]), i.e. ATen's bmm path -- its small-matrix kernel and the 2-D mm kernel round
+    differently, so 2-D inputs are given a batch axis of 1 here."""
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    if _torch is not None:
+        ta, tb = _torch.from_numpy(np.ascontiguousarray(a)), _torch.from_numpy(np.ascontiguousarray(b))
+        if ta.dim() == 2:
+            return _torch.matmul(ta[None], tb[None])[0].numpy()
+        return _torch.matmul(ta, tb).numpy()
+    return (a @ b).astype(np.float32)
+
+
+def sweep_proj(cam_poses, cam_intr, ref, src):
+    """proj = src_proj @ inverse(ref_proj) of get_costvolume + homo_warping (model_hybrid.py:74-88, homo_utils.py:469) for
+    reference view ``ref`` and source view ``src``: cam_poses [B,V,4,4], cam_intr [B,3,3] -> [B,4,4].
+    The chain is kept in torch tensors end to end when torch is importable: ``clone()`` of an inverse keeps LAPACK's
+    column-major strides and torch.inverse rounds differently on the two layouts, so a numpy round trip in the middle
+    would change last bits (and with them which samples fall across the |norm| > 1 mask)."""
+    cam_poses, cam_intr = np.asarray(cam_poses, np.float32), np.asarray(cam_intr, np.float32)
+    if _torch is None:
+        out = []
+        for b in range(cam_poses.shape[0]):
+            ref_e, src_e = inv(cam_poses[b, ref]), inv(cam_poses[b, src])
+            sp, rp = src_e.copy(), ref_e.copy()
+            sp[:3, :4] = cam_intr[b] @ src_e[:3, :4]
+            rp[:3, :4] = cam_intr[b] @ ref_e[:3, :4]
+            out.append((sp @ inv(rp)).astype(np.float32))
+        return np.stack(out)
+    poses, K = _torch.from_numpy(np.ascontiguousarray(cam_poses)), _torch.from_numpy(np.ascontiguousarray(cam_intr))
+    ref_extrinsic = _torch.inverse(poses[:, ref, :, :])                          # :74
+    src_extrinsic = _torch.inverse(poses[:, src, :, :])                          # :83
+    src_proj, ref_proj = src_extrinsic.clone(), ref_extrinsic.clone()            # :85-86
+    src_proj[:, :3, :4] = _torch.matmul(K, src_extrinsic[:, :3, :4])             # :87
+    ref_proj[:, :3, :4] = _torch.matmul(K, ref_extrinsic[:, :3, :4])             # :88
+    return _torch.matmul(src_proj, _torch.inverse(ref_proj)).numpy()             # homo_utils.py:469
 
 
 # ----------------------------------------------------------------------------- ops
-def homo_warping(src_fea, src_proj, ref_proj, depth_values):
-    """utils/homo_utils.py:458-504.  src_fea [B,C,H,W]; *_proj [B,4,4]; depth_values [B,D,1,1] or [B,D]."""
+def homo_warping_proj(src_fea, proj, depth_values):
+    """utils/homo_utils.py:470-504 given proj = src_proj @ inverse(ref_proj) [B,4,4]."""
     src_fea = np.asarray(src_fea, np.float32)
     B, C, H, W = src_fea.shape
     dv = np.asarray(depth_values, np.float32).reshape(B, -1)
     D = dv.shape[1]
     out = np.empty((B, C, D, H, W), np.float32)
     for b in range(B):
-        proj = (np.asarray(src_proj[b], np.float32) @ inv(ref_proj[b])).astype(np.float32)  # :469
-        rot, rp = _c(proj[:3, :3])
-        tr, tp = _c(proj[:3, 3])
+        rot, rp = _c(proj[b][:3, :3])
+        tr, tp = _c(proj[b][:3, 3])
         s, sp = _c(src_fea[b])
         d, dp = _c(dv[b])
         o = out[b]
         lib().orc_homo_warping(sp, rp, tp, dp, C, H, W, D, o.ctypes.data_as(_f))
     return out
+
+
+def homo_warping(src_fea, src_proj, ref_proj, depth_values):
+    """utils/homo_utils.py:458-504.  src_fea [B,C,H,W]; *_proj [B,4,4]; depth_values [B,D,1,1] or [B,D]."""
+    proj = matmul(np.asarray(src_proj, np.float32), inv(np.asarray(ref_proj, np.float32)))   # :469 (batched, like the reference)
+    return homo_warping_proj(src_fea, proj, depth_values)
 
 
 def set_id_grid(h, w):

@@ -69,11 +69,16 @@ def test_regulariser_variants_ragged(T, D, H, W):
     assert tuple(d3.shape) == (T, 1, 4 * H, 4 * W)
 
 
-@pytest.mark.parametrize("n_src", [1, 2, 3, 4, 5])
-def test_warp_attention_vs_oracle(n_src):
+@pytest.mark.parametrize("n_src,dims,motion", [(1, (6, 11, 19), 0.7), (2, (6, 11, 19), 0.7), (3, (6, 11, 19), 0.7), (4, (6, 11, 19), 0.7),
+                                                (5, (6, 11, 19), 0.7), (9, (6, 11, 19), 0.3), (16, (4, 9, 17), 0.2),
+                                                (3, (8, 24, 48), 0.5),       # whole 2x8x16 bricks, boxes staged in LDS
+                                                (2, (7, 21, 37), 6.0)])      # large relative motion: boxes beyond the LDS budget
+def test_warp_attention_vs_oracle(n_src, dims, motion):
+    """fused volume warp + attention vs the oracle: 1..16 sources (running softmax), partial and whole bricks, both the
+    LDS-staged and the global-gather path of the kernel (the box of a brick fits / does not fit the LDS budget)."""
     from estdepth_amd import synth, ops
     from oracle import ref_ops as O
-    D, H, W = 6, 11, 19
+    D, H, W = dims
     K = synth.intrinsics(H * 4, W * 4).copy()
     K[:2] *= 0.25
     dv = np.linspace(0.5, 4.0, D).astype(np.float32)
@@ -81,7 +86,7 @@ def test_warp_attention_vs_oracle(n_src):
     kv_t = _t(1, D, H, W, 32)
     kvs = [_t(2 + j, D, H, W, 32) for j in range(n_src)]
     pose_t = synth.camera_pose(0)
-    poses = [synth.camera_pose(j + 1, motion=0.7) for j in range(n_src)]
+    poses = [synth.camera_pose(j + 1, motion=motion) for j in range(n_src)]
     # oracle: warp_volume of K and V of every source, then attention
     depth = np.broadcast_to(dv.reshape(1, 1, D, 1), (1, 1, D, H * W))
     to_c = lambda kv, sl: np.ascontiguousarray(np.moveaxis(kv.numpy()[..., sl], -1, 0))[None]
@@ -104,8 +109,8 @@ def test_warp_attention_vs_oracle(n_src):
 def test_abi_rejects_bad_arguments():
     from estdepth_amd import ops, _native
     x = torch.zeros(4, 4, 4, 32, device=DEV)
-    with pytest.raises(RuntimeError, match="estd_status"):
-        ops.warp_attention(x, [x] * 9, torch.zeros(9, 30, device=DEV), torch.ones(4, device=DEV), 0.1, 0.1)   # > 8 sources
+    with pytest.raises(RuntimeError, match="estd_status|at most 16"):       # C ABI status (ctypes) / TORCH_CHECK (torch ops)
+        ops.warp_attention(x, [x] * 17, torch.zeros(17, 30, device=DEV), torch.ones(4, device=DEV), 0.1, 0.1)   # > 16 sources
     with pytest.raises(RuntimeError):
         ops.softargmin_up(torch.zeros(1, 4, 4, 4, device=DEV, dtype=torch.float64), torch.ones(4, device=DEV), 4)   # dtype
     d = _native.Conv3dDesc()

@@ -1,0 +1,191 @@
+"""GPU: correctness of the code paths the benchmark actually runs, at the benchmark's own configurations.
+
+BASELINE.json configs[1] (cfg2): seq_len=5, 480x640, D=64, ResNet-50, Joint-mode call 2 (carried memory, EST on)
+  (a) every accelerator bench.py switches on (NHWC 2D backbones, PSM on the MFMA conv2d kernel, fused BN epilogues,
+      side-stream semantic branch and heads, hipGraph replay) vs the plain eager path: all outputs within 5e-5;
+  (b) plain path and accelerated path vs the CPU ORACLE on the same inputs: every ("depth", t, s) within 1e-4 abs
+      (north_star tolerance) -- one oracle forward at full size, ~1 min on the box's host cores.
+BASELINE.json configs[4] (cfg5): 960x1280, D=128 ESTM steady-state window (2 memory volumes)
+  (d) the whole window vs the oracle (1e-4), the fused warp+attention identity / permutation properties and the
+      GroupNorm statistics of the ConvGRU against fp64 torch at 128x240x320 (157 M-element reductions).
+(c) SemanticEncoder(50): the fused-BN / 1x1-as-GEMM (incl. stride-2) ResNet-50 path vs the same nn.Module evaluated by torch on the CPU.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL_DEPTH = 1e-4
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _setup():
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    yield
+
+
+def _np(t):
+    return t.detach().float().cpu().contiguous().numpy()
+
+
+def _oracle_forward(workload, x_imgs, x_poses, intr, pre_costs, pre_poses):
+    import bench as B
+    from oracle import ref_model as M, ref_ops as O
+    from oracle.nets2d import Nets2D, sd_numpy
+    n = torch.get_num_threads()
+    O.set_num_threads(n)
+    cpu_model = B.build_model(workload, "cpu")
+    pc = {"keys": [_np(k) for k in pre_costs["keys"]], "values": [_np(v) for v in pre_costs["values"]]}
+    ref, _, _ = M.model_forward(sd_numpy(cpu_model), _np(x_imgs), _np(x_poses), _np(intr), pc, [_np(p) for p in pre_poses],
+                                Nets2D(model=cpu_model), ndepths=B.WORKLOADS[workload][3], depth_min=0.1, depth_max=10.0)
+    return ref
+
+
+def _worst(a, b, key0="depth"):
+    return max(float(np.abs(_np(a[k]) - (b[k] if isinstance(b[k], np.ndarray) else _np(b[k]))).max()) for k in a if k[0] == key0)
+
+
+@pytest.fixture(scope="module")
+def cfg2_joint():
+    """plain eager / accelerated hipGraph / oracle outputs of the SAME Joint call 2 (same inputs, same carried memory)."""
+    import bench as B
+    from estdepth_amd import DepthNetHybrid, synth
+    from estdepth_amd.graph import GraphedForward
+    dev = torch.device(DEV)
+    plain = DepthNetHybrid(ndepths=64, depth_min=0.1, depth_max=10.0, resnet=50, IF_EST_transformer=True)
+    synth.fill_state_dict(plain, seed=0, head_gain=1.0)
+    plain = plain.eval().to(dev)
+    imgs, poses, intr, sample = B.make_inputs("joint", 0, dev)
+    sl, frames, pre_costs, pre_poses = B.steady_state(plain, "joint", imgs, poses, intr, sample)      # call 1, plain path
+    x_imgs, x_poses = imgs[:, sl].contiguous(), poses[:, sl].contiguous()
+    x_sample = {k: v[:, sl] for k, v in sample.items()}
+    with torch.no_grad():
+        out_plain, _, _ = plain(x_imgs, x_poses, intr, x_sample, pre_costs, list(pre_poses), mode="val")
+    out_plain = {k: v.clone() for k, v in out_plain.items()}
+    acc = B.build_model("joint", dev)                               # exactly what bench.py times
+    fwd = GraphedForward(acc)
+    with torch.no_grad():
+        for _ in range(2):                                          # capture, then a pure replay
+            out_acc, costs_acc, _ = fwd(x_imgs, x_poses, intr, x_sample, pre_costs, list(pre_poses), mode="val")
+    out_acc = {k: v.clone() for k, v in out_acc.items()}
+    torch.cuda.synchronize()
+    ref = _oracle_forward("joint", x_imgs, x_poses, intr, pre_costs, pre_poses)
+    return out_plain, out_acc, ref
+
+
+def test_cfg2_accelerated_graph_path_matches_plain_eager_path(cfg2_joint):
+    out_plain, out_acc, _ = cfg2_joint
+    assert set(out_plain) == set(out_acc) and len(out_plain) == 18           # 3 targets x (4 depths + 2 probabilities)
+    for k in out_plain:
+        assert float((out_plain[k] - out_acc[k]).abs().max()) < 5e-5, k
+
+
+def test_cfg2_plain_and_accelerated_paths_match_the_oracle(cfg2_joint):
+    out_plain, out_acc, ref = cfg2_joint
+    for tag, out in (("plain", out_plain), ("accelerated+hipGraph", out_acc)):
+        for k, v in out.items():
+            d = float(np.abs(_np(v) - ref[k]).max())
+            bar = TOL_DEPTH if k[0] == "depth" else 5e-5                     # probabilities: max of a softmax over 64 planes
+            assert d < bar, (tag, k, d)
+
+
+def test_semantic_encoder_resnet50_fused_path_vs_torch_cpu():
+    """_Bottleneck fused branch + strided conv1x1_gemm (backbones.py) at full image size vs the plain module on the CPU."""
+    from estdepth_amd import synth
+    from estdepth_amd.backbones import SemanticEncoder, enable_fused_bn
+    enc = SemanticEncoder(50, "pretrained").eval()
+    synth.fill_state_dict(enc, seed=4)
+    x = synth.smooth_images(2, 480, 640, seed=11)[0] / 255.0 * 2 - 1        # [2,3,480,640]
+    with torch.no_grad():
+        ref = enc(x)
+        g = enc.to(DEV).to(memory_format=torch.channels_last)
+        enable_fused_bn(g, True)
+        got = g(x.to(DEV).contiguous(memory_format=torch.channels_last))
+    assert len(ref) == len(got) == 5
+    for r, o in zip(ref, got):
+        assert tuple(r.shape) == tuple(o.shape)
+        scale = float(r.abs().max())
+        assert float((o.cpu() - r).abs().max()) < 2e-4 * max(scale, 1.0), (tuple(r.shape), scale)
+
+
+@pytest.fixture(scope="module")
+def cfg5_window():
+    import bench as B
+    from estdepth_amd.graph import GraphedForward
+    dev = torch.device(DEV)
+    model = B.build_model("cfg5", dev)
+    imgs, poses, intr, sample = B.make_inputs("cfg5", 0, dev)
+    sl, frames, pre_costs, pre_poses = B.steady_state(model, "cfg5", imgs, poses, intr, sample)
+    x_imgs, x_poses = imgs[:, sl].contiguous(), poses[:, sl].contiguous()
+    x_sample = {k: v[:, sl] for k, v in sample.items()}
+    with torch.no_grad():
+        out, costs, cposes = GraphedForward(model)(x_imgs, x_poses, intr, x_sample, pre_costs, list(pre_poses), mode="val")
+    out = {k: v.clone() for k, v in out.items()}
+    torch.cuda.synchronize()
+    del model
+    torch.cuda.empty_cache()
+    ref = _oracle_forward("cfg5", x_imgs, x_poses, intr, pre_costs, pre_poses)
+    return out, ref, pre_costs
+
+
+def test_cfg5_estm_window_matches_the_oracle(cfg5_window):
+    out, ref, _ = cfg5_window
+    assert len(out) == 6 and tuple(out[("depth", 0, 0)].shape) == (1, 1, 960, 1280)
+    for k, v in out.items():
+        d = float(np.abs(_np(v) - ref[k]).max())
+        assert np.isfinite(d) and d < (TOL_DEPTH if k[0] == "depth" else 5e-5), (k, d)
+
+
+def test_cfg5_fusion_properties_and_groupnorm_statistics(cfg5_window):
+    """size-independent properties at 128x240x320 on REAL key/value volumes of the cfg5 window:
+    one source with the target's own pose and the target's own volume -> h == V_t (identity warp, softmax over one view);
+    permuting two sources leaves h unchanged; GroupNorm(1 group) mean / rstd of the gate convolution == fp64 torch."""
+    from estdepth_amd import ops, synth
+    from estdepth_amd.hybrid_depth_decoder import kv_from_pair
+    from estdepth_amd.epipolar_transformer import EpipolarTransformer
+    _, _, pre_costs = cfg5_window
+    D, H, W = 128, 240, 320
+    kv = [kv_from_pair(k, v) for k, v in zip(pre_costs["keys"], pre_costs["values"])]
+    assert tuple(kv[0].shape) == (D, H, W, 32)
+    K = torch.from_numpy(synth.intrinsics(960, 1280)).clone()
+    K[:2] *= 0.25
+    K = K.to(DEV)
+    dv = (torch.arange(D, dtype=torch.float32) * (9.9 / 127) + 0.1).to(DEV)
+    poses = [torch.from_numpy(synth.camera_pose(v)).to(DEV) for v in range(3)]
+    ident = ops.cam_volume_mats(poses[0], poses[0], K)
+    one = ops.warp_attention(kv[0], [kv[0]], ident[None], dv, 0.1, 9.9 / 127)
+    inner = (slice(1, D - 1), slice(1, H - 1), slice(1, W - 1))             # the half-voxel resample of SURVEY Q5 touches the border
+    # identity pose: sample position = x*W/(W-1) - 0.5: not the voxel centre, so compare against the level-1 warp instead
+    v0 = kv[0][..., :16].permute(3, 0, 1, 2).contiguous()
+    warped = ops.warp_volume_cdhw(v0, ident, dv, 0.1, 9.9 / 127)
+    assert float((one[..., 16:].permute(3, 0, 1, 2) - warped).abs().max()) < 1e-5
+    del warped, v0, one
+    m1 = ops.cam_volume_mats(poses[1], poses[0], K)
+    m2 = ops.cam_volume_mats(poses[2], poses[0], K)
+    a = ops.warp_attention(kv[0], [kv[0], kv[1]], torch.stack([m1, m2]), dv, 0.1, 9.9 / 127)
+    b = ops.warp_attention(kv[0], [kv[1], kv[0]], torch.stack([m2, m1]), dv, 0.1, 9.9 / 127)
+    assert float((a - b)[inner].abs().max()) < 1e-5
+    del b
+    est = EpipolarTransformer(16, 16, 3).eval()
+    synth.fill_state_dict(est, seed=8)
+    est = est.to(DEV)
+    gate, _ = est._plans()
+    nblk = ops.conv3d_grid(1, D, H, W)
+    part = torch.empty(nblk * 4, device=DEV, dtype=torch.float64)
+    ru = torch.empty((D, H, W, 32), device=DEV, dtype=torch.float32)
+    gate.run(a, (1, D, H, W), out=ru, out_stride=32, stats_partials=part)
+    st = ops.groupnorm_finalize(part, nblk, 16.0 * D * H * W, 1e-5).cpu().double()
+    for g in range(2):
+        x = ru[..., 16 * g:16 * g + 16].double()
+        mean = float(x.mean())
+        var = float(((x - mean) ** 2).mean())
+        assert abs(float(st[2 * g]) - mean) < 1e-6 * max(1.0, abs(mean))
+        assert abs(float(st[2 * g + 1]) - 1.0 / np.sqrt(var + 1e-5)) < 1e-5 / np.sqrt(var + 1e-5)

@@ -33,7 +33,7 @@ report("homo_warp_costvol", timeit(lambda: ops.homo_warp_costvol(src, ref, proj,
 kvs = [torch.randn(D, H, W, 32, device=dev, generator=g) for _ in range(4)]
 for n in (1, 2, 3):
     mats = torch.stack([ops.cam_volume_mats(poses[j + 1], poses[0], K) for j in range(n)])
-    report("warp_attention N=%d" % n, timeit(lambda: ops.warp_attention(kvs[0], kvs[1:1 + n], mats, dv, 0.1, 9.9 / 63)), 4 * 16 * vox * (2 + 2 * n + 2))
+    report("warp_attention N=%d" % n, timeit(lambda: ops.warp_attention(kvs[0], kvs[1:1 + n], mats, dv, 0.1, 9.9 / 63)), 4 * 16 * vox * (2 + 2 * n))   # SURVEY §8d algorithmic bytes (K_t, h, K_j, V_j)
 xh = kvs[0]; ru = kvs[1]; st = torch.tensor([0.1, 1.1, -0.1, 0.9], device=dev)
 gm = torch.ones(16, device=dev); bt = torch.zeros(16, device=dev)
 report("gru_reset_apply", timeit(lambda: ops.gru_reset_apply(xh, ru, st, gm, bt)), 4 * vox * (32 + 16 + 32))
