@@ -68,9 +68,51 @@ def _is_1x1(conv):
     return conv.kernel_size == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and conv.dilation == (1, 1)
 
 
-def conv_bn_act(conv, bn, x, relu, residual=None):
-    """library convolution (a GEMM for 1x1 kernels), then ONE in-place NHWC pass for BatchNorm2d(eval) [+ residual] [+ ReLU]."""
+HIP_3X3_MIN_ITEMS = 256     # work items (8x16-pixel tiles x 32-channel groups) below which the persistent MFMA kernel cannot fill 256 CUs
+
+
+def _hip_3x3_plan(conv, bn, x, relu, has_residual):
+    """Conv2dPlan (csrc/conv2d_mfma.hip: 3x3 / stride 1 / folded BN / ReLU / residual in ONE kernel) for a library-shaped
+    Conv2d + BatchNorm2d pair when the module opted in (enable_hip_3x3) and the map offers enough tiles; else None.
+    ResNet-50 stride-1 3x3 convolutions at 120x160 ... 30x40: 1.4-1.6x MIOpen's fp32 kernels (tools/r50_conv_bench.py)."""
+    if not conv.__dict__.get("_hip3x3", False) or conv.kernel_size != (3, 3) or conv.stride != (1, 1) or conv.groups != 1:
+        return None
+    if conv.bias is not None or conv.dilation not in ((1, 1), (2, 2)) or conv.padding != conv.dilation:
+        return None
+    if conv.in_channels % 32 or conv.out_channels % 32:
+        return None
+    n, _, h, w = x.shape
+    if n * ((h + 7) // 8) * ((w + 15) // 16) * (conv.out_channels // 32) < HIP_3X3_MIN_ITEMS:
+        return None
     from . import ops
+    key = (conv.weight.device, conv.weight._version, conv.weight.data_ptr(), bn.weight._version, bn.bias._version,
+           bn.running_mean._version, bn.running_var._version, relu, has_residual)
+    c = conv.__dict__.get("_estd_plan3x3")
+    if c is None or c[0] != key:
+        # epilogue order of the kernel: BN -> [ReLU] -> [+ residual] -> [ReLU]; with a residual the ReLU comes after the add
+        c = (key, ops.Conv2dPlan(conv, bn, relu_before=relu and not has_residual, relu_after=relu and has_residual))
+        conv.__dict__["_estd_plan3x3"] = c
+    return c[1]
+
+
+def enable_hip_3x3(root, enable=True):
+    """Opt-in: stride-1 3x3 Conv2d+BN(+ReLU)(+residual) pairs under ``root`` that reach conv_bn_act run on the MFMA conv2d
+    kernel where the map is large enough (ResNet encoder)."""
+    for m in root.modules():
+        if isinstance(m, nn.Conv2d):
+            m.__dict__["_hip3x3"] = bool(enable)
+    return root
+
+
+def conv_bn_act(conv, bn, x, relu, residual=None):
+    """library convolution (a GEMM for 1x1 kernels), then ONE in-place NHWC pass for BatchNorm2d(eval) [+ residual] [+ ReLU];
+    or, for opted-in stride-1 3x3 convolutions on large enough maps, everything in the MFMA conv2d kernel."""
+    from . import ops
+    plan = _hip_3x3_plan(conv, bn, x, relu, residual is not None)
+    if plan is not None:
+        xn = x.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        rn = residual.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1) if residual is not None else None
+        return plan.run(xn, residual=rn).permute(0, 3, 1, 2)
     y = conv1x1_gemm(conv, x) if _is_1x1(conv) else conv(x)
     if not y.is_contiguous(memory_format=torch.channels_last):
         y = y.contiguous(memory_format=torch.channels_last)

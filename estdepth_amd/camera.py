@@ -92,6 +92,24 @@ def relative_volume_matrix(rel_pose, cam_intr_q, device):
     return torch.cat([torch.inverse(K)[0].reshape(-1), m[0, :3, :].reshape(-1), K[0].reshape(-1)]).to(device)
 
 
+def forward_matrices(cam_poses, cam_intr_q, pre_poses, with_volume, device):
+    """Everything one DepthNetHybrid.forward needs, in ONE device-to-host copy, one C++ call and one host-to-device copy:
+    {"sweep": [T,2,12], "vol": [T,n,30] or None}.  The C++ operator estdepth_hip::camera_matrices_host (csrc/torch_ops.cpp)
+    makes the same ATen CPU calls as sweep_projections() / volume_matrices() above (bit-identical, tests/test_camera_host.py)
+    without ~40 trips through the Python dispatcher: while this runs the GPU has nothing queued, so host time is step time."""
+    pre = list(pre_poses) if (with_volume and pre_poses is not None) else []
+    flat = torch.cat([cam_poses.reshape(-1).float(), cam_intr_q.reshape(-1).float()] + [p.reshape(-1).float() for p in pre])
+    flat = flat.detach().to("cpu")                                     # the one synchronisation point of a forward
+    V = cam_poses.shape[1]
+    poses = flat[:V * 16].reshape(1, V, 4, 4)
+    K = flat[V * 16:V * 16 + 9].reshape(1, 3, 3)
+    pre_cpu = [flat[V * 16 + 9 + 16 * i:V * 16 + 25 + 16 * i].reshape(1, 4, 4) for i in range(len(pre))]
+    sweep, vol = ops.T().camera_matrices_host(poses, K, pre_cpu, bool(with_volume))
+    both = torch.cat([sweep.reshape(-1), vol.reshape(-1)]).to(device)
+    n_sweep = sweep.numel()
+    return {"sweep": both[:n_sweep].reshape(sweep.shape), "vol": both[n_sweep:].reshape(vol.shape) if with_volume else None}
+
+
 # ------------------------------------------------------------------------------------------------ device variants
 def sweep_projections_device(cam_poses, cam_intr_q):
     poses, K = cam_poses[0].contiguous().float(), cam_intr_q[0].contiguous().float()

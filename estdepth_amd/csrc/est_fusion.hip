@@ -339,39 +339,53 @@ __global__ __launch_bounds__(256) void gru_blend_kernel(const float* __restrict_
     *reinterpret_cast<float4*>(out + vox * out_stride + c * 4) = r;
 }
 
-// soft-argmin at low resolution, replicated s x s.  One thread per low-res pixel; loads are coalesced
-// along W for every depth plane; two passes over D (max, then sums) like the max-subtracted softmax.
+// soft-argmin at low resolution, replicated s x s (hybrid_depth_decoder.py:33-38 after F.interpolate(scale_factor=s)).
+// A 256-thread workgroup owns 32 consecutive low-res pixels of one row; thread (px, g) reduces the depth planes
+// d = g, g+8, g+16, ... of pixel px (every plane read is a coalesced 128-byte segment), the eight partial maxima / sums of
+// a pixel meet in LDS, and the eight threads of a pixel then write its s x s replicas of (depth, max probability).
+// (One thread per pixel looping over all D planes left 225 workgroups for a whole Joint step: pure latency.)
 __global__ __launch_bounds__(256) void softargmin_up_kernel(const float* __restrict__ logits, const float* __restrict__ dvals,
                                                             float* __restrict__ depth, float* __restrict__ prob,
                                                             int N, int D, int H, int W, int s)
 {
+    __shared__ float red[3][8][32];
+    const int px = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int wt = (W + 31) / 32;
+    const int bw = blockIdx.x % wt, y = (blockIdx.x / wt) % H, n = blockIdx.x / (wt * H);
+    const int x = bw * 32 + px;
+    const bool ok = x < W;
     const long long HW = (long long)H * W;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)N * HW) return;
-    const int n = (int)(t / HW);
-    const long long pix = t % HW;
-    const int y = (int)(pix / W), x = (int)(pix % W);
-    const float* l = logits + (long long)n * D * HW + pix;
+    const float* l = logits + (long long)n * D * HW + (long long)y * W + (ok ? x : W - 1);
     float mx = -INFINITY;
-    for (int d = 0; d < D; ++d) mx = fmaxf(mx, l[(long long)d * HW]);
+    for (int d = g; d < D; d += 8) mx = fmaxf(mx, l[(long long)d * HW]);
+    red[0][g][px] = mx;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) mx = fmaxf(mx, red[0][k][px]);
     float den = 0.0f, num = 0.0f;
-    for (int d = 0; d < D; ++d) {
-        const float e = expf(l[(long long)d * HW] - mx);
+    for (int d = g; d < D; d += 8) {
+        const float e = expf(l[(long long)d * HW] - mx);      // second read of the same lines: L2 / L1 resident
         den += e;
         num += e * dvals[d];
     }
+    red[1][g][px] = den;
+    red[2][g][px] = num;
+    __syncthreads();
+    den = 0.0f; num = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { den += red[1][k][px]; num += red[2][k][px]; }     // fixed order: deterministic
+    if (!ok) return;
     const float dep = num / den;
     const float pm = 1.0f / den;        // max_d softmax = exp(0)/den
     const int Wo = W * s;
-    float* dd = depth + (long long)n * HW * s * s + (long long)y * s * Wo + (long long)x * s;
-    float* pp = prob + (long long)n * HW * s * s + (long long)y * s * Wo + (long long)x * s;
-    for (int r = 0; r < s; ++r) {
-        if (s == 4) {
-            *reinterpret_cast<float4*>(dd + (long long)r * Wo) = make_float4(dep, dep, dep, dep);
-            *reinterpret_cast<float4*>(pp + (long long)r * Wo) = make_float4(pm, pm, pm, pm);
-        } else {
-            for (int c = 0; c < s; ++c) { dd[(long long)r * Wo + c] = dep; pp[(long long)r * Wo + c] = pm; }
-        }
+    const long long obase = (long long)n * HW * s * s + (long long)y * s * Wo + (long long)x * s;
+    // s * 2 row segments (s rows of depth, s rows of prob) spread over the 8 threads of the pixel
+    for (int q = g; q < 2 * s; q += 8) {
+        const int r = q % s;
+        float* dst = (q < s ? depth : prob) + obase + (long long)r * Wo;
+        const float v = q < s ? dep : pm;
+        if (s == 4) *reinterpret_cast<float4*>(dst) = make_float4(v, v, v, v);
+        else for (int c = 0; c < s; ++c) dst[c] = v;
     }
 }
 
@@ -492,8 +506,9 @@ extern "C" int estd_softargmin_up(const float* logits, const float* dvals, float
                                   int N, int D, int H, int W, int sc, estd_stream_t s)
 {
     if (!logits || !dvals || !depth || !prob || N <= 0 || D <= 0 || H <= 0 || W <= 0 || sc <= 0) return ESTD_ERR_ARG;
-    const long long T = (long long)N * H * W;
-    hipLaunchKernelGGL(softargmin_up_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, estd_stream(s),
+    const long long blocks = (long long)N * H * ((W + 31) / 32);
+    if (blocks > 0x7fffffffLL) return ESTD_ERR_ARG;
+    hipLaunchKernelGGL(softargmin_up_kernel, dim3((unsigned)blocks), dim3(256), 0, estd_stream(s),
                        logits, dvals, depth, prob, N, D, H, W, sc);
     return ESTD_LAUNCH_CHECK();
 }

@@ -337,6 +337,70 @@ Tensor vol_to_cdhw(const Tensor& src, int64_t C, at::IntArrayRef dims, int64_t s
     return out;
 }
 
+// ------------------------------------------------------------------------------------------------ camera algebra on the HOST
+// The reference composes its camera matrices with torch.inverse / torch.matmul on [B,4,4] CPU tensors (model_hybrid.py:74-88,
+// homo_utils.py:469-471, hybrid_depth_decoder.py:235, homo_utils.py:51,:258).  These matrices decide which samples fall across
+// the discontinuous |norm| > 1 masks, so the product evaluates them with the SAME ATen CPU kernels, shapes and association
+// order -- bit-identical matrices (estdepth_amd/camera.py is the line-by-line Python statement of this function; a CPU test
+// asserts equality).  One call per forward from C++ instead of ~40 Python-dispatched ATen calls (0.4 ms -> 0.06 ms of host
+// time during which the GPU would idle behind the D2H copy of the poses).
+std::tuple<Tensor, Tensor> camera_matrices_host(const Tensor& cam_poses, const Tensor& cam_intr_q, at::TensorList pre_poses, bool with_volume)
+{
+    TORCH_CHECK(cam_poses.device().is_cpu() && cam_intr_q.device().is_cpu(), "camera_matrices_host: CPU tensors expected (copy the poses once)");
+    TORCH_CHECK(cam_poses.dim() == 4 && cam_poses.size(0) == 1 && cam_poses.size(2) == 4 && cam_poses.size(3) == 4 && cam_poses.size(1) >= 3,
+                "camera_matrices_host: cam_poses must be [1,V,4,4] with V >= 3");
+    TORCH_CHECK(cam_intr_q.sizes() == at::IntArrayRef({1, 3, 3}), "camera_matrices_host: cam_intr must be [1,3,3]");
+    using namespace at::indexing;
+    const Tensor poses = cam_poses.to(at::kFloat), K = cam_intr_q.to(at::kFloat);
+    const int64_t V = poses.size(1), T = V - 2;
+    auto view_proj = [&](int64_t v) {
+        Tensor extrinsic = at::inverse(poses.index({Slice(), v, Slice(), Slice()}));                   // model_hybrid.py:74,:83
+        Tensor proj = extrinsic.clone();
+        proj.index_put_({Slice(), Slice(None, 3), Slice(None, 4)},
+                        at::matmul(K, extrinsic.index({Slice(), Slice(None, 3), Slice(None, 4)})));    // :87-88
+        return proj;
+    };
+    Tensor sweep = at::empty({T, 2, 12}, poses.options());
+    for (int64_t t = 0; t < T; ++t) {
+        const Tensor ref_inv = at::inverse(view_proj(t + 1));
+        const int64_t srcs[2] = {t, t + 2};
+        for (int k = 0; k < 2; ++k) {
+            const Tensor pr = at::matmul(view_proj(srcs[k]), ref_inv);                                 // homo_utils.py:469
+            sweep.index_put_({t, k, Slice(None, 9)}, pr.index({0, Slice(None, 3), Slice(None, 3)}).reshape({9}));   // :470
+            sweep.index_put_({t, k, Slice(9, None)}, pr.index({0, Slice(None, 3), 3}));                              // :471
+        }
+    }
+    Tensor vol;
+    if (with_volume) {
+        std::vector<Tensor> P;
+        for (int64_t t = 0; t < T; ++t) P.push_back(poses.index({Slice(), t + 1}).reshape({1, 4, 4}));
+        for (const Tensor& p : pre_poses) {
+            TORCH_CHECK(p.device().is_cpu() && p.numel() == 16, "camera_matrices_host: memory poses must be CPU [1,4,4] tensors");
+            P.push_back(p.to(at::kFloat).reshape({1, 4, 4}));
+        }
+        const int64_t n = (int64_t)P.size();
+        TORCH_CHECK(n >= 2, "camera_matrices_host: the EST fusion needs at least one other view");
+        const Tensor kinv = at::inverse(K);                                                            // homo_utils.py:51
+        vol = at::empty({T, n - 1, 30}, poses.options());
+        for (int64_t i = 0; i < T; ++i) {
+            const Tensor inv_i = at::inverse(P[i]);
+            int64_t r = 0;
+            for (int64_t j = 0; j < n; ++j) {
+                if (j == i) continue;
+                const Tensor rel = at::matmul(P[j], inv_i);                                            // hybrid_depth_decoder.py:235 (Q8)
+                const Tensor m = at::inverse(rel);                                                     // homo_utils.py:258
+                vol.index_put_({i, r, Slice(None, 9)}, kinv[0].reshape({9}));
+                vol.index_put_({i, r, Slice(9, 21)}, m.index({0, Slice(None, 3), Slice()}).reshape({12}));
+                vol.index_put_({i, r, Slice(21, None)}, K[0].reshape({9}));
+                ++r;
+            }
+        }
+    } else {
+        vol = at::empty({0}, poses.options());
+    }
+    return {sweep, vol};
+}
+
 void profile_mark(int64_t id) { check_status(estd_profile_mark((int)id, cur_stream()), "estd_profile_mark"); }
 int64_t conv3d_grid(int64_t N, int64_t D, int64_t H, int64_t W)
 {
@@ -373,6 +437,7 @@ TORCH_LIBRARY(estdepth_hip, m)
     m.def("spp_upsample_cat(Tensor raw, Tensor skip, Tensor[] branches) -> Tensor");
     m.def("cdhw_to_vol(Tensor src, Tensor(a!) dst, int dst_stride, int dst_off) -> ()");
     m.def("vol_to_cdhw(Tensor src, int C, int[] dims, int src_stride, int src_off) -> Tensor");
+    m.def("camera_matrices_host(Tensor cam_poses, Tensor cam_intr, Tensor[] pre_poses, bool with_volume) -> (Tensor, Tensor)");
     m.def("profile_mark(int id) -> ()");
     m.def("conv3d_grid(int N, int D, int H, int W) -> int");
 }
@@ -401,6 +466,11 @@ TORCH_LIBRARY_IMPL(estdepth_hip, CUDA, m)
     m.impl("spp_upsample_cat", spp_upsample_cat);
     m.impl("cdhw_to_vol", cdhw_to_vol);
     m.impl("vol_to_cdhw", vol_to_cdhw);
+}
+
+TORCH_LIBRARY_IMPL(estdepth_hip, CPU, m)
+{
+    m.impl("camera_matrices_host", camera_matrices_host);      // host-side algebra on CPU tensors (not a compute fallback)
 }
 
 TORCH_LIBRARY_IMPL(estdepth_hip, CompositeExplicitAutograd, m)

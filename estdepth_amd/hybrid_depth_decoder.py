@@ -282,6 +282,8 @@ class DepthHybridDecoder(nn.Module):
         if side is not None:
             main.wait_stream(side)
         d2, p2 = ops.softargmin_up(fused_logits, dv, 4)                   # :259-260
+        if getattr(self, "keep_logits", False):          # test hook: the low-resolution logit volumes of stereo_head0 / stereo_head1
+            self.last_logits = {"init": init_logits, "fused": fused_logits}
         for i in range(num):
             outputs[("depth", i, 2)] = d2[i:i + 1]
             outputs[("fused_prob", i)] = p2[i:i + 1]
@@ -309,6 +311,8 @@ class DepthHybridDecoder(nn.Module):
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         d2, p2 = ops.softargmin_up(fused_logits, dv, 4)                                      # :379-381
+        if getattr(self, "keep_logits", False):
+            self.last_logits = {"init": init_logits, "fused": fused_logits}
         s1, s0 = self._refine(semantic_vs, fused_logits, semantic_features)
         for i in range(num):
             outputs[("depth", i, 3)] = d3[i:i + 1]

@@ -79,8 +79,7 @@ class DepthNetHybrid(nn.Module):
                     "vol": camera.volume_matrices_device([p.to(dev) for p in plist], T, cam_intr_stage1.to(dev)) if est else None}
         if self.camera_algebra != "host":
             raise RuntimeError("camera_algebra must be 'host' or 'device', got %r" % (self.camera_algebra,))
-        return {"sweep": camera.sweep_projections(cam_poses, cam_intr_stage1, dev),
-                "vol": camera.volume_matrices(plist, T, cam_intr_stage1, dev) if est else None}
+        return camera.forward_matrices(cam_poses, cam_intr_stage1, pre_cam_poses, est, dev)
 
     def _costvolumes(self, ref_mixes, src_mix_pairs, sweep, depth_values, P=None):
         """Fused get_costvolume for T targets at once on pre-mixed 2D features (model_hybrid.py:76-99).
@@ -187,8 +186,10 @@ class DepthNetHybrid(nn.Module):
     def use_hip_psm(self, enable=True):
         """Opt-in: the 3x3 convolutions of the PSM matching-feature extractor on the MFMA conv2d kernel
         (SURVEY §8f rank 2).  Implies NHWC 2D backbones."""
+        from .backbones import enable_hip_3x3
         self.use_channels_last_2d(True)
         self.matchingFeature.use_hip_convs(enable)
+        enable_hip_3x3(self.semanticFeature, enable)       # ResNet stride-1 3x3 convs (with fuse_bn_2d(); SURVEY §8f rank 3)
         for name, child in self.CostRegNet.named_children():      # 2D decoder ConvBlocks with enough tiles (120x160 and up)
             if name.startswith("upconv"):
                 child._hip = bool(enable)

@@ -72,3 +72,17 @@ def test_volume_matrices_equal_the_oracle_composition_bitwise():
             assert np.array_equal(got[i, r, 21:], K[0].numpy().reshape(-1))
     one = camera.relative_volume_matrix(torch.from_numpy(O.matmul(plist[2][0].numpy(), O.inv(plist[0][0].numpy()))), K[0], "cpu").numpy()
     assert np.array_equal(one, got[0, 1])
+
+
+def test_cpp_operator_equals_the_python_statement_bitwise():
+    """estdepth_hip::camera_matrices_host (one C++ call per forward) == camera.sweep_projections / volume_matrices."""
+    poses = _poses(7)
+    K = torch.from_numpy(synth.intrinsics(480, 640))[None].clone()
+    K[:, :2] *= 0.25
+    pre = [poses[:, 5], poses[:, 6]]
+    got = camera.forward_matrices(poses[:, :5], K, pre, True, "cpu")
+    assert torch.equal(got["sweep"], camera.sweep_projections(poses[:, :5], K, "cpu"))
+    plist = [poses[:, t + 1] for t in range(3)] + pre
+    assert torch.equal(got["vol"], camera.volume_matrices(plist, 3, K, "cpu"))
+    nov = camera.forward_matrices(poses[:, :3], K, None, False, "cpu")
+    assert nov["vol"] is None and torch.equal(nov["sweep"], camera.sweep_projections(poses[:, :3], K, "cpu"))

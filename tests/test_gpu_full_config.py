@@ -172,7 +172,7 @@ def test_cfg5_fusion_properties_and_groupnorm_statistics(cfg5_window):
     m2 = ops.cam_volume_mats(poses[2], poses[0], K)
     a = ops.warp_attention(kv[0], [kv[0], kv[1]], torch.stack([m1, m2]), dv, 0.1, 9.9 / 127)
     b = ops.warp_attention(kv[0], [kv[1], kv[0]], torch.stack([m2, m1]), dv, 0.1, 9.9 / 127)
-    assert float((a - b)[inner].abs().max()) < 1e-5
+    assert float((a - b)[inner].abs().max()) < 5e-5      # real keys (ReLU outputs, |corr| in the hundreds): exp() argument rounding
     del b
     est = EpipolarTransformer(16, 16, 3).eval()
     synth.fill_state_dict(est, seed=8)

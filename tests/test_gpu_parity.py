@@ -249,7 +249,9 @@ def _stream_model():
 def test_estm_stream(golden_dir):
     """eval_hybrid_seq.py:160-193: sliding windows of 3 frames, memory of 2 (configs[2] protocol, small size)."""
     g = _g(golden_dir, "g8_estm_stream.npz")
+    g11 = _g(golden_dir, "g11_estm_logits.npz")
     m = _stream_model()
+    m.CostRegNet.keep_logits = True
     imgs, poses, intr, sample = S.e2e_inputs(6, S.E2E_HI, S.E2E_WI, seed=1003)
     imgs, poses, intr = imgs.to(DEV), poses.to(DEV), intr.to(DEV)
     mem_costs, mem_poses = [], []
@@ -271,6 +273,10 @@ def test_estm_stream(golden_dir):
         _cmp_outputs(outputs, g, prefix="w%d|" % w)
         assert np.array_equal(cposes[0].cpu().numpy(), g["w%d|pose" % w])
         assert checksum_close(checksum(costs["values"][0].cpu().numpy()), g["w%d|value_ck" % w])
+        if w >= 2:      # G11: logit volumes of stereo_head0 / stereo_head1 vs the reference's (1.5e-4 abs on a range of +-5.7 / +-0.8)
+            lg = m.CostRegNet.last_logits
+            assert np.abs(lg["init"][0].cpu().numpy() - g11["w%d|init" % w]).max() < 1.5e-4
+            assert np.abs(lg["fused"][0].cpu().numpy() - g11["w%d|fused" % w]).max() < 1.5e-4
 
 
 def test_joint_carry(golden_dir):

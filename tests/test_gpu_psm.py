@@ -33,6 +33,39 @@ def test_conv2d_mfma_vs_torch_fp64(cin, cout, dil, dims, relu, res):
     assert (out - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("c,dims", [(64, (3, 120, 160)), (128, (3, 60, 80)), (256, (3, 30, 40))])
+def test_resnet50_stride1_3x3_on_the_mfma_kernel_vs_torch_fp64(c, dims):
+    """the stride-1 3x3 convolutions of ResNet-50 (resnet_encoder.py:43-49) at their cfg2 shapes through
+    backbones.conv_bn_act with enable_hip_3x3: Conv + folded BN + ReLU in the MFMA conv2d kernel vs torch fp64; and the
+    residual form relu(bn(conv(x)) + r) of the basic block (ReLU AFTER the add)."""
+    from estdepth_amd import synth
+    from estdepth_amd.backbones import conv_bn_act, enable_hip_3x3, _hip_3x3_plan
+    N, H, W = dims
+    conv = torch.nn.Conv2d(c, c, 3, 1, 1, bias=False)
+    bn = torch.nn.BatchNorm2d(c).eval()
+    seq = torch.nn.Sequential(conv, bn).eval()
+    synth.fill_state_dict(seq, seed=c)
+    g = torch.Generator().manual_seed(c)
+    x = torch.randn(N, c, H, W, generator=g)
+    r = torch.randn(N, c, H, W, generator=g)
+    with torch.no_grad():
+        y64 = seq.double()(x.double())
+        ref_plain, ref_res = torch.relu(y64), torch.relu(y64 + r.double())
+    seq = seq.float().to(DEV).to(memory_format=torch.channels_last)
+    enable_hip_3x3(seq)
+    xg = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    rg = r.to(DEV).contiguous(memory_format=torch.channels_last)
+    assert _hip_3x3_plan(seq[0], seq[1], xg, True, False) is not None          # the MFMA kernel is what runs
+    with torch.no_grad():
+        out_plain = conv_bn_act(seq[0], seq[1], xg, relu=True)
+        out_res = conv_bn_act(seq[0], seq[1], xg, relu=True, residual=rg)
+    for out, ref in ((out_plain, ref_plain), (out_res, ref_res)):
+        assert tuple(out.shape) == (N, c, H, W)
+        assert (out.cpu().double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    small = torch.randn(1, c, 15, 20, device=DEV).contiguous(memory_format=torch.channels_last)
+    assert _hip_3x3_plan(seq[0], seq[1], small, True, False) is None          # too few tiles for 256 CUs: library convolution
+
+
 def test_psm_hip_path_matches_torch_path():
     from estdepth_amd import synth
     from estdepth_amd.backbones import PSMFeatures

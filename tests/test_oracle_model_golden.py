@@ -66,6 +66,9 @@ def test_g7_e2e_cfg1(golden_dir):
     assert checksum_close(checksum(costs["values"][0]), g["value_ck"])
 
 
+LOGIT_TOL = 1.5e-4      # abs, on logits of range +-5.7 (init) / +-0.8 (fused); ~4x the reference's own thread-count noise
+
+
 def _stream_model():
     m = DepthNetHybrid(ndepths=64, depth_min=0.1, depth_max=10.0, resnet=18, IF_EST_transformer=True).eval()
     synth.fill_state_dict(m, seed=2, head_gain=1.0)
@@ -75,6 +78,7 @@ def _stream_model():
 def test_g8_estm_stream(golden_dir):
     """eval_hybrid_seq.py:160-193 protocol: sliding windows of 3, memory of 2 (pins Q7 on every window)."""
     g = np.load(os.path.join(golden_dir, "g8_estm_stream.npz"))
+    g11 = np.load(os.path.join(golden_dir, "g11_estm_logits.npz"))
     m = _stream_model()
     P = sd_numpy(m)
     nets = Nets2D(model=m)
@@ -97,6 +101,9 @@ def test_g8_estm_stream(golden_dir):
         _cmp_outputs(outputs, g, prefix="w%d|" % w)
         assert np.array_equal(np.asarray(cposes[0]), g["w%d|pose" % w])
         assert checksum_close(checksum(costs["values"][0]), g["w%d|value_ck" % w])
+        if w >= 2:      # G11: the logit volumes themselves (a flat softmax cannot hide an error here); reference's own 1-vs-8-thread noise 3.6e-5
+            assert np.abs(outputs[("init_logits",)][0] - g11["w%d|init" % w]).max() < LOGIT_TOL
+            assert np.abs(outputs[("fused_logits",)][0] - g11["w%d|fused" % w]).max() < LOGIT_TOL
 
 
 def test_g9_joint_carry(golden_dir):

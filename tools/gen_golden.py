@@ -166,6 +166,14 @@ def main():
     imgs, poses, intr, sample = S.e2e_inputs(6, S.E2E_HI, S.E2E_WI, seed=1003)
     mem_costs, mem_poses = [], []
     out = {}
+    # G11: the low-resolution LOGIT volumes of the same stream (outputs of stereo_head0 / stereo_head1, captured with forward
+    # hooks): a check that a near-flat softmax cannot forgive.  The reference's own 1-vs-8-thread noise on them is 3.6e-5
+    # (range +-5.7, tools/ref_noise_probe.py); end-to-end DEPTH fixtures cannot be made sharper than head gain ~3 because
+    # that noise, amplified by the gain, exceeds the 1e-4 bar (gain 10: 5e-4 m, gain 30: 1.7e-3 m).
+    logit_log = []
+    hooks = [m.CostRegNet.stereo_head0.register_forward_hook(lambda mod, i, o: logit_log.append(("init", npy(o)))),
+             m.CostRegNet.stereo_head1.register_forward_hook(lambda mod, i, o: logit_log.append(("fused", npy(o))))]
+    g11 = {}
     for w_ in range(4):
         sl = slice(w_, w_ + 3)
         smp = {k: v[:, sl] for k, v in sample.items()}
@@ -185,7 +193,15 @@ def main():
         out["w%d|pose" % w_] = npy(cposes[0])
         out["w%d|value_ck" % w_] = checksum(costs["values"][0])
         print("G8 window", w_, "depth2", outputs[("depth", 0, 2)].mean().item(), "depth0", outputs[("depth", 0, 0)].mean().item())
+        if w_ >= 2:                                   # steady-state windows (1 and 2 memory volumes): EST fusion on
+            for name, lg in logit_log:
+                g11["w%d|%s" % (w_, name)] = lg.reshape(lg.shape[-4:])[0]          # [D,H,W]
+        logit_log.clear()
+    for h_ in hooks:
+        h_.remove()
     np.savez(os.path.join(OUT, "g8_estm_stream.npz"), **out)
+    np.savez(os.path.join(OUT, "g11_estm_logits.npz"), **g11)
+    print("G11 logits", {k: (v.shape, float(np.abs(v).max())) for k, v in g11.items()})
 
     # G9 Joint with carry-over: two consecutive 5-frame calls (eval_hybrid.py:229-243), stride seq_len-2
     imgs, poses, intr, sample = S.e2e_inputs(8, S.E2E_HI, S.E2E_WI, seed=1004)

@@ -2,11 +2,11 @@
 
     python tools/parity_diag.py --workload cfg5|joint|estm [--no-oracle]
 
-1. camera matrices: device fp64 Gauss-Jordan (estd_cam_*) vs the oracle's fp32 LAPACK composition, bit level;
-2. plane sweep: voxels whose sample flips across the |norm| > 1 mask because of (1) -- HIP kernel with device matrices vs
-   the same kernel with the oracle's matrices uploaded vs the C oracle;
-3. whole forward: HIP (device matrices), HIP with the oracle's matrices injected, oracle -- max |d depth| and the number
-   of pixels beyond 1e-4 per output scale;
+1. camera matrices: device fp64 Gauss-Jordan (camera_algebra="device", estd_cam_*) vs the reference's torch-CPU composition
+   (camera_algebra="host", the default; estdepth_amd/camera.py), bit level;
+2. plane sweep: voxels whose sample flips across the |norm| > 1 mask because of (1);
+3. whole forward: HIP with device matrices, HIP with host matrices, oracle -- max |d depth| and the number of pixels
+   beyond 1e-4 per output scale;
 4. per-operator wall time of the oracle step (what bench.py's cpu_baseline is made of).
 """
 import argparse
@@ -21,25 +21,6 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench as B  # noqa: E402
-
-
-def host_sweep_proj(ref_pose, src_pose, K):
-    from oracle import ref_ops as O
-    ref_pose, src_pose, K = [np.asarray(a.detach().cpu().numpy(), np.float32) for a in (ref_pose, src_pose, K)]
-    ref_extr, src_extr = O.inv(ref_pose), O.inv(src_pose)
-    sp, rp = src_extr.copy(), ref_extr.copy()
-    sp[:3, :4] = K @ src_extr[:3, :4]
-    rp[:3, :4] = K @ ref_extr[:3, :4]
-    proj = (sp @ O.inv(rp)).astype(np.float32)
-    return np.concatenate([proj[:3, :3].reshape(-1), proj[:3, 3]]).astype(np.float32)
-
-
-def host_volume_mats(pose_j, pose_i, K):
-    from oracle import ref_ops as O
-    pose_j, pose_i, K = [np.asarray(a.detach().cpu().numpy(), np.float32) for a in (pose_j, pose_i, K)]
-    rel = (pose_j @ O.inv(pose_i)).astype(np.float32)
-    m = O.inv(rel)
-    return np.concatenate([O.inv(K).reshape(-1), m.reshape(-1)[:12], K.reshape(-1)]).astype(np.float32)
 
 
 def main():
@@ -60,56 +41,38 @@ def main():
     D = B.WORKLOADS[args.workload][3]
     report = {"workload": args.workload}
 
-    # ---- 1. matrices ----
-    k4 = intr[0].clone()
-    k4[:2] *= 0.25
-    p = x_poses[0]
-    worst_rel, same = 0.0, True
-    for t in range(p.shape[0] - 2):
-        for s in (t, t + 2):
-            g = ops.cam_sweep_proj(p[t + 1].contiguous(), p[s].contiguous(), k4.contiguous()).cpu().numpy()
-            h = host_sweep_proj(p[t + 1], p[s], k4)
-            same &= bool(np.array_equal(g, h))
-            worst_rel = max(worst_rel, float(np.max(np.abs(g - h) / np.maximum(np.abs(h), 1e-6))))
-    report["sweep_proj"] = {"bit_identical": same, "max_rel_diff": worst_rel}
+    # ---- 1. matrices: the reference's torch-CPU composition (camera_algebra="host", the default) vs the fp64 device kernels ----
+    k4 = model.scale_cam_intr(intr, 0.25)
+    model.camera_algebra = "host"
+    host = model.camera_matrices(x_poses, k4, pre_poses)
+    model.camera_algebra = "device"
+    devm = model.camera_matrices(x_poses, k4, pre_poses)
+    report["camera_matrices_device_vs_host"] = {
+        name: {"bit_identical": bool(torch.equal(host[name], devm[name])),
+               "max_rel_diff": float(((host[name] - devm[name]).abs() / host[name].abs().clamp_min(1e-6)).max())}
+        for name in host if host[name] is not None}
 
     # ---- 2. flips in the plane sweep of target 0 / source 0 ----
     with torch.no_grad():
         feats = model.matchingFeature(model.normalise_images(x_imgs[0]).contiguous(memory_format=torch.channels_last))
     dv = model.depth_cands.view(-1).to(dev)
-    g12 = ops.cam_sweep_proj(p[1].contiguous(), p[0].contiguous(), k4.contiguous())
-    h12 = torch.from_numpy(host_sweep_proj(p[1], p[0], k4)).to(dev)
     src = feats[0].contiguous()
-    wg = ops.homo_warping_chw(src, g12, dv, D)
-    wh = ops.homo_warping_chw(src, h12, dv, D)
+    wg = ops.homo_warping_chw(src, devm["sweep"][0, 0].contiguous(), dv, D)
+    wh = ops.homo_warping_chw(src, host["sweep"][0, 0].contiguous(), dv, D)
     dgh = (wg - wh).abs().amax(0)
     report["plane_sweep_device_vs_host_matrices"] = {"voxels": int(dgh.numel()), "voxels_gt_1e-3": int((dgh > 1e-3).sum()),
                                                      "max": float(dgh.max())}
     del wg, wh, dgh
 
-    def run_gpu():
+    def run_gpu(mode):
+        model.camera_algebra = mode
         with torch.no_grad():
             out, _, _ = model(x_imgs, x_poses, intr, x_sample, pre_costs, list(pre_poses) if pre_poses else None, mode="val")
         torch.cuda.synchronize()
         return {k: v.cpu().numpy() for k, v in out.items()}
 
-    out_dev = run_gpu()
-    # ---- inject the oracle's matrices ----
-    orig = (ops.cam_sweep_proj, ops.cam_volume_mats)
-
-    def inj_sweep(ref_pose, src_pose, K):
-        return torch.from_numpy(host_sweep_proj(ref_pose, src_pose, K)).to(ref_pose.device)
-
-    def inj_vol(pose_j, pose_i, K, out=None):
-        m = torch.from_numpy(host_volume_mats(pose_j, pose_i, K)).to(pose_j.device)
-        if out is not None:
-            out.copy_(m)
-            return out
-        return m
-
-    ops.cam_sweep_proj, ops.cam_volume_mats = inj_sweep, inj_vol
-    out_inj = run_gpu()
-    ops.cam_sweep_proj, ops.cam_volume_mats = orig
+    out_dev = run_gpu("device")
+    out_inj = run_gpu("host")
     dd = {}
     for k in out_dev:
         if k[0] == "depth":
