@@ -15,8 +15,8 @@ matrices; the per-voxel arithmetic in the kernels then reproduces the reference'
     hybrid_depth_decoder.py:235 rel = pose_j @ inverse(pose_i)                       
     homo_utils.py:258, :51      inverse(rel), inverse(K)
 
-Cost: one small D2H copy of the poses (a synchronisation point unless they are handed in as CPU tensors), ~40 ATen CPU
-calls, one H2D copy -- about 0.2 ms per forward.  ``mode="device"`` keeps everything on the GPU (estd_cam_* kernels, fp64
+Cost: one small D2H copy of the poses, ~40 ATen CPU calls (one C++ operator), one H2D copy.  The copy is queued before the 2D
+networks of the forward and awaited after they are launched (begin() / finish()), so the host work overlaps GPU work.  ``mode="device"`` keeps everything on the GPU (estd_cam_* kernels, fp64
 Gauss-Jordan, no synchronisation) for latency-critical eager callers that accept the boundary-sample caveat above.
 """
 import torch
@@ -92,22 +92,74 @@ def relative_volume_matrix(rel_pose, cam_intr_q, device):
     return torch.cat([torch.inverse(K)[0].reshape(-1), m[0, :3, :].reshape(-1), K[0].reshape(-1)]).to(device)
 
 
-def forward_matrices(cam_poses, cam_intr_q, pre_poses, with_volume, device):
-    """Everything one DepthNetHybrid.forward needs, in ONE device-to-host copy, one C++ call and one host-to-device copy:
-    {"sweep": [T,2,12], "vol": [T,n,30] or None}.  The C++ operator estdepth_hip::camera_matrices_host (csrc/torch_ops.cpp)
-    makes the same ATen CPU calls as sweep_projections() / volume_matrices() above (bit-identical, tests/test_camera_host.py)
-    without ~40 trips through the Python dispatcher: while this runs the GPU has nothing queued, so host time is step time."""
+class _PinnedRing:
+    """a few page-locked staging buffers per size, reused round-robin: asynchronous copies need pinned memory, and a buffer
+    must not be rewritten while a copy that reads it may still be queued (4 forwards deep is far beyond what can be in flight)."""
+
+    def __init__(self, depth=4):
+        self.depth, self.bufs, self.next = depth, {}, {}
+
+    def get(self, n):
+        ring = self.bufs.setdefault(n, [])
+        if len(ring) < self.depth:
+            ring.append(torch.empty(n, dtype=torch.float32).pin_memory())
+            return ring[-1]
+        i = self.next.get(n, 0)
+        self.next[n] = (i + 1) % self.depth
+        return ring[i]
+
+
+_pinned = _PinnedRing()
+
+
+class _Pending:
+    __slots__ = ("flat_cpu", "event", "V", "n_pre", "with_volume", "device")
+
+
+def begin(cam_poses, cam_intr_q, pre_poses, with_volume, device):
+    """Queue ONE asynchronous device-to-host copy of the poses / intrinsics / memory poses of a forward and return a handle
+    for finish().  Called BEFORE the 2D networks are launched: the copy only waits for work that was queued earlier, and the
+    host meets its completion event while the GPU is busy with the 2D networks (CPU tensors: nothing to wait for)."""
     pre = list(pre_poses) if (with_volume and pre_poses is not None) else []
-    flat = torch.cat([cam_poses.reshape(-1).float(), cam_intr_q.reshape(-1).float()] + [p.reshape(-1).float() for p in pre])
-    flat = flat.detach().to("cpu")                                     # the one synchronisation point of a forward
-    V = cam_poses.shape[1]
+    parts = [cam_poses.reshape(-1).float(), cam_intr_q.reshape(-1).float()] + [p.reshape(-1).float() for p in pre]
+    p = _Pending()
+    p.V, p.n_pre, p.with_volume, p.device = cam_poses.shape[1], len(pre), bool(with_volume), device
+    if all(t.is_cuda for t in parts):
+        flat = torch.cat(parts).detach()
+        p.flat_cpu = _pinned.get(flat.numel())
+        p.flat_cpu.copy_(flat, non_blocking=True)
+        p.event = torch.cuda.Event()
+        p.event.record()
+    else:
+        p.flat_cpu, p.event = torch.cat([t.detach().cpu() for t in parts]), None
+    return p
+
+
+def finish(p):
+    """{"sweep": [T,2,12], "vol": [T,n,30] or None} on the device.  One C++ call -- estdepth_hip::camera_matrices_host
+    (csrc/torch_ops.cpp) makes the same ATen CPU calls as sweep_projections() / volume_matrices() above (bit-identical,
+    tests/test_camera_host.py) without ~40 trips through the Python dispatcher -- and one asynchronous host-to-device copy."""
+    if p.event is not None:
+        p.event.synchronize()
+    flat, V = p.flat_cpu, p.V
     poses = flat[:V * 16].reshape(1, V, 4, 4)
     K = flat[V * 16:V * 16 + 9].reshape(1, 3, 3)
-    pre_cpu = [flat[V * 16 + 9 + 16 * i:V * 16 + 25 + 16 * i].reshape(1, 4, 4) for i in range(len(pre))]
-    sweep, vol = ops.T().camera_matrices_host(poses, K, pre_cpu, bool(with_volume))
-    both = torch.cat([sweep.reshape(-1), vol.reshape(-1)]).to(device)
-    n_sweep = sweep.numel()
-    return {"sweep": both[:n_sweep].reshape(sweep.shape), "vol": both[n_sweep:].reshape(vol.shape) if with_volume else None}
+    pre_cpu = [flat[V * 16 + 9 + 16 * i:V * 16 + 25 + 16 * i].reshape(1, 4, 4) for i in range(p.n_pre)]
+    sweep, vol = ops.T().camera_matrices_host(poses, K, pre_cpu, p.with_volume)
+    n_sweep, n = sweep.numel(), sweep.numel() + vol.numel()
+    if torch.device(p.device).type == "cuda":
+        stage = _pinned.get(n)
+        stage[:n_sweep].copy_(sweep.reshape(-1))
+        stage[n_sweep:].copy_(vol.reshape(-1))
+        both = stage.to(p.device, non_blocking=True)
+    else:
+        both = torch.cat([sweep.reshape(-1), vol.reshape(-1)])
+    return {"sweep": both[:n_sweep].reshape(sweep.shape), "vol": both[n_sweep:].reshape(vol.shape) if p.with_volume else None}
+
+
+def forward_matrices(cam_poses, cam_intr_q, pre_poses, with_volume, device):
+    """begin() + finish() back to back (callers with nothing to overlap)."""
+    return finish(begin(cam_poses, cam_intr_q, pre_poses, with_volume, device))
 
 
 # ------------------------------------------------------------------------------------------------ device variants

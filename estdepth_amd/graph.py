@@ -2,7 +2,9 @@
 
 A forward pass is ~330 kernel launches (MIOpen 2D backbones + our HIP kernels) with static shapes; launched
 eagerly the GPU idles ~12 % of the step between launches (profiles/).  ``GraphedForward`` captures one forward
-per call signature into a hipGraph on first use and replays it afterwards.  It is a drop-in for the model in
+per call signature into TWO hipGraphs on first use -- stage A: the camera-independent 2D networks, stage B: everything from
+the plane sweep on -- and replays them afterwards; between the two launches the host composes the camera matrices
+(estdepth_amd/camera.py) while the GPU is busy with stage A, so the exact host-side algebra costs no GPU time.  It is a drop-in for the model in
 every inference call site of the reference (``eval_hybrid.py:229-243``, ``eval_hybrid_seq.py:160-193``) and in
 ``estdepth_amd.streaming.ESTMStream`` (attribute access falls through to the wrapped model).
 
@@ -21,6 +23,7 @@ weights epoch of the model): ``load_state_dict`` / ``.to()`` bump the epoch and 
 """
 import torch
 
+from . import camera
 from .hybrid_depth_decoder import kv_from_pair, kv_views
 from .layers_op import PlanCache
 
@@ -44,12 +47,8 @@ class GraphedForward:
         n_mem = 0 if pre_costs is None else len(pre_costs["keys"])
         from . import ops
         return (tuple(imgs.shape), n_mem, matching_features is not None, mode, ops.CONV3D_ARITH, ops.CONV2D_ARITH,
-                getattr(self.model, "_estd_weights_epoch", 0))     # a captured graph bakes kernel choice and weight buffers in
-
-    def _camera(self, cam_poses, cam_intr, pre_cam_poses):
-        m = self.model
-        k4 = m.scale_cam_intr(cam_intr, scale=1. / m.stage_infos["stage1"]["scale"])
-        return m.camera_matrices(cam_poses, k4, pre_cam_poses)
+                self.model.camera_algebra,
+                getattr(self.model, "_estd_weights_epoch", 0))     # (last) a captured graph bakes kernel choice and weight buffers in
 
     def _capture(self, key, imgs, cam_poses, cam_intr, sample, pre_costs, pre_cam_poses, mode, matching_features):
         m = self.model
@@ -59,30 +58,36 @@ class GraphedForward:
         if pre_costs is not None:
             st["kv"] = [kv_from_pair(k, v).clone() for k, v in zip(pre_costs["keys"], pre_costs["values"])]
             st["mem_poses"] = [p.clone() for p in pre_cam_poses]
-        # camera matrices are evaluated on the host (estdepth_amd/camera.py) OUTSIDE the graph and enter it as static inputs
-        st["cam"] = self._camera(cam_poses, cam_intr, pre_cam_poses)
+        # Host camera algebra (estdepth_amd/camera.py): the matrices enter stage B as static inputs.  In "device" mode they
+        # are formed by kernels inside stage B from the static pose buffers.
+        pending = m.camera_begin(cam_poses, cam_intr, pre_cam_poses)
+        st["cam"] = camera.finish(pending) if pending is not None else None
 
-        def run():
+        def run_a():                                     # stage A: camera-independent 2D networks, streams joined at the end
+            return m.forward_2d(st["imgs"], st["feats"], join=True)
+
+        def run_b(feats):                                # stage B: everything downstream of the plane sweep
             pc, pp = None, None
             if pre_costs is not None:
                 pairs = [kv_views(kv) for kv in st["kv"]]
                 pc = {"keys": [k for k, _ in pairs], "values": [v for _, v in pairs]}
                 pp = list(st["mem_poses"])
-            return m(st["imgs"], st["poses"], st["intr"], st["sample"], pc, pp, mode=mode, matching_features=st["feats"],
-                     cam_mats=st["cam"])
+            return m.forward_3d(feats, st["poses"], st["intr"], st["sample"], pc, pp, mode, cam_mats=st["cam"])
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(self.warmup):      # MIOpen algorithm search, hipFuncSetAttribute, plan packing: all before capture
-                run()
+                run_b(run_a())
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # thread_local: other threads (e.g. the RCCL watchdog polling events) may keep issuing HIP calls during capture
-        with torch.no_grad(), torch.cuda.graph(g, capture_error_mode="thread_local"):
-            out = run()
-        st["graph"], st["out"] = g, out
+        with torch.no_grad(), torch.cuda.graph(ga, capture_error_mode="thread_local"):
+            feats = run_a()
+        with torch.no_grad(), torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
+            out = run_b(feats)
+        st["graph_a"], st["graph_b"], st["feats2d"], st["out"] = ga, gb, feats, out
         # the replay reads the packed-weight buffers that existed at capture time: keep them alive even if a PlanCache
         # is rebuilt later (stale-but-valid until the epoch check re-captures), never a use-after-free
         st["keepalive"] = [c._plans for c in (getattr(mod, "_cache", None) for mod in m.modules()) if isinstance(c, PlanCache)]
@@ -100,10 +105,8 @@ class GraphedForward:
         st = self._graphs.get(key)
         if st is None:
             st = self._capture(key, imgs, cam_poses, cam_intr, sample, pre_costs, pre_cam_poses, mode, matching_features)
-        cam = self._camera(cam_poses, cam_intr, pre_cam_poses)
-        for name, t in cam.items():
-            if t is not None:
-                st["cam"][name].copy_(t)
+        # 1. the asynchronous device-to-host copy of the poses goes FIRST into the stream ...
+        pending = self.model.camera_begin(cam_poses, cam_intr, pre_cam_poses)
         st["imgs"].copy_(imgs)
         st["poses"].copy_(cam_poses)
         st["intr"].copy_(cam_intr)
@@ -118,7 +121,15 @@ class GraphedForward:
                     dst.copy_(src)
             for dst, p in zip(st["mem_poses"], pre_cam_poses):
                 dst.copy_(p)
-        st["graph"].replay()
+        # 2. ... then stage A (the 2D networks, ~25 % of a step) is launched; 3. while it runs the host waits for the copy,
+        # composes the camera matrices with the reference's own torch-CPU calls and queues their upload; 4. stage B.
+        st["graph_a"].replay()
+        if pending is not None:
+            cam = camera.finish(pending)
+            for name, t in cam.items():
+                if t is not None:
+                    st["cam"][name].copy_(t)
+        st["graph_b"].replay()
         outputs, costs, cposes = st["out"]
         # memory handed back to the caller: fresh tensors (they outlive the next replay)
         key_t, value_t = costs["keys"][0], costs["values"][0]

@@ -151,7 +151,8 @@ class DepthHybridDecoder(nn.Module):
         if pre is not None:
             self._semantic_vs_pre = None
             stream, sv = pre
-            torch.cuda.current_stream().wait_stream(stream)           # join the semantic branch
+            if stream is not None:
+                torch.cuda.current_stream().wait_stream(stream)       # join the semantic branch
             return sv
         return self._semantic_vs(semantic_features)
 

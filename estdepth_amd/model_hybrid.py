@@ -5,6 +5,8 @@ EST fusion and soft-argmin executed by hand-written gfx950 kernels.
 Inference only ('val' / 'test' style calls); the loss/metric bookkeeping of the reference's 'train'
 mode is outside this path.  abs_rel (model_hybrid.py:306) is provided for the benchmark report.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -189,35 +191,35 @@ class DepthNetHybrid(nn.Module):
         from .backbones import enable_hip_3x3
         self.use_channels_last_2d(True)
         self.matchingFeature.use_hip_convs(enable)
-        enable_hip_3x3(self.semanticFeature, enable)       # ResNet stride-1 3x3 convs (with fuse_bn_2d())
+        if os.environ.get("ESTD_R50_HIP", "1") == "1":     # A/B switch
+            enable_hip_3x3(self.semanticFeature, enable)   # ResNet stride-1 3x3 convs (with fuse_bn_2d())
         for name, child in self.CostRegNet.named_children():      # 2D decoder ConvBlocks with enough tiles (120x160 and up)
             if name.startswith("upconv"):
                 child._hip = bool(enable)
         return self
 
-    @torch.no_grad()        # inference-only implementation: the HIP operators do not record autograd graphs
-    def forward(self, imgs, cam_poses, cam_intr, sample, pre_costs=None, pre_cam_poses=None, mode='train',
-                matching_features=None, cam_mats=None):
-        """model_hybrid.py:110-184.  Two optional extensions: ``matching_features`` (estdepth_amd.streaming) = precomputed
-        PSM features [V,32,H/4,W/4] of the frames, so overlapping windows do not recompute them; ``cam_mats``
-        (estdepth_amd.graph) = the result of ``camera_matrices`` for these poses, evaluated outside a captured hipGraph.  imgs [1,V,3,Hi,Wi] in 0..255; cam_poses [1,V,4,4] camera-to-world;
-        cam_intr [1,3,3] full-resolution pixels; returns (outputs, cur_costs, cur_cam_poses) for
-        inference modes."""
-        if mode == 'train' or self.training:
-            raise RuntimeError("estdepth_amd implements the inference path (mode='val'/'test'); training is out of scope")
-        imgs = 2 * (imgs / 255.) - 1.
+    # The forward pass in two stages, so that the host can evaluate the camera matrices while the GPU is busy:
+    #   forward_2d  -- everything that does not depend on the cameras: PSM matching features of every frame and the semantic
+    #                  branch (ResNet + 2D decoder scales 4..2) of the target frames, ~25 % of a step;
+    #   forward_3d  -- plane sweeps, cost volumes, 3D regularisation, EST fusion, soft-argmin, 2D refinement.
+    # forward() starts the (asynchronous) device-to-host copy of the poses, launches stage 1, and only then waits for the
+    # copy and composes the matrices (estdepth_amd/camera.py): the synchronisation the exact host algebra needs costs no GPU time.
+    @torch.no_grad()
+    def forward_2d(self, imgs, matching_features=None, join=False):
+        """imgs [1,V,3,Hi,Wi] in 0..255 -> the camera-independent features.  ``join``: wait for the side stream before returning
+        (a captured hipGraph has to end with its streams joined)."""
+        imgs = 2 * (imgs / 255.) - 1.                                                                         # :119
         batch_size, views_num, _, height_img, width_img = imgs.shape
-        height, width = height_img // 4, width_img // 4
         assert views_num > 2  # the views_num should be larger than 2 (model_hybrid.py:123)
         if batch_size != 1:
             raise RuntimeError("estdepth_amd runs one sequence per call (the reference's view() also fails for batch > 1)")
         target_num = views_num - 2
-
         flat = imgs.reshape(batch_size * views_num, 3, height_img, width_img)
         if getattr(self, "_channels_last_2d", False):
             flat = flat.contiguous(memory_format=torch.channels_last)      # MIOpen NHWC kernels for the 2D backbones
+        sv_pre = None
         if getattr(self, "_overlap_semantic", False):
-            # fork: ResNet + 2D decoder scales 4..2 (many small MIOpen kernels) on a side stream, concurrently with the
+            # fork: ResNet + 2D decoder scales 4..2 (many small kernels) on a side stream, concurrently with the
             # PSM -> plane sweep -> pre1/pre2 chain; joined in the decoder right before dres2 needs the plane scores
             main = torch.cuda.current_stream()
             if getattr(self, "_side_stream", None) is None:
@@ -229,20 +231,30 @@ class DepthNetHybrid(nn.Module):
                 sv = self.CostRegNet._semantic_vs(semantic_features)
             for t_ in list(semantic_features) + [sv]:
                 t_.record_stream(main)
-            self.CostRegNet._semantic_vs_pre = (side, sv)
             matching = matching_features if matching_features is not None else self.matchingFeature(flat)   # :128
+            if join:
+                main.wait_stream(side)
+            sv_pre = (None if join else side, sv)
         else:
             matching = matching_features if matching_features is not None else self.matchingFeature(flat)   # :128
             semantic_features = self.semanticFeature(flat[1:1 + target_num])                               # :138-139 (batch 1)
+        return {"matching": matching, "semantic_features": semantic_features, "sv_pre": sv_pre, "views_num": views_num,
+                "device": imgs.device, "dtype": imgs.dtype}
+
+    @torch.no_grad()
+    def forward_3d(self, feats, cam_poses, cam_intr, sample, pre_costs=None, pre_cam_poses=None, mode="val", cam_mats=None):
+        matching, semantic_features, views_num = feats["matching"], feats["semantic_features"], feats["views_num"]
+        target_num = views_num - 2
         cam_intr_stage1 = self.scale_cam_intr(cam_intr, scale=1. / self.stage_infos["stage1"]["scale"])     # :142
-        dkey = (imgs.device, imgs.dtype)
+        dkey = (feats["device"], feats["dtype"])
         if getattr(self, "_dv_cache", None) is None or self._dv_cache[0] != dkey:      # one H2D copy, not one per call
-            self._dv_cache = (dkey, self.depth_cands.view(1, self.ndepths, 1, 1).to(imgs.dtype).to(imgs.device))
+            self._dv_cache = (dkey, self.depth_cands.view(1, self.ndepths, 1, 1).to(dkey[1]).to(dkey[0]))
         depth_values = self._dv_cache[1]                                                                     # :144-145
         dv = depth_values.reshape(-1).contiguous()
         if cam_mats is None:                                 # :74-88, homo_utils.py:469, decoder :235 (estdepth_amd/camera.py)
             cam_mats = self.camera_matrices(cam_poses, cam_intr_stage1, pre_cam_poses)
         self.CostRegNet._vol_mats_pre = cam_mats.get("vol")
+        self.CostRegNet._semantic_vs_pre = feats["sv_pre"]
 
         # every view is a source for up to two targets: mix each 2D feature once (pre0 pushed in front of the warp)
         P = self._plans()                                   # one cache-key check per forward
@@ -261,6 +273,29 @@ class DepthNetHybrid(nn.Module):
             masks = [sample["dmasks"][:, t + 1] for t in range(target_num)]
             return outputs, self.depth_metrics(outputs, [0, 2], gts, masks, target_num)
         return outputs, cur_costs, cur_cam_poses
+
+    def camera_begin(self, cam_poses, cam_intr, pre_cam_poses=None):
+        """start the asynchronous device-to-host copy of everything the host camera algebra reads (None in "device" mode)."""
+        if self.camera_algebra != "host":
+            return None
+        k4 = self.scale_cam_intr(cam_intr, scale=1. / self.stage_infos["stage1"]["scale"])
+        est = self.IF_EST_transformer and pre_cam_poses is not None
+        return camera.begin(cam_poses, k4, pre_cam_poses, est, self.pre0[0].weight.device)
+
+    @torch.no_grad()        # inference-only implementation: the HIP operators do not record autograd graphs
+    def forward(self, imgs, cam_poses, cam_intr, sample, pre_costs=None, pre_cam_poses=None, mode='train',
+                matching_features=None, cam_mats=None):
+        """model_hybrid.py:110-184.  imgs [1,V,3,Hi,Wi] in 0..255; cam_poses [1,V,4,4] camera-to-world; cam_intr [1,3,3]
+        full-resolution pixels; returns (outputs, cur_costs, cur_cam_poses) for inference modes.  Two optional extensions:
+        ``matching_features`` (estdepth_amd.streaming) = precomputed PSM features [V,32,H/4,W/4] of the frames, so overlapping
+        windows do not recompute them; ``cam_mats`` = the result of ``camera_matrices`` for these poses."""
+        if mode == 'train' or self.training:
+            raise RuntimeError("estdepth_amd implements the inference path (mode='val'/'test'); training is out of scope")
+        pending = self.camera_begin(cam_poses, cam_intr, pre_cam_poses) if cam_mats is None else None
+        feats = self.forward_2d(imgs, matching_features)
+        if pending is not None:
+            cam_mats = camera.finish(pending)
+        return self.forward_3d(feats, cam_poses, cam_intr, sample, pre_costs, pre_cam_poses, mode, cam_mats)
 
     METRIC_NAMES = ("a1", "a2", "a3", "abs_diff", "abs_rel", "sq_rel", "rmse", "rmse_log")
 
