@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--conv3d-arith", default=os.environ.get("ESTD_CONV3D_ARITH", "f32"), choices=["f32", "bf16x3"],
                     help="products of the plain 32->32 3D convolutions: native fp32 MFMA (default) or the exact 3-way bf16 "
                          "operand split with six bf16 MFMAs per product block (fp32-level error, opt-in)")
+    ap.add_argument("--conv3d-algo", default=os.environ.get("ESTD_CONV3D_ALGO", "wino"), choices=["wino", "direct"],
+                    help="plain 32->32 3D convolutions under f32 arithmetic: depth axis in Winograd F(2,3) form (2/3 of the fp32 MFMA "
+                         "products, csrc/conv3d_wino.hip; default) or the direct 27-tap implicit GEMM (csrc/conv3d_mfma.hip)")
     ap.add_argument("--no-alt", action="store_true", help="skip the second timed loop with the other convolution arithmetic")
     ap.add_argument("--conv2d-arith", default=os.environ.get("ESTD_CONV2D_ARITH", "f32"), choices=["f32", "bf16x3"],
                     help="same choice for the 3x3 NHWC convolutions of the PSM extractor / 2D decoder (opt-in)")
@@ -270,6 +273,7 @@ def main():
     from estdepth_amd import ops, parallel
     ops.CONV3D_ARITH = args.conv3d_arith
     ops.CONV2D_ARITH = args.conv2d_arith
+    ops.CONV3D_ALGO = args.conv3d_algo
     if args.workload == "stream":
         stream_bench(args, device, rank, world)
         if world > 1:
@@ -399,6 +403,7 @@ def main():
         value = frames * world * args.steps / elapsed
         peak = PEAK_FP32_MATRIX_TFLOPS if args.conv3d_arith == "f32" else PEAK_BF16_MATRIX_TFLOPS / 6.0
         mfma, hbm = summarize(prof, peak)
+        wino = args.conv3d_arith == "f32" and args.conv3d_algo == "wino"
         dom = mfma.get("conv3d:32->32", {"launches": 0, "avg_launch_ms": 0.0, "achieved_tflops": 0.0, "frac": 0.0, "gflop_per_launch": 0.0})
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 correction +
         # WRITE_SIZE, tools/pmc_collect.sh), scaled to this run's average volumes per launch; null if the file is absent
@@ -423,14 +428,21 @@ def main():
                        "input_frames_per_s": round(x_imgs.shape[1] * world * args.steps / elapsed, 3),
                        "launch": "eager" if (args.no_graph or state["fwd"] is model) else "hipGraph replay",
                        "conv3d_arith": args.conv3d_arith, "conv2d_arith": args.conv2d_arith,
+                       "conv3d_algo_32to32": args.conv3d_algo if args.conv3d_arith == "f32" else "direct",
                        "notes": state["notes"],
                        "per_rank_ms_per_step": per_rank_ms,
                        "parallelism": "1 sequence per GPU" + ("; RCCL all-gather of {K,V,pose} per step, overlapped with the next step" if gathered else "")},
             "roofline": {"bound": "mfma",
-                         "kernel": "conv3d_k3_kernel<32,2> (3x3x3 conv 32->32, fp32 MFMA 16x16x4)" if args.conv3d_arith == "f32" else
+                         "kernel": ("conv3d_wino_kernel (3x3x3 conv 32->32, fp32 MFMA 16x16x4, depth axis in Winograd F(2,3) form)" if wino else
+                                    "conv3d_k3_kernel<32,2> (3x3x3 conv 32->32, fp32 MFMA 16x16x4)") if args.conv3d_arith == "f32" else
                                    "conv3d_k3_split_kernel (3x3x3 conv 32->32, 6 x bf16 MFMA 16x16x32 per fp32 product block; peak = bf16 dense / 6)",
                          "achieved": dom["achieved_tflops"], "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": dom["frac"], "traffic": traffic,
+                         "frac": dom["frac"],
+                         # ALGORITHMIC FLOPs = the direct convolution's 2*27*Cin*Cout per voxel.  The Winograd kernel issues
+                         # 2/3 of them as MFMA products: `executed` is what the matrix pipe actually sustains, the figure to hold against the peak.
+                         "executed": round(dom["achieved_tflops"] * (2.0 / 3.0 if wino else 1.0), 2),
+                         "executed_frac": round(dom["frac"] * (2.0 / 3.0 if wino else 1.0), 4),
+                         "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, %s)" % traffic_src,
                          "launches": dom["launches"], "avg_launch_ms": dom["avg_launch_ms"],
                          "how": "HIP events around every launch in %d eager steps after the timed loop (same streams / overlap as the timed step)" % args.steps,

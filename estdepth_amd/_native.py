@@ -29,6 +29,7 @@ class Conv3dDesc(ctypes.Structure):
         ("head_w", ctypes.c_void_p), ("head_b", ctypes.c_void_p), ("out_head", ctypes.c_void_p),
         ("stats_partials", ctypes.c_void_p),
         ("w_split", ctypes.c_void_p),
+        ("w_wino", ctypes.c_void_p),
     ]
 
 
@@ -58,6 +59,7 @@ _SIGNATURES = {
                                               ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
     "estd_conv3d_k3": (ctypes.c_int, [ctypes.POINTER(Conv3dDesc), c_stream]),
     "estd_conv3d_k3_split": (ctypes.c_int, [ctypes.POINTER(Conv3dDesc), c_stream]),
+    "estd_conv3d_k3_wino": (ctypes.c_int, [ctypes.POINTER(Conv3dDesc), c_stream]),
     "estd_conv2d_k3": (ctypes.c_int, [ctypes.POINTER(Conv2dDesc), c_stream]),
     "estd_conv2d_k3_split": (ctypes.c_int, [ctypes.POINTER(Conv2dDesc), c_stream]),
     "estd_conv3d_k3_grid": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),

@@ -1,0 +1,354 @@
+// conv3d_wino.hip -- the plain 32 -> 32 3x3x3 convolution with the DEPTH axis in Winograd F(2,3) form, on gfx950 fp32 MFMA.
+//
+// Same operator and descriptor as estd_conv3d_k3 (csrc/conv3d_mfma.hip; networks/layers_op.py:16-39 as used at
+// hybrid_models/model_hybrid.py:59-60,:95, hybrid_models/hybrid_depth_decoder.py:84-95,:190-191 and the gate convolution of
+// transformer/epipolar_transformer.py:21): 24 of the ~33 volume convolutions of a Joint step are this instance, and the direct
+// kernel already keeps the matrix pipe 90 % busy -- the way to go faster in fp32 is to issue fewer multiplies.
+//
+// F(2,3) along d (Lavin & Gray; exact in real arithmetic, every product still an fp32 MFMA with fp32 accumulation):
+//   two output planes y_d, y_d+1 from four input planes x_d-1 .. x_d+2 and the three depth taps g0, g1, g2 of a (kh, kw) filter
+//   column:
+//       t0 = x_d-1 - x_d+1      U0 = g0                   y_d   = m0 + m1 + m2
+//       t1 = x_d   + x_d+1      U1 = (g0 + g1 + g2) / 2   y_d+1 = m1 - m2 - m3        with m_i = conv2d_3x3(t_i, U_i)
+//       t2 = x_d+1 - x_d        U2 = (g0 - g1 + g2) / 2
+//       t3 = x_d   - x_d+2      U3 = g2
+//   4 x 9 tap products instead of 2 x 27: 2/3 of the MFMA work.  The transformed filters U are packed on the host in fp64
+//   (estdepth_amd/packing.py::pack_conv3d_wino); the input transform is two subtractions and an addition per element, done in
+//   registers when a slice pair enters LDS.  Rounding: one extra fp32 rounding on the inputs (|t| <= 2 max|x|) and on U1, U2 --
+//   the measured error against an fp64 convolution is 1.3x the direct kernel's (tests/test_gpu_wino.py).
+//
+// Work decomposition (CDNA4):
+//   * a 512-thread workgroup (8 waves, ONE per CU: 92 KB of LDS) owns an output tile of 2 x 8 x 16 voxels (d, h, w) and walks a
+//     contiguous range of the column-major tile list upwards in d (persistent, XCD-aware ranges as in the direct kernel);
+//   * wave w = (row pair w & 3, channel half w >> 2): two 16-voxel M tiles (tile rows 2rp, 2rp+1) x one 16-channel N tile
+//     (channels 16nh .. 16nh+15) x the four products m0..m3 = 32 accumulator registers; the two waves of a SIMD cover each
+//     other's LDS latency and epilogue, which is what two co-resident workgroups do for the direct kernel;
+//   * LDS holds the four transformed slices (10 x 18 voxels x 32 channels each, same 16-byte XOR swizzle as the direct kernel);
+//     the two NEW raw planes of the next tile are fetched into registers during the MFMA loop (one 16-byte buffer load in each
+//     of the first six taps), the two planes shared with the current tile stay in registers;
+//   * weights stream from L2 in packed [tap][half][quad][lane] order, one tap ahead (2 KB per wave and tap, 295 KB in all);
+//   * epilogue: folded BN / bias, ReLU, residual(s), scale, running accumulation, GroupNorm partial sums -- the descriptor
+//     fields of the direct kernel's plain instance, applied to both output planes.
+// Measured (MI355X, 3 volumes of 64x120x160): 1.16-1.18 ms vs 1.56-1.59 ms for the direct kernel (1.35x; 173-176 TFLOP/s of
+// ALGORITHMIC work = 115-117 TFLOP/s executed on the matrix pipe).  Tried and dropped (profiles/README.md, round 2): a six-slot
+// ring of RAW slices with the input transform applied between LDS and the MFMA (one barrier per tile, no fill phase:
+// 1.31 ms -- twice the LDS reads), the tile's output stores issued from inside the next tile's tap loop (1.17 ms, no gain:
+// both waves of a SIMD are in the same phase), the next planes requested after the tap loop (1.20 ms).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "estd_hip.h"
+#include "estd_common.h"
+
+#ifndef ESTD_WABL
+#define ESTD_WABL 0     // timing ablations only (results are wrong when != 0): 1 no output stores, 2 no transform writes,
+#endif                  // 8 no weight stream, 16 no next-plane prefetch
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
+
+constexpr int TH = 8, TW = 16;
+constexpr int IN_H = TH + 2, IN_W = TW + 2;
+constexpr int SL_VOX = IN_H * IN_W;                 // 180 voxels per input slice (with halo)
+constexpr int SLICE_BYTES = SL_VOX * 128;           // 32 channels
+constexpr int NTHREADS = 512;
+constexpr int SL_CHUNKS = SL_VOX * 8;               // 16-byte chunks per slice: 1440
+constexpr int SIT = (SL_CHUNKS + NTHREADS - 1) / NTHREADS;     // chunks per thread per slice: 3
+constexpr int RED_BYTES = 8 * 2 * 8;                // GroupNorm scratch: 8 waves x {sum, sumsq} doubles
+constexpr int LDS_BYTES = 4 * SLICE_BYTES + RED_BYTES;
+constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;        // beyond num_records of any descriptor: loads return 0, stores are dropped
+
+__device__ __forceinline__ float4 as_float4(u32x4 v)
+{
+    float4 f;
+    __builtin_memcpy(&f, &v, 16);
+    return f;
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, size_t elems)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(elems * 4), 0x00020000);
+}
+
+// workgroup barrier that only orders LDS traffic (no vmcnt drain: prefetches and output stores stay in flight)
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__device__ __forceinline__ int lds_chunk_off(int v, int c) { return v * 128 + ((c ^ ((v >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ float act_apply(float v, int act)
+{
+    if (act == ESTD_ACT_RELU) return v > 0.0f ? v : 0.0f;
+    if (act == ESTD_ACT_TANH) return tanhf(v);
+    return v;
+}
+
+__device__ __forceinline__ float4 f4_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+__global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int dpairs, int total_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rp = wave & 3;            // tile rows 2rp, 2rp+1
+    const int nh = wave >> 2;           // output channels 16nh .. 16nh+15
+    const int g = lane >> 4;            // k index inside an MFMA
+    const int i = lane & 15;            // M row (A) / N column (B, D)
+    const int D = p.D, H = p.H, W = p.W;
+    const int HW = H * W;
+    const size_t vol = (size_t)D * HW;
+
+    // ---- range of the flattened tile list (column-major: the d pairs of one (n, h-tile, w-tile) column are consecutive) ----
+    int u, u_end;
+    {
+        const int G = gridDim.x, bid = blockIdx.x;
+        const int r = ((G & 7) == 0) ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;       // XCD x owns a contiguous block of ranges
+        u = (int)((long long)total_tiles * r / G);
+        u_end = (int)((long long)total_tiles * (r + 1) / G);
+    }
+    if (u >= u_end) return;
+
+    const int ch = 16 * nh + i;                     // this lane's output channel
+    const float sc = p.scale[ch], sh = p.shift[ch];
+    const int act0 = ch < p.act_split ? p.act_a : p.act_b;
+    // packed weights: [37 taps (36 + 1 the prefetch may read)][2 halves][2 quads][64 lanes][4]
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w_wino, (size_t)37 * 2 * 2 * 256);
+    const int wlane = lane * 16 + nh * 2048;
+    const int row0 = 2 * rp;
+
+    while (u < u_end) {
+        // ---- column segment [u, seg_end): same (n, h-tile, w-tile), consecutive depth pairs ----
+        const int col = u / dpairs;
+        int dp = u - col * dpairs;
+        const int twi = col % tiles_w, c2 = col / tiles_w;
+        const int thi = c2 % tiles_h, n = c2 / tiles_h;
+        const int tw0 = twi * TW, th0 = thi * TH;
+        const int seg_end = min(u_end, (col + 1) * dpairs);
+
+        const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in_main + (size_t)n * vol * p.in_stride, vol * p.in_stride);
+        __amdgpu_buffer_rsrc_t rs_out = rs_in, rs_res = rs_in, rs_res2 = rs_in;
+        rs_out = make_rsrc(p.out_main + (size_t)n * vol * p.out_stride, vol * p.out_stride);
+        if (p.residual) rs_res = make_rsrc(p.residual + (size_t)n * vol * p.out_stride, vol * p.out_stride);
+        if (p.residual2) rs_res2 = make_rsrc(p.residual2 + (size_t)n * vol * p.out_stride, vol * p.out_stride);
+        const int in_slice_bytes = HW * p.in_stride * 4;
+        const int out_plane_bytes = HW * p.out_stride * 4;
+
+        // per-thread slice elements (validity in y / x does not depend on d)
+        unsigned voff[SIT];
+        int loff[SIT];
+#pragma unroll
+        for (int it = 0; it < SIT; ++it) {
+            const int e = tid + it * NTHREADS;
+            const int vs = e >> 3, c = e & 7;
+            const int zy = vs / IN_W, zx = vs % IN_W;
+            const int gy = th0 - 1 + zy, gx = tw0 - 1 + zx;
+            const bool ok = e < SL_CHUNKS && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            voff[it] = ok ? (unsigned)((gy * W + gx) * p.in_stride + c * 4) * 4u : OOB_OFFSET;
+            loff[it] = e < SL_CHUNKS ? lds_chunk_off(vs, c) : -1;
+        }
+        auto load_plane = [&](int pd, float4 (&dst)[SIT]) {
+            const bool pv = (unsigned)pd < (unsigned)D;        // wave-uniform; planes outside the volume are zero padding
+#pragma unroll
+            for (int it = 0; it < SIT; ++it)
+                dst[it] = pv ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[it], pd * in_slice_bytes, 0))
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+
+        // epilogue lane offsets (bytes inside one depth plane): rows row0, row0+1; columns 4g .. 4g+3 of the tile
+        const int ey0 = th0 + row0, ex0 = tw0 + 4 * g;
+        unsigned eoff[2][4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int y = ey0 + m, x = ex0 + r;
+                eoff[m][r] = (y < H && x < W) ? (unsigned)((y * W + x) * p.out_stride + ch) * 4u : OOB_OFFSET;
+            }
+
+        // one (plane, tile row) of the epilogue: the four voxels of row m this lane holds
+        auto epi_row = [&](const f32x4& a, int m, int dd) {
+            const int so = dd * out_plane_bytes;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned eo = eoff[m][r];
+                float v = act_apply(a[r] * sc + sh, act0);
+                if (p.residual) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, eo, so, 0));
+                if (p.residual2) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res2, eo, so, 0));
+                v *= p.out_scale;
+                if (p.accumulate) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_out, eo, so, 0));
+                if (!(ESTD_WABL & 1)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, eo, so, 0);
+            }
+        };
+        // GroupNorm(1 group) partial sums of the raw outputs of one plane: group = channel half nh.  Fixed-order reduction
+        // (lanes by butterfly, the four row-pair waves of a half through LDS) -> deterministic.  Workgroup-uniform call.
+        auto plane_stats = [&](const f32x4 (&a)[2], int dd) {
+            double s_sum = 0.0, s_sq = 0.0;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (eoff[m][r] != OOB_OFFSET) { const double v = (double)(a[m][r] * sc + sh); s_sum += v; s_sq += v * v; }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { s_sum += __shfl_xor(s_sum, o); s_sq += __shfl_xor(s_sq, o); }
+            double* red = reinterpret_cast<double*>(smem + 4 * SLICE_BYTES);
+            __syncthreads();                                     // the previous plane's scratch has been consumed
+            if (lane == 0) { red[wave * 2] = s_sum; red[wave * 2 + 1] = s_sq; }
+            __syncthreads();
+            if (tid < 4) {
+                const int grp = tid >> 1, q = tid & 1;
+                const double tot = red[(grp * 4 + 0) * 2 + q] + red[(grp * 4 + 1) * 2 + q] + red[(grp * 4 + 2) * 2 + q] + red[(grp * 4 + 3) * 2 + q];
+                // partial index = canonical tile id (n, d, thi, twi), as the direct kernel writes it
+                const size_t tile_id = (((size_t)n * D + dd) * tiles_h + thi) * tiles_w + twi;
+                p.stats_partials[tile_id * 4 + tid] = tot;
+            }
+        };
+
+        // raw planes in registers: xa = x[d0-1], xb = x[d0], xc = x[d0+1], xd = x[d0+2]
+        float4 xa[SIT], xb[SIT], xc[SIT], xd[SIT];
+        {
+            const int d0 = 2 * dp;
+            load_plane(d0 - 1, xa);
+            load_plane(d0, xb);
+            load_plane(d0 + 1, xc);
+            load_plane(d0 + 2, xd);
+        }
+
+        for (; u < seg_end; ++u, ++dp) {
+            const int d0 = 2 * dp;
+            lds_barrier();                              // every wave is done reading the previous tile's slices
+            // ---- input transform B^T x along depth, straight into the four LDS slices ----
+#pragma unroll
+            for (int it = 0; it < SIT; ++it) {
+                if ((it < SIT - 1 || loff[it] >= 0) && !(ESTD_WABL & 2)) {
+                    *reinterpret_cast<float4*>(smem + 0 * SLICE_BYTES + loff[it]) = f4_sub(xa[it], xc[it]);
+                    *reinterpret_cast<float4*>(smem + 1 * SLICE_BYTES + loff[it]) = f4_add(xb[it], xc[it]);
+                    *reinterpret_cast<float4*>(smem + 2 * SLICE_BYTES + loff[it]) = f4_sub(xc[it], xb[it]);
+                    *reinterpret_cast<float4*>(smem + 3 * SLICE_BYTES + loff[it]) = f4_sub(xb[it], xd[it]);
+                }
+                xa[it] = xc[it];                         // planes d0+1, d0+2 are planes d0'-1, d0' of the next tile
+                xb[it] = xd[it];
+            }
+            lds_barrier();
+
+            const bool has_next = (u + 1 < seg_end);     // wave-uniform
+            const int nd = d0 + 3;                       // new planes of the next tile: nd, nd + 1
+            const bool v0 = nd < D, v1 = nd + 1 < D;
+
+            f32x4 acc[4][2];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[s][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+            float4 bcur[2], bnext[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) bcur[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, q * 1024, 0));
+#ifdef ESTD_TIMELINE
+            if (tid == 0 && p.stats_partials) {     // debug build only: per-tile start stamps instead of GroupNorm sums
+                const size_t tile_id = (((size_t)n * D + d0) * tiles_h + thi) * tiles_w + twi;
+                p.stats_partials[tile_id * 4 + 0] = (double)__builtin_amdgcn_s_memtime();
+                p.stats_partials[tile_id * 4 + 1] = (double)blockIdx.x;
+                p.stats_partials[tile_id * 4 + 2] = (double)wall_clock64();
+            }
+#endif
+            // A fragments of (transform s, tap kh kw): two 16-byte LDS reads per M tile (channels 4g.., 16+4g..)
+            auto load_a = [&](int tap, float4 (&a0)[2], float4 (&a1)[2]) {
+                const int s = tap / 9, kh = (tap % 9) / 3, kw = tap % 3;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int vs = (row0 + m + kh) * IN_W + kw + i;
+                    const int off0 = s * SLICE_BYTES + lds_chunk_off(vs, g);
+                    a0[m] = *reinterpret_cast<const float4*>(smem + off0);
+                    a1[m] = *reinterpret_cast<const float4*>(smem + (off0 ^ 64));
+                }
+            };
+            float4 a0c[2], a1c[2], a0n[2], a1n[2];
+            load_a(0, a0c, a1c);
+
+#pragma clang loop unroll(full)
+            for (int tap = 0; tap < 36; ++tap) {
+                const int s = tap / 9;
+                // next tap's weights (the packed buffer carries one padding tap)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (ESTD_WABL & 8) { bnext[q] = bcur[q]; asm volatile("" : "+v"(bnext[q].x)); }
+                    else bnext[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, (tap + 1) * 4096 + q * 1024, 0));
+                }
+                // one 16-byte chunk of the NEXT tile's two new planes per tap
+                if (has_next && tap < 2 * SIT && !(ESTD_WABL & 16)) {
+                    const int it = tap % SIT;
+                    if (tap < SIT) xc[it] = v0 ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[it], nd * in_slice_bytes, 0))
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+                    else           xd[it] = v1 ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[it], (nd + 1) * in_slice_bytes, 0))
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                if (tap + 1 < 36) load_a(tap + 1, a0n, a1n);          // next tap's A fragments: LDS latency under this tap's MFMAs
+                const float av0[8] = {a0c[0].x, a0c[0].y, a0c[0].z, a0c[0].w, a1c[0].x, a1c[0].y, a1c[0].z, a1c[0].w};
+                const float av1[8] = {a0c[1].x, a0c[1].y, a0c[1].z, a0c[1].w, a1c[1].x, a1c[1].y, a1c[1].z, a1c[1].w};
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {     // the two M tiles alternate: no MFMA waits for its own predecessor
+                    const float4 bq = bcur[ks >> 2];
+                    const float b = (ks & 3) == 0 ? bq.x : (ks & 3) == 1 ? bq.y : (ks & 3) == 2 ? bq.z : bq.w;
+                    acc[s][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[ks], b, acc[s][0], 0, 0, 0);
+                    acc[s][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[ks], b, acc[s][1], 0, 0, 0);
+                }
+                bcur[0] = bnext[0];
+                bcur[1] = bnext[1];
+                a0c[0] = a0n[0]; a0c[1] = a0n[1]; a1c[0] = a1n[0]; a1c[1] = a1n[1];
+                __builtin_amdgcn_sched_barrier(0);       // keep each tap's loads inside the tap (bounds live registers)
+            }
+
+            // ---- output transform A^T m and the epilogue of the two planes ----
+            f32x4 y0[2], y1[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                y0[m] = acc[0][m] + acc[1][m] + acc[2][m];
+                y1[m] = acc[1][m] - acc[2][m] - acc[3][m];
+            }
+            if (p.stats_partials) {                      // uniform; the GRU gate convolution (one volume per launch)
+                plane_stats(y0, d0);
+                if (d0 + 1 < D) plane_stats(y1, d0 + 1);              // (odd D: the last pair has one plane)
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                epi_row(y0[m], m, d0);
+                if (d0 + 1 < D) epi_row(y1[m], m, d0 + 1);
+            }
+        }
+    }
+}
+
+constexpr int PERSISTENT_WGS = 256;     // one 512-thread workgroup per CU (LDS-limited)
+
+}  // namespace
+
+extern "C" int estd_conv3d_k3_wino(const estd_conv3d_desc* dp, estd_stream_t s)
+{
+    if (!dp) return ESTD_ERR_ARG;
+    const estd_conv3d_desc& d = *dp;
+    if (d.N <= 0 || d.D <= 0 || d.H <= 0 || d.W <= 0) return ESTD_ERR_ARG;
+    if (!d.in_main || !d.w_wino || !d.scale || !d.shift || !d.out_main) return ESTD_ERR_ARG;
+    // the plain 32 -> 32 instance only: no extra input channel, no 33rd output, no fused head
+    if (d.cin_main != 32 || d.n_tiles != 2 || d.in_extra || d.out_extra || d.out_head) return ESTD_ERR_UNSUPPORTED;
+    if (d.in_stride < 32 || (d.in_stride & 3) || d.out_stride < 32 || (d.act_split & 1)) return ESTD_ERR_ARG;
+    const int tiles_w = (d.W + TW - 1) / TW, tiles_h = (d.H + TH - 1) / TH, dpairs = (d.D + 1) / 2;
+    const long long total = (long long)d.N * dpairs * tiles_h * tiles_w;
+    if (total > 0x7fffffffLL) return ESTD_ERR_ARG;
+    {   // buffer descriptors address one volume of the batch with 32-bit byte offsets
+        const long long vox = (long long)d.D * d.H * d.W;
+        const int widest = d.in_stride > d.out_stride ? d.in_stride : d.out_stride;
+        if (vox * widest * 4 >= 0x7fffff00LL) return ESTD_ERR_UNSUPPORTED;
+    }
+    int grid = total < PERSISTENT_WGS ? (int)total : PERSISTENT_WGS;
+    if (grid >= 8) grid &= ~7;
+    estd_allow_dynamic_lds<conv3d_wino_kernel>(LDS_BYTES);
+    hipLaunchKernelGGL(conv3d_wino_kernel, dim3(grid), dim3(NTHREADS), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h, dpairs, (int)total);
+    return ESTD_LAUNCH_CHECK();
+}

@@ -113,11 +113,11 @@ void homo_warp_costvol(const Tensor& src_mix, const Tensor& ref_mix, const Tenso
 // Volumes are addressed as base pointers + strides (views into wider channels-last records are allowed), so only device
 // and dtype are checked for them; the C ABI validates the stride / channel combinations.
 void conv3d_k3(const Tensor& x, const OptTensor& x_extra, const Tensor& w_main, const OptTensor& w_extra, const OptTensor& w_xout,
-               const OptTensor& w_split, const Tensor& scale, const Tensor& shift, at::IntArrayRef dims, int64_t cin_main,
+               const OptTensor& w_alt, const Tensor& scale, const Tensor& shift, at::IntArrayRef dims, int64_t cin_main,
                int64_t in_stride, int64_t n_tiles, int64_t act_a, int64_t act_b, int64_t act_split, const OptTensor& out,
                int64_t out_stride, int64_t out_channels, const OptTensor& residual, const OptTensor& residual2, double out_scale,
                bool accumulate, const OptTensor& out_extra, const OptTensor& head_w, const OptTensor& head_b, const OptTensor& out_head,
-               const OptTensor& stats_partials, bool split_arith)
+               const OptTensor& stats_partials, int64_t variant)
 {
     TORCH_CHECK(dims.size() == 4, "conv3d_k3: dims = (N, D, H, W)");
     estd_conv3d_desc d{};
@@ -151,11 +151,17 @@ void conv3d_k3(const Tensor& x, const OptTensor& x_extra, const Tensor& w_main, 
         TORCH_CHECK(blocks > 0 && stats_partials->numel() >= (int64_t)blocks * 4, "conv3d_k3: stats_partials needs 4 doubles per tile");
         d.stats_partials = stats_partials->data_ptr<double>();
     }
-    if (split_arith) {
-        TORCH_CHECK(w_split.has_value() && w_split->defined() && w_split->is_cuda(), "conv3d_k3: split arithmetic needs the split weights");
-        d.w_split = w_split->data_ptr();
+    // variant: 0 = direct fp32 MFMA; 1 = exact 3 x bf16 operand split (w_alt = split weights); 2 = fp32 MFMA with the depth
+    // axis in Winograd F(2,3) form (w_alt = transformed filters)
+    if (variant != 0) TORCH_CHECK(w_alt.has_value() && w_alt->defined() && w_alt->is_cuda(), "conv3d_k3: this variant needs its packed weights");
+    if (variant == 1) {
+        d.w_split = w_alt->data_ptr();
         check_status(estd_conv3d_k3_split(&d, cur_stream()), "estd_conv3d_k3_split");
+    } else if (variant == 2) {
+        d.w_wino = fptr(*w_alt, "Winograd-packed weights");
+        check_status(estd_conv3d_k3_wino(&d, cur_stream()), "estd_conv3d_k3_wino");
     } else {
+        TORCH_CHECK(variant == 0, "conv3d_k3: unknown variant ", variant);
         check_status(estd_conv3d_k3(&d, cur_stream()), "estd_conv3d_k3");
     }
 }
@@ -419,10 +425,10 @@ TORCH_LIBRARY(estdepth_hip, m)
     m.def("homo_warping(Tensor src_fea, Tensor proj12, Tensor depth_values, int D) -> Tensor");
     m.def("mix1x1(Tensor feature, Tensor weight, Tensor? bias) -> Tensor");
     m.def("homo_warp_costvol(Tensor src_mix, Tensor ref_mix, Tensor proj12, Tensor depth_values, int D, Tensor(a!) out) -> ()");
-    m.def("conv3d_k3(Tensor x, Tensor? x_extra, Tensor w_main, Tensor? w_extra, Tensor? w_xout, Tensor? w_split, Tensor scale, Tensor shift, "
+    m.def("conv3d_k3(Tensor x, Tensor? x_extra, Tensor w_main, Tensor? w_extra, Tensor? w_xout, Tensor? w_alt, Tensor scale, Tensor shift, "
           "int[] dims, int cin_main, int in_stride, int n_tiles, int act_a, int act_b, int act_split, Tensor(a!)? out, int out_stride, "
           "int out_channels, Tensor? residual, Tensor? residual2, float out_scale, bool accumulate, Tensor(b!)? out_extra, Tensor? head_w, "
-          "Tensor? head_b, Tensor(c!)? out_head, Tensor(d!)? stats_partials, bool split_arith) -> ()");
+          "Tensor? head_b, Tensor(c!)? out_head, Tensor(d!)? stats_partials, int variant) -> ()");
     m.def("conv2d_k3(Tensor x_nhwc, Tensor w, Tensor? w_split, Tensor scale, Tensor shift, int cout, int dilation, int group_tiles, "
           "bool relu_before_residual, bool relu_after_residual, Tensor? residual, bool split_arith) -> Tensor");
     m.def("groupnorm_finalize(Tensor partials, int n_blocks, float count, float eps) -> Tensor");

@@ -73,6 +73,9 @@ class _Prof:
 # "bf16x3" = exact 3-way bf16 operand split, six bf16 MFMAs per product block (csrc/conv3d_split_bf16.hip).
 CONV3D_ARITH = os.environ.get("ESTD_CONV3D_ARITH", "f32")
 CONV2D_ARITH = os.environ.get("ESTD_CONV2D_ARITH", "f32")     # same choice for the 3x3 / dilation-1 NHWC convolutions
+# Algorithm of the plain 32->32 3x3x3 convolutions under CONV3D_ARITH == "f32" (every product an fp32 MFMA either way):
+# "wino" = depth axis in Winograd F(2,3) form, 2/3 of the products (csrc/conv3d_wino.hip); "direct" = 27 taps (csrc/conv3d_mfma.hip)
+CONV3D_ALGO = os.environ.get("ESTD_CONV3D_ALGO", "wino")
 
 
 def _stream():
@@ -184,6 +187,8 @@ class Conv3dPlan:
         splittable = len(main_idx) == 32 and head_w is None and \
             (n_tiles == 2 or (n_tiles == 3 and extra_idx is not None) or (n_tiles == 1 and extra_idx is None))
         self.w_split = packing.pack_conv3d_split(weight, main_idx, out_idx, extra_idx, n_tiles).to(device) if splittable else None
+        wino_ok = len(main_idx) == 32 and n_tiles == 2 and extra_idx is None and head_w is None and len(out_idx) == 32
+        self.w_wino = packing.pack_conv3d_wino(weight, main_idx, out_idx).to(device) if wino_ok else None
         self.w_main = wm.to(device)
         self.w_extra = wx.to(device) if wx is not None else None
         self.scale = scale.float().contiguous().to(device)
@@ -226,13 +231,18 @@ class Conv3dPlan:
         else:
             inst = not tanh
         split = CONV3D_ARITH == "bf16x3" and self.w_split is not None and out is not None and inst
+        if CONV3D_ALGO not in ("wino", "direct"):
+            raise RuntimeError("ESTD_CONV3D_ALGO must be wino or direct, got %r" % (CONV3D_ALGO,))
+        wino = (not split) and CONV3D_ALGO == "wino" and self.w_wino is not None and out is not None and not tanh \
+            and out_extra is None and out_head is None and out_channels == 32
+        variant, w_alt = (1, self.w_split) if split else (2, self.w_wino) if wino else (0, None)
         cin = self.cin_main + (1 if self.w_extra is not None else 0)
         with _Prof("conv3d:%d->%d" % (cin, self.n_out), 2.0 * 27 * cin * self.n_out * Nn * D * H * W):
             if _use_torch():
-                T().conv3d_k3(x, in_extra, self.w_main, self.w_extra, self.w_xout, self.w_split if split else None, self.scale, self.shift,
+                T().conv3d_k3(x, in_extra, self.w_main, self.w_extra, self.w_xout, w_alt, self.scale, self.shift,
                               (Nn, D, H, W), self.cin_main, in_stride, self.n_tiles, self.act_a, self.act_b, self.act_split, out,
                               out_stride, out_channels, residual, residual2, float(out_scale), bool(accumulate), out_extra, head_w, head_b,
-                              out_head, stats_partials, split)
+                              out_head, stats_partials, variant)
                 return
             d = N.Conv3dDesc()
             d.N, d.D, d.H, d.W = Nn, D, H, W
@@ -258,6 +268,9 @@ class Conv3dPlan:
             if split:
                 d.w_split = self.w_split.data_ptr()
                 N.check(N.lib().estd_conv3d_k3_split(ctypes.byref(d), _stream()), "estd_conv3d_k3_split")
+            elif wino:
+                d.w_wino = self.w_wino.data_ptr()
+                N.check(N.lib().estd_conv3d_k3_wino(ctypes.byref(d), _stream()), "estd_conv3d_k3_wino")
             else:
                 N.check(N.lib().estd_conv3d_k3(ctypes.byref(d), _stream()), "estd_conv3d_k3")
 

@@ -201,3 +201,26 @@ def pack_conv2d_split(weight):
     rec = np.zeros((cout // 32, cin // 32, 9, 4096), np.uint16)
     rec[..., :3072] = np.stack(bf16_split3(sel), axis=3).reshape(cout // 32, cin // 32, 9, 3072)
     return torch.from_numpy(rec.view(np.int16).copy())
+
+
+def pack_conv3d_wino(weight, main_idx, out_idx):
+    """32 -> 32 filters for csrc/conv3d_wino.hip: the depth taps g0, g1, g2 of every (kh, kw) column in Winograd F(2,3) form
+    U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2 (evaluated in float64, rounded once to float32), packed
+    as float32 [37 taps][2 channel halves][2 quads][64 lanes][4]: tap = 9 s + 3 kh + kw (s = transform index), lane (g, j) of
+    half nh holds, at k-step t = 4 q + e, U_s[out_idx[16 nh + j]][main_idx[ch(g, t)]][kh][kw]; tap 36 is zero padding that
+    the kernel's one-tap-ahead prefetch may read."""
+    assert len(main_idx) == 32 and len(out_idx) == 32
+    w = weight.detach().double().cpu().numpy()                       # [Cout, Cin, kd, kh, kw]
+    g0, g1, g2 = w[:, :, 0], w[:, :, 1], w[:, :, 2]
+    U = np.stack([g0, (g0 + g1 + g2) * 0.5, (g0 - g1 + g2) * 0.5, g2], 0).astype(np.float32)       # [4, Cout, Cin, 3, 3]
+    U = U.reshape(4, U.shape[1], U.shape[2], 9)
+    out = np.zeros((37, 2, 2, 64, 4), np.float32)
+    oi, mi = np.asarray(out_idx), np.asarray(main_idx)
+    for lane in range(64):
+        g, j = lane >> 4, lane & 15
+        for t in range(8):
+            ci = mi[_ch(32, g, t)]
+            for nh in range(2):
+                # [4 s, 9 taps] -> taps 9 s + k
+                out[:36, nh, t // 4, lane, t % 4] = U[:, oi[16 * nh + j], ci, :].reshape(36)
+    return torch.from_numpy(out)

@@ -115,6 +115,9 @@ typedef struct estd_conv3d_desc {
     /* estd_conv3d_k3_split only: the 32->32 weights split into three bf16 pieces,
      * uint16 [27 taps][3 pieces][2 n-tiles][64 lanes][8] (packing.py::pack_conv3d_split), else NULL */
     const void* w_split;
+    /* estd_conv3d_k3_wino only: the 32->32 filters in depth-Winograd F(2,3) form, float32
+     * [37 taps (4 x 9 + 1 pad)][2 channel halves][2 quads][64 lanes][4] (packing.py::pack_conv3d_wino), else NULL */
+    const float* w_wino;
 } estd_conv3d_desc;
 
 int estd_conv3d_k3(const estd_conv3d_desc* desc, estd_stream_t stream);
@@ -123,6 +126,11 @@ int estd_conv3d_k3(const estd_conv3d_desc* desc, estd_stream_t stream);
  * fp32 accumulation; dropped terms <= 2^-26 |ab|): fp32-level error at 96 instead of 256 matrix-pipe cycles per
  * 16x16x32 block.  Reads w_split instead of w_main.  ESTD_ERR_UNSUPPORTED for any other shape. */
 int estd_conv3d_k3_split(const estd_conv3d_desc* desc, estd_stream_t stream);
+/* Same operator for the plain 32->32 instance (cin_main = 32, n_tiles = 2, no extra channel / head / 33rd output; BN, ReLU,
+ * residuals, scale, accumulation and GroupNorm partials as estd_conv3d_k3) with the depth axis in Winograd F(2,3) form:
+ * two output planes from four transformed input planes, 36 instead of 54 tap products, every product an fp32 MFMA with
+ * fp32 accumulation (csrc/conv3d_wino.hip).  Reads w_wino instead of w_main.  ESTD_ERR_UNSUPPORTED for any other shape. */
+int estd_conv3d_k3_wino(const estd_conv3d_desc* desc, estd_stream_t stream);
 /* number of thread blocks estd_conv3d_k3 launches for a volume (size of stats_partials / 4 doubles) */
 int estd_conv3d_k3_grid(int N, int D, int H, int W);
 

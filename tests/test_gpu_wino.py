@@ -1,0 +1,136 @@
+"""estd_conv3d_k3_wino (32 -> 32, depth axis in Winograd F(2,3) form on fp32 MFMA; csrc/conv3d_wino.hip) against
+  * an fp64 convolution of the same fp32 data (how much error does the transform add to the direct kernel's?),
+  * the direct fp32 MFMA kernel on every epilogue feature the plain instance has and on ragged shapes (odd D, D = 1, partial
+    tiles, batches), including the GroupNorm partial sums,
+  * the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X (no CPU path exists)")
+
+
+def _plan(seed, act="relu"):
+    from estdepth_amd import synth
+    from estdepth_amd.layers_op import ConvBN3d
+    mod = ConvBN3d(32, 32, 3, 1, 1, act).eval()
+    synth.fill_state_dict(mod, seed=seed)
+    mod = mod.to(DEV)
+    return mod, mod.plan()
+
+
+def _run(plan, algo, x, dims, **kw):
+    from estdepth_amd import ops
+    old = ops.CONV3D_ALGO
+    ops.CONV3D_ALGO = algo
+    try:
+        out = kw.pop("out", None)
+        if out is None:
+            out = torch.empty(dims + (kw.get("out_stride", 32),), device=DEV)
+        plan.run(x, dims, out=out, **kw)
+        torch.cuda.synchronize()
+        return out
+    finally:
+        ops.CONV3D_ALGO = old
+
+
+@pytest.mark.parametrize("dims,scale", [((1, 6, 19, 45), 1.0), ((2, 3, 8, 32), 100.0), ((1, 1, 5, 7), 1e-3), ((1, 64, 24, 32), 1.0)])
+def test_wino_error_vs_fp64_is_at_the_direct_kernels_level(dims, scale):
+    mod, plan = _plan(11, act=None)
+    N, D, H, W = dims
+    x = torch.randn(N, D, H, W, 32, generator=torch.Generator().manual_seed(5)) * scale
+    w64 = mod[0].weight.detach().double().cpu()
+    bn = mod[1]
+    sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).double().cpu()
+    sh = bn.bias.double().cpu() - bn.running_mean.double().cpu() * sc
+    ref = torch.nn.functional.conv3d(x.permute(0, 4, 1, 2, 3).double(), w64, padding=1)
+    ref = (ref * sc[None, :, None, None, None] + sh[None, :, None, None, None]).permute(0, 2, 3, 4, 1)
+    xd = x.to(DEV)
+    e_dir = (_run(plan, "direct", xd, dims).double().cpu() - ref).abs().max().item()
+    e_win = (_run(plan, "wino", xd, dims).double().cpu() - ref).abs().max().item()
+    mag = ref.abs().max().item()
+    print("fp64 check dims=%s scale=%g: |ref|max %.3g  err direct %.3g  err wino %.3g" % (dims, scale, mag, e_dir, e_win))
+    assert e_win <= 3.0 * e_dir + 1e-7 * mag, (e_win, e_dir)
+    assert e_win < 3e-6 * mag
+
+
+@pytest.mark.parametrize("dims", [(1, 4, 8, 32), (3, 5, 13, 50), (1, 2, 120, 160), (2, 1, 9, 33), (1, 7, 8, 16), (1, 70, 8, 32)])
+def test_wino_matches_direct_kernel_all_epilogues(dims):
+    """ReLU / none, residual, two residuals + scale, running accumulation, strided output, GroupNorm partial sums."""
+    from estdepth_amd import ops
+    N, D, H, W = dims
+    g = torch.Generator().manual_seed(sum(dims))
+    x = torch.randn(N, D, H, W, 32, generator=g).to(DEV)
+    r1 = torch.randn(N, D, H, W, 32, generator=g).to(DEV)
+    r2 = torch.randn(N, D, H, W, 32, generator=g).to(DEV)
+    for act in ("relu", None):
+        _, plan = _plan(3, act=act)
+        cases = [dict(), dict(residual=r1), dict(residual=r1, residual2=r2, out_scale=0.5)]
+        for kw in cases:
+            a = _run(plan, "direct", x, dims, **kw)
+            b = _run(plan, "wino", x, dims, **kw)
+            tol = 5e-6 * max(1.0, float(a.abs().max()))
+            assert float((a - b).abs().max()) < tol, (act, sorted(kw), float((a - b).abs().max()))
+        # running accumulation (mean over source views): out += result
+        base = torch.randn(N, D, H, W, 32, generator=g).to(DEV)
+        a = _run(plan, "direct", x, dims, out=base.clone(), accumulate=True, out_scale=0.5)
+        b = _run(plan, "wino", x, dims, out=base.clone(), accumulate=True, out_scale=0.5)
+        assert float((a - b).abs().max()) < 5e-6 * max(1.0, float(a.abs().max()))
+    # GroupNorm partial sums (the GRU gate convolution: bias, no activation, N = 1 volume at a time)
+    _, plan = _plan(9, act=None)
+    nblk = ops.conv3d_grid(N, D, H, W)
+    pa = torch.zeros(nblk * 4, device=DEV, dtype=torch.float64)
+    pb = torch.zeros(nblk * 4, device=DEV, dtype=torch.float64)
+    a = _run(plan, "direct", x, dims, stats_partials=pa)
+    b = _run(plan, "wino", x, dims, stats_partials=pb)
+    assert float((a - b).abs().max()) < 5e-6 * max(1.0, float(a.abs().max()))
+    sa = ops.groupnorm_finalize(pa, nblk, 16.0 * N * D * H * W).cpu()
+    sb = ops.groupnorm_finalize(pb, nblk, 16.0 * N * D * H * W).cpu()
+    assert float((sa - sb).abs().max()) < 1e-5 * max(1.0, float(sa.abs().max()))
+    # every tile wrote its partials (none left at the initial zero in BOTH sum slots)
+    assert int((pb.view(-1, 4)[:, 1] == 0).sum()) == 0
+
+
+def test_wino_vs_oracle_ragged():
+    from oracle import ref_ops as O
+    mod, plan = _plan(21, act="relu")
+    dims = (2, 5, 11, 19)
+    x = torch.randn(*dims, 32, generator=torch.Generator().manual_seed(2))
+    bn = mod[1]
+    ref = O.bn_act(O.conv3d(x.permute(0, 4, 1, 2, 3).numpy(), mod[0].weight.detach().cpu().numpy()),
+                   (bn.weight.detach().cpu().numpy(), bn.bias.detach().cpu().numpy(), bn.running_mean.cpu().numpy(),
+                    bn.running_var.cpu().numpy()), "relu")
+    out = _run(plan, "wino", x.to(DEV), dims).cpu().numpy()
+    assert np.abs(np.moveaxis(out, -1, 1) - ref).max() < 2e-5
+
+
+def test_wino_full_size_linearity_and_match():
+    """BASELINE configs[1] size (3 volumes of 64x120x160): against the direct kernel and a linearity property."""
+    _, plan = _plan(5, act=None)
+    dims = (3, 64, 120, 160)
+    x = torch.randn(*dims, 32, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    a = _run(plan, "direct", x, dims)
+    b = _run(plan, "wino", x, dims)
+    assert float((a - b).abs().max()) < 5e-6 * float(a.abs().max())
+    del a
+    zero = _run(plan, "wino", torch.zeros_like(x), dims)              # = folded shift
+    c = _run(plan, "wino", x * -2.0, dims)
+    assert float((c - zero + 2.0 * (b - zero)).abs().max()) < 2e-5 * float(b.abs().max())
+
+
+def test_wino_rejects_other_shapes():
+    from estdepth_amd import _native
+    d = _native.Conv3dDesc()
+    d.N = d.D = d.H = d.W = 4
+    assert _native.lib().estd_conv3d_k3_wino(d, None) == -1                 # null pointers
+    x = torch.zeros(4, 4, 4, 32, device=DEV)
+    d.in_main = d.out_main = d.w_wino = d.scale = d.shift = x.data_ptr()
+    d.cin_main, d.n_tiles, d.in_stride, d.out_stride = 16, 1, 32, 32
+    assert _native.lib().estd_conv3d_k3_wino(d, None) == -3                 # not the plain 32 -> 32 instance
