@@ -40,7 +40,7 @@ class Conv2dDesc(ctypes.Structure):
         ("dilation", ctypes.c_int), ("group_tiles", ctypes.c_int),
         ("in_", ctypes.c_void_p), ("w", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
         ("relu_before_residual", ctypes.c_int), ("relu_after_residual", ctypes.c_int),
-        ("residual", ctypes.c_void_p), ("out", ctypes.c_void_p), ("w_split", ctypes.c_void_p),
+        ("residual", ctypes.c_void_p), ("out", ctypes.c_void_p), ("w_split", ctypes.c_void_p), ("w_wino", ctypes.c_void_p),
     ]
 
 
@@ -62,6 +62,7 @@ _SIGNATURES = {
     "estd_conv3d_k3_wino": (ctypes.c_int, [ctypes.POINTER(Conv3dDesc), c_stream]),
     "estd_conv2d_k3": (ctypes.c_int, [ctypes.POINTER(Conv2dDesc), c_stream]),
     "estd_conv2d_k3_split": (ctypes.c_int, [ctypes.POINTER(Conv2dDesc), c_stream]),
+    "estd_conv2d_k3_wino": (ctypes.c_int, [ctypes.POINTER(Conv2dDesc), c_stream]),
     "estd_conv3d_k3_grid": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "estd_groupnorm_finalize": (ctypes.c_int, [c_float_p, ctypes.c_int, ctypes.c_double, ctypes.c_float,
                                                c_float_p, c_stream]),

@@ -166,9 +166,9 @@ void conv3d_k3(const Tensor& x, const OptTensor& x_extra, const Tensor& w_main, 
     }
 }
 
-Tensor conv2d_k3(const Tensor& x_nhwc, const Tensor& w, const OptTensor& w_split, const Tensor& scale, const Tensor& shift,
+Tensor conv2d_k3(const Tensor& x_nhwc, const Tensor& w, const OptTensor& w_alt, const Tensor& scale, const Tensor& shift,
                  int64_t cout, int64_t dilation, int64_t group_tiles, bool relu_before_residual, bool relu_after_residual,
-                 const OptTensor& residual, bool split_arith)
+                 const OptTensor& residual, int64_t variant)
 {
     TORCH_CHECK(x_nhwc.dim() == 4, "conv2d_k3: input must be [N,H,W,Cin] (NHWC, contiguous)");
     estd_conv2d_desc d{};
@@ -183,11 +183,16 @@ Tensor conv2d_k3(const Tensor& x_nhwc, const Tensor& w, const OptTensor& w_split
     d.residual = opt_fptr(residual, "conv2d residual");
     if (d.residual) TORCH_CHECK(residual->sizes() == out.sizes(), "conv2d_k3: residual must be contiguous NHWC of the output shape");
     d.out = out.data_ptr<float>();
-    if (split_arith) {
-        TORCH_CHECK(w_split.has_value() && w_split->defined() && w_split->is_cuda(), "conv2d_k3: split arithmetic needs the split weights");
-        d.w_split = w_split->data_ptr();
+    // variant: 0 = direct fp32 MFMA; 1 = exact 3 x bf16 operand split; 2 = fp32 MFMA with the row axis in Winograd F(2,3) form
+    if (variant != 0) TORCH_CHECK(w_alt.has_value() && w_alt->defined() && w_alt->is_cuda(), "conv2d_k3: this variant needs its packed weights");
+    if (variant == 1) {
+        d.w_split = w_alt->data_ptr();
         check_status(estd_conv2d_k3_split(&d, cur_stream()), "estd_conv2d_k3_split");
+    } else if (variant == 2) {
+        d.w_wino = fptr(*w_alt, "Winograd-packed weights");
+        check_status(estd_conv2d_k3_wino(&d, cur_stream()), "estd_conv2d_k3_wino");
     } else {
+        TORCH_CHECK(variant == 0, "conv2d_k3: unknown variant ", variant);
         check_status(estd_conv2d_k3(&d, cur_stream()), "estd_conv2d_k3");
     }
     return out;
@@ -429,8 +434,8 @@ TORCH_LIBRARY(estdepth_hip, m)
           "int[] dims, int cin_main, int in_stride, int n_tiles, int act_a, int act_b, int act_split, Tensor(a!)? out, int out_stride, "
           "int out_channels, Tensor? residual, Tensor? residual2, float out_scale, bool accumulate, Tensor(b!)? out_extra, Tensor? head_w, "
           "Tensor? head_b, Tensor(c!)? out_head, Tensor(d!)? stats_partials, int variant) -> ()");
-    m.def("conv2d_k3(Tensor x_nhwc, Tensor w, Tensor? w_split, Tensor scale, Tensor shift, int cout, int dilation, int group_tiles, "
-          "bool relu_before_residual, bool relu_after_residual, Tensor? residual, bool split_arith) -> Tensor");
+    m.def("conv2d_k3(Tensor x_nhwc, Tensor w, Tensor? w_alt, Tensor scale, Tensor shift, int cout, int dilation, int group_tiles, "
+          "bool relu_before_residual, bool relu_after_residual, Tensor? residual, int variant) -> Tensor");
     m.def("groupnorm_finalize(Tensor partials, int n_blocks, float count, float eps) -> Tensor");
     m.def("softargmin_up(Tensor logits, Tensor depth_values, int scale) -> (Tensor, Tensor)");
     m.def("warp_volume(Tensor feat_volume, Tensor mats30, Tensor depth_values, float depth_min, float depth_interval) -> Tensor");

@@ -76,6 +76,8 @@ CONV2D_ARITH = os.environ.get("ESTD_CONV2D_ARITH", "f32")     # same choice for 
 # Algorithm of the plain 32->32 3x3x3 convolutions under CONV3D_ARITH == "f32" (every product an fp32 MFMA either way):
 # "wino" = depth axis in Winograd F(2,3) form, 2/3 of the products (csrc/conv3d_wino.hip); "direct" = 27 taps (csrc/conv3d_mfma.hip)
 CONV3D_ALGO = os.environ.get("ESTD_CONV3D_ALGO", "wino")
+# same choice for the 3x3 / dilation-1 NHWC convolutions: row axis in Winograd F(2,3) form (csrc/conv2d_wino.hip) or direct
+CONV2D_ALGO = os.environ.get("ESTD_CONV2D_ALGO", "wino")
 
 
 def _stream():
@@ -294,6 +296,7 @@ class Conv2dPlan:
         if self.cout % 64 == 0:
             self.w_nt[4] = packing.pack_conv2d(conv.weight, 4).to(dev)
         self.w_split = packing.pack_conv2d_split(conv.weight).to(dev)
+        self.w_wino = {nt: packing.pack_conv2d_wino(conv.weight, nt).to(dev) for nt in self.w_nt}
         sc, sh = packing.fold_bn_fp32(bn, list(range(self.cout)))
         self.scale, self.shift = sc.to(dev), sh.to(dev)
         self.relu_before, self.relu_after = int(relu_before), int(relu_after)
@@ -317,9 +320,15 @@ class Conv2dPlan:
             raise RuntimeError("Conv2dPlan.run: residual must be contiguous NHWC of the output shape")
         nt = self._pick_nt(Nn, H, W)
         split = CONV2D_ARITH == "bf16x3" and self.w_split is not None
+        if self.dil == 2 and not split and CONV2D_ALGO == "wino":
+            nt = 2        # the 64-channel work item of the dilated Winograd kernel spills registers into its MFMA loop (5x slower)
+        if CONV2D_ALGO not in ("wino", "direct"):
+            raise RuntimeError("ESTD_CONV2D_ALGO must be wino or direct, got %r" % (CONV2D_ALGO,))
+        wino = (not split) and CONV2D_ALGO == "wino" and nt in self.w_wino
+        variant, w_alt = (1, self.w_split) if split else (2, self.w_wino[nt]) if wino else (0, None)
         if _use_torch():
-            return T().conv2d_k3(x_nhwc, self.w_nt[nt], self.w_split if split else None, self.scale, self.shift, self.cout, self.dil, nt,
-                                 bool(self.relu_before), bool(self.relu_after), residual, split)
+            return T().conv2d_k3(x_nhwc, self.w_nt[nt], w_alt, self.scale, self.shift, self.cout, self.dil, nt,
+                                 bool(self.relu_before), bool(self.relu_after), residual, variant)
         out = torch.empty((Nn, H, W, self.cout), device=x_nhwc.device, dtype=torch.float32)
         d = N.Conv2dDesc()
         d.N, d.H, d.W, d.cin, d.cout, d.dilation, d.group_tiles = Nn, H, W, self.cin, self.cout, self.dil, nt
@@ -331,6 +340,9 @@ class Conv2dPlan:
         if split:
             d.w_split = self.w_split.data_ptr()
             N.check(N.lib().estd_conv2d_k3_split(ctypes.byref(d), _stream()), "estd_conv2d_k3_split")
+        elif wino:
+            d.w_wino = self.w_wino[nt].data_ptr()
+            N.check(N.lib().estd_conv2d_k3_wino(ctypes.byref(d), _stream()), "estd_conv2d_k3_wino")
         else:
             N.check(N.lib().estd_conv2d_k3(ctypes.byref(d), _stream()), "estd_conv2d_k3")
         return out

@@ -224,3 +224,30 @@ def pack_conv3d_wino(weight, main_idx, out_idx):
                 # [4 s, 9 taps] -> taps 9 s + k
                 out[:36, nh, t // 4, lane, t % 4] = U[:, oi[16 * nh + j], ci, :].reshape(36)
     return torch.from_numpy(out)
+
+
+def pack_conv2d_wino(weight, group_tiles):
+    """3x3 Conv2d weight [Cout, Cin, 3, 3] for csrc/conv2d_wino.hip: the row taps g0, g1, g2 of every kw column in Winograd
+    F(2,3) form U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2 (float64, rounded once to float32), packed as
+    float32 [Cout/(16*NT)][Cin/32][13 taps (12 + zero pad)][2*NT quads][64 lanes][4] with tap = 3 i + kw and the lane / k-step /
+    N-tile indexing of pack_conv2d."""
+    nt = group_tiles
+    w = weight.detach().double().cpu().numpy()
+    cout, cin = w.shape[:2]
+    assert cin % 32 == 0 and cout % (16 * nt) == 0 and w.shape[2:] == (3, 3)
+    g0, g1, g2 = w[:, :, 0], w[:, :, 1], w[:, :, 2]                                        # [Cout, Cin, kw]
+    U = np.stack([g0, (g0 + g1 + g2) * 0.5, (g0 - g1 + g2) * 0.5, g2], 2).astype(np.float32)   # [Cout, Cin, 4, 3]
+    U = U.reshape(cout, cin, 12)
+    groups, chunks = cout // (16 * nt), cin // 32
+    out = np.zeros((groups, chunks, 13, 2 * nt, 64, 4), np.float32)
+    lane = np.arange(64)
+    g, j = lane >> 4, lane & 15
+    for t in range(8):
+        ci_in_chunk = np.array([_ch(32, int(gg), t) for gg in g])           # [64]
+        for n in range(nt):
+            idx = t * nt + n
+            for grp in range(groups):
+                co = grp * 16 * nt + nt * j + n                             # [64]
+                for c in range(chunks):
+                    out[grp, c, :12, idx // 4, :, idx % 4] = U[co, c * 32 + ci_in_chunk, :].T
+    return torch.from_numpy(out)

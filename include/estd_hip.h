@@ -153,9 +153,15 @@ typedef struct estd_conv2d_desc {
     float* out;               /* [N][H][W][cout] */
     /* estd_conv2d_k3_split only: int16 [cout/32][cin/32][9 taps][4096] bf16 split weights (packing.py::pack_conv2d_split) */
     const void* w_split;
+    /* estd_conv2d_k3_wino only: the filters with the ROW taps in Winograd F(2,3) form, float32
+     * [cout/(16*group_tiles)][cin/32][13 taps (4 x 3 + 1 pad)][2*group_tiles][64][4] (packing.py::pack_conv2d_wino) */
+    const float* w_wino;
 } estd_conv2d_desc;
 
 int estd_conv2d_k3(const estd_conv2d_desc* desc, estd_stream_t stream);
+/* Same operator with the row axis in Winograd F(2,3) form: two output rows from four transformed input rows, 12 instead of
+ * 18 tap products, every product an fp32 MFMA with fp32 accumulation (csrc/conv2d_wino.hip).  Reads w_wino instead of w. */
+int estd_conv2d_k3_wino(const estd_conv2d_desc* desc, estd_stream_t stream);
 /* Same operator (group_tiles ignored: 32 output channels per work item) with every fp32 product as six
  * bf16 MFMA products of exactly 3-way split operands, fp32 accumulation (see estd_conv3d_k3_split). */
 int estd_conv2d_k3_split(const estd_conv2d_desc* desc, estd_stream_t stream);

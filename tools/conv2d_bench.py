@@ -12,8 +12,9 @@ for (h, w, cin, cout, dil) in [(240, 320, 32, 32, 1), (120, 160, 64, 64, 1), (12
     x = torch.randn(5, h, w, cin, device=dev)
     gf = 2.0 * 9 * 5 * h * w * cin * cout / 1e9
     line = "%3dx%-3d %3d->%-3d dil %d" % (h, w, cin, cout, dil)
-    for arith in ("f32", "bf16x3"):
-        ops.CONV2D_ARITH = arith
+    for arith in ("f32/wino", "f32/direct", "bf16x3"):
+        ops.CONV2D_ARITH = arith.split("/")[0]
+        ops.CONV2D_ALGO = "direct" if arith.endswith("direct") else "wino"
         for _ in range(3): plan.run(x)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
