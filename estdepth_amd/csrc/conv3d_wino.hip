@@ -56,8 +56,9 @@ constexpr int SLICE_BYTES = SL_VOX * 128;           // 32 channels
 constexpr int NTHREADS = 512;
 constexpr int SL_CHUNKS = SL_VOX * 8;               // 16-byte chunks per slice: 1440
 constexpr int SIT = (SL_CHUNKS + NTHREADS - 1) / NTHREADS;     // chunks per thread per slice: 3
+constexpr int XSL_BYTES = 4 * SL_VOX * 4;           // the four transformed slices of the scalar 33rd input channel
 constexpr int RED_BYTES = 8 * 2 * 8;                // GroupNorm scratch: 8 waves x {sum, sumsq} doubles
-constexpr int LDS_BYTES = 4 * SLICE_BYTES + RED_BYTES;
+constexpr int LDS_BYTES = 4 * SLICE_BYTES + XSL_BYTES + RED_BYTES;
 constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;        // beyond num_records of any descriptor: loads return 0, stores are dropped
 
 __device__ __forceinline__ float4 as_float4(u32x4 v)
@@ -90,9 +91,15 @@ __device__ __forceinline__ float act_apply(float v, int act)
 __device__ __forceinline__ float4 f4_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
+// EXTRA: a scalar 33rd INPUT channel (the semantic plane scores of dres2, the 33rd channel of its output for key||value): its
+//        3x3 taps per transform form three more k-steps (lane group g multiplies tap 4s+g; taps 9..11 carry zero weights).
+//        (A 33rd OUTPUT channel -- dres2 -- evaluated on the VALU from the A fragments, as the direct kernel does, was built and
+//        dropped: it pushes this kernel 54 registers over the 256 a wave may hold and the spill traffic sits in the MFMA loop.)
+template <bool EXTRA>
 __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int dpairs, int total_tiles)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* lds_x = reinterpret_cast<float*>(smem + 4 * SLICE_BYTES);       // [4][SL_VOX] transformed scalar-channel slices
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -122,6 +129,15 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w_wino, (size_t)37 * 2 * 2 * 256);
     const int wlane = lane * 16 + nh * 2048;
     const int row0 = 2 * rp;
+    // scalar-channel weights: [2 halves][3 quads][64 lanes][4], element 3 s + k of lane (g, j) = U_s[16 nh + j][extra][tap 4 k + g]
+    const __amdgpu_buffer_rsrc_t rs_wx = make_rsrc(EXTRA ? p.w_extra : p.w_wino, (size_t)2 * 3 * 256);
+    // this lane's taps of the scalar channel: k-step k covers tap 4k + g (clamped: taps 9..11 have zero weights)
+    int xtap_off[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int tp = min(4 * k + g, 8);
+        xtap_off[k] = (tp / 3) * IN_W + (tp % 3) + i;
+    }
 
     while (u < u_end) {
         // ---- column segment [u, seg_end): same (n, h-tile, w-tile), consecutive depth pairs ----
@@ -133,6 +149,17 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
         const int seg_end = min(u_end, (col + 1) * dpairs);
 
         const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in_main + (size_t)n * vol * p.in_stride, vol * p.in_stride);
+        __amdgpu_buffer_rsrc_t rs_ex = rs_in;
+        if (EXTRA) rs_ex = make_rsrc(p.in_extra + (size_t)n * vol, vol);
+        unsigned voffx = OOB_OFFSET;                 // this thread's voxel of a scalar slice (threads 0..179)
+        if (EXTRA) {
+            const int zy = tid / IN_W, zx = tid % IN_W;
+            const int gy = th0 - 1 + zy, gx = tw0 - 1 + zx;
+            if (tid < SL_VOX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) voffx = (unsigned)(gy * W + gx) * 4u;
+        }
+        auto load_x = [&](int pd) {
+            return (unsigned)pd < (unsigned)D ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ex, voffx, pd * HW * 4, 0)) : 0.0f;
+        };
         __amdgpu_buffer_rsrc_t rs_out = rs_in, rs_res = rs_in, rs_res2 = rs_in;
         rs_out = make_rsrc(p.out_main + (size_t)n * vol * p.out_stride, vol * p.out_stride);
         if (p.residual) rs_res = make_rsrc(p.residual + (size_t)n * vol * p.out_stride, vol * p.out_stride);
@@ -163,21 +190,24 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
 
         // epilogue lane offsets (bytes inside one depth plane): rows row0, row0+1; columns 4g .. 4g+3 of the tile
         const int ey0 = th0 + row0, ex0 = tw0 + 4 * g;
-        unsigned eoff[2][4];
+        auto eoff_of = [&](int m, int r) {
+            const int y = ey0 + m, x = ex0 + r;
+            return (y < H && x < W) ? (unsigned)((y * W + x) * p.out_stride + ch) * 4u : OOB_OFFSET;
+        };
+        unsigned eoff[2][4];                        // held in registers by the plain instance, recomputed by the 33-channel ones
+        if (!EXTRA) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int y = ey0 + m, x = ex0 + r;
-                eoff[m][r] = (y < H && x < W) ? (unsigned)((y * W + x) * p.out_stride + ch) * 4u : OOB_OFFSET;
-            }
+                for (int r = 0; r < 4; ++r) eoff[m][r] = eoff_of(m, r);
+        }
 
         // one (plane, tile row) of the epilogue: the four voxels of row m this lane holds
         auto epi_row = [&](const f32x4& a, int m, int dd) {
             const int so = dd * out_plane_bytes;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const unsigned eo = eoff[m][r];
+                const unsigned eo = EXTRA ? eoff_of(m, r) : eoff[m][r];
                 float v = act_apply(a[r] * sc + sh, act0);
                 if (p.residual) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, eo, so, 0));
                 if (p.residual2) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res2, eo, so, 0));
@@ -194,10 +224,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (eoff[m][r] != OOB_OFFSET) { const double v = (double)(a[m][r] * sc + sh); s_sum += v; s_sq += v * v; }
+                    if ((EXTRA ? eoff_of(m, r) : eoff[m][r]) != OOB_OFFSET) { const double v = (double)(a[m][r] * sc + sh); s_sum += v; s_sq += v * v; }
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) { s_sum += __shfl_xor(s_sum, o); s_sq += __shfl_xor(s_sq, o); }
-            double* red = reinterpret_cast<double*>(smem + 4 * SLICE_BYTES);
+            double* red = reinterpret_cast<double*>(smem + 4 * SLICE_BYTES + XSL_BYTES);
             __syncthreads();                                     // the previous plane's scratch has been consumed
             if (lane == 0) { red[wave * 2] = s_sum; red[wave * 2 + 1] = s_sq; }
             __syncthreads();
@@ -210,14 +240,16 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
             }
         };
 
-        // raw planes in registers: xa = x[d0-1], xb = x[d0], xc = x[d0+1], xd = x[d0+2]
+        // raw planes in registers: xa = x[d0-1], xb = x[d0], xc = x[d0+1], xd = x[d0+2]  (+ the scalar channel's: ea..ed)
         float4 xa[SIT], xb[SIT], xc[SIT], xd[SIT];
+        float ea = 0.f, eb = 0.f, ec = 0.f, ed = 0.f;
         {
             const int d0 = 2 * dp;
             load_plane(d0 - 1, xa);
             load_plane(d0, xb);
             load_plane(d0 + 1, xc);
             load_plane(d0 + 2, xd);
+            if (EXTRA) { ea = load_x(d0 - 1); eb = load_x(d0); ec = load_x(d0 + 1); ed = load_x(d0 + 2); }
         }
 
         for (; u < seg_end; ++u, ++dp) {
@@ -234,6 +266,15 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
                 }
                 xa[it] = xc[it];                         // planes d0+1, d0+2 are planes d0'-1, d0' of the next tile
                 xb[it] = xd[it];
+            }
+            if (EXTRA) {
+                if (tid < SL_VOX) {
+                    lds_x[0 * SL_VOX + tid] = ea - ec;
+                    lds_x[1 * SL_VOX + tid] = eb + ec;
+                    lds_x[2 * SL_VOX + tid] = ec - eb;
+                    lds_x[3 * SL_VOX + tid] = eb - ed;
+                }
+                ea = ec; eb = ed;
             }
             lds_barrier();
 
@@ -269,8 +310,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
                     a1[m] = *reinterpret_cast<const float4*>(smem + (off0 ^ 64));
                 }
             };
+            constexpr bool APF = !EXTRA;                 // A fragments one tap ahead (the 33-channel instances need the registers)
             float4 a0c[2], a1c[2], a0n[2], a1n[2];
-            load_a(0, a0c, a1c);
+            if (APF) load_a(0, a0c, a1c);
 
 #pragma clang loop unroll(full)
             for (int tap = 0; tap < 36; ++tap) {
@@ -289,7 +331,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
                     else           xd[it] = v1 ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[it], (nd + 1) * in_slice_bytes, 0))
                                                : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-                if (tap + 1 < 36) load_a(tap + 1, a0n, a1n);          // next tap's A fragments: LDS latency under this tap's MFMAs
+                if (EXTRA && has_next && (tap == 2 * SIT || tap == 2 * SIT + 1)) {          // the scalar channel's two new planes
+                    if (tap == 2 * SIT) ec = v0 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ex, voffx, nd * HW * 4, 0)) : 0.f;
+                    else                ed = v1 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ex, voffx, (nd + 1) * HW * 4, 0)) : 0.f;
+                }
+                if (APF) { if (tap + 1 < 36) load_a(tap + 1, a0n, a1n); }        // next tap's A fragments: LDS latency under this tap's MFMAs
+                else load_a(tap, a0c, a1c);
                 const float av0[8] = {a0c[0].x, a0c[0].y, a0c[0].z, a0c[0].w, a1c[0].x, a1c[0].y, a1c[0].z, a1c[0].w};
                 const float av1[8] = {a0c[1].x, a0c[1].y, a0c[1].z, a0c[1].w, a1c[1].x, a1c[1].y, a1c[1].z, a1c[1].w};
 #pragma unroll
@@ -301,8 +348,29 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
                 }
                 bcur[0] = bnext[0];
                 bcur[1] = bnext[1];
-                a0c[0] = a0n[0]; a0c[1] = a0n[1]; a1c[0] = a1n[0]; a1c[1] = a1n[1];
+                if (APF) { a0c[0] = a0n[0]; a0c[1] = a0n[1]; a1c[0] = a1n[0]; a1c[1] = a1n[1]; }
                 __builtin_amdgcn_sched_barrier(0);       // keep each tap's loads inside the tap (bounds live registers)
+            }
+
+            // ---- the scalar input channel: per transform three more k-steps (lane group g = tap 4k + g of the 3x3 window) ----
+            if (EXTRA) {
+                // (the 12 weights of this stage are fetched here, L2-resident, rather than held across the tap loop)
+                float4 bx[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) bx[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_wx, lane * 16, (nh * 3 + q) * 1024, 0));
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int idx = s * 3 + k;
+                        const float4 bq = bx[idx >> 2];
+                        const float b = (idx & 3) == 0 ? bq.x : (idx & 3) == 1 ? bq.y : (idx & 3) == 2 ? bq.z : bq.w;
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            const float a = lds_x[s * SL_VOX + (row0 + m) * IN_W + xtap_off[k]];
+                            acc[s][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[s][m], 0, 0, 0);
+                        }
+                    }
             }
 
             // ---- output transform A^T m and the epilogue of the two planes ----
@@ -335,8 +403,12 @@ extern "C" int estd_conv3d_k3_wino(const estd_conv3d_desc* dp, estd_stream_t s)
     const estd_conv3d_desc& d = *dp;
     if (d.N <= 0 || d.D <= 0 || d.H <= 0 || d.W <= 0) return ESTD_ERR_ARG;
     if (!d.in_main || !d.w_wino || !d.scale || !d.shift || !d.out_main) return ESTD_ERR_ARG;
-    // the plain 32 -> 32 instance only: no extra input channel, no 33rd output, no fused head
-    if (d.cin_main != 32 || d.n_tiles != 2 || d.in_extra || d.out_extra || d.out_head) return ESTD_ERR_UNSUPPORTED;
+    // 32 main input channels -> 32 output channels on the MFMA, optionally a scalar 33rd input channel (w_extra in Winograd
+    // packing); no 33rd output channel, no fused head
+    if (d.cin_main != 32 || d.n_tiles != 2 || d.out_extra || d.out_head) return ESTD_ERR_UNSUPPORTED;
+    const bool extra = d.in_extra != nullptr;
+    if (extra != (d.w_extra != nullptr)) return ESTD_ERR_ARG;
+    if (d.stats_partials && extra) return ESTD_ERR_UNSUPPORTED;
     if (d.in_stride < 32 || (d.in_stride & 3) || d.out_stride < 32 || (d.act_split & 1)) return ESTD_ERR_ARG;
     const int tiles_w = (d.W + TW - 1) / TW, tiles_h = (d.H + TH - 1) / TH, dpairs = (d.D + 1) / 2;
     const long long total = (long long)d.N * dpairs * tiles_h * tiles_w;
@@ -348,7 +420,12 @@ extern "C" int estd_conv3d_k3_wino(const estd_conv3d_desc* dp, estd_stream_t s)
     }
     int grid = total < PERSISTENT_WGS ? (int)total : PERSISTENT_WGS;
     if (grid >= 8) grid &= ~7;
-    estd_allow_dynamic_lds<conv3d_wino_kernel>(LDS_BYTES);
-    hipLaunchKernelGGL(conv3d_wino_kernel, dim3(grid), dim3(NTHREADS), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h, dpairs, (int)total);
+    if (extra) {
+        estd_allow_dynamic_lds<conv3d_wino_kernel<true>>(LDS_BYTES);
+        hipLaunchKernelGGL((conv3d_wino_kernel<true>), dim3(grid), dim3(NTHREADS), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h, dpairs, (int)total);
+    } else {
+        estd_allow_dynamic_lds<conv3d_wino_kernel<false>>(LDS_BYTES);
+        hipLaunchKernelGGL((conv3d_wino_kernel<false>), dim3(grid), dim3(NTHREADS), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h, dpairs, (int)total);
+    }
     return ESTD_LAUNCH_CHECK();
 }

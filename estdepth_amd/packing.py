@@ -203,6 +203,27 @@ def pack_conv2d_split(weight):
     return torch.from_numpy(rec.view(np.int16).copy())
 
 
+def pack_conv3d_wino_extra(weight, extra_idx, out_idx):
+    """the scalar 33rd input channel of a 33 -> 32 convolution for csrc/conv3d_wino.hip<EXTRA>: float32
+    [2 channel halves][3 quads][64 lanes][4]; element 3 s + k of lane (g, j) of half nh = U_s[out_idx[16 nh + j]][extra_idx] at
+    tap 4 k + g of the 3x3 (kh, kw) window (taps 9..11: zero), U_s as in pack_conv3d_wino."""
+    w = weight.detach().double().cpu().numpy()[:, extra_idx]         # [Cout, kd, kh, kw]
+    g0, g1, g2 = w[:, 0], w[:, 1], w[:, 2]
+    U = np.stack([g0, (g0 + g1 + g2) * 0.5, (g0 - g1 + g2) * 0.5, g2], 0).astype(np.float32).reshape(4, w.shape[0], 9)
+    out = np.zeros((2, 3, 64, 4), np.float32)
+    oi = np.asarray(out_idx)
+    for lane in range(64):
+        g, j = lane >> 4, lane & 15
+        for nh in range(2):
+            for s_ in range(4):
+                for k in range(3):
+                    tap = 4 * k + g
+                    if tap < 9:
+                        idx = 3 * s_ + k
+                        out[nh, idx // 4, lane, idx % 4] = U[s_, oi[16 * nh + j], tap]
+    return torch.from_numpy(out)
+
+
 def pack_conv3d_wino(weight, main_idx, out_idx):
     """32 -> 32 filters for csrc/conv3d_wino.hip: the depth taps g0, g1, g2 of every (kh, kw) column in Winograd F(2,3) form
     U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2 (evaluated in float64, rounded once to float32), packed

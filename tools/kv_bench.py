@@ -1,0 +1,19 @@
+import sys, os
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch
+from estdepth_amd import ops
+dev = torch.device("cuda:0")
+N, D, H, W = 3, 64, 120, 160
+g = torch.Generator().manual_seed(1)
+w = torch.randn(32, 33, 3, 3, 3, generator=g) * 0.05
+plan = ops.Conv3dPlan(w, list(range(32)), 32, list(range(32)), 2, torch.ones(32), torch.zeros(32), act_a="relu", device=dev)
+x = torch.randn(N, D, H, W, 32, device=dev); e = torch.randn(N, D, H, W, device=dev); y = torch.empty_like(x)
+for algo in ("direct", "wino", "direct", "wino"):
+    ops.CONV3D_ALGO = algo
+    for _ in range(3): plan.run(x, (N, D, H, W), in_extra=e, out=y)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): plan.run(x, (N, D, H, W), in_extra=e, out=y)
+    e1.record(); torch.cuda.synchronize()
+    print(algo, "kv 33->32 N=3: %.4f ms" % (e0.elapsed_time(e1) / 20))
