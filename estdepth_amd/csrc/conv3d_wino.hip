@@ -58,7 +58,8 @@ constexpr int SL_CHUNKS = SL_VOX * 8;               // 16-byte chunks per slice:
 constexpr int SIT = (SL_CHUNKS + NTHREADS - 1) / NTHREADS;     // chunks per thread per slice: 3
 constexpr int XSL_BYTES = 4 * SL_VOX * 4;           // the four transformed slices of the scalar 33rd input channel
 constexpr int RED_BYTES = 8 * 2 * 8;                // GroupNorm scratch: 8 waves x {sum, sumsq} doubles
-constexpr int LDS_BYTES = 4 * SLICE_BYTES + XSL_BYTES + RED_BYTES;
+constexpr int WXO_BYTES = (36 * 2 + 3) * 64;        // the 33rd output channel's weights (XOUT)
+constexpr int LDS_BYTES = 4 * SLICE_BYTES + XSL_BYTES + RED_BYTES + WXO_BYTES;
 constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;        // beyond num_records of any descriptor: loads return 0, stores are dropped
 
 __device__ __forceinline__ float4 as_float4(u32x4 v)
@@ -93,9 +94,11 @@ __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float
 
 // EXTRA: a scalar 33rd INPUT channel (the semantic plane scores of dres2, the 33rd channel of its output for key||value): its
 //        3x3 taps per transform form three more k-steps (lane group g multiplies tap 4s+g; taps 9..11 carry zero weights).
-//        (A 33rd OUTPUT channel -- dres2 -- evaluated on the VALU from the A fragments, as the direct kernel does, was built and
-//        dropped: it pushes this kernel 54 registers over the 256 a wave may hold and the spill traffic sits in the MFMA loop.)
-template <bool EXTRA>
+// XOUT:  a 33rd OUTPUT channel (dres2): a GEMV, 1/16 efficient on the MFMA -> evaluated on the VALU in a second pass over the
+//        transformed slices still in LDS, after the epilogue of the 32 MFMA channels (whose accumulators are dead by then: doing
+//        it inside the tap loop from the A fragments, as the direct kernel does, needs 54 registers more than a wave may hold).
+//        Wave (rp, nh) takes tile row 2 rp + nh; its lane groups split the channels like the A fragments; two shuffles reduce.
+template <bool EXTRA, bool XOUT>
 __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int dpairs, int total_tiles)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -121,6 +124,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
         u_end = (int)((long long)total_tiles * (r + 1) / G);
     }
     if (u >= u_end) return;
+
+    char* lds_wxo = smem + 4 * SLICE_BYTES + XSL_BYTES + RED_BYTES;               // XOUT: the 33rd output channel's weights
+    if (XOUT && tid < (36 * 2 + 3) * 4)                                     // (visible after the first tile's barriers)
+        reinterpret_cast<float4*>(lds_wxo)[tid] = reinterpret_cast<const float4*>(p.w_xout)[tid];
 
     const int ch = 16 * nh + i;                     // this lane's output channel
     const float sc = p.scale[ch], sh = p.shift[ch];
@@ -389,6 +396,60 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
                 epi_row(y0[m], m, d0);
                 if (d0 + 1 < D) epi_row(y1[m], m, d0 + 1);
             }
+
+            // ---- 33rd output channel: out[32] = sum over (s, tap, channel) of the transformed inputs x U_s[32] ----
+            if (XOUT) {
+                // weights (LDS copy made at kernel start): [36 taps][2 quads][4 lane groups][4] + scalar input channel [3 quads][4][4]
+                float xacc[4] = {0.f, 0.f, 0.f, 0.f};
+                int ix = i, gx_ = g;                          // opaque copies: this pass's LDS addresses are formed HERE, not hoisted
+                asm volatile("" : "+v"(ix), "+v"(gx_));       // over the tap loop above, whose register budget is spent
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    float t = 0.f;
+#pragma clang loop unroll(disable)
+                    for (int kh = 0; kh < 3; ++kh) {             // rolled: addresses formed per row, nothing to hoist or spill
+                        const char* wrow = lds_wxo + ((s * 9 + kh * 3) * 2) * 64 + gx_ * 16;
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const int vs = (row0 + nh + kh) * IN_W + kw + ix;
+                            const int off0 = s * SLICE_BYTES + lds_chunk_off(vs, gx_);
+                            const float4 a0 = *reinterpret_cast<const float4*>(smem + off0);
+                            const float4 a1 = *reinterpret_cast<const float4*>(smem + (off0 ^ 64));
+                            const float4 w0 = *reinterpret_cast<const float4*>(wrow + (kw * 2 + 0) * 64);
+                            const float4 w1 = *reinterpret_cast<const float4*>(wrow + (kw * 2 + 1) * 64);
+                            t = fmaf(a0.x, w0.x, t); t = fmaf(a0.y, w0.y, t); t = fmaf(a0.z, w0.z, t); t = fmaf(a0.w, w0.w, t);
+                            t = fmaf(a1.x, w1.x, t); t = fmaf(a1.y, w1.y, t); t = fmaf(a1.z, w1.z, t); t = fmaf(a1.w, w1.w, t);
+                        }
+                    }
+                    xacc[s] = t;
+                }
+                {
+                    float4 wx[3];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) wx[q] = *reinterpret_cast<const float4*>(lds_wxo + (72 + q) * 64 + gx_ * 16);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const int idx = s * 3 + k;
+                            const float4 wq = wx[idx >> 2];
+                            const float wv = (idx & 3) == 0 ? wq.x : (idx & 3) == 1 ? wq.y : (idx & 3) == 2 ? wq.z : wq.w;
+                            xacc[s] = fmaf(lds_x[s * SL_VOX + (row0 + nh) * IN_W + xtap_off[k]], wv, xacc[s]);
+                        }
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    xacc[s] += __shfl_xor(xacc[s], 16);
+                    xacc[s] += __shfl_xor(xacc[s], 32);
+                }
+                const float sc2 = p.scale[32], sh2 = p.shift[32];
+                const int act2 = 32 < p.act_split ? p.act_a : p.act_b;
+                const int y = th0 + row0 + nh, x = tw0 + i;
+                const int dd = d0 + g;                                   // lane group 0 stores plane d0, group 1 plane d0 + 1
+                const float raw = g == 0 ? xacc[0] + xacc[1] + xacc[2] : xacc[1] - xacc[2] - xacc[3];
+                if (g < 2 && dd < D && y < H && x < W)
+                    p.out_extra[((size_t)n * D + dd) * HW + (size_t)y * W + x] = act_apply(raw * sc2 + sh2, act2);
+            }
         }
     }
 }
@@ -404,10 +465,12 @@ extern "C" int estd_conv3d_k3_wino(const estd_conv3d_desc* dp, estd_stream_t s)
     if (d.N <= 0 || d.D <= 0 || d.H <= 0 || d.W <= 0) return ESTD_ERR_ARG;
     if (!d.in_main || !d.w_wino || !d.scale || !d.shift || !d.out_main) return ESTD_ERR_ARG;
     // 32 main input channels -> 32 output channels on the MFMA, optionally a scalar 33rd input channel (w_extra in Winograd
-    // packing); no 33rd output channel, no fused head
-    if (d.cin_main != 32 || d.n_tiles != 2 || d.out_extra || d.out_head) return ESTD_ERR_UNSUPPORTED;
-    const bool extra = d.in_extra != nullptr;
+    // packing) and, with it, a 33rd output channel (n_tiles == 3, w_xout in Winograd packing); no fused head
+    if (d.cin_main != 32 || (d.n_tiles != 2 && d.n_tiles != 3) || d.out_head) return ESTD_ERR_UNSUPPORTED;
+    const bool extra = d.in_extra != nullptr, xout = d.n_tiles == 3;
     if (extra != (d.w_extra != nullptr)) return ESTD_ERR_ARG;
+    if (xout && (!extra || !d.out_extra || !d.w_xout)) return ESTD_ERR_ARG;
+    if (!xout && d.out_extra) return ESTD_ERR_UNSUPPORTED;
     if (d.stats_partials && extra) return ESTD_ERR_UNSUPPORTED;
     if (d.in_stride < 32 || (d.in_stride & 3) || d.out_stride < 32 || (d.act_split & 1)) return ESTD_ERR_ARG;
     const int tiles_w = (d.W + TW - 1) / TW, tiles_h = (d.H + TH - 1) / TH, dpairs = (d.D + 1) / 2;
@@ -420,12 +483,15 @@ extern "C" int estd_conv3d_k3_wino(const estd_conv3d_desc* dp, estd_stream_t s)
     }
     int grid = total < PERSISTENT_WGS ? (int)total : PERSISTENT_WGS;
     if (grid >= 8) grid &= ~7;
-    if (extra) {
-        estd_allow_dynamic_lds<conv3d_wino_kernel<true>>(LDS_BYTES);
-        hipLaunchKernelGGL((conv3d_wino_kernel<true>), dim3(grid), dim3(NTHREADS), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h, dpairs, (int)total);
-    } else {
-        estd_allow_dynamic_lds<conv3d_wino_kernel<false>>(LDS_BYTES);
-        hipLaunchKernelGGL((conv3d_wino_kernel<false>), dim3(grid), dim3(NTHREADS), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h, dpairs, (int)total);
-    }
+#define ESTD_WINO_LAUNCH(E, X)                                                                                                   \
+    do {                                                                                                                         \
+        estd_allow_dynamic_lds<conv3d_wino_kernel<E, X>>(LDS_BYTES);                                                             \
+        hipLaunchKernelGGL((conv3d_wino_kernel<E, X>), dim3(grid), dim3(NTHREADS), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h, \
+                           dpairs, (int)total);                                                                                  \
+    } while (0)
+    if (xout) ESTD_WINO_LAUNCH(true, true);
+    else if (extra) ESTD_WINO_LAUNCH(true, false);
+    else ESTD_WINO_LAUNCH(false, false);
+#undef ESTD_WINO_LAUNCH
     return ESTD_LAUNCH_CHECK();
 }

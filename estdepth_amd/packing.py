@@ -224,6 +224,32 @@ def pack_conv3d_wino_extra(weight, extra_idx, out_idx):
     return torch.from_numpy(out)
 
 
+def pack_conv3d_wino_xout(weight, main_idx, extra_idx, out_ch):
+    """the 33rd OUTPUT channel of a 33 -> 33 convolution for csrc/conv3d_wino.hip<EXTRA, XOUT>: float32
+    [36 taps (s, kh, kw)][2 quads][4 lane groups][4] -- element r of (tap, q, g) = U_s[out_ch][main_idx[16 q + 4 g + r]] at (kh, kw),
+    the channel an A-fragment lane of group g holds there -- followed by the scalar input channel's [3 quads][4 lane groups][4]
+    (element 3 s + k of group g = U_s[out_ch][extra_idx] at tap 4 k + g; taps 9..11: zero)."""
+    w = weight.detach().double().cpu().numpy()[out_ch]               # [Cin, kd, kh, kw]
+    g0, g1, g2 = w[:, 0], w[:, 1], w[:, 2]
+    U = np.stack([g0, (g0 + g1 + g2) * 0.5, (g0 - g1 + g2) * 0.5, g2], 0).astype(np.float32)    # [4, Cin, 3, 3]
+    mi = np.asarray(main_idx)
+    out = np.zeros((36 * 2 + 3, 4, 4), np.float32)
+    for s_ in range(4):
+        for t in range(9):
+            for q in range(2):
+                for g in range(4):
+                    out[(s_ * 9 + t) * 2 + q, g] = U[s_, mi[16 * q + 4 * g:16 * q + 4 * g + 4], t // 3, t % 3]
+    Ux = U[:, extra_idx].reshape(4, 9)
+    for g in range(4):
+        for s_ in range(4):
+            for k in range(3):
+                tap = 4 * k + g
+                if tap < 9:
+                    idx = 3 * s_ + k
+                    out[72 + idx // 4, g, idx % 4] = Ux[s_, tap]
+    return torch.from_numpy(out)
+
+
 def pack_conv3d_wino(weight, main_idx, out_idx):
     """32 -> 32 filters for csrc/conv3d_wino.hip: the depth taps g0, g1, g2 of every (kh, kw) column in Winograd F(2,3) form
     U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2 (evaluated in float64, rounded once to float32), packed

@@ -1,3 +1,4 @@
+"""Time the 33-channel convolutions (key||value 33 -> 32, dres2 33 -> 33; 3 volumes of 64x120x160): direct vs Winograd kernel."""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
@@ -17,3 +18,16 @@ for algo in ("direct", "wino", "direct", "wino"):
     for _ in range(20): plan.run(x, (N, D, H, W), in_extra=e, out=y)
     e1.record(); torch.cuda.synchronize()
     print(algo, "kv 33->32 N=3: %.4f ms" % (e0.elapsed_time(e1) / 20))
+
+w = torch.randn(33, 33, 3, 3, 3, generator=g) * 0.05
+plan = ops.Conv3dPlan(w, list(range(1, 33)), 0, list(range(33)), 3, torch.ones(33), torch.zeros(33), act_a="relu", device=dev)
+ex = torch.empty(N, D, H, W, device=dev)
+for algo in ("direct", "wino", "direct", "wino"):
+    ops.CONV3D_ALGO = algo
+    for _ in range(3): plan.run(x, (N, D, H, W), in_extra=e, out=y, out_extra=ex)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): plan.run(x, (N, D, H, W), in_extra=e, out=y, out_extra=ex)
+    e1.record(); torch.cuda.synchronize()
+    print(algo, "dres2 33->33 N=3: %.4f ms" % (e0.elapsed_time(e1) / 20))
