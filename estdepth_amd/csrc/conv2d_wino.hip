@@ -211,9 +211,30 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(const estd_conv2d_d
             for (int nn = 0; nn < NT; ++nn) { sc[nn] = p.scale[cb + nn]; sh[nn] = p.shift[cb + nn]; }
             const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(p.out + (size_t)n * img_out, img_out);
             const __amdgpu_buffer_rsrc_t rs_res = make_rsrc((p.residual ? p.residual : p.out) + (size_t)n * img_out, img_out);
+            // the residual pixels: loads issued back to back and waited for once per batch (one load -> wait -> store per pixel
+            // serialises eight memory round trips per tile).  NT = 2: both rows in one batch; NT = 4: a row at a time (registers).
+            float rres[2][4][NT];
+            auto load_res_row = [&](int m) {
+                const int y = th0 + a_w + m * DIL;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int x = tw0 + 4 * g + r;
+                    const unsigned eo = (y < H && x < W) ? (unsigned)((y * W + x) * Cout + cb) * 4u : OOB_OFFSET;
+                    if (NT == 4) {
+                        const float4 rr = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_res, eo, 0, 0));
+                        rres[m][r][0] = rr.x; rres[m][r][1] = rr.y; rres[m][r][NT - 2] = rr.z; rres[m][r][NT - 1] = rr.w;
+                    } else {
+                        const u32x2 rv = __builtin_amdgcn_raw_buffer_load_b64(rs_res, eo, 0, 0);
+                        float2 rr; __builtin_memcpy(&rr, &rv, 8);
+                        rres[m][r][0] = rr.x; rres[m][r][1] = rr.y;
+                    }
+                }
+            };
+            if (NT == 2 && p.residual) { load_res_row(0); load_res_row(1); }
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const int y = th0 + a_w + m * DIL;
+                if (NT == 4 && p.residual) load_res_row(m);
                 f32x4 yv[NT];
 #pragma unroll
                 for (int nn = 0; nn < NT; ++nn)
@@ -230,14 +251,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(const estd_conv2d_d
                         for (int nn = 0; nn < NT; ++nn) v[nn] = v[nn] > 0.f ? v[nn] : 0.f;
                     }
                     if (p.residual) {
-                        if (NT == 4) {
-                            const float4 rr = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_res, eo, 0, 0));
-                            v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
-                        } else {
-                            const u32x2 rv = __builtin_amdgcn_raw_buffer_load_b64(rs_res, eo, 0, 0);
-                            float2 rr; __builtin_memcpy(&rr, &rv, 8);
-                            v[0] += rr.x; v[1] += rr.y;
-                        }
+#pragma unroll
+                        for (int nn = 0; nn < NT; ++nn) v[nn] += rres[m][r][nn];
                     }
                     if (p.relu_after_residual) {
 #pragma unroll

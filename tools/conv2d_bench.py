@@ -24,3 +24,16 @@ for (h, w, cin, cout, dil) in [(240, 320, 32, 32, 1), (120, 160, 64, 64, 1), (12
         ms = e0.elapsed_time(e1) / 20
         line += "   %s %.4f ms (%.1f TF/s)" % (arith, ms, gf / ms)
     print(line)
+    if cin == cout:                                         # BasicBlock tail: conv + BN + residual add
+        res = torch.randn(5, h, w, cout, device=dev)
+        line = "%3dx%-3d %3d->%-3d dil %d + residual" % (h, w, cin, cout, dil)
+        for algo in ("wino", "direct"):
+            ops.CONV2D_ARITH, ops.CONV2D_ALGO = "f32", algo
+            for _ in range(3): plan.run(x, residual=res)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20): plan.run(x, residual=res)
+            e1.record(); torch.cuda.synchronize()
+            line += "   f32/%s %.4f ms" % (algo, e0.elapsed_time(e1) / 20)
+        print(line)

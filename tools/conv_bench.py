@@ -27,3 +27,16 @@ torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
 gf = N * 2 * 27 * 32 * 32 * D * H * W / 1e9
 print("conv3d 32->32 N=%d D=%d: %.4f ms  %.1f TFLOP/s  (%.1f%% of 157.3)" % (N, D, ms, gf / ms, gf / ms / 157.3 * 100))
+if os.environ.get("CB_EPI"):                               # the read-back epilogues of pre1 (running sum) / pre2 (two residuals)
+    r1, r2 = torch.randn_like(x), torch.randn_like(x)
+    for name, kw in (("accumulate", dict(accumulate=True)), ("residual", dict(residual=r1)),
+                     ("2 residuals + scale", dict(residual=r1, residual2=r2, out_scale=0.5))):
+        for _ in range(3):
+            plan.run(x, (N, D, H, W), out=y, out_stride=32, **kw)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            plan.run(x, (N, D, H, W), out=y, out_stride=32, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        print("   + %-20s %.4f ms" % (name, e0.elapsed_time(e1) / iters))

@@ -20,7 +20,7 @@ span = t1 - t0
 
 
 def fam(n):
-    for key in ("conv3d_k3_split", "conv3d_k3_kernel", "conv2d_k3", "warp_attention", "homo_warp", "gru_", "softargmin", "groupnorm",
+    for key in ("conv3d_wino", "conv2d_wino", "conv3d_k3_split", "conv3d_k3_kernel", "conv2d_k3", "bn_act_nhwc", "warp_attention", "homo_warp", "gru_", "softargmin", "groupnorm",
                 "BatchNorm", "igemm", "xdl", "Cijk", "elementwise", "avg_pool", "upsample", "CatArray", "mix1x1", "cam_"):
         if key in n:
             return key
@@ -81,3 +81,13 @@ if "--gaps" in sys.argv:
                 print("    gap %.2f ms at +%.2f ms: after %s -> before %s" % ((s - prev_e) / 1e6, (prev_e - s0) / 1e6, prev_n[:60], n[:60]))
             if e > prev_e:
                 prev_e, prev_n = e, n
+
+# ---- every kernel of the LAST step in start order: +start ms, duration us, queue, name ----
+if "--seq" in sys.argv:
+    import re
+    step_len = span // steps
+    s0 = t1 - step_len
+    for s, e, n, q, st in region:
+        if s >= s0:
+            short = re.sub(r"\(anonymous namespace\)::|void |at::native::", "", n)[:70]
+            print("+%7.3f %8.1f us  q%s  %s" % ((s - s0) / 1e6, (e - s) / 1e3, q, short))
