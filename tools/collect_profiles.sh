@@ -11,7 +11,7 @@ for wl in joint estm cfg5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$wl -o p -- python $R/bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline --no-alt > $OUT/r2_bench_${wl}_profiled.json 2> $OUT/r2_bench_${wl}_profiled.err
   T=$(find /tmp/prof_$wl -name "p_kernel_trace.csv" | head -1)
   python $R/tools/prof_summary.py $T $OUT/r2_bench_${wl}_kernel_stats.csv 5
-  python $R/tools/prof_timeline.py $T 5 > $OUT/r2_bench_${wl}_timeline.txt 2>&1
+  python $R/tools/prof_timeline.py $T 5 --gaps > $OUT/r2_bench_${wl}_timeline.txt 2>&1
   S=$(find /tmp/prof_$wl -name "p_kernel_stats.csv" | head -1)
   [ -n "$S" ] && head -41 $S > $OUT/r2_bench_${wl}_rocprof_stats_top40.csv
 done
@@ -21,11 +21,13 @@ ESTD_CONV3D_ALGO=direct bash $R/tools/pmc_collect.sh "FETCH_SIZE WRITE_SIZE" $OU
 bash $R/tools/pmc_collect.sh "FETCH_SIZE WRITE_SIZE" $OUT/r2_hbm_kernels_pmc.csv -- python $R/tools/hbm_bench.py > /dev/null 2>&1
 cd $R
 python tools/hbm_bench.py > $OUT/r2_hbm_bench.txt 2>&1
-python tools/conv_bench.py 3 30 > $OUT/r2_conv_bench.txt 2>&1
+CB_EPI=1 python tools/conv_bench.py 3 30 > $OUT/r2_conv_bench.txt 2>&1
 python tools/conv_bench.py 1 30 >> $OUT/r2_conv_bench.txt 2>&1
-ESTD_CONV3D_ALGO=direct python tools/conv_bench.py 3 30 >> $OUT/r2_conv_bench.txt 2>&1
+CB_EPI=1 ESTD_CONV3D_ALGO=direct python tools/conv_bench.py 3 30 >> $OUT/r2_conv_bench.txt 2>&1
 ESTD_CONV3D_ALGO=direct python tools/conv_bench.py 1 30 >> $OUT/r2_conv_bench.txt 2>&1
 python tools/head_bench.py >> $OUT/r2_conv_bench.txt 2>&1
+python tools/kv_bench.py >> $OUT/r2_conv_bench.txt 2>&1
+python tools/conv2d_bench.py > $OUT/r2_conv2d_bench.txt 2>&1
 # eager host overhead: torch custom ops vs raw ctypes binding (same kernels, ~330 launches per step)
 for b in torch ctypes; do
   ESTD_BINDING=$b python bench.py --no-graph --steps 10 --warmup 3 --no-cpu-baseline --no-alt 2>/dev/null | python -c "
