@@ -64,11 +64,34 @@ def conv1x1_gemm(conv, x):
     return y.view(n, h, w, conv.out_channels).permute(0, 3, 1, 2)
 
 
+GEMM_EPILOGUE = os.environ.get("ESTD_GEMM_EPILOGUE", "1") == "1"     # A/B switch, read once at import
+
+
+def conv1x1_bn_gemm(conv, bn, x, relu):
+    """1x1 convolution + BatchNorm2d(eval) [+ ReLU] as ONE library GEMM with a bias [+ ReLU] epilogue: the BN scale is folded
+    into the weight columns, the BN shift is the bias."""
+    key = (conv.weight.device, conv.weight._version, conv.weight.data_ptr(), bn.weight._version, bn.bias._version,
+           bn.running_mean._version, bn.running_var._version)
+    c = conv.__dict__.get("_estd_w2bn")
+    if c is None or c[0] != key:
+        sc, sh = _folded(bn)
+        w2 = conv.weight.detach().reshape(conv.out_channels, conv.in_channels).t() * sc[None, :]
+        c = (key, w2.contiguous(), sh.contiguous())
+        conv.__dict__["_estd_w2bn"] = c
+    if conv.stride != (1, 1):
+        x = x[:, :, ::conv.stride[0], ::conv.stride[1]]
+    x = x.contiguous(memory_format=torch.channels_last)
+    n, cin, h, w = x.shape
+    x2 = x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
+    y = torch._addmm_activation(c[2], x2, c[1], use_gelu=False) if relu else torch.addmm(c[2], x2, c[1])
+    return y.view(n, h, w, conv.out_channels).permute(0, 3, 1, 2)
+
+
 def _is_1x1(conv):
     return conv.kernel_size == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and conv.dilation == (1, 1)
 
 
-HIP_3X3_MIN_ITEMS = 256     # work items (8x16-pixel tiles x 32-channel groups) below which the persistent MFMA kernel cannot fill 256 CUs
+HIP_3X3_MIN_ITEMS = int(os.environ.get("ESTD_HIP3X3_MIN_ITEMS", "256"))     # work items (8x16-pixel tiles x 32-channel groups) below which the persistent MFMA kernel cannot fill 256 CUs
 
 
 def _hip_3x3_plan(conv, bn, x, relu, has_residual):
@@ -113,6 +136,8 @@ def conv_bn_act(conv, bn, x, relu, residual=None):
         xn = x.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
         rn = residual.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1) if residual is not None else None
         return plan.run(xn, residual=rn).permute(0, 3, 1, 2)
+    if GEMM_EPILOGUE and residual is None and _is_1x1(conv) and conv.bias is None:
+        return conv1x1_bn_gemm(conv, bn, x, relu)
     y = conv1x1_gemm(conv, x) if _is_1x1(conv) else conv(x)
     if not y.is_contiguous(memory_format=torch.channels_last):
         y = y.contiguous(memory_format=torch.channels_last)
@@ -397,8 +422,8 @@ class UpBlock(nn.Module):
         if getattr(self, "_hip", False) and x.is_cuda and not self.training:
             conv = self.conv[0]
             n, _, h, w = x.shape
-            items = n * ((h + 7) // 8) * ((w + 15) // 16) * (conv.out_channels // (64 if conv.out_channels % 64 == 0 else 32))
-            if conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0 and items >= 256:     # enough tiles to fill 256 CUs
+            items = n * ((h + 7) // 8) * ((w + 15) // 16) * (conv.out_channels // 32)
+            if conv.in_channels % 32 == 0 and conv.out_channels % 32 == 0 and items >= HIP_3X3_MIN_ITEMS:     # enough tiles to fill 256 CUs
                 from . import ops
                 key = tuple((p.data_ptr(), p._version) for p in self.parameters())
                 if getattr(self, "_plan", None) is None or self._plan[0] != key:
