@@ -41,8 +41,9 @@
 #include "estd_common.h"
 
 #ifndef ESTD_WABL
-#define ESTD_WABL 0     // timing ablations only (results are wrong when != 0): 1 no output stores, 2 no transform writes,
-#endif                  // 8 no weight stream, 16 no next-plane prefetch
+#define ESTD_WABL 0     // timing ablations only (results are wrong for 1..16): 1 no output stores, 2 no transform writes,
+#endif                  // 8 no weight stream, 16 no next-plane prefetch; correct A/B switches: 32 slice writes between the
+                        // tiles only (no in-loop write of the next tile's slices), 64 weights one tap ahead instead of two
 
 namespace {
 
@@ -286,31 +287,48 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
             if (EXTRA) { ea = load_x(d0 - 1); eb = load_x(d0); ec = load_x(d0 + 1); ed = load_x(d0 + 2); }
         }
 
-        for (; u < seg_end; ++u, ++dp) {
-            const int d0 = 2 * dp;
-            lds_barrier();                              // every wave is done reading the previous tile's slices
-            // ---- input transform B^T x along depth, straight into the four LDS slices ----
+        // input transform B^T x along depth of the planes in (xa, xb, xc, xd), straight into LDS slice sl
+        auto write_slice = [&](int sl) {
 #pragma unroll
             for (int it = 0; it < SIT; ++it) {
                 if ((it < SIT - 1 || loff[it] >= 0) && !(ESTD_WABL & 2)) {
-                    *reinterpret_cast<float4*>(smem + 0 * SLICE_BYTES + loff[it]) = f4_sub(xa[it], xc[it]);
-                    *reinterpret_cast<float4*>(smem + 1 * SLICE_BYTES + loff[it]) = f4_add(xb[it], xc[it]);
-                    *reinterpret_cast<float4*>(smem + 2 * SLICE_BYTES + loff[it]) = f4_sub(xc[it], xb[it]);
-                    *reinterpret_cast<float4*>(smem + 3 * SLICE_BYTES + loff[it]) = f4_sub(xb[it], xd[it]);
+                    const float4 v = sl == 0 ? f4_sub(xa[it], xc[it]) : sl == 1 ? f4_add(xb[it], xc[it])
+                                   : sl == 2 ? f4_sub(xc[it], xb[it]) : f4_sub(xb[it], xd[it]);
+                    *reinterpret_cast<float4*>(smem + sl * SLICE_BYTES + loff[it]) = v;
                 }
-                xa[it] = xc[it];                         // planes d0+1, d0+2 are planes d0'-1, d0' of the next tile
-                xb[it] = xd[it];
             }
-            if (EXTRA) {
-                if (tid < SL_VOX) {
-                    lds_x[0 * SL_VOX + tid] = ea - ec;
-                    lds_x[1 * SL_VOX + tid] = eb + ec;
-                    lds_x[2 * SL_VOX + tid] = ec - eb;
-                    lds_x[3 * SL_VOX + tid] = eb - ed;
-                }
-                ea = ec; eb = ed;
+        };
+        auto write_x_slices = [&]() {
+            if (tid < SL_VOX) {
+                lds_x[0 * SL_VOX + tid] = ea - ec;
+                lds_x[1 * SL_VOX + tid] = eb + ec;
+                lds_x[2 * SL_VOX + tid] = ec - eb;
+                lds_x[3 * SL_VOX + tid] = eb - ed;
             }
-            lds_barrier();
+        };
+        auto shift_planes = [&]() {                      // planes d0+1, d0+2 are planes d0'-1, d0' of the next tile
+#pragma unroll
+            for (int it = 0; it < SIT; ++it) { xa[it] = xc[it]; xb[it] = xd[it]; }
+            if (EXTRA) { ea = ec; eb = ed; }
+        };
+        // PIPE: slice s is only read by taps 9s .. 9s+8, so the NEXT tile's slices 0..2 are written inside this tile's tap loop
+        // (one barrier each, at taps 9 / 18 / 27) and only slice 3 between two tiles; the epilogue then runs with no barrier
+        // behind it, so the waves drift apart and overlap it with the next tile's first taps.  (XOUT re-reads all four slices
+        // after its epilogue: it keeps the plain order.)
+        constexpr bool PIPE = !XOUT && !(ESTD_WABL & 32);
+        bool first = true;
+
+        for (; u < seg_end; ++u, ++dp) {
+            const int d0 = 2 * dp;
+            if (!PIPE || first) {
+                lds_barrier();                          // every wave is done reading the previous tile's slices
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) write_slice(sl);
+                if (EXTRA) write_x_slices();
+                shift_planes();
+                lds_barrier();
+                first = false;
+            }
 
             const bool has_next = (u + 1 < seg_end);     // wave-uniform
             const int nd = d0 + 3;                       // new planes of the next tile: nd, nd + 1
@@ -322,9 +340,14 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
 #pragma unroll
                 for (int m = 0; m < 2; ++m) acc[s][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-            float4 bcur[2], bnext[2];
+            constexpr bool W2 = !EXTRA && !(ESTD_WABL & 64);     // weights two taps ahead (8 more registers: the plain instance only)
+            float4 bcur[2], bnext[2], bnext2[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) bcur[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, q * 1024, 0));
+            if (W2) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) bnext[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, 4096 + q * 1024, 0));
+            }
 #ifdef ESTD_TIMELINE
             if (tid == 0 && p.stats_partials) {     // debug build only: per-tile start stamps instead of GroupNorm sums
                 const size_t tile_id = (((size_t)n * D + d0) * tiles_h + thi) * tiles_w + twi;
@@ -344,17 +367,24 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
                     a1[m] = *reinterpret_cast<const float4*>(smem + (off0 ^ 64));
                 }
             };
-            constexpr bool APF = !EXTRA;                 // A fragments one tap ahead (the 33-channel instances need the registers)
+            constexpr bool APF = !XOUT;                  // A fragments one tap ahead (the 33 -> 33 instance needs the registers)
             float4 a0c[2], a1c[2], a0n[2], a1n[2];
             if (APF) load_a(0, a0c, a1c);
 
 #pragma clang loop unroll(full)
             for (int tap = 0; tap < 36; ++tap) {
                 const int s = tap / 9;
+                if (PIPE && has_next && tap == 27) {
+                    lds_barrier();                       // slices 0..2 have been read for the last time by every wave
+                    write_slice(0);
+                    write_slice(1);
+                    write_slice(2);
+                }
                 // next tap's weights (the packed buffer carries one padding tap)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     if (ESTD_WABL & 8) { bnext[q] = bcur[q]; asm volatile("" : "+v"(bnext[q].x)); }
+                    else if (W2) { if (tap + 2 < 36) bnext2[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, (tap + 2) * 4096 + q * 1024, 0)); }
                     else bnext[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, (tap + 1) * 4096 + q * 1024, 0));
                 }
                 // one 16-byte chunk of the NEXT tile's two new planes per tap
@@ -382,6 +412,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
                 }
                 bcur[0] = bnext[0];
                 bcur[1] = bnext[1];
+                if (W2) { bnext[0] = bnext2[0]; bnext[1] = bnext2[1]; }
                 if (APF) { a0c[0] = a0n[0]; a0c[1] = a0n[1]; a1c[0] = a1n[0]; a1c[1] = a1n[1]; }
                 __builtin_amdgcn_sched_barrier(0);       // keep each tap's loads inside the tap (bounds live registers)
             }
@@ -405,6 +436,14 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
                             acc[s][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[s][m], 0, 0, 0);
                         }
                     }
+            }
+
+            if (PIPE && has_next) {                       // slice 3 (+ the scalar channel's slices) of the next tile
+                lds_barrier();
+                write_slice(3);
+                if (EXTRA) write_x_slices();
+                shift_planes();
+                lds_barrier();
             }
 
             // ---- output transform A^T m and the epilogue of the two planes ----
