@@ -290,6 +290,11 @@ def main():
     fwd = model if args.no_graph else GraphedForward(model)     # hipGraph replay of the same forward (same kernels)
 
     state = {"pending": None, "fwd": fwd, "allgather": world > 1 and not args.no_allgather, "notes": []}
+    if state["allgather"] and not oversub:
+        # the RCCL all-gather of step k runs on a few CUs WHILE step k+1 computes.  The convolutions launch one or two resident
+        # workgroups per CU with static tile ranges: were all 256 CUs claimed, the workgroups displaced by the collective would
+        # queue behind the others and double the launch.  Leave one CU per XCD free (costs ~3 % of the convolution rate at N > 1).
+        state["reserved_cus"] = ops.set_reserved_cus(int(os.environ.get("ESTD_RESERVED_CUS", "8")))
     if oversub:
         state["notes"].append("%d ranks share %d GPU(s), gloo collectives: code-path check, not a scaling measurement" % (world, oversub))
 
@@ -431,7 +436,8 @@ def main():
                        "conv3d_algo_32to32": args.conv3d_algo if args.conv3d_arith == "f32" else "direct",
                        "notes": state["notes"],
                        "per_rank_ms_per_step": per_rank_ms,
-                       "parallelism": "1 sequence per GPU" + ("; RCCL all-gather of {K,V,pose} per step, overlapped with the next step" if gathered else "")},
+                       "parallelism": "1 sequence per GPU" + ("; RCCL all-gather of {K,V,pose} per step, overlapped with the next step" if gathered else "")
+                                      + (("; %d CUs left free for the collective" % state["reserved_cus"]) if state.get("reserved_cus") else "")},
             "roofline": {"bound": "mfma",
                          "kernel": ("conv3d_wino_kernel (3x3x3 conv 32->32, fp32 MFMA 16x16x4, depth axis in Winograd F(2,3) form)" if wino else
                                     "conv3d_k3_kernel<32,2> (3x3x3 conv 32->32, fp32 MFMA 16x16x4)") if args.conv3d_arith == "f32" else

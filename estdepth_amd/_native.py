@@ -48,6 +48,8 @@ _SIGNATURES = {
     "estd_version": (ctypes.c_int, []),
     "estd_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "estd_profile_mark": (ctypes.c_int, [ctypes.c_int, c_stream]),
+    "estd_set_reserved_cus": (ctypes.c_int, [ctypes.c_int]),
+    "estd_get_reserved_cus": (ctypes.c_int, []),
     "estd_cam_pair_proj": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_stream]),
     "estd_cam_sweep_proj": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_stream]),
     "estd_cam_volume_mats": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_stream]),

@@ -251,7 +251,8 @@ int launch2d(const estd_conv2d_desc& d, hipStream_t stream)
     const int groups = d.cout / (16 * NT);
     const int total = groups * d.N * tiles_h * tiles_w;
     const size_t lds = (size_t)2 * IN_H * IN_W * 128;
-    int grid = total < 512 ? total : 512;
+    const int slots = estd_persistent_wgs(2);
+    int grid = total < slots ? total : slots;
     if (grid >= 8) grid &= ~7;
     estd_allow_dynamic_lds<conv2d_k3_kernel<NT, DIL>>((int)lds);
     hipLaunchKernelGGL((conv2d_k3_kernel<NT, DIL>), dim3(grid), dim3(256), lds, stream, d, tiles_w, tiles_h, total);

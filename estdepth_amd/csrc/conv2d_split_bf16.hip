@@ -376,7 +376,8 @@ int launch_split2d(const estd_conv2d_desc& d, hipStream_t stream)
     const int tiles_w = (d.W + G_::TW - 1) / G_::TW, tiles_h = (d.H + TH - 1) / TH;
     const long long total = (long long)(d.cout >> 5) * d.N * tiles_h * tiles_w;
     if (total > 0x7fffffffLL) return ESTD_ERR_ARG;
-    int grid = total < 256 ? (int)total : 256;
+    const int slots = estd_persistent_wgs(1);
+    int grid = total < slots ? (int)total : slots;
     if (grid >= 8) grid &= ~7;
     estd_allow_dynamic_lds<conv2d_k3_split_kernel<DIL, RES>>((int)G_::LDS_TOTAL);
     hipLaunchKernelGGL((conv2d_k3_split_kernel<DIL, RES>), dim3(grid), dim3(512), G_::LDS_TOTAL, stream, d, tiles_w, tiles_h, (int)total);

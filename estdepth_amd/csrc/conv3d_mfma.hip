@@ -511,7 +511,8 @@ int launch(const estd_conv3d_desc& d, hipStream_t stream)
 {
     const int tiles_w = (d.W + TW - 1) / TW, tiles_h = (d.H + TH - 1) / TH;
     const int total = d.N * d.D * tiles_h * tiles_w;
-    int grid = total < PERSISTENT_WGS ? total : PERSISTENT_WGS;
+    const int slots = estd_persistent_wgs(PERSISTENT_WGS / 256);
+    int grid = total < slots ? total : slots;
     if (grid >= 8) grid &= ~7;
     const size_t lds = (size_t)3 * SL_VOX * CM * 4 + (EXTRA ? 3 * SL_VOX * 4 : 0) + 128;
     estd_allow_dynamic_lds<conv3d_k3_kernel<CM, NT, EXTRA, XOUT>>((int)lds);

@@ -591,7 +591,8 @@ __global__ __launch_bounds__(512, 1) void conv3d_k3_split_kernel(const estd_conv
 template <int NT, bool EXTRA, bool TANH, bool STATS, bool RES>
 int launch_inst(const estd_conv3d_desc& d, hipStream_t stream, int tiles_w, int tiles_h, int total)
 {
-    int grid = total < 256 ? total : 256;       // one workgroup per CU (LDS-limited)
+    const int slots = estd_persistent_wgs(1);      // one workgroup per CU (LDS-limited)
+    int grid = total < slots ? total : slots;
     if (grid >= 8) grid &= ~7;
     estd_allow_dynamic_lds<conv3d_k3_split_kernel<NT, EXTRA, TANH, STATS, RES>>((int)LDS_TOTAL);
     hipLaunchKernelGGL((conv3d_k3_split_kernel<NT, EXTRA, TANH, STATS, RES>), dim3(grid), dim3(512), LDS_TOTAL, stream, d, tiles_w, tiles_h, total);

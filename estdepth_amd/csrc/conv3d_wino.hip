@@ -544,7 +544,8 @@ extern "C" int estd_conv3d_k3_wino(const estd_conv3d_desc* dp, estd_stream_t s)
         const int widest = d.in_stride > d.out_stride ? d.in_stride : d.out_stride;
         if (vox * widest * 4 >= 0x7fffff00LL) return ESTD_ERR_UNSUPPORTED;
     }
-    int grid = total < PERSISTENT_WGS ? (int)total : PERSISTENT_WGS;
+    const int slots = estd_persistent_wgs(PERSISTENT_WGS / 256);
+    int grid = total < slots ? (int)total : slots;
     if (grid >= 8) grid &= ~7;
 #define ESTD_WINO_LAUNCH(E, X)                                                                                                   \
     do {                                                                                                                         \

@@ -15,6 +15,8 @@
 #include <stdint.h>
 
 #include "estd_hip.h"
+#include <cstdlib>
+
 #include "estd_common.h"
 
 namespace {
@@ -538,6 +540,17 @@ extern "C" int estd_profile_mark(int id, estd_stream_t s)
 }
 
 extern "C" int estd_version(void) { return 100; }
+
+namespace {
+int clamp_reserved(int n) { n = n < 0 ? 0 : n > 128 ? 128 : n; return (n + 7) & ~7; }
+std::atomic<int>& reserved_cus()
+{
+    static std::atomic<int> v{[] { const char* e = getenv("ESTD_RESERVED_CUS"); return clamp_reserved(e ? atoi(e) : 0); }()};
+    return v;
+}
+}  // namespace
+extern "C" int estd_set_reserved_cus(int n) { reserved_cus().store(clamp_reserved(n)); return reserved_cus().load(); }
+extern "C" int estd_get_reserved_cus(void) { return reserved_cus().load(); }
 
 extern "C" const char* estd_status_string(int st)
 {

@@ -10,6 +10,10 @@
 
 static inline hipStream_t estd_stream(estd_stream_t s) { return static_cast<hipStream_t>(s); }
 
+// persistent-grid size of a kernel with `per_cu` resident workgroups per CU (256 CUs, minus the reserve of estd_set_reserved_cus)
+extern "C" int estd_get_reserved_cus(void);
+static inline int estd_persistent_wgs(int per_cu) { return (256 - estd_get_reserved_cus()) * per_cu; }
+
 static inline int estd_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of (function, device): raise it once per device ordinal and

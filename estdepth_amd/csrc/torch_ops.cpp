@@ -412,6 +412,7 @@ std::tuple<Tensor, Tensor> camera_matrices_host(const Tensor& cam_poses, const T
     return {sweep, vol};
 }
 
+int64_t set_reserved_cus(int64_t n) { return estd_set_reserved_cus((int)n); }
 void profile_mark(int64_t id) { check_status(estd_profile_mark((int)id, cur_stream()), "estd_profile_mark"); }
 int64_t conv3d_grid(int64_t N, int64_t D, int64_t H, int64_t W)
 {
@@ -450,6 +451,7 @@ TORCH_LIBRARY(estdepth_hip, m)
     m.def("vol_to_cdhw(Tensor src, int C, int[] dims, int src_stride, int src_off) -> Tensor");
     m.def("camera_matrices_host(Tensor cam_poses, Tensor cam_intr, Tensor[] pre_poses, bool with_volume) -> (Tensor, Tensor)");
     m.def("profile_mark(int id) -> ()");
+    m.def("set_reserved_cus(int n) -> int");
     m.def("conv3d_grid(int N, int D, int H, int W) -> int");
 }
 
@@ -487,5 +489,6 @@ TORCH_LIBRARY_IMPL(estdepth_hip, CPU, m)
 TORCH_LIBRARY_IMPL(estdepth_hip, CompositeExplicitAutograd, m)
 {
     m.impl("profile_mark", profile_mark);
+    m.impl("set_reserved_cus", set_reserved_cus);
     m.impl("conv3d_grid", conv3d_grid);
 }

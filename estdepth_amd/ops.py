@@ -100,6 +100,13 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def set_reserved_cus(n):
+    """Compute units the persistent convolution grids leave free for a concurrent collective (include/estd_hip.h)."""
+    if _use_torch():
+        return int(T().set_reserved_cus(int(n)))
+    return int(N.lib().estd_set_reserved_cus(int(n)))
+
+
 def profile_mark(idx):
     if _use_torch():
         return T().profile_mark(int(idx))

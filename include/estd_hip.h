@@ -41,6 +41,14 @@ int estd_version(void);
 /* launches the empty kernel `estd_mark_kernel` so a rocprofv3 kernel trace can be cut to a timed region */
 int estd_profile_mark(int id, estd_stream_t stream);
 const char* estd_status_string(int status);
+/* Compute units the persistent convolution grids leave free (0..128, rounded up to a multiple of 8 = one per XCD; default 0, or
+ * the environment variable ESTD_RESERVED_CUS read at load time).  The convolution kernels launch one or two resident
+ * workgroups per CU with STATIC tile ranges: a concurrent kernel that holds even a few CUs (an RCCL collective overlapped
+ * with the step) would push the workgroups that no longer fit behind all the others and double the launch's duration.
+ * Multi-GPU hosts reserve 8 (bench.py does for N > 1).  Process-wide; takes effect for launches (and graph captures) made
+ * afterwards.  Returns the value in effect. */
+int estd_set_reserved_cus(int n);
+int estd_get_reserved_cus(void);
 
 /* ---- camera algebra on device (tiny fp64 kernels; keeps the forward free of host syncs) ------
  * Replaces the torch.inverse / matmul calls at hybrid_models/model_hybrid.py:74-88,

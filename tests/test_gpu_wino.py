@@ -174,6 +174,32 @@ def test_wino_33_to_33_matches_direct_kernel_and_fp64(dims):
     assert float((outs["direct"] - outs["wino"]).abs().max()) < 5e-6 * max(1.0, mag)
 
 
+def test_reserved_cus_changes_the_partition_not_the_result():
+    """estd_set_reserved_cus (persistent grids leave CUs to a concurrent collective, N > 1): 248- and 128-CU grids give
+    bit-identical outputs and GroupNorm partial sums on both conv3d kernels and the conv2d kernel; the setting round-trips."""
+    from estdepth_amd import ops
+    _, plan = _plan(13, act=None)
+    dims = (2, 9, 40, 70)
+    x = torch.randn(*dims, 32, generator=torch.Generator().manual_seed(4)).to(DEV)
+    conv = torch.nn.Conv2d(64, 64, 3, 1, 1, bias=False).to(DEV)
+    bn = torch.nn.BatchNorm2d(64).to(DEV).eval()
+    p2 = ops.Conv2dPlan(conv, bn, relu_before=True)
+    x2 = torch.randn(3, 120, 160, 64, generator=torch.Generator().manual_seed(5)).to(DEV)
+    nblk = ops.conv3d_grid(*dims)
+    res = {}
+    try:
+        for r in (0, 8, 5, 128, 1000):
+            eff = ops.set_reserved_cus(r)
+            assert eff == {0: 0, 8: 8, 5: 8, 128: 128, 1000: 128}[r]
+            part = torch.zeros(nblk * 4, device=DEV, dtype=torch.float64)
+            res[r] = (_run(plan, "wino", x, dims, stats_partials=part), part, _run(plan, "direct", x, dims), p2.run(x2))
+    finally:
+        ops.set_reserved_cus(0)
+    for r in (8, 128):
+        for a, b in zip(res[0], res[r]):
+            assert torch.equal(a, b)
+
+
 def test_wino_rejects_other_shapes():
     from estdepth_amd import _native
     d = _native.Conv3dDesc()
