@@ -200,6 +200,15 @@ def test_reserved_cus_changes_the_partition_not_the_result():
             assert torch.equal(a, b)
 
 
+def test_fuzz_winograd_kernels_against_direct_kernels():
+    """tools/fuzz_convs.py for 15 s (~400 random cases): ragged shapes, batches, every instance and epilogue flag of the 3D and
+    2D Winograd kernels against the direct kernels of the same operator."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_convs.py"), "15", "7"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "random cases agree" in r.stdout, (r.stdout[-500:], r.stderr[-500:])
+
+
 def test_wino_rejects_other_shapes():
     from estdepth_amd import _native
     d = _native.Conv3dDesc()

@@ -1,0 +1,114 @@
+"""Randomised A/B of the Winograd kernels against the direct kernels (same operator, same descriptor): random ragged shapes,
+batch sizes, epilogue flags, instances.  python tools/fuzz_convs.py [seconds] [seed]     (GPU; prints the first mismatch and exits 1)"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from estdepth_amd import ops
+
+DEV = torch.device("cuda:0")
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+
+
+def rnd(*shape, scale=1.0):
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def run3d(plan, algo, x, dims, **kw):
+    ops.CONV3D_ALGO = algo
+    out = kw.pop("out")
+    plan.run(x, dims, out=out, **kw)
+    torch.cuda.synchronize()
+    return out
+
+
+def case_conv3d():
+    N, D, H, W = int(rng.integers(1, 4)), int(rng.integers(1, 12)), int(rng.integers(1, 40)), int(rng.integers(1, 70))
+    inst = rng.choice(["plain", "extra", "xout"])
+    dims = (N, D, H, W)
+    x = rnd(N, D, H, W, 32)
+    kw_common = {}
+    if inst == "plain":
+        w = rnd(32, 32, 3, 3, 3, scale=0.06).cpu()
+        act = str(rng.choice(["relu", "none", "tanh"]))
+        plan = ops.Conv3dPlan(w, list(range(32)), None, list(range(32)), 2, torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.1,
+                              act_a=act, device=DEV)
+        mode = rng.choice(["none", "res", "res2", "acc", "stats"])
+        if mode == "res":
+            kw_common = dict(residual=rnd(N, D, H, W, 32))
+        elif mode == "res2":
+            kw_common = dict(residual=rnd(N, D, H, W, 32), residual2=rnd(N, D, H, W, 32), out_scale=0.5)
+        elif mode == "acc":
+            kw_common = dict(accumulate=True, out_scale=float(rng.uniform(0.3, 1.0)))
+        outs = {}
+        base = rnd(N, D, H, W, 32)
+        for algo in ("direct", "wino"):
+            kw = dict(kw_common)
+            if mode == "stats":
+                kw["stats_partials"] = torch.zeros(ops.conv3d_grid(*dims) * 4, device=DEV, dtype=torch.float64)
+            outs[algo] = (run3d(plan, algo, x, dims, out=base.clone(), **kw), kw.get("stats_partials"))
+        a, b = outs["direct"][0], outs["wino"][0]
+        tol = 4e-5 * max(1.0, float(a.abs().max()))
+        ok = float((a - b).abs().max()) < tol
+        if mode == "stats" and ok:
+            sa = ops.groupnorm_finalize(outs["direct"][1], ops.conv3d_grid(*dims), 16.0 * N * D * H * W)
+            sb = ops.groupnorm_finalize(outs["wino"][1], ops.conv3d_grid(*dims), 16.0 * N * D * H * W)
+            ok = float((sa - sb).abs().max()) < 1e-4 * max(1.0, float(sa.abs().max()))
+        return ok, ("conv3d", inst, dims, act, mode, float((a - b).abs().max()))
+    e = rnd(N, D, H, W)
+    if inst == "extra":
+        w = rnd(32, 33, 3, 3, 3, scale=0.06).cpu()
+        plan = ops.Conv3dPlan(w, list(range(32)), 32, list(range(32)), 2, torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.1,
+                              act_a="tanh", act_b="relu", act_split=16, device=DEV)
+        a = run3d(plan, "direct", x, dims, in_extra=e, out=torch.empty_like(x))
+        b = run3d(plan, "wino", x, dims, in_extra=e, out=torch.empty_like(x))
+    else:
+        w = rnd(33, 33, 3, 3, 3, scale=0.06).cpu()
+        plan = ops.Conv3dPlan(w, list(range(1, 33)), 0, list(range(33)), 3, torch.rand(33, generator=g) + 0.5, torch.randn(33, generator=g) * 0.1,
+                              act_a="relu", device=DEV)
+        ea, eb = torch.full((N, D, H, W), float("nan"), device=DEV), torch.full((N, D, H, W), float("nan"), device=DEV)
+        a = run3d(plan, "direct", x, dims, in_extra=e, out=torch.empty_like(x), out_extra=ea)
+        b = run3d(plan, "wino", x, dims, in_extra=e, out=torch.empty_like(x), out_extra=eb)
+        a, b = torch.cat([a, ea[..., None]], -1), torch.cat([b, eb[..., None]], -1)
+    d = float((a - b).abs().max())
+    return (d == d) and d < 4e-5 * max(1.0, float(a.abs().max())), ("conv3d", inst, dims, d)
+
+
+def case_conv2d():
+    cin, cout = int(rng.choice([32, 64, 96, 128, 320])), int(rng.choice([32, 64, 128]))
+    dil = int(rng.choice([1, 2]))
+    N, H, W = int(rng.integers(1, 6)), int(rng.integers(1, 60)), int(rng.integers(1, 90))
+    conv = torch.nn.Conv2d(cin, cout, 3, 1, dil, dil, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.05)
+    conv = conv.to(DEV)
+    bn = torch.nn.BatchNorm2d(cout).eval()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(cout, generator=g) + 0.5); bn.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+        bn.running_mean.copy_(torch.randn(cout, generator=g) * 0.1); bn.running_var.copy_(torch.rand(cout, generator=g) + 0.5)
+    bn = bn.to(DEV)
+    rb, ra = bool(rng.integers(2)), bool(rng.integers(2))
+    plan = ops.Conv2dPlan(conv, bn, relu_before=rb, relu_after=ra)
+    x = rnd(N, H, W, cin)
+    res = rnd(N, H, W, cout) if rng.integers(2) else None
+    outs = {}
+    for algo in ("direct", "wino"):
+        ops.CONV2D_ALGO = algo
+        outs[algo] = plan.run(x, residual=res)
+        torch.cuda.synchronize()
+    a, b = outs["direct"], outs["wino"]
+    d = float((a - b).abs().max())
+    return (d == d) and d < 4e-5 * max(1.0, float(a.abs().max())), ("conv2d", (N, H, W), cin, cout, dil, rb, ra, res is not None, d)
+
+
+t0, n = time.time(), 0
+while time.time() - t0 < budget:
+    ok, info = (case_conv3d if rng.integers(3) else case_conv2d)()
+    n += 1
+    if not ok:
+        print("MISMATCH after %d cases:" % n, info)
+        sys.exit(1)
+print("fuzz_convs: %d random cases agree (direct vs Winograd kernels)" % n)
