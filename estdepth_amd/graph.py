@@ -115,15 +115,26 @@ class GraphedForward:
         if matching_features is not None:
             st["feats"].copy_(matching_features)
         if pre_costs is not None:
-            for dst, k, v in zip(st["kv"], pre_costs["keys"], pre_costs["values"]):
-                src = kv_from_pair(k, v)
-                if src.data_ptr() != dst.data_ptr():
-                    dst.copy_(src)
-            for dst, p in zip(st["mem_poses"], pre_cam_poses):
-                dst.copy_(p)
+            # the memory volumes (157 MB each at cfg2 size) are inputs of stage B only: their copies run on a side stream
+            # beside stage A instead of in front of it.  The side stream starts after everything queued so far (the previous
+            # replay of stage B, which reads these buffers; the kernels that produced pre_costs) and stage B waits for it.
+            main = torch.cuda.current_stream()
+            side = st.get("copy_stream")
+            if side is None:
+                side = st["copy_stream"] = torch.cuda.Stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for dst, k, v in zip(st["kv"], pre_costs["keys"], pre_costs["values"]):
+                    src = kv_from_pair(k, v)
+                    if src.data_ptr() != dst.data_ptr():
+                        dst.copy_(src)
+                for dst, p in zip(st["mem_poses"], pre_cam_poses):
+                    dst.copy_(p)
         # 2. ... then stage A (the 2D networks, ~25 % of a step) is launched; 3. while it runs the host waits for the copy,
         # composes the camera matrices with the reference's own torch-CPU calls and queues their upload; 4. stage B.
         st["graph_a"].replay()
+        if pre_costs is not None:
+            main.wait_stream(side)
         if pending is not None:
             cam = camera.finish(pending)
             for name, t in cam.items():
