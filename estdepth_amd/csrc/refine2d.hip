@@ -1,0 +1,155 @@
+// 2D refinement tail of DepthHybridDecoder (hybrid_depth_decoder.py:267-290 / :392-415): the glue around its 3x3 convolutions,
+// HBM bound, one pass each (gfx950 only).
+//
+//   estd_planes_cat_nhwc      cat([semantic_vs, relu(all_fused_logits)], 1) (:268) of two NCHW plane stacks, written directly as the
+//                             NHWC map the next convolution reads (was: cat kernel + channels-last copy)
+//   estd_upsample2_cat_nhwc   cat([upsample(x), skip], 1) (:269-272): nearest x2 of an NHWC map beside its full-resolution skip
+//   estd_disp_head_nhwc       depth_max * sigmoid(Conv2d(C, 1, 3, padding 1, bias)(x)) (:274, :279), optionally nearest x2 (:274
+//                             F.interpolate(scale_factor=2)): C -> 1 channels is a GEMV per pixel -- one thread per pixel on the VALU
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "estd_hip.h"
+
+#include "estd_common.h"
+
+namespace {
+
+// ---- [N][Ca][HW] and [N][Cb][HW] planes -> [N][HW][Ca + Cb] records, through an LDS tile so both sides coalesce ----
+template <int PIX>            // pixels per block
+__global__ __launch_bounds__(256) void planes_cat_nhwc_kernel(const float* __restrict__ a, int Ca, const float* __restrict__ b, int Cb,
+                                                              int relu_b, float* __restrict__ out, long long HW)
+{
+    extern __shared__ float tile[];                 // [C][PIX + 1]
+    const int C = Ca + Cb;
+    const long long blocks_per_img = (HW + PIX - 1) / PIX;
+    const long long n = blockIdx.x / blocks_per_img;
+    const long long p0 = (blockIdx.x % blocks_per_img) * PIX;
+    for (int e = threadIdx.x; e < C * PIX; e += 256) {
+        const int c = e / PIX, k = e % PIX;
+        float v = 0.f;
+        if (p0 + k < HW) {
+            if (c < Ca) v = a[(n * Ca + c) * HW + p0 + k];
+            else {
+                v = b[(n * Cb + (c - Ca)) * HW + p0 + k];
+                if (relu_b) v = v > 0.f ? v : 0.f;
+            }
+        }
+        tile[c * (PIX + 1) + k] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < C * PIX; e += 256) {
+        const int k = e / C, c = e % C;
+        if (p0 + k < HW) out[(n * HW + p0 + k) * C + c] = tile[c * (PIX + 1) + k];
+    }
+}
+
+// ---- out[n][y][x] = cat(x[n][y/2][x/2][0..Cx), skip[n][y][x][0..Cs)); one thread per 16-byte chunk ----
+__global__ __launch_bounds__(256) void upsample2_cat_nhwc_kernel(const float4* __restrict__ x, int Cx4, const float4* __restrict__ skip, int Cs4,
+                                                                 float4* __restrict__ out, int N, int H, int W)
+{
+    const int C4 = Cx4 + Cs4;
+    const long long total = (long long)N * H * W * C4;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int c = (int)(e % C4);
+    const long long pix = e / C4;
+    const int xx = (int)(pix % W), yy = (int)((pix / W) % H);
+    const long long n = pix / ((long long)W * H);
+    float4 v;
+    if (c < Cx4) v = x[((n * (H >> 1) + (yy >> 1)) * (W >> 1) + (xx >> 1)) * Cx4 + c];
+    else v = skip[pix * Cs4 + (c - Cx4)];
+    out[e] = v;
+}
+
+// ---- depth head: one thread per input-resolution pixel; weights [9][C] in LDS ----
+template <int C>
+__global__ __launch_bounds__(256) void disp_head_nhwc_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias, float depth_max,
+                                                             float* __restrict__ out, int N, int H, int W, int up)
+{
+    __shared__ float ws[9 * C];
+    for (int e = threadIdx.x; e < 9 * C; e += 256) {           // w is [1][C][3][3] (Conv2d layout) -> [tap][c]
+        const int t = e / C, c = e % C;
+        ws[e] = w[c * 9 + t];
+    }
+    __syncthreads();
+    const long long total = (long long)N * H * W;
+    const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= total) return;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    const long long n = pix / ((long long)W * H);
+    float acc = bias[0];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yy = y + ky - 1;
+        if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int xx = x + kx - 1;
+            if ((unsigned)xx >= (unsigned)W) continue;
+            const float4* src = reinterpret_cast<const float4*>(in + ((n * H + yy) * W + xx) * C);
+            const float* wt = ws + (ky * 3 + kx) * C;
+#pragma unroll
+            for (int q = 0; q < C / 4; ++q) {
+                const float4 v = src[q];
+                acc = fmaf(v.x, wt[4 * q + 0], acc);
+                acc = fmaf(v.y, wt[4 * q + 1], acc);
+                acc = fmaf(v.z, wt[4 * q + 2], acc);
+                acc = fmaf(v.w, wt[4 * q + 3], acc);
+            }
+        }
+    }
+    const float d = depth_max * (1.0f / (1.0f + expf(-acc)));
+    if (up == 1) {
+        out[pix] = d;
+    } else {                                                     // nearest x2: the 2x2 block of the output
+        const int W2 = 2 * W;
+        float* o = out + (n * (2 * H) + 2 * y) * (long long)W2 + 2 * x;
+        *reinterpret_cast<float2*>(o) = make_float2(d, d);
+        *reinterpret_cast<float2*>(o + W2) = make_float2(d, d);
+    }
+}
+
+}  // namespace
+
+extern "C" int estd_planes_cat_nhwc(const float* a, int Ca, const float* b, int Cb, int relu_b, float* out, int N, int64_t HW, estd_stream_t s)
+{
+    if (!a || !b || !out || Ca <= 0 || Cb <= 0 || N <= 0 || HW <= 0) return ESTD_ERR_ARG;
+    const int C = Ca + Cb;
+    const int pix = (size_t)C * 65 * sizeof(float) <= 64 * 1024 ? 64 : 32;                   // LDS tile [C][pix + 1] within 64 KB
+    const size_t lds = (size_t)C * (pix + 1) * sizeof(float);
+    if (lds > 64 * 1024) return ESTD_ERR_UNSUPPORTED;                                        // <= 496 channels
+    const long long blocks = (long long)N * ((HW + pix - 1) / pix);
+    if (blocks > 0x7fffffffLL) return ESTD_ERR_ARG;
+    if (pix == 64)
+        hipLaunchKernelGGL(planes_cat_nhwc_kernel<64>, dim3((unsigned)blocks), dim3(256), lds, estd_stream(s), a, Ca, b, Cb, relu_b, out, (long long)HW);
+    else
+        hipLaunchKernelGGL(planes_cat_nhwc_kernel<32>, dim3((unsigned)blocks), dim3(256), lds, estd_stream(s), a, Ca, b, Cb, relu_b, out, (long long)HW);
+    return ESTD_LAUNCH_CHECK();
+}
+
+extern "C" int estd_upsample2_cat_nhwc(const float* x, int Cx, const float* skip, int Cs, float* out, int N, int H, int W, estd_stream_t s)
+{
+    if (!x || !skip || !out || Cx <= 0 || Cs <= 0 || (Cx & 3) || (Cs & 3) || N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return ESTD_ERR_ARG;
+    const long long total = (long long)N * H * W * ((Cx + Cs) / 4);
+    const long long blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return ESTD_ERR_ARG;
+    hipLaunchKernelGGL(upsample2_cat_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, estd_stream(s), reinterpret_cast<const float4*>(x), Cx / 4,
+                       reinterpret_cast<const float4*>(skip), Cs / 4, reinterpret_cast<float4*>(out), N, H, W);
+    return ESTD_LAUNCH_CHECK();
+}
+
+extern "C" int estd_disp_head_nhwc(const float* in, const float* w, const float* bias, float depth_max, float* out, int N, int H, int W, int C,
+                                   int upscale, estd_stream_t s)
+{
+    if (!in || !w || !bias || !out || N <= 0 || H <= 0 || W <= 0 || (upscale != 1 && upscale != 2)) return ESTD_ERR_ARG;
+    if (C != 16 && C != 32) return ESTD_ERR_UNSUPPORTED;
+    const long long total = (long long)N * H * W;
+    const long long blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return ESTD_ERR_ARG;
+    if (C == 16)
+        hipLaunchKernelGGL(disp_head_nhwc_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, estd_stream(s), in, w, bias, depth_max, out, N, H, W, upscale);
+    else
+        hipLaunchKernelGGL(disp_head_nhwc_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, estd_stream(s), in, w, bias, depth_max, out, N, H, W, upscale);
+    return ESTD_LAUNCH_CHECK();
+}

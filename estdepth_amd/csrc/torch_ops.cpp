@@ -328,6 +328,40 @@ Tensor spp_upsample_cat(const Tensor& raw, const Tensor& skip, at::TensorList br
     return out;
 }
 
+Tensor planes_cat_nhwc(const Tensor& a, const Tensor& b, bool relu_b)
+{
+    TORCH_CHECK(a.dim() == 4 && b.dim() == 4 && a.size(0) == b.size(0) && a.size(2) == b.size(2) && a.size(3) == b.size(3),
+                "planes_cat_nhwc: two NCHW stacks of the same N, H, W expected");
+    const int64_t n = a.size(0), ca = a.size(1), cb = b.size(1), h = a.size(2), w = a.size(3);
+    Tensor out = new_f32({n, h, w, ca + cb}, a);
+    check_status(estd_planes_cat_nhwc(fptr(a, "a"), (int)ca, fptr(b, "b"), (int)cb, relu_b ? 1 : 0, out.data_ptr<float>(), (int)n, h * w,
+                                      cur_stream()), "estd_planes_cat_nhwc");
+    return out;
+}
+
+Tensor upsample2_cat_nhwc(const Tensor& x, const Tensor& skip)
+{
+    TORCH_CHECK(x.dim() == 4 && skip.dim() == 4 && x.size(0) == skip.size(0) && 2 * x.size(1) == skip.size(1) && 2 * x.size(2) == skip.size(2),
+                "upsample2_cat_nhwc: NHWC x [N,H/2,W/2,Cx] and skip [N,H,W,Cs] expected");
+    const int64_t n = skip.size(0), h = skip.size(1), w = skip.size(2), cx = x.size(3), cs = skip.size(3);
+    Tensor out = new_f32({n, h, w, cx + cs}, x);
+    check_status(estd_upsample2_cat_nhwc(fptr(x, "x"), (int)cx, fptr(skip, "skip"), (int)cs, out.data_ptr<float>(), (int)n, (int)h, (int)w,
+                                         cur_stream()), "estd_upsample2_cat_nhwc");
+    return out;
+}
+
+Tensor disp_head_nhwc(const Tensor& x, const Tensor& weight, const Tensor& bias, double depth_max, int64_t upscale)
+{
+    TORCH_CHECK(x.dim() == 4 && weight.dim() == 4 && weight.size(0) == 1 && weight.size(1) == x.size(3) && weight.size(2) == 3 &&
+                weight.size(3) == 3 && bias.numel() == 1, "disp_head_nhwc: NHWC x [N,H,W,C], weight [1,C,3,3], bias [1] expected");
+    TORCH_CHECK(upscale == 1 || upscale == 2, "disp_head_nhwc: upscale must be 1 or 2");
+    const int64_t n = x.size(0), h = x.size(1), w = x.size(2), c = x.size(3);
+    Tensor out = new_f32({n, 1, upscale * h, upscale * w}, x);
+    check_status(estd_disp_head_nhwc(fptr(x, "x"), fptr(weight, "weight"), fptr(bias, "bias"), (float)depth_max, out.data_ptr<float>(), (int)n,
+                                     (int)h, (int)w, (int)c, (int)upscale, cur_stream()), "estd_disp_head_nhwc");
+    return out;
+}
+
 void cdhw_to_vol(const Tensor& src, Tensor dst, int64_t dst_stride, int64_t dst_off)
 {
     TORCH_CHECK(src.dim() >= 2, "cdhw_to_vol: src must be [C, ...]");
@@ -447,6 +481,9 @@ TORCH_LIBRARY(estdepth_hip, m)
           "Tensor beta_o, Tensor(a!) out_value, int out_stride) -> ()");
     m.def("bn_act_nhwc_(Tensor(a!) x, Tensor scale, Tensor shift, bool relu, Tensor? residual) -> Tensor(a!)");
     m.def("spp_upsample_cat(Tensor raw, Tensor skip, Tensor[] branches) -> Tensor");
+    m.def("planes_cat_nhwc(Tensor a, Tensor b, bool relu_b) -> Tensor");
+    m.def("upsample2_cat_nhwc(Tensor x, Tensor skip) -> Tensor");
+    m.def("disp_head_nhwc(Tensor x, Tensor weight, Tensor bias, float depth_max, int upscale) -> Tensor");
     m.def("cdhw_to_vol(Tensor src, Tensor(a!) dst, int dst_stride, int dst_off) -> ()");
     m.def("vol_to_cdhw(Tensor src, int C, int[] dims, int src_stride, int src_off) -> Tensor");
     m.def("camera_matrices_host(Tensor cam_poses, Tensor cam_intr, Tensor[] pre_poses, bool with_volume) -> (Tensor, Tensor)");
@@ -477,6 +514,9 @@ TORCH_LIBRARY_IMPL(estdepth_hip, CUDA, m)
     m.impl("gru_blend", gru_blend);
     m.impl("bn_act_nhwc_", bn_act_nhwc_);
     m.impl("spp_upsample_cat", spp_upsample_cat);
+    m.impl("planes_cat_nhwc", planes_cat_nhwc);
+    m.impl("upsample2_cat_nhwc", upsample2_cat_nhwc);
+    m.impl("disp_head_nhwc", disp_head_nhwc);
     m.impl("cdhw_to_vol", cdhw_to_vol);
     m.impl("vol_to_cdhw", vol_to_cdhw);
 }

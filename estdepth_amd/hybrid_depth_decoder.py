@@ -158,6 +158,8 @@ class DepthHybridDecoder(nn.Module):
 
     def _refine(self, semantic_vs, all_fused_logits, semantic_features):
         """scales 1,0 (:267-290 / :392-415) -> (depth_s1 [T,1,4H,4W], depth_s0 [T,1,4H,4W])."""
+        if getattr(self, "_hip_refine", False) and all_fused_logits.is_cuda and not self.training and self.use_skips:
+            return self._refine_hip(semantic_vs, all_fused_logits, semantic_features)
         x = self.upconv_1_0(torch.cat([semantic_vs, torch.relu(all_fused_logits)], dim=1))
         x = [upsample(x)]
         if self.use_skips:
@@ -167,6 +169,30 @@ class DepthHybridDecoder(nn.Module):
         x = self.upconv_0_0(x)
         x = self.upconv_0_1(upsample(x))
         s0 = self.depth_max * self.sigmoid(self.dispconv_0(x))
+        return s1, s0
+
+    def _refine_hip(self, semantic_vs, all_fused_logits, semantic_features):
+        """_refine with its glue in three HBM-bound kernels (csrc/refine2d.hip): the two concatenations are written directly as
+        the NHWC maps the convolutions read, the 3x3 C -> 1 depth heads + sigmoid (+ nearest x2) are one pass each."""
+        def nhwc(t):                                     # NCHW-shaped tensor -> its [N,H,W,C] memory (a copy only if it is not NHWC yet)
+            return t.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        x = ops.planes_cat_nhwc(semantic_vs.contiguous(), all_fused_logits.contiguous(), relu_b=True)      # :268
+        x = self.upconv_1_0(x.permute(0, 3, 1, 2))
+        x = ops.upsample2_cat_nhwc(nhwc(x), nhwc(semantic_features[0]))                                    # :269-272
+        x = self.upconv_1_1(x.permute(0, 3, 1, 2))
+        def head_weight(conv):                           # [1,C,3,3] in NCHW order (the module may hold it in channels_last memory)
+            key = (conv.weight.data_ptr(), conv.weight._version, conv.weight.device)
+            c = conv.__dict__.get("_estd_w_nchw")
+            if c is None or c[0] != key:
+                c = (key, conv.weight.detach().contiguous(memory_format=torch.contiguous_format).clone())
+                conv.__dict__["_estd_w_nchw"] = c
+            return c[1]
+        d1 = self.dispconv_1
+        s1 = ops.disp_head_nhwc(nhwc(x), head_weight(d1), d1.bias, self.depth_max, 2)                      # :274
+        x = self.upconv_0_0(x)
+        x = self.upconv_0_1(upsample(x))
+        d0 = self.dispconv_0
+        s0 = ops.disp_head_nhwc(nhwc(x), head_weight(d0), d0.bias, self.depth_max, 1)                      # :279
         return s1, s0
 
     # ------------------------------------------------------------------------------ hot path

@@ -196,6 +196,7 @@ class DepthNetHybrid(nn.Module):
         for name, child in self.CostRegNet.named_children():      # 2D decoder ConvBlocks with enough tiles (120x160 and up)
             if name.startswith("upconv"):
                 child._hip = bool(enable)
+        self.CostRegNet._hip_refine = bool(enable) and os.environ.get("ESTD_HIP_REFINE", "1") == "1"     # A/B switch (csrc/refine2d.hip)
         return self
 
     # The forward pass in two stages, so that the host can evaluate the camera matrices while the GPU is busy:

@@ -464,6 +464,54 @@ def bn_act_nhwc_(x, scale, shift, relu, residual=None):
     return x
 
 
+def _need_f32_cuda(name, *ts):
+    for t in ts:
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise RuntimeError("%s: contiguous float32 ROCm tensors expected (no CPU path)" % name)
+
+
+def planes_cat_nhwc(a, b, relu_b=False):
+    """torch.cat([a, relu?(b)], 1) of NCHW stacks -> NHWC map [N,H,W,Ca+Cb] (hybrid_depth_decoder.py:268)."""
+    if _use_torch():
+        return T().planes_cat_nhwc(a, b, bool(relu_b))
+    _need_f32_cuda("planes_cat_nhwc", a, b)
+    n, ca, h, w = a.shape
+    cb = b.shape[1]
+    if tuple(b.shape) != (n, cb, h, w):
+        raise RuntimeError("planes_cat_nhwc: two NCHW stacks of the same N, H, W expected")
+    out = torch.empty((n, h, w, ca + cb), device=a.device, dtype=torch.float32)
+    N.check(N.lib().estd_planes_cat_nhwc(_p(a), ca, _p(b), cb, int(bool(relu_b)), _p(out), n, h * w, _stream()), "estd_planes_cat_nhwc")
+    return out
+
+
+def upsample2_cat_nhwc(x, skip):
+    """torch.cat([nearest_x2(x), skip], 1) on NHWC maps: x [N,H/2,W/2,Cx], skip [N,H,W,Cs] -> [N,H,W,Cx+Cs] (:269-272)."""
+    if _use_torch():
+        return T().upsample2_cat_nhwc(x, skip)
+    _need_f32_cuda("upsample2_cat_nhwc", x, skip)
+    n, h, w, cs = skip.shape
+    if tuple(x.shape[:3]) != (n, h // 2, w // 2) or h % 2 or w % 2:
+        raise RuntimeError("upsample2_cat_nhwc: NHWC x [N,H/2,W/2,Cx] and skip [N,H,W,Cs] expected")
+    cx = x.shape[3]
+    out = torch.empty((n, h, w, cx + cs), device=x.device, dtype=torch.float32)
+    N.check(N.lib().estd_upsample2_cat_nhwc(_p(x), cx, _p(skip), cs, _p(out), n, h, w, _stream()), "estd_upsample2_cat_nhwc")
+    return out
+
+
+def disp_head_nhwc(x, weight, bias, depth_max, upscale=1):
+    """depth_max * sigmoid(Conv2d(C,1,3,padding=1,bias)(x)) on an NHWC map, optionally nearest x2 -> [N,1,uH,uW] (:274, :279)."""
+    if _use_torch():
+        return T().disp_head_nhwc(x, weight, bias, float(depth_max), int(upscale))
+    _need_f32_cuda("disp_head_nhwc", x, weight, bias)
+    n, h, w, c = x.shape
+    if tuple(weight.shape) != (1, c, 3, 3) or bias.numel() != 1:
+        raise RuntimeError("disp_head_nhwc: NHWC x [N,H,W,C], weight [1,C,3,3], bias [1] expected")
+    out = torch.empty((n, 1, upscale * h, upscale * w), device=x.device, dtype=torch.float32)
+    N.check(N.lib().estd_disp_head_nhwc(_p(x), _p(weight), _p(bias), float(depth_max), _p(out), n, h, w, c, int(upscale), _stream()),
+            "estd_disp_head_nhwc")
+    return out
+
+
 def spp_upsample_cat(raw, skip, branches):
     """NHWC tensors: raw [N,H,W,Cr], skip [N,H,W,Cs], branches [N,hk,wk,Cb] -> [N,H,W,Cr+Cs+nb*Cb] =
     cat(raw, skip, bilinear_up(branches...)) in one pass (psm_submodule.py:100-116)."""

@@ -245,6 +245,21 @@ int estd_spp_upsample_cat(const float* raw, int c_raw, const float* skip, int c_
                           const int* bh, const int* bw, int nb, int c_b, float* out, int N, int H, int W,
                           estd_stream_t stream);
 
+/* ---- 2D refinement tail of the decoder (hybrid_models/hybrid_depth_decoder.py:267-290 / :392-415), glue around its convolutions --
+ * estd_planes_cat_nhwc:    torch.cat([a, relu?(b)], 1) of two NCHW stacks a [N][Ca][HW], b [N][Cb][HW] (:268
+ *                          cat([semantic_vs, relu(all_fused_logits)])) written as the NHWC map [N][HW][Ca+Cb]; Ca+Cb <= 496.
+ * estd_upsample2_cat_nhwc: torch.cat([upsample(x), skip], 1) (:269-272, :280-281): x [N][H/2][W/2][Cx] nearest x2 beside
+ *                          skip [N][H][W][Cs] -> out [N][H][W][Cx+Cs] (NHWC; channel counts multiples of 4, H and W even).
+ * estd_disp_head_nhwc:     depth_max * sigmoid(Conv2d(C, 1, 3, stride 1, padding 1, bias)(in)) (:274 dispconv_1, :279 dispconv_0):
+ *                          in [N][H][W][C] NHWC, w [1][C][3][3], bias [1] (device), C = 16 | 32; out [N][1][upscale*H][upscale*W],
+ *                          upscale = 1, or 2 = the F.interpolate(scale_factor=2) (nearest) of :274 fused in. */
+int estd_planes_cat_nhwc(const float* a, int Ca, const float* b, int Cb, int relu_b, float* out, int N, int64_t HW,
+                         estd_stream_t stream);
+int estd_upsample2_cat_nhwc(const float* x, int Cx, const float* skip, int Cs, float* out, int N, int H, int W,
+                            estd_stream_t stream);
+int estd_disp_head_nhwc(const float* in, const float* w, const float* bias, float depth_max, float* out, int N, int H, int W,
+                        int C, int upscale, estd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
