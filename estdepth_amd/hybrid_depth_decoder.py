@@ -129,6 +129,17 @@ class DepthHybridDecoder(nn.Module):
     # ------------------------------------------------------------------------------ 2D decoder pieces
     def _semantic_vs(self, semantic_features):
         """scales 4,3,2 of the 2D decoder -> plane scores [T, D, H, W] (after ReLU)  (:162-184)."""
+        if getattr(self, "_hip_refine", False) and self.use_skips and semantic_features[4].is_cuda and not self.training:
+            def nhwc(t):
+                return t.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+            x = self.upconv_4_0(semantic_features[4])
+            for skip, conv1, conv0 in ((semantic_features[3], self.upconv_4_1, self.upconv_3_0),
+                                       (semantic_features[2], self.upconv_3_1, self.upconv_2_0),
+                                       (semantic_features[1], self.upconv_2_1, None)):
+                x = conv1(ops.upsample2_cat_nhwc(nhwc(x), nhwc(skip)).permute(0, 3, 1, 2))     # cat([upsample(x), skip], 1) in one pass
+                if conv0 is not None:
+                    x = conv0(x)
+            return x
         x = self.upconv_4_0(semantic_features[4])
         x = [upsample(x)]
         if self.use_skips:
