@@ -259,8 +259,19 @@ class DepthNetHybrid(nn.Module):
 
         # every view is a source for up to two targets: mix each 2D feature once (pre0 pushed in front of the warp)
         P = self._plans()                                   # one cache-key check per forward
-        src_mix = [self._mix(matching[v].contiguous(), "src", P) for v in range(views_num)]
-        ref_mix = [self._mix(matching[t + 1].contiguous(), "ref", P) for t in range(target_num)]
+        if matching.is_cuda and matching.dim() == 4 and matching.shape[1] == 32 and \
+                matching.is_contiguous(memory_format=torch.channels_last) and os.environ.get("ESTD_MIX_GEMM", "1") == "1":
+            # NHWC matching features (HIP PSM path): pre0's two halves are plain [pixels, 32] x [32, 32] library GEMMs on the
+            # records as they lie -- two launches for all views instead of a CHW copy + one mix kernel per view and role
+            V, _, Hf, Wf = matching.shape
+            rec = matching.permute(0, 2, 3, 1).reshape(V * Hf * Wf, 32)
+            src_all = torch.mm(rec, P["w_src"].t()).view(V, Hf, Wf, 32)
+            ref_all = torch.addmm(P["b_ref"], rec[Hf * Wf:(target_num + 1) * Hf * Wf], P["w_ref"].t()).view(target_num, Hf, Wf, 32)
+            src_mix = [src_all[v] for v in range(views_num)]
+            ref_mix = [ref_all[t] for t in range(target_num)]
+        else:
+            src_mix = [self._mix(matching[v].contiguous(), "src", P) for v in range(views_num)]
+            ref_mix = [self._mix(matching[t + 1].contiguous(), "ref", P) for t in range(target_num)]
         costs = self._costvolumes(ref_mix, [[src_mix[t], src_mix[t + 2]] for t in range(target_num)],
                                   cam_mats["sweep"], dv, P)                                             # :152-156
         cost_volumes = [costs[t].permute(3, 0, 1, 2).unsqueeze(0) for t in range(target_num)]
