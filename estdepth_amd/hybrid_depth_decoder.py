@@ -271,7 +271,7 @@ class DepthHybridDecoder(nn.Module):
         num = len(costvolumes)
         B, C, D, H, W = costvolumes[0].shape
         outputs = {}
-        semantic_vs = self._take_semantic_vs(semantic_features)
+        semantic_vs = self._take_semantic_vs(semantic_features).contiguous()     # [T,D,H,W] planes, once: dres2's scalar volume and :268
         side = self._heads_stream()
         main = torch.cuda.current_stream() if side is not None else None
         kv, init_logits, d3, p3, dv = self._regularise(costvolumes, semantic_vs, depth_values, side)
@@ -340,7 +340,7 @@ class DepthHybridDecoder(nn.Module):
         num = len(costvolumes)
         B, C, D, H, W = costvolumes[0].shape
         outputs = {}
-        semantic_vs = self._take_semantic_vs(semantic_features)
+        semantic_vs = self._take_semantic_vs(semantic_features).contiguous()     # [T,D,H,W] planes, once: dres2's scalar volume and :268
         side = self._heads_stream()
         kv, init_logits, d3, p3, dv = self._regularise(costvolumes, semantic_vs, depth_values, side)
         P = self._plans()

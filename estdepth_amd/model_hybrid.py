@@ -229,7 +229,7 @@ class DepthNetHybrid(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 semantic_features = self.semanticFeature(flat[1:1 + target_num])                           # :138-139
-                sv = self.CostRegNet._semantic_vs(semantic_features)
+                sv = self.CostRegNet._semantic_vs(semantic_features).contiguous()     # [T,D,H,W] planes (the decoder's layout)
             for t_ in list(semantic_features) + [sv]:
                 t_.record_stream(main)
             matching = matching_features if matching_features is not None else self.matchingFeature(flat)   # :128
