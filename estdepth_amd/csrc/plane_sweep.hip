@@ -6,6 +6,7 @@
 // HBM-bound: the D x H x W x 32 volume is written exactly once, as whole 128-byte voxel records
 // (8 lanes x float4), the 2.5 MB source map stays in L2.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <math.h>
 #include <stdint.h>
 
@@ -221,24 +222,44 @@ __global__ __launch_bounds__(256) void mix1x1_kernel(const float* __restrict__ i
 //      gather the four 128-byte source records from the L2-resident map and write whole 128-byte voxel records.
 constexpr int SWEEP_VOX_PER_BLOCK = 256;
 
+// Block -> voxel mapping: hardware hands consecutive workgroups to the eight XCDs round-robin.  With the linear mapping every XCD
+// sweeps the whole image in every depth plane, so each 4 MB L2 has to hold both 2.5 MB feature maps under a 157 MB output stream:
+// measured 2 x 96 MiB fetched per launch for 4.9 MB of maps.  BANDED (H a multiple of 8): XCD k = blockIdx % 8 owns image rows
+// [k H/8, (k+1) H/8) of every plane -- its share of the reference map and the band of the source map those rows project into.
+template <bool BANDED>
 __global__ __launch_bounds__(256) void homo_warp_costvol_kernel(const float* __restrict__ src, const float* __restrict__ ref,
                                                                 const float* __restrict__ P, const float* __restrict__ dvals,
                                                                 float* __restrict__ out, int D, int H, int W)
 {
     __shared__ __attribute__((aligned(16))) int s_off[SWEEP_VOX_PER_BLOCK][4];
     __shared__ __attribute__((aligned(16))) float s_w[SWEEP_VOX_PER_BLOCK][4];
-    const long long HW = (long long)H * W;
-    const long long total = (long long)D * HW;
-    const long long base = (long long)blockIdx.x * SWEEP_VOX_PER_BLOCK;
+    __shared__ int s_idx[SWEEP_VOX_PER_BLOCK];           // linear voxel index (d, y, x) of the block's voxels; -1: none
+    const int HW = H * W;
     {
-        const long long raw = base + threadIdx.x;
-        const long long idx = raw < total ? raw : total - 1;
-        const int x = (int)(idx % W);
-        const int y = (int)((idx / W) % H);
-        const int d = (int)(idx / HW);
+        int x, y, d;
+        bool valid;
+        if (BANDED) {
+            const int k = blockIdx.x & 7, j = blockIdx.x >> 3;
+            const int Hb = H >> 3, band_plane = Hb * W;
+            const long long m = (long long)j * SWEEP_VOX_PER_BLOCK + threadIdx.x;     // index inside the band's (d, y, x) order
+            valid = m < (long long)D * band_plane;
+            const long long mm = valid ? m : 0;
+            d = (int)(mm / band_plane);
+            const int rem = (int)(mm % band_plane);
+            y = k * Hb + rem / W;
+            x = rem % W;
+        } else {
+            const long long raw = (long long)blockIdx.x * SWEEP_VOX_PER_BLOCK + threadIdx.x;
+            valid = raw < (long long)D * HW;
+            const long long idx = valid ? raw : 0;
+            x = (int)(idx % W);
+            y = (int)((idx / W) % H);
+            d = (int)(idx / HW);
+        }
         const Bilin b = sweep_coords(P, dvals[d], x, y, H, W);
         *reinterpret_cast<int4*>(s_off[threadIdx.x]) = make_int4(b.o00, b.o01, b.o10, b.o11);
         *reinterpret_cast<float4*>(s_w[threadIdx.x]) = make_float4(b.w00, b.w01, b.w10, b.w11);
+        s_idx[threadIdx.x] = valid ? (d * H + y) * W + x : -1;
     }
     __syncthreads();
     const int sub = threadIdx.x & 7;
@@ -249,13 +270,13 @@ __global__ __launch_bounds__(256) void homo_warp_costvol_kernel(const float* __r
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         const int v = s * 32 + grp;
-        const long long idx = base + v;
-        if (idx < total) {
+        const int idx = s_idx[v];
+        if (idx >= 0) {
             const int4 of = *reinterpret_cast<const int4*>(s_off[v]);
             const float4 w = *reinterpret_cast<const float4*>(s_w[v]);
             const float4 c00 = s4[(long long)of.x * 8], c01 = s4[(long long)of.y * 8];
             const float4 c10 = s4[(long long)of.z * 8], c11 = s4[(long long)of.w * 8];
-            const float4 rf = r4[(idx % HW) * 8];
+            const float4 rf = r4[(long long)(idx % HW) * 8];
             float4 o;
             o.x = rf.x + (c00.x * w.x + c01.x * w.y + c10.x * w.z + c11.x * w.w);
             o.y = rf.y + (c00.y * w.x + c01.y * w.y + c10.y * w.z + c11.y * w.w);
@@ -263,7 +284,7 @@ __global__ __launch_bounds__(256) void homo_warp_costvol_kernel(const float* __r
             o.w = rf.w + (c00.w * w.x + c01.w * w.y + c10.w * w.z + c11.w * w.w);
             typedef float nt_f4 __attribute__((ext_vector_type(4)));
             nt_f4 ov = {o.x, o.y, o.z, o.w};
-            __builtin_nontemporal_store(ov, reinterpret_cast<nt_f4*>(&o4[idx * 8]));   // streamed once, read later by the conv
+            __builtin_nontemporal_store(ov, reinterpret_cast<nt_f4*>(&o4[(long long)idx * 8]));   // streamed once, read later by the conv
         }
     }
 }
@@ -314,8 +335,15 @@ extern "C" int estd_homo_warp_costvol(const float* src, const float* ref, const 
 {
     if (!src || !ref || !P || !dvals || !out || D <= 0 || H <= 0 || W <= 0) return ESTD_ERR_ARG;
     const long long total = (long long)D * H * W;
+    if (total >= 0x7fffffffLL) return ESTD_ERR_UNSUPPORTED;                 // 32-bit voxel indices
     const long long per_block = SWEEP_VOX_PER_BLOCK;
-    hipLaunchKernelGGL(homo_warp_costvol_kernel, dim3((unsigned)((total + per_block - 1) / per_block)), dim3(256), 0,
-                       estd_stream(s), src, ref, P, dvals, out, D, H, W);
+    if ((H & 7) == 0 && !getenv("ESTD_SWEEP_LINEAR")) {
+        const long long per_band = (total / 8 + per_block - 1) / per_block;          // blocks per XCD band
+        hipLaunchKernelGGL(homo_warp_costvol_kernel<true>, dim3((unsigned)(8 * per_band)), dim3(256), 0, estd_stream(s), src, ref, P, dvals,
+                           out, D, H, W);
+    } else {
+        hipLaunchKernelGGL(homo_warp_costvol_kernel<false>, dim3((unsigned)((total + per_block - 1) / per_block)), dim3(256), 0,
+                           estd_stream(s), src, ref, P, dvals, out, D, H, W);
+    }
     return ESTD_LAUNCH_CHECK();
 }
