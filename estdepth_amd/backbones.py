@@ -64,6 +64,7 @@ def conv1x1_gemm(conv, x):
     return y.view(n, h, w, conv.out_channels).permute(0, 3, 1, 2)
 
 
+HIP_STEM = os.environ.get("ESTD_HIP_STEM", "1") == "1"       # A/B switch: PSM first layer on csrc/refine2d.hip
 GEMM_EPILOGUE = os.environ.get("ESTD_GEMM_EPILOGUE", "1") == "1"     # A/B switch, read once at import
 
 
@@ -252,8 +253,21 @@ class PSMFeatures(nn.Module):
         P = self._plans()
         fc = self.firstconv
         x = x.contiguous(memory_format=torch.channels_last)
-        x = conv_bn_act(fc[0][0], fc[0][1], x, relu=True) if fused_on(self, x) else fc[1](fc[0](x))      # 3->32 stride 2: MIOpen
-        x = P["first2"].run(P["first1"].run(self._nhwc(x)))
+        c0 = fc[0][0]
+        if HIP_STEM and c0.in_channels == 3 and c0.out_channels == 32 and c0.kernel_size == (3, 3) and c0.stride == (2, 2) \
+                and c0.padding == (1, 1) and c0.dilation == (1, 1) and c0.bias is None:
+            from . import ops                                                     # 3 -> 32 stride 2 + BN + ReLU: one VALU pass
+            key = (c0.weight.data_ptr(), c0.weight._version, c0.weight.device)
+            cw = c0.__dict__.get("_estd_w_nchw")
+            if cw is None or cw[0] != key:
+                cw = (key, c0.weight.detach().contiguous(memory_format=torch.contiguous_format).clone())
+                c0.__dict__["_estd_w_nchw"] = cw
+            sc, sh = _folded(fc[0][1])
+            x = ops.stem3x3s2_nhwc(self._nhwc(x), cw[1], sc, sh)
+        else:
+            x = conv_bn_act(c0, fc[0][1], x, relu=True) if fused_on(self, x) else fc[1](fc[0](x))        # 3->32 stride 2: MIOpen
+            x = self._nhwc(x)
+        x = P["first2"].run(P["first1"].run(x))
         for lname in ("layer1", "layer2", "layer3", "layer4"):
             for bi, blk in enumerate(getattr(self, lname)):
                 if (lname, bi, 1) in P:

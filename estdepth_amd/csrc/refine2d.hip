@@ -6,6 +6,9 @@
 //   estd_upsample2_cat_nhwc   cat([upsample(x), skip], 1) (:269-272): nearest x2 of an NHWC map beside its full-resolution skip
 //   estd_disp_head_nhwc       depth_max * sigmoid(Conv2d(C, 1, 3, padding 1, bias)(x)) (:274, :279), optionally nearest x2 (:274
 //                             F.interpolate(scale_factor=2)): C -> 1 channels is a GEMV per pixel -- one thread per pixel on the VALU
+//   estd_stem3x3s2_nhwc       first layer of the PSM extractor (networks/psm_submodule.py:47: convbn(3, 32, 3, 2, 1, 1) + ReLU): 3 input
+//                             channels are 27 multiplies per output channel -- one thread per output pixel on the VALU, the padded
+//                             copy, library convolution and BatchNorm pass it replaces moved 5x the bytes
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -110,7 +113,83 @@ __global__ __launch_bounds__(256) void disp_head_nhwc_kernel(const float* __rest
     }
 }
 
+// ---- 3x3 / stride 2 / padding 1, 3 -> 32 channels, folded BatchNorm, ReLU; NHWC in [N][H][W][3] -> out [N][Ho][Wo][32] ----
+__global__ __launch_bounds__(256) void stem3x3s2_nhwc_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, float* __restrict__ out, int N, int H, int W, int Ho,
+                                                             int Wo)
+{
+    __shared__ __attribute__((aligned(16))) float ws[27 * 32];          // [tap = (ky, kx, ci)][co]
+    for (int e = threadIdx.x; e < 27 * 32; e += 256) {                  // w is [32][3][3][3] (Conv2d layout)
+        const int t = e >> 5, co = e & 31;
+        const int ky = t / 9, kx = (t / 3) % 3, ci = t % 3;
+        ws[e] = w[((co * 3 + ci) * 3 + ky) * 3 + kx];
+    }
+    __syncthreads();
+    const long long total = (long long)N * Ho * Wo;
+    const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long pc = pix < total ? pix : total - 1;     // lanes past the end recompute the last pixel and store nothing
+    const int xo = (int)(pc % Wo), yo = (int)((pc / Wo) % Ho);
+    const long long n = pc / ((long long)Wo * Ho);
+    float acc[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+#pragma clang loop unroll(disable)
+    for (int t = 0; t < 9; ++t) {                          // rolled: fully unrolled the 216 weight reads are hoisted (356 spills)
+        const int ky = t / 3, kx = t - 3 * ky;
+        const int y = 2 * yo - 1 + ky, x = 2 * xo - 1 + kx;
+        const bool ok = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        const float* src = in + ((n * H + (ok ? y : 0)) * W + (ok ? x : 0)) * 3;
+        const float v3[3] = {ok ? src[0] : 0.f, ok ? src[1] : 0.f, ok ? src[2] : 0.f};
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+            const float v = v3[ci];
+            const float4* wt = reinterpret_cast<const float4*>(ws + (t * 3 + ci) * 32);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 wq = wt[q];
+                acc[4 * q + 0] = fmaf(v, wq.x, acc[4 * q + 0]);
+                acc[4 * q + 1] = fmaf(v, wq.y, acc[4 * q + 1]);
+                acc[4 * q + 2] = fmaf(v, wq.z, acc[4 * q + 2]);
+                acc[4 * q + 3] = fmaf(v, wq.w, acc[4 * q + 3]);
+            }
+        }
+    }
+    // BN + ReLU, then through LDS so that a store instruction writes whole 128-byte records (lane l: chunk l % 8 of pixel l / 8)
+    __shared__ __attribute__((aligned(16))) float4 stage[4][64][9];            // [wave][pixel lane][8 chunks + pad]
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float4 sc = reinterpret_cast<const float4*>(scale)[q], sh = reinterpret_cast<const float4*>(shift)[q];
+        float4 r;
+        r.x = fmaxf(acc[4 * q + 0] * sc.x + sh.x, 0.f);
+        r.y = fmaxf(acc[4 * q + 1] * sc.y + sh.y, 0.f);
+        r.z = fmaxf(acc[4 * q + 2] * sc.z + sh.z, 0.f);
+        r.w = fmaxf(acc[4 * q + 3] * sc.w + sh.w, 0.f);
+        stage[wv][ln][q] = r;
+    }
+    __syncthreads();
+    const long long wave_pix0 = pix - ln;                  // first pixel of this wave
+    float4* o = reinterpret_cast<float4*>(out);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int e = it * 64 + ln, pl = e >> 3, ch = e & 7;
+        if (wave_pix0 + pl < total) o[(wave_pix0 + pl) * 8 + ch] = stage[wv][pl][ch];
+    }
+}
+
 }  // namespace
+
+extern "C" int estd_stem3x3s2_nhwc(const float* in, const float* w, const float* scale, const float* shift, float* out, int N, int H, int W,
+                                   estd_stream_t s)
+{
+    if (!in || !w || !scale || !shift || !out || N <= 0 || H <= 0 || W <= 0) return ESTD_ERR_ARG;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long total = (long long)N * Ho * Wo;
+    const long long blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return ESTD_ERR_ARG;
+    hipLaunchKernelGGL(stem3x3s2_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, estd_stream(s), in, w, scale, shift, out, N, H, W, Ho, Wo);
+    return ESTD_LAUNCH_CHECK();
+}
 
 extern "C" int estd_planes_cat_nhwc(const float* a, int Ca, const float* b, int Cb, int relu_b, float* out, int N, int64_t HW, estd_stream_t s)
 {

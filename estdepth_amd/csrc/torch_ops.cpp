@@ -328,6 +328,18 @@ Tensor spp_upsample_cat(const Tensor& raw, const Tensor& skip, at::TensorList br
     return out;
 }
 
+Tensor stem3x3s2_nhwc(const Tensor& x, const Tensor& weight, const Tensor& scale, const Tensor& shift)
+{
+    TORCH_CHECK(x.dim() == 4 && x.size(3) == 3 && weight.dim() == 4 && weight.size(0) == 32 && weight.size(1) == 3 && weight.size(2) == 3 &&
+                weight.size(3) == 3 && scale.numel() == 32 && shift.numel() == 32,
+                "stem3x3s2_nhwc: NHWC x [N,H,W,3], weight [32,3,3,3], scale/shift [32] expected");
+    const int64_t n = x.size(0), h = x.size(1), w = x.size(2);
+    Tensor out = new_f32({n, (h - 1) / 2 + 1, (w - 1) / 2 + 1, 32}, x);
+    check_status(estd_stem3x3s2_nhwc(fptr(x, "x"), fptr(weight, "weight"), fptr(scale, "scale"), fptr(shift, "shift"), out.data_ptr<float>(), (int)n,
+                                     (int)h, (int)w, cur_stream()), "estd_stem3x3s2_nhwc");
+    return out;
+}
+
 Tensor planes_cat_nhwc(const Tensor& a, const Tensor& b, bool relu_b)
 {
     TORCH_CHECK(a.dim() == 4 && b.dim() == 4 && a.size(0) == b.size(0) && a.size(2) == b.size(2) && a.size(3) == b.size(3),
@@ -481,6 +493,7 @@ TORCH_LIBRARY(estdepth_hip, m)
           "Tensor beta_o, Tensor(a!) out_value, int out_stride) -> ()");
     m.def("bn_act_nhwc_(Tensor(a!) x, Tensor scale, Tensor shift, bool relu, Tensor? residual) -> Tensor(a!)");
     m.def("spp_upsample_cat(Tensor raw, Tensor skip, Tensor[] branches) -> Tensor");
+    m.def("stem3x3s2_nhwc(Tensor x, Tensor weight, Tensor scale, Tensor shift) -> Tensor");
     m.def("planes_cat_nhwc(Tensor a, Tensor b, bool relu_b) -> Tensor");
     m.def("upsample2_cat_nhwc(Tensor x, Tensor skip) -> Tensor");
     m.def("disp_head_nhwc(Tensor x, Tensor weight, Tensor bias, float depth_max, int upscale) -> Tensor");
@@ -514,6 +527,7 @@ TORCH_LIBRARY_IMPL(estdepth_hip, CUDA, m)
     m.impl("gru_blend", gru_blend);
     m.impl("bn_act_nhwc_", bn_act_nhwc_);
     m.impl("spp_upsample_cat", spp_upsample_cat);
+    m.impl("stem3x3s2_nhwc", stem3x3s2_nhwc);
     m.impl("planes_cat_nhwc", planes_cat_nhwc);
     m.impl("upsample2_cat_nhwc", upsample2_cat_nhwc);
     m.impl("disp_head_nhwc", disp_head_nhwc);

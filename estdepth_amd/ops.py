@@ -470,6 +470,20 @@ def _need_f32_cuda(name, *ts):
             raise RuntimeError("%s: contiguous float32 ROCm tensors expected (no CPU path)" % name)
 
 
+def stem3x3s2_nhwc(x, weight, scale, shift):
+    """Conv2d(3, 32, 3, stride 2, padding 1) + folded BatchNorm2d + ReLU on an NHWC image batch [N,H,W,3] -> [N,Ho,Wo,32]
+    (networks/psm_submodule.py:47)."""
+    if _use_torch():
+        return T().stem3x3s2_nhwc(x, weight, scale, shift)
+    _need_f32_cuda("stem3x3s2_nhwc", x, weight, scale, shift)
+    n, h, w, c = x.shape
+    if c != 3 or tuple(weight.shape) != (32, 3, 3, 3) or scale.numel() != 32 or shift.numel() != 32:
+        raise RuntimeError("stem3x3s2_nhwc: NHWC x [N,H,W,3], weight [32,3,3,3], scale/shift [32] expected")
+    out = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, 32), device=x.device, dtype=torch.float32)
+    N.check(N.lib().estd_stem3x3s2_nhwc(_p(x), _p(weight), _p(scale), _p(shift), _p(out), n, h, w, _stream()), "estd_stem3x3s2_nhwc")
+    return out
+
+
 def planes_cat_nhwc(a, b, relu_b=False):
     """torch.cat([a, relu?(b)], 1) of NCHW stacks -> NHWC map [N,H,W,Ca+Cb] (hybrid_depth_decoder.py:268)."""
     if _use_torch():

@@ -253,6 +253,11 @@ int estd_spp_upsample_cat(const float* raw, int c_raw, const float* skip, int c_
  * estd_disp_head_nhwc:     depth_max * sigmoid(Conv2d(C, 1, 3, stride 1, padding 1, bias)(in)) (:274 dispconv_1, :279 dispconv_0):
  *                          in [N][H][W][C] NHWC, w [1][C][3][3], bias [1] (device), C = 16 | 32; out [N][1][upscale*H][upscale*W],
  *                          upscale = 1, or 2 = the F.interpolate(scale_factor=2) (nearest) of :274 fused in. */
+/* first layer of the PSM matching-feature extractor (networks/psm_submodule.py:47 convbn(3, 32, 3, 2, 1, 1) + ReLU, :14-22):
+ * in [N][H][W][3] NHWC, w [32][3][3][3] (Conv2d layout), scale/shift [32] = folded BatchNorm2d -> out [N][Ho][Wo][32] NHWC,
+ * Ho = (H-1)/2 + 1, Wo = (W-1)/2 + 1 (kernel 3, stride 2, zero padding 1). */
+int estd_stem3x3s2_nhwc(const float* in, const float* w, const float* scale, const float* shift, float* out, int N, int H, int W,
+                        estd_stream_t stream);
 int estd_planes_cat_nhwc(const float* a, int Ca, const float* b, int Cb, int relu_b, float* out, int N, int64_t HW,
                          estd_stream_t stream);
 int estd_upsample2_cat_nhwc(const float* x, int Cx, const float* skip, int Cs, float* out, int N, int H, int W,

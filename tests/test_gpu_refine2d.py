@@ -100,3 +100,24 @@ def test_refine_hip_matches_refine():
         b1, b0 = dec._refine(sem, logits, feats)
     assert tuple(b1.shape) == tuple(a1.shape) == (T, 1, 4 * H, 4 * W) and tuple(b0.shape) == tuple(a0.shape)
     assert float((a1 - b1).abs().max()) < 2e-5 and float((a0 - b0).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(5, 480, 640), (1, 7, 9), (2, 33, 64), (1, 1, 1)])
+def test_stem3x3s2_nhwc_vs_torch_fp64(shape):
+    """first PSM layer: Conv2d(3,32,3,2,1) + BatchNorm2d(eval) + ReLU (networks/psm_submodule.py:47) incl. odd sizes."""
+    from estdepth_amd import ops, packing
+    n, h, w = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.rand(n, h, w, 3, generator=g) * 2 - 1).to(DEV)
+    conv = torch.nn.Conv2d(3, 32, 3, 2, 1, bias=False)
+    bn = torch.nn.BatchNorm2d(32).eval()
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.3)
+        bn.weight.copy_(torch.rand(32, generator=g) + 0.5); bn.bias.copy_(torch.randn(32, generator=g) * 0.2)
+        bn.running_mean.copy_(torch.randn(32, generator=g) * 0.2); bn.running_var.copy_(torch.rand(32, generator=g) + 0.5)
+    sc, sh = packing.fold_bn_fp32(bn, list(range(32)))
+    wd = conv.weight.detach().to(DEV)
+    got = _both_bindings(lambda: ops.stem3x3s2_nhwc(x, wd, sc.to(DEV), sh.to(DEV)))
+    ref = torch.relu(bn.double()(conv.double()(x.cpu().double().permute(0, 3, 1, 2)))).permute(0, 2, 3, 1)
+    assert tuple(got.shape) == tuple(ref.shape) == (n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, 32)
+    assert float((got.cpu().double() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
