@@ -26,6 +26,10 @@
 #include "estd_hip.h"
 #include "estd_common.h"
 
+#ifndef ESTD_W2ABL
+#define ESTD_W2ABL 0    // timing ablations only (wrong results when != 0): 1 no output stores, 2 no transform writes, 8 no weight stream,
+#endif                  // 16 no brick prefetch
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(const estd_conv2d_d
         for (int c = 0; c < nchunks; ++c, ++k) {
             char* slot = smem + (k & 1) * SLOT_BYTES;
             // ---- input transform B^T d along rows, from the column registers straight into the slot ----
-            if (loader) {
+            if (loader && !(ESTD_W2ABL & 2)) {
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
                     const int a = DIL == 1 ? 2 * w : (w & 1) + 4 * (w >> 1);           // compile-time after unrolling
@@ -179,9 +183,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(const estd_conv2d_d
             for (int tap = 0; tap < 12; ++tap) {
                 const int i = tap / 3;
 #pragma unroll
-                for (int q = 0; q < QN; ++q)
-                    bnext[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, (wbase + (tap + 1) * QN + q) * 1024, 0));
-                if (do_pf && tap < IN_H)
+                for (int q = 0; q < QN; ++q) {
+                    if (ESTD_W2ABL & 8) { bnext[q] = bcur[q]; asm volatile("" : "+v"(bnext[q].x)); }
+                    else bnext[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, (wbase + (tap + 1) * QN + q) * 1024, 0));
+                }
+                if (do_pf && tap < IN_H && !(ESTD_W2ABL & 16))
                     pf[tap] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[tap], pf_soff, 0));
                 if (tap + 1 < 12) load_a(tap + 1, a0n, a1n);           // next tap's A fragment: LDS latency under this tap's MFMAs
                 const float av[8] = {a0c.x, a0c.y, a0c.z, a0c.w, a1c.x, a1c.y, a1c.z, a1c.w};
@@ -258,7 +264,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(const estd_conv2d_d
 #pragma unroll
                         for (int nn = 0; nn < NT; ++nn) v[nn] = v[nn] > 0.f ? v[nn] : 0.f;
                     }
-                    if (NT == 4) {
+                    if (ESTD_W2ABL & 1) {
+                        asm volatile("" :: "v"(v[0]), "v"(v[NT - 1]));
+                    } else if (NT == 4) {
                         __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(make_float4(v[0], v[1], v[2], v[3])), rs_out, eo, 0, 0);
                     } else {
                         const float2 ov = make_float2(v[0], v[1]);
