@@ -258,9 +258,10 @@ def main():
     backend = None
     if world > 1:
         import torch.distributed as dist
-        # The only collective is the per-step memory-bank all-gather (157 MB per rank, ~37 GB/s of ingress at N = 8): a few RCCL
-        # channels carry it inside one step, and every channel is a workgroup taken from the convolutions it overlaps with.
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", "4")
+        # The only collective is the per-step memory-bank all-gather (157 MB per rank, ~48 GB/s of ingress at N = 8): a few RCCL
+        # channels carry it inside one step.  Every channel is a workgroup that holds a CU: as many channels as CUs the
+        # convolution grids leave free (estd_set_reserved_cus(8) below: one per XCD).
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
         backend = os.environ.get("ESTD_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)
