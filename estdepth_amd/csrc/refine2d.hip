@@ -6,6 +6,8 @@
 //   estd_upsample2_cat_nhwc   cat([upsample(x), skip], 1) (:269-272): nearest x2 of an NHWC map beside its full-resolution skip
 //   estd_disp_head_nhwc       depth_max * sigmoid(Conv2d(C, 1, 3, padding 1, bias)(x)) (:274, :279), optionally nearest x2 (:274
 //                             F.interpolate(scale_factor=2)): C -> 1 channels is a GEMV per pixel -- one thread per pixel on the VALU
+//   estd_normalise_nhwc       imgs -> 2 * (imgs / 255) - 1 (model_hybrid.py:119) written as the NHWC image batch the 2D networks read
+//                             (was: three elementwise kernels + a channels-last copy); same three roundings, contraction off
 //   estd_stem3x3s2_nhwc       first layer of the PSM extractor (networks/psm_submodule.py:47: convbn(3, 32, 3, 2, 1, 1) + ReLU): 3 input
 //                             channels are 27 multiplies per output channel -- one thread per output pixel on the VALU, the padded
 //                             copy, library convolution and BatchNorm pass it replaces moved 5x the bytes
@@ -113,6 +115,23 @@ __global__ __launch_bounds__(256) void disp_head_nhwc_kernel(const float* __rest
     }
 }
 
+// ---- [N][3][HW] image planes in 0..255 -> [N][HW][3] records in -1..1 ----
+__global__ __launch_bounds__(256) void normalise_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, long long HW, long long total)
+{
+#pragma clang fp contract(off)
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;         // one thread per pixel
+    if (e >= total) return;
+    const long long n = e / HW, p = e - n * HW;
+    const float* src = in + n * 3 * HW + p;
+    float* dst = out + e * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float q = src[c * HW] / 255.0f;                               // three roundings, as the reference's three ATen ops
+        const float d = 2.0f * q;
+        dst[c] = d - 1.0f;
+    }
+}
+
 // ---- 3x3 / stride 2 / padding 1, 3 -> 32 channels, folded BatchNorm, ReLU; NHWC in [N][H][W][3] -> out [N][Ho][Wo][32] ----
 __global__ __launch_bounds__(256) void stem3x3s2_nhwc_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, float* __restrict__ out, int N, int H, int W, int Ho,
@@ -178,6 +197,16 @@ __global__ __launch_bounds__(256) void stem3x3s2_nhwc_kernel(const float* __rest
 }
 
 }  // namespace
+
+extern "C" int estd_normalise_nhwc(const float* in, float* out, int N, int64_t HW, estd_stream_t s)
+{
+    if (!in || !out || N <= 0 || HW <= 0) return ESTD_ERR_ARG;
+    const long long total = (long long)N * HW;
+    const long long blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return ESTD_ERR_ARG;
+    hipLaunchKernelGGL(normalise_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, estd_stream(s), in, out, (long long)HW, total);
+    return ESTD_LAUNCH_CHECK();
+}
 
 extern "C" int estd_stem3x3s2_nhwc(const float* in, const float* w, const float* scale, const float* shift, float* out, int N, int H, int W,
                                    estd_stream_t s)

@@ -328,6 +328,15 @@ Tensor spp_upsample_cat(const Tensor& raw, const Tensor& skip, at::TensorList br
     return out;
 }
 
+Tensor normalise_nhwc(const Tensor& imgs)
+{
+    TORCH_CHECK(imgs.dim() == 4 && imgs.size(1) == 3, "normalise_nhwc: [N,3,H,W] images expected");
+    const int64_t n = imgs.size(0), h = imgs.size(2), w = imgs.size(3);
+    Tensor out = new_f32({n, h, w, 3}, imgs);
+    check_status(estd_normalise_nhwc(fptr(imgs, "imgs"), out.data_ptr<float>(), (int)n, h * w, cur_stream()), "estd_normalise_nhwc");
+    return out;
+}
+
 Tensor stem3x3s2_nhwc(const Tensor& x, const Tensor& weight, const Tensor& scale, const Tensor& shift)
 {
     TORCH_CHECK(x.dim() == 4 && x.size(3) == 3 && weight.dim() == 4 && weight.size(0) == 32 && weight.size(1) == 3 && weight.size(2) == 3 &&
@@ -493,6 +502,7 @@ TORCH_LIBRARY(estdepth_hip, m)
           "Tensor beta_o, Tensor(a!) out_value, int out_stride) -> ()");
     m.def("bn_act_nhwc_(Tensor(a!) x, Tensor scale, Tensor shift, bool relu, Tensor? residual) -> Tensor(a!)");
     m.def("spp_upsample_cat(Tensor raw, Tensor skip, Tensor[] branches) -> Tensor");
+    m.def("normalise_nhwc(Tensor imgs) -> Tensor");
     m.def("stem3x3s2_nhwc(Tensor x, Tensor weight, Tensor scale, Tensor shift) -> Tensor");
     m.def("planes_cat_nhwc(Tensor a, Tensor b, bool relu_b) -> Tensor");
     m.def("upsample2_cat_nhwc(Tensor x, Tensor skip) -> Tensor");
@@ -527,6 +537,7 @@ TORCH_LIBRARY_IMPL(estdepth_hip, CUDA, m)
     m.impl("gru_blend", gru_blend);
     m.impl("bn_act_nhwc_", bn_act_nhwc_);
     m.impl("spp_upsample_cat", spp_upsample_cat);
+    m.impl("normalise_nhwc", normalise_nhwc);
     m.impl("stem3x3s2_nhwc", stem3x3s2_nhwc);
     m.impl("planes_cat_nhwc", planes_cat_nhwc);
     m.impl("upsample2_cat_nhwc", upsample2_cat_nhwc);

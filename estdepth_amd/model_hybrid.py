@@ -209,11 +209,16 @@ class DepthNetHybrid(nn.Module):
     def forward_2d(self, imgs, matching_features=None, join=False):
         """imgs [1,V,3,Hi,Wi] in 0..255 -> the camera-independent features.  ``join``: wait for the side stream before returning
         (a captured hipGraph has to end with its streams joined)."""
-        imgs = 2 * (imgs / 255.) - 1.                                                                         # :119
         batch_size, views_num, _, height_img, width_img = imgs.shape
         assert views_num > 2  # the views_num should be larger than 2 (model_hybrid.py:123)
         if batch_size != 1:
             raise RuntimeError("estdepth_amd runs one sequence per call (the reference's view() also fails for batch > 1)")
+        fused_norm = getattr(self, "_channels_last_2d", False) and imgs.is_cuda and imgs.dtype == torch.float32 and imgs.shape[2] == 3 \
+            and os.environ.get("ESTD_FUSED_NORM", "1") == "1"
+        if fused_norm:                                   # :119 and the NHWC layout of the 2D networks in one pass (csrc/refine2d.hip)
+            imgs = ops.normalise_nhwc(imgs.reshape(views_num, 3, height_img, width_img).contiguous()).permute(0, 3, 1, 2)[None]
+        else:
+            imgs = 2 * (imgs / 255.) - 1.                                                                     # :119
         target_num = views_num - 2
         flat = imgs.reshape(batch_size * views_num, 3, height_img, width_img)
         if getattr(self, "_channels_last_2d", False):

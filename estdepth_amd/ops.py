@@ -470,6 +470,19 @@ def _need_f32_cuda(name, *ts):
             raise RuntimeError("%s: contiguous float32 ROCm tensors expected (no CPU path)" % name)
 
 
+def normalise_nhwc(imgs):
+    """[N,3,H,W] images in 0..255 -> 2 * (imgs / 255) - 1 as an NHWC batch [N,H,W,3] (model_hybrid.py:119)."""
+    if _use_torch():
+        return T().normalise_nhwc(imgs)
+    _need_f32_cuda("normalise_nhwc", imgs)
+    n, c, h, w = imgs.shape
+    if c != 3:
+        raise RuntimeError("normalise_nhwc: [N,3,H,W] images expected")
+    out = torch.empty((n, h, w, 3), device=imgs.device, dtype=torch.float32)
+    N.check(N.lib().estd_normalise_nhwc(_p(imgs), _p(out), n, h * w, _stream()), "estd_normalise_nhwc")
+    return out
+
+
 def stem3x3s2_nhwc(x, weight, scale, shift):
     """Conv2d(3, 32, 3, stride 2, padding 1) + folded BatchNorm2d + ReLU on an NHWC image batch [N,H,W,3] -> [N,Ho,Wo,32]
     (networks/psm_submodule.py:47)."""

@@ -253,6 +253,9 @@ int estd_spp_upsample_cat(const float* raw, int c_raw, const float* skip, int c_
  * estd_disp_head_nhwc:     depth_max * sigmoid(Conv2d(C, 1, 3, stride 1, padding 1, bias)(in)) (:274 dispconv_1, :279 dispconv_0):
  *                          in [N][H][W][C] NHWC, w [1][C][3][3], bias [1] (device), C = 16 | 32; out [N][1][upscale*H][upscale*W],
  *                          upscale = 1, or 2 = the F.interpolate(scale_factor=2) (nearest) of :274 fused in. */
+/* image normalisation of DepthNetHybrid.forward (hybrid_models/model_hybrid.py:119: imgs = 2 * (imgs / 255.) - 1.):
+ * in [N][3][HW] planes (0..255) -> out [N][HW][3] NHWC records; the same three fp32 roundings as the reference's three ops. */
+int estd_normalise_nhwc(const float* in, float* out, int N, int64_t HW, estd_stream_t stream);
 /* first layer of the PSM matching-feature extractor (networks/psm_submodule.py:47 convbn(3, 32, 3, 2, 1, 1) + ReLU, :14-22):
  * in [N][H][W][3] NHWC, w [32][3][3][3] (Conv2d layout), scale/shift [32] = folded BatchNorm2d -> out [N][Ho][Wo][32] NHWC,
  * Ho = (H-1)/2 + 1, Wo = (W-1)/2 + 1 (kernel 3, stride 2, zero padding 1). */

@@ -121,3 +121,17 @@ def test_stem3x3s2_nhwc_vs_torch_fp64(shape):
     ref = torch.relu(bn.double()(conv.double()(x.cpu().double().permute(0, 3, 1, 2)))).permute(0, 2, 3, 1)
     assert tuple(got.shape) == tuple(ref.shape) == (n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, 32)
     assert float((got.cpu().double() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_normalise_nhwc_is_bit_identical_to_the_reference_cpu_ops():
+    """2 * (imgs / 255.) - 1. (model_hybrid.py:119) as torch evaluates it on the CPU (the reference path): a true division, then two
+    more roundings.  (torch on the GPU multiplies by fl(1/255) instead -- up to 1 ulp away from the reference.)"""
+    from estdepth_amd import ops
+    g = torch.Generator().manual_seed(9)
+    imgs = (torch.rand(5, 3, 480, 640, generator=g) * 255).to(DEV)
+    imgs[0, 0, 0, :4] = torch.tensor([0.0, 255.0, 127.5, 1e-3], device=DEV)
+    got = _both_bindings(lambda: ops.normalise_nhwc(imgs))
+    ref = (2 * (imgs.cpu() / 255.) - 1.).permute(0, 2, 3, 1)
+    assert tuple(got.shape) == (5, 480, 640, 3) and torch.equal(got.cpu(), ref)
+    odd = (torch.rand(2, 3, 7, 13, generator=g) * 255).to(DEV)
+    assert torch.equal(ops.normalise_nhwc(odd).cpu(), (2 * (odd.cpu() / 255.) - 1.).permute(0, 2, 3, 1))
