@@ -432,6 +432,24 @@ class UpBlock(nn.Module):
         self.conv = conv_bn2d(int(cin), int(cout), 3, 1, 1, 1)
         self.nonlin = nn.ReLU(inplace=True)
 
+    def forward_to16(self, x_nhwc, upsample):
+        """conv3x3 (16|32 -> 16) + BN + ReLU of an NHWC map [N,H,W,C] on csrc/refine2d.hip, optionally reading the nearest-x2
+        upsampling of ``x_nhwc`` without materialising it.  Returns NHWC [N,uH,uW,16]."""
+        from . import ops, packing
+        conv, bn = self.conv[0], self.conv[1]
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters()) + (bn.running_mean._version, bn.running_var._version)
+        c = self.__dict__.get("_plan16")
+        if c is None or c[0] != key:
+            sc, sh = _folded(bn)
+            c = (key, packing.pack_conv2d_to16(conv.weight).to(conv.weight.device), sc, sh)
+            self.__dict__["_plan16"] = c
+        return ops.conv2d_k3_to16_nhwc(x_nhwc, c[1], c[2], c[3], upsample)
+
+    def to16_ok(self):
+        conv = self.conv[0]
+        return conv.out_channels == 16 and conv.in_channels in (16, 32) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) \
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
+
     def forward(self, x):
         if getattr(self, "_hip", False) and x.is_cuda and not self.training:
             conv = self.conv[0]

@@ -8,6 +8,10 @@
 //                             F.interpolate(scale_factor=2)): C -> 1 channels is a GEMV per pixel -- one thread per pixel on the VALU
 //   estd_normalise_nhwc       imgs -> 2 * (imgs / 255) - 1 (model_hybrid.py:119) written as the NHWC image batch the 2D networks read
 //                             (was: three elementwise kernels + a channels-last copy); same three roundings, contraction off
+//   estd_conv2d_k3_to16_nhwc  ConvBlocks of the full-resolution end of the decoder (hybrid_depth_decoder.py:276-278: upconv_0_0 32 -> 16 at
+//                             1/2 resolution, upconv_0_1 16 -> 16 on the nearest-x2 upsampled map): 16 output channels are one MFMA N
+//                             tile; the upsampling is an address computation in the operand loads (no 59 MB intermediate), BN + ReLU
+//                             in the epilogue, operands straight from L1/L2 (the whole input is 15-30 MB)
 //   estd_stem3x3s2_nhwc       first layer of the PSM extractor (networks/psm_submodule.py:47: convbn(3, 32, 3, 2, 1, 1) + ReLU): 3 input
 //                             channels are 27 multiplies per output channel -- one thread per output pixel on the VALU, the padded
 //                             copy, library convolution and BatchNorm pass it replaces moved 5x the bytes
@@ -115,6 +119,80 @@ __global__ __launch_bounds__(256) void disp_head_nhwc_kernel(const float* __rest
     }
 }
 
+// ---- 3x3 / stride 1 / padding 1, CIN (16 | 32) -> 16 channels, optional nearest x2 upsampling of the input, folded BN, ReLU ----
+// One wave = a strip of ROWS output rows x 16 output pixels.  MFMA 16x16x4 f32, issued transposed (weights as A, pixels as B):
+// lane (g, i) loads channels 16 q + 4 g .. + 3 of input pixel i (one 16-byte load per tap and 16-channel half) as the k-steps
+// ks = 0..3 (K order permuted, weights packed to match) and ends up holding output channels 4 g .. 4 g + 3 of pixel i.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4_t __attribute__((__vector_size__(16)));
+constexpr int TO16_ROWS = 8;
+
+template <int CIN, bool UP>
+__global__ __launch_bounds__(256) void conv2d_k3_to16_kernel(const float* __restrict__ in, const float4* __restrict__ wpk, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, float* __restrict__ out, int N, int H, int W,
+                                                             int strips_y, int segs_x)
+{
+    constexpr int Q = CIN / 16;
+    const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);          // wave id -> (n, strip, segment)
+    const long long nwaves = (long long)N * strips_y * segs_x;
+    if (wid >= nwaves) return;
+    const int seg = (int)(wid % segs_x);
+    const int strip = (int)((wid / segs_x) % strips_y);
+    const int n = (int)(wid / ((long long)segs_x * strips_y));
+    const int Hin = UP ? H >> 1 : H, Win = UP ? W >> 1 : W;
+
+    float4 wr[9][Q];                                          // this lane's weights: [tap][half] x 4 k-steps
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) wr[t][q] = wpk[(t * Q + q) * 64 + lane];
+    const float4 sc = reinterpret_cast<const float4*>(scale)[g], sh = reinterpret_cast<const float4*>(shift)[g];
+
+    const __amdgpu_buffer_rsrc_t rs_in =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + (size_t)n * Hin * Win * CIN), 0, (int)((size_t)Hin * Win * CIN * 4), 0x00020000);
+    const int x = seg * 16 + i;
+    unsigned coloff[3];                                       // byte offset of the source column of tap kx (OOB: beyond the buffer)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int xx = x + kx - 1;
+        coloff[kx] = ((unsigned)xx < (unsigned)W) ? (unsigned)((UP ? xx >> 1 : xx) * CIN + 4 * g) * 4u : 0xFFFFFF00u;
+    }
+    for (int r = 0; r < TO16_ROWS; ++r) {
+        const int y = strip * TO16_ROWS + r;
+        if (y >= H) break;                                    // wave-uniform
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = y + ky - 1;
+            if ((unsigned)yy >= (unsigned)H) continue;        // wave-uniform: zero padding rows
+            const int rowoff = (UP ? yy >> 1 : yy) * Win * CIN * 4;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(rs_in, coloff[kx], rowoff + q * 64, 0);
+                    float4 a;
+                    __builtin_memcpy(&a, &raw, 16);
+                    const float4 wq = wr[ky * 3 + kx][q];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wq.x, a.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wq.y, a.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wq.z, a.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wq.w, a.w, acc, 0, 0, 0);
+                }
+            }
+        }
+        if (x < W) {
+            float4 o;
+            o.x = fmaxf(acc[0] * sc.x + sh.x, 0.f);
+            o.y = fmaxf(acc[1] * sc.y + sh.y, 0.f);
+            o.z = fmaxf(acc[2] * sc.z + sh.z, 0.f);
+            o.w = fmaxf(acc[3] * sc.w + sh.w, 0.f);
+            *reinterpret_cast<float4*>(out + (((size_t)n * H + y) * W + x) * 16 + 4 * g) = o;
+        }
+    }
+}
+
 // ---- [N][3][HW] image planes in 0..255 -> [N][HW][3] records in -1..1 ----
 __global__ __launch_bounds__(256) void normalise_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, long long HW, long long total)
 {
@@ -197,6 +275,27 @@ __global__ __launch_bounds__(256) void stem3x3s2_nhwc_kernel(const float* __rest
 }
 
 }  // namespace
+
+extern "C" int estd_conv2d_k3_to16_nhwc(const float* in, const float* w_packed, const float* scale, const float* shift, float* out, int N, int H,
+                                        int W, int cin, int upsample, estd_stream_t s)
+{
+    if (!in || !w_packed || !scale || !shift || !out || N <= 0 || H <= 0 || W <= 0) return ESTD_ERR_ARG;
+    if ((cin != 16 && cin != 32) || (upsample != 0 && upsample != 1)) return ESTD_ERR_UNSUPPORTED;
+    if (upsample && ((H | W) & 1)) return ESTD_ERR_ARG;
+    const long long hin = upsample ? H / 2 : H, win = upsample ? W / 2 : W;
+    if (hin * win * cin * 4 >= 0x7fffff00LL) return ESTD_ERR_UNSUPPORTED;       // one image through a 32-bit buffer descriptor
+    const int strips_y = (H + TO16_ROWS - 1) / TO16_ROWS, segs_x = (W + 15) / 16;
+    const long long waves = (long long)N * strips_y * segs_x;
+    const long long blocks = (waves + 3) / 4;
+    if (blocks > 0x7fffffffLL) return ESTD_ERR_ARG;
+    const float4* wp = reinterpret_cast<const float4*>(w_packed);
+#define ESTD_TO16(C, U) hipLaunchKernelGGL((conv2d_k3_to16_kernel<C, U>), dim3((unsigned)blocks), dim3(256), 0, estd_stream(s), in, wp, scale, shift, \
+                                           out, N, H, W, strips_y, segs_x)
+    if (cin == 16) { if (upsample) ESTD_TO16(16, true); else ESTD_TO16(16, false); }
+    else { if (upsample) ESTD_TO16(32, true); else ESTD_TO16(32, false); }
+#undef ESTD_TO16
+    return ESTD_LAUNCH_CHECK();
+}
 
 extern "C" int estd_normalise_nhwc(const float* in, float* out, int N, int64_t HW, estd_stream_t s)
 {

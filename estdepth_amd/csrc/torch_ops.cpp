@@ -328,6 +328,19 @@ Tensor spp_upsample_cat(const Tensor& raw, const Tensor& skip, at::TensorList br
     return out;
 }
 
+Tensor conv2d_k3_to16_nhwc(const Tensor& x, const Tensor& w_packed, const Tensor& scale, const Tensor& shift, bool upsample)
+{
+    TORCH_CHECK(x.dim() == 4 && (x.size(3) == 16 || x.size(3) == 32), "conv2d_k3_to16_nhwc: NHWC x with 16 or 32 channels expected");
+    const int64_t n = x.size(0), c = x.size(3), h = (upsample ? 2 : 1) * x.size(1), w = (upsample ? 2 : 1) * x.size(2);
+    TORCH_CHECK(w_packed.numel() == 9 * (c / 16) * 64 * 4 && scale.numel() == 16 && shift.numel() == 16,
+                "conv2d_k3_to16_nhwc: packed weights [9][cin/16][64][4] and scale/shift [16] expected");
+    Tensor out = new_f32({n, h, w, 16}, x);
+    check_status(estd_conv2d_k3_to16_nhwc(fptr(x, "x"), fptr(w_packed, "packed weights"), fptr(scale, "scale"), fptr(shift, "shift"),
+                                          out.data_ptr<float>(), (int)n, (int)h, (int)w, (int)c, upsample ? 1 : 0, cur_stream()),
+                 "estd_conv2d_k3_to16_nhwc");
+    return out;
+}
+
 Tensor normalise_nhwc(const Tensor& imgs)
 {
     TORCH_CHECK(imgs.dim() == 4 && imgs.size(1) == 3, "normalise_nhwc: [N,3,H,W] images expected");
@@ -502,6 +515,7 @@ TORCH_LIBRARY(estdepth_hip, m)
           "Tensor beta_o, Tensor(a!) out_value, int out_stride) -> ()");
     m.def("bn_act_nhwc_(Tensor(a!) x, Tensor scale, Tensor shift, bool relu, Tensor? residual) -> Tensor(a!)");
     m.def("spp_upsample_cat(Tensor raw, Tensor skip, Tensor[] branches) -> Tensor");
+    m.def("conv2d_k3_to16_nhwc(Tensor x, Tensor w_packed, Tensor scale, Tensor shift, bool upsample) -> Tensor");
     m.def("normalise_nhwc(Tensor imgs) -> Tensor");
     m.def("stem3x3s2_nhwc(Tensor x, Tensor weight, Tensor scale, Tensor shift) -> Tensor");
     m.def("planes_cat_nhwc(Tensor a, Tensor b, bool relu_b) -> Tensor");
@@ -537,6 +551,7 @@ TORCH_LIBRARY_IMPL(estdepth_hip, CUDA, m)
     m.impl("gru_blend", gru_blend);
     m.impl("bn_act_nhwc_", bn_act_nhwc_);
     m.impl("spp_upsample_cat", spp_upsample_cat);
+    m.impl("conv2d_k3_to16_nhwc", conv2d_k3_to16_nhwc);
     m.impl("normalise_nhwc", normalise_nhwc);
     m.impl("stem3x3s2_nhwc", stem3x3s2_nhwc);
     m.impl("planes_cat_nhwc", planes_cat_nhwc);

@@ -7,6 +7,8 @@ scope for hand kernels).  Quirks reproduced on purpose: stale pose (Q7), P_j @ P
 pose (Q8), Gauss-Seidel target loop (Q9), mean-of-softmax attention (Q10).
 Inference only, batch size 1 per call (the reference itself cannot batch sequences, Q15).
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -200,9 +202,14 @@ class DepthHybridDecoder(nn.Module):
             return c[1]
         d1 = self.dispconv_1
         s1 = ops.disp_head_nhwc(nhwc(x), head_weight(d1), d1.bias, self.depth_max, 2)                      # :274
+        d0 = self.dispconv_0
+        if self.upconv_0_0.to16_ok() and self.upconv_0_1.to16_ok() and os.environ.get("ESTD_HIP_TO16", "1") == "1":
+            x = self.upconv_0_0.forward_to16(nhwc(x), False)                                               # :276
+            x = self.upconv_0_1.forward_to16(x, True)                                                      # :277-278 upsample + conv
+            s0 = ops.disp_head_nhwc(x, head_weight(d0), d0.bias, self.depth_max, 1)                        # :279
+            return s1, s0
         x = self.upconv_0_0(x)
         x = self.upconv_0_1(upsample(x))
-        d0 = self.dispconv_0
         s0 = ops.disp_head_nhwc(nhwc(x), head_weight(d0), d0.bias, self.depth_max, 1)                      # :279
         return s1, s0
 

@@ -470,6 +470,21 @@ def _need_f32_cuda(name, *ts):
             raise RuntimeError("%s: contiguous float32 ROCm tensors expected (no CPU path)" % name)
 
 
+def conv2d_k3_to16_nhwc(x, w_packed, scale, shift, upsample=False):
+    """3x3 conv (cin 16|32 -> 16) + folded BN + ReLU on an NHWC map, optionally on its nearest-x2 upsampling (never materialised)."""
+    if _use_torch():
+        return T().conv2d_k3_to16_nhwc(x, w_packed, scale, shift, bool(upsample))
+    _need_f32_cuda("conv2d_k3_to16_nhwc", x, w_packed, scale, shift)
+    n, h, w, c = x.shape
+    if c not in (16, 32) or w_packed.numel() != 9 * (c // 16) * 256 or scale.numel() != 16 or shift.numel() != 16:
+        raise RuntimeError("conv2d_k3_to16_nhwc: NHWC x with 16|32 channels, packed weights [9][cin/16][64][4], scale/shift [16] expected")
+    u = 2 if upsample else 1
+    out = torch.empty((n, u * h, u * w, 16), device=x.device, dtype=torch.float32)
+    N.check(N.lib().estd_conv2d_k3_to16_nhwc(_p(x), _p(w_packed), _p(scale), _p(shift), _p(out), n, u * h, u * w, c, int(bool(upsample)), _stream()),
+            "estd_conv2d_k3_to16_nhwc")
+    return out
+
+
 def normalise_nhwc(imgs):
     """[N,3,H,W] images in 0..255 -> 2 * (imgs / 255) - 1 as an NHWC batch [N,H,W,3] (model_hybrid.py:119)."""
     if _use_torch():

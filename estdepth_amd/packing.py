@@ -273,6 +273,22 @@ def pack_conv3d_wino(weight, main_idx, out_idx):
     return torch.from_numpy(out)
 
 
+def pack_conv2d_to16(weight):
+    """Conv2d weight [16, cin, 3, 3] (cin = 16 | 32) for csrc/refine2d.hip conv2d_k3_to16_kernel: float32 [9 taps][cin/16][64 lanes][4];
+    element ks of lane (g, i) of (tap, half q) = weight[i][16 q + 4 g + ks][ky][kx] -- output channel i as the MFMA's M row, the
+    four consecutive input channels a lane loads as its four k-steps."""
+    w = weight.detach().float().cpu().numpy()
+    cout, cin = w.shape[:2]
+    assert cout == 16 and cin in (16, 32) and w.shape[2:] == (3, 3)
+    out = np.zeros((9, cin // 16, 64, 4), np.float32)
+    for lane in range(64):
+        g, i = lane >> 4, lane & 15
+        for q in range(cin // 16):
+            for ks in range(4):
+                out[:, q, lane, ks] = w[i, 16 * q + 4 * g + ks].reshape(9)
+    return torch.from_numpy(out)
+
+
 def pack_conv2d_wino(weight, group_tiles):
     """3x3 Conv2d weight [Cout, Cin, 3, 3] for csrc/conv2d_wino.hip: the row taps g0, g1, g2 of every kw column in Winograd
     F(2,3) form U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2 (float64, rounded once to float32), packed as

@@ -253,6 +253,12 @@ int estd_spp_upsample_cat(const float* raw, int c_raw, const float* skip, int c_
  * estd_disp_head_nhwc:     depth_max * sigmoid(Conv2d(C, 1, 3, stride 1, padding 1, bias)(in)) (:274 dispconv_1, :279 dispconv_0):
  *                          in [N][H][W][C] NHWC, w [1][C][3][3], bias [1] (device), C = 16 | 32; out [N][1][upscale*H][upscale*W],
  *                          upscale = 1, or 2 = the F.interpolate(scale_factor=2) (nearest) of :274 fused in. */
+/* 3x3 / stride 1 / padding 1 convolution to 16 channels + folded BatchNorm2d + ReLU on NHWC maps, the full-resolution ConvBlocks
+ * of the decoder (hybrid_models/hybrid_depth_decoder.py:17-30 ConvBlock; :276 upconv_0_0, :277-278 upconv_0_1(upsample(x))):
+ * in [N][Hin][Win][cin], cin = 16 | 32; upsample = 1: the convolution reads the nearest-x2 upsampled map (Hin = H/2, Win = W/2,
+ * :11-14) without materialising it; out [N][H][W][16].  w_packed: packing.pack_conv2d_to16 ([9 taps][cin/16][64 lanes][4]). */
+int estd_conv2d_k3_to16_nhwc(const float* in, const float* w_packed, const float* scale, const float* shift, float* out, int N,
+                             int H, int W, int cin, int upsample, estd_stream_t stream);
 /* image normalisation of DepthNetHybrid.forward (hybrid_models/model_hybrid.py:119: imgs = 2 * (imgs / 255.) - 1.):
  * in [N][3][HW] planes (0..255) -> out [N][HW][3] NHWC records; the same three fp32 roundings as the reference's three ops. */
 int estd_normalise_nhwc(const float* in, float* out, int N, int64_t HW, estd_stream_t stream);

@@ -135,3 +135,28 @@ def test_normalise_nhwc_is_bit_identical_to_the_reference_cpu_ops():
     assert tuple(got.shape) == (5, 480, 640, 3) and torch.equal(got.cpu(), ref)
     odd = (torch.rand(2, 3, 7, 13, generator=g) * 255).to(DEV)
     assert torch.equal(ops.normalise_nhwc(odd).cpu(), (2 * (odd.cpu() / 255.) - 1.).permute(0, 2, 3, 1))
+
+
+@pytest.mark.parametrize("cin,up,shape", [(32, False, (3, 240, 320)), (16, True, (3, 240, 320)), (16, False, (1, 5, 7)), (32, True, (2, 3, 9)),
+                                          (16, True, (1, 1, 1)), (32, False, (1, 17, 33))])
+def test_conv2d_k3_to16_vs_torch_fp64(cin, up, shape):
+    """ConvBlock (conv3x3 + BN + ReLU) to 16 channels, optionally on the nearest-x2 upsampled input, incl. ragged sizes."""
+    from estdepth_amd import ops, packing
+    n, h, w = shape
+    g = torch.Generator().manual_seed(sum(shape) + cin + int(up))
+    x = torch.randn(n, h, w, cin, generator=g).to(DEV)
+    conv = torch.nn.Conv2d(cin, 16, 3, 1, 1, bias=False)
+    bn = torch.nn.BatchNorm2d(16).eval()
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.1)
+        bn.weight.copy_(torch.rand(16, generator=g) + 0.5); bn.bias.copy_(torch.randn(16, generator=g) * 0.2)
+        bn.running_mean.copy_(torch.randn(16, generator=g) * 0.2); bn.running_var.copy_(torch.rand(16, generator=g) + 0.5)
+    sc, sh = packing.fold_bn_fp32(bn, list(range(16)))
+    wp = packing.pack_conv2d_to16(conv.weight).to(DEV)
+    got = _both_bindings(lambda: ops.conv2d_k3_to16_nhwc(x, wp, sc.to(DEV), sh.to(DEV), up))
+    xin = x.cpu().double().permute(0, 3, 1, 2)
+    if up:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = torch.relu(bn.double()(conv.double()(xin))).permute(0, 2, 3, 1)
+    assert tuple(got.shape) == tuple(ref.shape)
+    assert float((got.cpu().double() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
