@@ -118,7 +118,8 @@ def test_stem3x3s2_nhwc_vs_torch_fp64(shape):
     sc, sh = packing.fold_bn_fp32(bn, list(range(32)))
     wd = conv.weight.detach().to(DEV)
     got = _both_bindings(lambda: ops.stem3x3s2_nhwc(x, wd, sc.to(DEV), sh.to(DEV)))
-    ref = torch.relu(bn.double()(conv.double()(x.cpu().double().permute(0, 3, 1, 2)))).permute(0, 2, 3, 1)
+    with torch.no_grad():
+        ref = torch.relu(bn.double()(conv.double()(x.cpu().double().permute(0, 3, 1, 2)))).permute(0, 2, 3, 1)
     assert tuple(got.shape) == tuple(ref.shape) == (n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, 32)
     assert float((got.cpu().double() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
 
@@ -157,6 +158,7 @@ def test_conv2d_k3_to16_vs_torch_fp64(cin, up, shape):
     xin = x.cpu().double().permute(0, 3, 1, 2)
     if up:
         xin = F.interpolate(xin, scale_factor=2, mode="nearest")
-    ref = torch.relu(bn.double()(conv.double()(xin))).permute(0, 2, 3, 1)
+    with torch.no_grad():
+        ref = torch.relu(bn.double()(conv.double()(xin))).permute(0, 2, 3, 1)
     assert tuple(got.shape) == tuple(ref.shape)
     assert float((got.cpu().double() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
