@@ -72,6 +72,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(const estd_conv2d_d
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // row pair: output rows a_w, a_w + DIL
     const int a_w = DIL == 1 ? 2 * wave : (wave & 1) + 4 * (wave >> 1);
     const int g = lane >> 4, col = lane & 15;
+    // MFMA row <-> pixel of a tile row (see csrc/conv3d_wino.hip): rows {0-3,12-15} = even pixels, rows {4-11} = odd pixels, so that the
+    // two halves of a ds_read_b128 lane group never meet in a bank row -- conflict-free A reads for every tap parity.
+    const int pcol = (ESTD_W2ABL & 32) ? col : (col < 4 ? 2 * col : col < 12 ? 2 * col - 7 : 2 * col - 16);
+    const int px0 = (ESTD_W2ABL & 32) ? 4 * g : (g == 0 ? 0 : g == 1 ? 1 : g == 2 ? 9 : 8);      // pixel of D row 4g + r = px0 + pxs * r
+    const int pxs = (ESTD_W2ABL & 32) ? 1 : 2;
     const int H = p.H, W = p.W, Cin = p.cin, Cout = p.cout;
     const int nchunks = Cin >> 5;
     const int tiles_per_group = p.N * tiles_h * tiles_w;
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(const estd_conv2d_d
             // A fragment of (transformed row i, column tap kw): two 16-byte LDS reads (channels 4g.., 16+4g..)
             auto load_a = [&](int tap, float4& a0, float4& a1) {
                 const int i = tap / 3, kw = tap % 3;
-                const int off0 = lds_chunk_off((wave * 4 + i) * IN_W + kw * DIL + col, g);
+                const int off0 = lds_chunk_off((wave * 4 + i) * IN_W + kw * DIL + pcol, g);
                 a0 = *reinterpret_cast<const float4*>(slot + off0);
                 a1 = *reinterpret_cast<const float4*>(slot + (off0 ^ 64));
             };
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(const estd_conv2d_d
                 const int y = th0 + a_w + m * DIL;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int x = tw0 + 4 * g + r;
+                    const int x = tw0 + px0 + pxs * r;
                     const unsigned eo = (y < H && x < W) ? (unsigned)((y * W + x) * Cout + cb) * 4u : OOB_OFFSET;
                     if (NT == 4) {
                         const float4 rr = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_res, eo, 0, 0));
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(const estd_conv2d_d
                     yv[nn] = m == 0 ? acc[0][nn] + acc[1][nn] + acc[2][nn] : acc[1][nn] - acc[2][nn] - acc[3][nn];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int x = tw0 + 4 * g + r;
+                    const int x = tw0 + px0 + pxs * r;
                     const unsigned eo = (y < H && x < W) ? (unsigned)((y * W + x) * Cout + cb) * 4u : OOB_OFFSET;
                     float v[NT];
 #pragma unroll

@@ -124,6 +124,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4;            // k index inside an MFMA
     const int i = lane & 15;            // M row (A) / N column (B, D)
+    // MFMA row <-> voxel of a tile row: rows {0-3,12-15} = even voxels, rows {4-11} = odd voxels, so that the two halves of a
+    // ds_read_b128 lane group ({0-3,12-15} of lane group g with {4-11} of g^1) never meet in a 256-byte bank row (csrc/conv3d_wino.hip)
+    const int pi = i < 4 ? 2 * i : i < 12 ? 2 * i - 7 : 2 * i - 16;
     const int D = p.D, H = p.H, W = p.W;
 
     // ---- range of the flattened tile list owned by this workgroup ----
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
         const int in_slice_bytes = HW * p.in_stride * 4;
 
         // epilogue lane offsets (bytes inside one depth plane); rows/columns past the volume are dropped
-        const int ey0 = th0 + row0, ex0 = tw0 + 4 * g;
+        const int ey0 = th0 + row0, ex0 = tw0 + (g == 0 ? 0 : g == 1 ? 1 : g == 2 ? 9 : 8);    // D row 4g + r = voxel pi(4g + r) = ex0 + 2r
 
         // output descriptors and per-lane output offsets of this segment (bytes inside one depth plane)
         __amdgpu_buffer_rsrc_t rs_out = rs_in, rs_res = rs_in, rs_res2 = rs_in;
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int y = ey0 + m, x = ex0 + r;
+                const int y = ey0 + m, x = ex0 + 2 * r;
                 eoff[m][r] = (y < H && x < W) ? (unsigned)((y * W + x) * p.out_stride + cbase) * 4u : OOB_OFFSET;
             }
 
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
                 const int y = ey0 + m;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int x = ex0 + r;
+                    const int x = ex0 + 2 * r;
                     const bool valid = (y < H) && (x < W);
                     const size_t vox = plane + (size_t)y * W + x;
                     float v0 = a[m][0][r] * sc[0] + sh[0];
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
                 }
                 if (XOUT) {
                     // ax[m] = channel 32 of voxel (row m, column i), identical in the four lane groups
-                    const int xx = tw0 + i;
+                    const int xx = tw0 + pi;
                     if (g == 0 && y < H && xx < W) p.out_extra[plane + (size_t)y * W + xx] = act_apply(ax[m] * sc2 + sh2, p.act_b);
                 }
             }
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
             const bool has_next = (u + 1 < seg_end);            // wave-uniform
             // The XOUT variant is register-tight: make the lane ids opaque per tile so the 54 loop-invariant LDS offsets
             // are recomputed in the MFMA shadow instead of being hoisted out of the tile loop (which spills).
-            int gi = g, ii = i;
+            int gi = g, ii = pi;
             if (XOUT) asm volatile("" : "+v"(gi), "+v"(ii));
             const bool next_valid = (d + 2 < D);
             const int next_soff = (d + 2) * in_slice_bytes;
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
                     const int xb = kd == 0 ? xb0 : kd == 1 ? xb1 : xb2;
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
-                        const float a = lds_extra[xb + (row0 + m + kh) * IN_W + kw + i];
+                        const float a = lds_extra[xb + (row0 + m + kh) * IN_W + kw + pi];
                         if (XOUT) {
                             const float4 wq4 = wxx[s >> 2];
                             const float wv = (s & 3) == 0 ? wq4.x : (s & 3) == 1 ? wq4.y : (s & 3) == 2 ? wq4.z : wq4.w;

@@ -112,6 +112,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
     const int nh = wave >> 2;           // output channels 16nh .. 16nh+15
     const int g = lane >> 4;            // k index inside an MFMA
     const int i = lane & 15;            // M row (A) / N column (B, D)
+    // MFMA row <-> voxel of a tile row: ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... --
+    // rows {0-3,12-15} of lane group g TOGETHER with rows {4-11} of lane group g^1.  With row i = voxel i the XOR swizzle below
+    // leaves a 2-way conflict on every tap whose first voxel is odd (PMC: 36 % of the LDS cycles).  Rows {0-3,12-15} take the even
+    // voxels and rows {4-11} the odd ones: the two halves of a hardware group then sit in different halves of every 256-byte
+    // bank row, and inside a half the eight voxels have distinct swizzle keys -- conflict-free for every tap.
+    const int pi = ESTD_WABL & 512 ? i : (i < 4 ? 2 * i : i < 12 ? 2 * i - 7 : 2 * i - 16);
     const int D = p.D, H = p.H, W = p.W;
     const int HW = H * W;
     const size_t vol = (size_t)D * HW;
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int tp = min(4 * k + g, 8);
-        xtap_off[k] = (tp / 3) * IN_W + (tp % 3) + i;
+        xtap_off[k] = (tp / 3) * IN_W + (tp % 3) + pi;
     }
 
     while (u < u_end) {
@@ -197,9 +203,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
         };
 
         // epilogue lane offsets (bytes inside one depth plane): rows row0, row0+1; columns 4g .. 4g+3 of the tile
-        const int ey0 = th0 + row0, ex0 = tw0 + 4 * g;
+        // D rows 4g + r of lane group g are the voxels pi(4g + r): 2r, 2r + 1, 2r + 9, 2r + 8 for g = 0..3
+        const int ey0 = th0 + row0;
+        const int ex0 = tw0 + ((ESTD_WABL & 512) ? 4 * g : (g == 0 ? 0 : g == 1 ? 1 : g == 2 ? 9 : 8));
+        const int exs = (ESTD_WABL & 512) ? 1 : 2;
         auto eoff_of = [&](int m, int r) {
-            const int y = ey0 + m, x = ex0 + r;
+            const int y = ey0 + m, x = ex0 + exs * r;
             return (y < H && x < W) ? (unsigned)((y * W + x) * p.out_stride + ch) * 4u : OOB_OFFSET;
         };
         unsigned eoff[2][4];                        // held in registers by the plain instance, recomputed by the 33-channel ones
@@ -361,7 +370,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
                 const int s = tap / 9, kh = (tap % 9) / 3, kw = tap % 3;
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const int vs = (row0 + m + kh) * IN_W + kw + i;
+                    const int vs = (row0 + m + kh) * IN_W + kw + pi;
                     const int off0 = s * SLICE_BYTES + lds_chunk_off(vs, g);
                     a0[m] = *reinterpret_cast<const float4*>(smem + off0);
                     a1[m] = *reinterpret_cast<const float4*>(smem + (off0 ^ 64));
@@ -464,7 +473,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
             if (XOUT) {
                 // weights (LDS copy made at kernel start): [36 taps][2 quads][4 lane groups][4] + scalar input channel [3 quads][4][4]
                 float xacc[4] = {0.f, 0.f, 0.f, 0.f};
-                int ix = i, gx_ = g;                          // opaque copies: this pass's LDS addresses are formed HERE, not hoisted
+                int ix = pi, gx_ = g;                          // opaque copies: this pass's LDS addresses are formed HERE, not hoisted
                 asm volatile("" : "+v"(ix), "+v"(gx_));       // over the tap loop above, whose register budget is spent
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
@@ -507,7 +516,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
                 }
                 const float sc2 = p.scale[32], sh2 = p.shift[32];
                 const int act2 = 32 < p.act_split ? p.act_a : p.act_b;
-                const int y = th0 + row0 + nh, x = tw0 + i;
+                const int y = th0 + row0 + nh, x = tw0 + pi;
                 const int dd = d0 + g;                                   // lane group 0 stores plane d0, group 1 plane d0 + 1
                 const float raw = g == 0 ? xacc[0] + xacc[1] + xacc[2] : xacc[1] - xacc[2] - xacc[3];
                 if (g < 2 && dd < D && y < H && x < W)
