@@ -60,7 +60,16 @@ constexpr int SIT = (SL_CHUNKS + NTHREADS - 1) / NTHREADS;     // chunks per thr
 constexpr int XSL_BYTES = 4 * SL_VOX * 4;           // the four transformed slices of the scalar 33rd input channel
 constexpr int RED_BYTES = 8 * 2 * 8;                // GroupNorm scratch: 8 waves x {sum, sumsq} doubles
 constexpr int WXO_BYTES = (36 * 2 + 3) * 64;        // the 33rd output channel's weights (XOUT)
-constexpr int LDS_BYTES = 4 * SLICE_BYTES + XSL_BYTES + RED_BYTES + WXO_BYTES;
+// The first WLDS_TAPS taps of every tile take their weights from an LDS copy made once per workgroup: vector-memory loads return in
+// order, so a weight load issued after the next tile's plane prefetch (HBM, taps 0..5) cannot be consumed before those planes have
+// arrived -- 2-4 taps of stall per tile (SQ_WAIT_INST_ANY 57 % of the wave cycles, "no plane prefetch" ablation -8 %).  With LDS
+// weights the first vector-memory weight load after the prefetch is the one for tap WLDS_TAPS, issued two taps earlier.
+#ifndef ESTD_WLDS_TAPS
+#define ESTD_WLDS_TAPS 14
+#endif
+constexpr int WLDS_TAPS = ESTD_WLDS_TAPS;
+constexpr int WLDS_BYTES = WLDS_TAPS * 4096;         // [tap][2 halves][2 quads][64 lanes][4]
+constexpr int LDS_BYTES = 4 * SLICE_BYTES + XSL_BYTES + RED_BYTES + WXO_BYTES + WLDS_BYTES;
 constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;        // beyond num_records of any descriptor: loads return 0, stores are dropped
 
 __device__ __forceinline__ float4 as_float4(u32x4 v)
@@ -133,6 +142,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
     if (u >= u_end) return;
 
     char* lds_wxo = smem + 4 * SLICE_BYTES + XSL_BYTES + RED_BYTES;               // XOUT: the 33rd output channel's weights
+    char* lds_w = lds_wxo + WXO_BYTES;                                            // weights of taps 0 .. WLDS_TAPS-1
+    for (int e = tid; e < WLDS_BYTES / 16; e += NTHREADS)                         // (visible after the first tile's barriers)
+        reinterpret_cast<float4*>(lds_w)[e] = reinterpret_cast<const float4*>(p.w_wino)[e];
     if (XOUT && tid < (36 * 2 + 3) * 4)                                     // (visible after the first tile's barriers)
         reinterpret_cast<float4*>(lds_wxo)[tid] = reinterpret_cast<const float4*>(p.w_xout)[tid];
 
@@ -351,11 +363,15 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
 
             constexpr bool W2 = !EXTRA && !(ESTD_WABL & 64);     // weights two taps ahead (8 more registers: the plain instance only)
             float4 bcur[2], bnext[2], bnext2[2];
+            auto load_w = [&](int t, int q) {               // t is a compile-time constant after unrolling
+                if (t < WLDS_TAPS) return *reinterpret_cast<const float4*>(lds_w + t * 4096 + q * 1024 + wlane);
+                return as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, t * 4096 + q * 1024, 0));
+            };
 #pragma unroll
-            for (int q = 0; q < 2; ++q) bcur[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, q * 1024, 0));
+            for (int q = 0; q < 2; ++q) bcur[q] = load_w(0, q);
             if (W2) {
 #pragma unroll
-                for (int q = 0; q < 2; ++q) bnext[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, 4096 + q * 1024, 0));
+                for (int q = 0; q < 2; ++q) bnext[q] = load_w(1, q);
             }
 #ifdef ESTD_TIMELINE
             if (tid == 0 && p.stats_partials) {     // debug build only: per-tile start stamps instead of GroupNorm sums
@@ -393,8 +409,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     if (ESTD_WABL & 8) { bnext[q] = bcur[q]; asm volatile("" : "+v"(bnext[q].x)); }
-                    else if (W2) { if (tap + 2 < 36) bnext2[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, (tap + 2) * 4096 + q * 1024, 0)); }
-                    else bnext[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, (tap + 1) * 4096 + q * 1024, 0));
+                    else if (W2) { if (tap + 2 < 36) bnext2[q] = load_w(tap + 2, q); }
+                    else bnext[q] = load_w(tap + 1, q);
                 }
                 // one 16-byte chunk of the NEXT tile's two new planes per tap
                 if (has_next && tap < 2 * SIT && !(ESTD_WABL & 16)) {
