@@ -19,6 +19,11 @@ done
 bash $R/tools/pmc_collect.sh "FETCH_SIZE WRITE_SIZE" $OUT/r2_conv3d_wino_pmc.csv -- python $R/tools/conv_bench.py 3 10 > /dev/null 2>&1
 ESTD_CONV3D_ALGO=direct bash $R/tools/pmc_collect.sh "FETCH_SIZE WRITE_SIZE" $OUT/r2_conv3d_direct_pmc.csv -- python $R/tools/conv_bench.py 3 10 > /dev/null 2>&1
 bash $R/tools/pmc_collect.sh "FETCH_SIZE WRITE_SIZE" $OUT/r2_hbm_kernels_pmc.csv -- python $R/tools/hbm_bench.py > /dev/null 2>&1
+# the hardware's own matrix-pipe utilisation counter (and LDS bank conflicts) of every convolution kernel, stand-alone benches
+for b in "conv_bench.py 3 10" "kv_bench.py" "head_bench.py" "conv2d_bench.py"; do
+  bash $R/tools/pmc_collect.sh "MfmaUtil SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" /tmp/mfma_one.csv -- python $R/tools/$b > /dev/null 2>&1
+  echo "# python tools/$b" >> $OUT/r2_mfma_util_pmc.csv; grep -v "at::native\|rocclr" /tmp/mfma_one.csv >> $OUT/r2_mfma_util_pmc.csv
+done
 cd $R
 python tools/hbm_bench.py > $OUT/r2_hbm_bench.txt 2>&1
 CB_EPI=1 python tools/conv_bench.py 3 30 > $OUT/r2_conv_bench.txt 2>&1
