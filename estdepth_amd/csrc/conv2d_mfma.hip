@@ -57,6 +57,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_k3_kernel(const estd_conv2d_des
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i = lane & 15;
+    // MFMA row <-> pixel of a tile row (csrc/conv3d_wino.hip): rows {0-3,12-15} = even pixels, rows {4-11} = odd pixels, matched to
+    // the ds_read_b128 lane groups -- conflict-free A reads for every tap parity
+    const int pi = i < 4 ? 2 * i : i < 12 ? 2 * i - 7 : 2 * i - 16;
+    const int px0 = g == 0 ? 0 : g == 1 ? 1 : g == 2 ? 9 : 8;             // pixel of D row 4g + r = px0 + 2r
     const int H = p.H, W = p.W, Cin = p.cin, Cout = p.cout;
     const int nchunks = Cin >> 5;
     const int tiles_per_group = p.N * tiles_h * tiles_w;
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_k3_kernel(const estd_conv2d_des
                     pf[tap] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, nvoff[tap], pf_soff, 0));
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    const int vs = (row0 + m + kh * DIL) * IN_W + kw * DIL + i;
+                    const int vs = (row0 + m + kh * DIL) * IN_W + kw * DIL + pi;
                     const int off0 = lds_chunk_off(vs, g);
                     const float4 a0 = *reinterpret_cast<const float4*>(slot + off0);
                     const float4 a1 = *reinterpret_cast<const float4*>(slot + (off0 ^ 64));
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_k3_kernel(const estd_conv2d_des
                 const int y = th0 + row0 + m;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int x = tw0 + 4 * g + r;
+                    const int x = tw0 + px0 + 2 * r;
                     const unsigned eo = (y < H && x < W) ? (unsigned)((y * W + x) * Cout + cb) * 4u : OOB_OFFSET;
                     float v[NT];
 #pragma unroll
