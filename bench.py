@@ -320,7 +320,8 @@ def main():
                 # memory bank {K, V_fused, pose} of this window -> every rank; the collective of step k overlaps step k+1
                 try:
                     drain()
-                    state["pending"] = parallel.allgather_memory_bank_async(costs, cposes)
+                    # GraphedForward hands back fresh memory tensors: they are sent from where they lie (no staging copy)
+                    state["pending"] = parallel.allgather_memory_bank_async(costs, cposes, stage=state["fwd"] is model)
                 except Exception as e:                   # same failure on every rank (collective): keep the shards running
                     state["notes"].append("memory-bank all-gather failed (%s: %s): disabled" % (type(e).__name__, str(e)[:80]))
                     state["allgather"], state["pending"] = False, None

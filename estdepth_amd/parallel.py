@@ -44,21 +44,54 @@ def _unpack_bank(recv, n, world, kv_shape, key_shape, value_shape, pose_shape, c
     return out
 
 
-def allgather_memory_bank_async(costs, cam_poses, group=None):
+def allgather_memory_bank_async(costs, cam_poses, group=None, stage=True):
     """Non-blocking variant: stages {K, V_fused, pose} into one send buffer (so the source may be overwritten by the
-    next forward / graph replay) and starts ONE all-gather on the communication stream.  ``.wait()`` returns the bank."""
+    next forward / graph replay) and starts ONE all-gather on the communication stream.  ``.wait()`` returns the bank.
+    ``stage=False``: the caller guarantees that the memory it hands in is not written again before ``.wait()`` (the fresh
+    tensors GraphedForward returns): the 157 MB record stream is sent from where it lies, the pose in a second, tiny
+    all-gather -- no staging copy on the compute stream."""
     world = dist.get_world_size(group)
     key, value, pose = costs["keys"][0], costs["values"][0], cam_poses[0]
     kv = getattr(value, "_estd_kv", None)
     channels_last = kv is not None and getattr(key, "_estd_kv", None) is kv
+    meta = (world, tuple(kv.shape) if channels_last else None, tuple(key.shape), tuple(value.shape), tuple(pose.shape), channels_last)
+    if not stage and channels_last and kv.is_contiguous():
+        flat = kv.reshape(-1)
+        psend = pose.reshape(-1).to(flat.dtype).contiguous()
+        n, m = flat.numel(), psend.numel()
+        recv_kv = torch.empty(world * n, device=flat.device, dtype=flat.dtype)
+        recv_p = torch.empty(world * m, device=flat.device, dtype=flat.dtype)
+        dist.all_gather_into_tensor(recv_p, psend, group=group, async_op=True)          # same communicator: runs before the big one
+        work = dist.all_gather_into_tensor(recv_kv, flat, group=group, async_op=True)
+        pend = _PendingBank2(work, recv_kv.view(world, n), recv_p.view(world, m), meta)
+        pend._send = (flat, psend, kv)  # keep the source alive until the collective has run
+        return pend
     flat = kv.reshape(-1) if channels_last else torch.cat([value.reshape(-1), key.reshape(-1)])
     send = torch.cat([flat, pose.reshape(-1).to(flat.dtype)])
     recv = torch.empty(world * send.numel(), device=send.device, dtype=send.dtype)
     work = dist.all_gather_into_tensor(recv, send, group=group, async_op=True)
-    meta = (world, tuple(kv.shape) if channels_last else None, tuple(key.shape), tuple(value.shape), tuple(pose.shape), channels_last)
     pend = _PendingBank(work, recv.view(world, send.numel()), flat.numel(), meta)
     pend._send = send                   # keep the staging buffer alive until the collective has run
     return pend
+
+
+class _PendingBank2:
+    """in-flight memory-bank all-gather without a staging copy: records and poses arrive in two receive buffers."""
+
+    def __init__(self, work, recv_kv, recv_p, meta):
+        self.work, self.recv_kv, self.recv_p, self.meta = work, recv_kv, recv_p, meta
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()            # collectives of one communicator complete in order: the pose gather is done as well
+            self.work = None
+        world, kv_shape, key_shape, value_shape, pose_shape, _ = self.meta
+        from .hybrid_depth_decoder import kv_views
+        out = []
+        for r in range(world):
+            k, v = kv_views(self.recv_kv[r].reshape(kv_shape))
+            out.append(({"keys": [k], "values": [v]}, [self.recv_p[r].reshape(pose_shape)]))
+        return out
 
 
 def allgather_memory_bank(costs, cam_poses, group=None):

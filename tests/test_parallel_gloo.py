@@ -50,6 +50,17 @@ def _worker(rank, world, port, ret):
     for r in range(world):
         ref = torch.randn(4, 3, 5, 32, generator=torch.Generator().manual_seed(200 + r))
         ok = ok and torch.equal(bank3[r][0]["values"][0], kv_views(ref)[1])
+    # no-staging variant (the caller keeps the source untouched until wait(): GraphedForward's fresh memory tensors)
+    kv4 = torch.randn(4, 3, 5, 32, generator=torch.Generator().manual_seed(300 + rank))
+    k4, v4 = kv_views(kv4)
+    pose4 = torch.randn(1, 4, 4, generator=torch.Generator().manual_seed(400 + rank))
+    bank4 = parallel.allgather_memory_bank_async({"keys": [k4], "values": [v4]}, [pose4], stage=False).wait()
+    ok = ok and len(bank4) == world
+    for r in range(world):
+        ref = torch.randn(4, 3, 5, 32, generator=torch.Generator().manual_seed(300 + r))
+        rk, rv = kv_views(ref)
+        rp = torch.randn(1, 4, 4, generator=torch.Generator().manual_seed(400 + r))
+        ok = ok and torch.equal(bank4[r][0]["keys"][0], rk) and torch.equal(bank4[r][0]["values"][0], rv) and torch.equal(bank4[r][1][0], rp)
     ret[rank] = bool(ok)
     dist.destroy_process_group()
 
