@@ -57,6 +57,9 @@ def kv_from_pair(key, value):
     return kv
 
 
+HIP_TO16 = os.environ.get("ESTD_HIP_TO16", "1") == "1"      # A/B switch, read once at import: full-resolution ConvBlocks on csrc/refine2d.hip
+
+
 class DepthHybridDecoder(nn.Module):
     def __init__(self, num_ch_enc, num_output_channels=1, use_skips=True,
                  ndepths=64, depth_max=10.0, IF_EST_transformer=True):
@@ -203,7 +206,7 @@ class DepthHybridDecoder(nn.Module):
         d1 = self.dispconv_1
         s1 = ops.disp_head_nhwc(nhwc(x), head_weight(d1), d1.bias, self.depth_max, 2)                      # :274
         d0 = self.dispconv_0
-        if self.upconv_0_0.to16_ok() and self.upconv_0_1.to16_ok() and os.environ.get("ESTD_HIP_TO16", "1") == "1":
+        if self.upconv_0_0.to16_ok() and self.upconv_0_1.to16_ok() and HIP_TO16:
             x = self.upconv_0_0.forward_to16(nhwc(x), False)                                               # :276
             x = self.upconv_0_1.forward_to16(x, True)                                                      # :277-278 upsample + conv
             s0 = ops.disp_head_nhwc(x, head_weight(d0), d0.bias, self.depth_max, 1)                        # :279

@@ -19,6 +19,13 @@ from .layers_op import PlanCache, convbn_3d, convbnrelu_3d
 Align_Corners_Range = False
 
 
+# A/B switches, read once at import
+FUSED_NORM = os.environ.get("ESTD_FUSED_NORM", "1") == "1"     # image normalisation + NHWC layout in one kernel
+MIX_GEMM = os.environ.get("ESTD_MIX_GEMM", "1") == "1"         # pre0 halves as two library GEMMs on NHWC features
+R50_HIP = os.environ.get("ESTD_R50_HIP", "1") == "1"           # ResNet stride-1 3x3 convolutions on the MFMA conv2d kernel
+HIP_REFINE = os.environ.get("ESTD_HIP_REFINE", "1") == "1"     # decoder 2D tail glue kernels (csrc/refine2d.hip)
+
+
 class DepthNetHybrid(nn.Module):
     def __init__(self, ndepths=64, depth_min=0.01, depth_max=10.0, resnet=50, IF_EST_transformer=True):
         super().__init__()
@@ -191,12 +198,12 @@ class DepthNetHybrid(nn.Module):
         from .backbones import enable_hip_3x3
         self.use_channels_last_2d(True)
         self.matchingFeature.use_hip_convs(enable)
-        if os.environ.get("ESTD_R50_HIP", "1") == "1":     # A/B switch
+        if R50_HIP:                                        # A/B switch
             enable_hip_3x3(self.semanticFeature, enable)   # ResNet stride-1 3x3 convs (with fuse_bn_2d())
         for name, child in self.CostRegNet.named_children():      # 2D decoder ConvBlocks with enough tiles (120x160 and up)
             if name.startswith("upconv"):
                 child._hip = bool(enable)
-        self.CostRegNet._hip_refine = bool(enable) and os.environ.get("ESTD_HIP_REFINE", "1") == "1"     # A/B switch (csrc/refine2d.hip)
+        self.CostRegNet._hip_refine = bool(enable) and HIP_REFINE                                    # A/B switch (csrc/refine2d.hip)
         return self
 
     # The forward pass in two stages, so that the host can evaluate the camera matrices while the GPU is busy:
@@ -214,7 +221,7 @@ class DepthNetHybrid(nn.Module):
         if batch_size != 1:
             raise RuntimeError("estdepth_amd runs one sequence per call (the reference's view() also fails for batch > 1)")
         fused_norm = getattr(self, "_channels_last_2d", False) and imgs.is_cuda and imgs.dtype == torch.float32 and imgs.shape[2] == 3 \
-            and os.environ.get("ESTD_FUSED_NORM", "1") == "1"
+            and FUSED_NORM
         if fused_norm:                                   # :119 and the NHWC layout of the 2D networks in one pass (csrc/refine2d.hip)
             imgs = ops.normalise_nhwc(imgs.reshape(views_num, 3, height_img, width_img).contiguous()).permute(0, 3, 1, 2)[None]
         else:
@@ -265,7 +272,7 @@ class DepthNetHybrid(nn.Module):
         # every view is a source for up to two targets: mix each 2D feature once (pre0 pushed in front of the warp)
         P = self._plans()                                   # one cache-key check per forward
         if matching.is_cuda and matching.dim() == 4 and matching.shape[1] == 32 and \
-                matching.is_contiguous(memory_format=torch.channels_last) and os.environ.get("ESTD_MIX_GEMM", "1") == "1":
+                matching.is_contiguous(memory_format=torch.channels_last) and MIX_GEMM:
             # NHWC matching features (HIP PSM path): pre0's two halves are plain [pixels, 32] x [32, 32] library GEMMs on the
             # records as they lie -- two launches for all views instead of a CHW copy + one mix kernel per view and role
             V, _, Hf, Wf = matching.shape
