@@ -30,6 +30,7 @@ class Conv3dDesc(ctypes.Structure):
         ("stats_partials", ctypes.c_void_p),
         ("w_split", ctypes.c_void_p),
         ("w_wino", ctypes.c_void_p),
+        ("w_wino2", ctypes.c_void_p),
     ]
 
 
@@ -62,6 +63,7 @@ _SIGNATURES = {
     "estd_conv3d_k3": (ctypes.c_int, [ctypes.POINTER(Conv3dDesc), c_stream]),
     "estd_conv3d_k3_split": (ctypes.c_int, [ctypes.POINTER(Conv3dDesc), c_stream]),
     "estd_conv3d_k3_wino": (ctypes.c_int, [ctypes.POINTER(Conv3dDesc), c_stream]),
+    "estd_conv3d_k3_wino2": (ctypes.c_int, [ctypes.POINTER(Conv3dDesc), c_stream]),
     "estd_conv2d_k3": (ctypes.c_int, [ctypes.POINTER(Conv2dDesc), c_stream]),
     "estd_conv2d_k3_split": (ctypes.c_int, [ctypes.POINTER(Conv2dDesc), c_stream]),
     "estd_conv2d_k3_wino": (ctypes.c_int, [ctypes.POINTER(Conv2dDesc), c_stream]),

@@ -1,0 +1,413 @@
+// conv3d_wino2.hip -- the plain 32 -> 32 3x3x3 convolution with TWO axes (depth and image rows) in Winograd F(2,3) form, on
+// gfx950 fp32 MFMA: F(2x2, 3x3) over (d, h), a 3-tap direct convolution along w.
+//
+// Same operator and descriptor as estd_conv3d_k3 / estd_conv3d_k3_wino (networks/layers_op.py:16-39 as used at
+// hybrid_models/model_hybrid.py:59-60,:95, hybrid_models/hybrid_depth_decoder.py:84-95,:190-191 and the gate convolution of
+// transformer/epipolar_transformer.py:21).  The depth-only Winograd kernel (csrc/conv3d_wino.hip) keeps the matrix pipe 80 % busy
+// with 2/3 of the direct kernel's products; the lever left in fp32 is fewer products again:
+//
+//   2 x 2 outputs (planes d, d+1; rows y, y+1) of one w position from the 4 x 4 input patch (planes d-1..d+2, rows y-1..y+2):
+//       T = B^T x B   (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1] on the depth axis, then on the row axis)
+//       U = G g G^T   (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1] on kd, then on kh; float64 on the host, rounded once)
+//       m[sd][sh] = conv1d_w(T[sd][sh], U[sd][sh][kw])        16 x 3 tap products
+//       y = A^T m A   (A^T = [1 1 1 0; 0 1 -1 -1])
+//   48 tap products per 4 outputs instead of 4 x 27: 0.444 of the direct MFMA work (depth-only form: 0.667); every product is
+//   still a v_mfma_f32_16x16x4_f32 with fp32 accumulation.
+//
+// Work decomposition: the depth-only kernel's (512 threads = 8 waves, ONE workgroup per CU, output tile 2 x 8 x 16 voxels,
+// persistent XCD-contiguous ranges of the column-major tile list, the four DEPTH-transformed slices of 10 x 18 voxels x 32
+// channels in LDS with the same swizzle and MFMA row <-> voxel permutation, raw planes carried in registers, the next tile's
+// slices written inside the tap loop, the same epilogue).  What differs:
+//   * the ROW transform is applied in registers between LDS and the MFMA: wave (rp, nh) owns the row pair 2rp, 2rp+1 of the tile,
+//     i.e. halo rows 2rp .. 2rp+3; per group (sd, kw) it reads those four rows ONCE (8 ds_read_b128, as many as the depth-only
+//     kernel reads per four taps) and forms the four transformed fragments with one VALU add/sub per operand register
+//     (1 VALU per MFMA, issued in the MFMA's shadow): t0 = r0 - r2, t1 = r1 + r2, t2 = r2 - r1, t3 = r1 - r3;
+//   * 16 accumulators m[sd][sh] (64 registers) for one 16-voxel M tile x one 16-channel N tile; two of them alternate inside a
+//     step (the 16x16x4 MFMA has a 40-cycle dependent latency at a 32-cycle issue interval);
+//   * 48 weight taps of 4 KB (192 KB): taps 0..15 from an LDS copy made once per workgroup, the rest streamed from L2 one step
+//     (two taps) ahead; tap = (3 sd + kw) * 4 + sh.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "estd_hip.h"
+#include "estd_common.h"
+
+#ifndef ESTD_W2ABL
+#define ESTD_W2ABL 0    // timing ablations only (results are wrong): 1 no output stores, 2 no slice writes, 8 no weight stream,
+#endif                  // 16 no next-plane prefetch, 128 no row transform (raw rows as operands)
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
+
+constexpr int TH = 8, TW = 16;
+constexpr int IN_H = TH + 2, IN_W = TW + 2;
+constexpr int SL_VOX = IN_H * IN_W;                 // 180 voxels per input slice (with halo)
+constexpr int SLICE_BYTES = SL_VOX * 128;           // 32 channels
+constexpr int NTHREADS = 512;
+constexpr int SL_CHUNKS = SL_VOX * 8;               // 16-byte chunks per slice: 1440
+constexpr int SIT = (SL_CHUNKS + NTHREADS - 1) / NTHREADS;     // chunks per thread per slice: 3
+constexpr int RED_BYTES = 8 * 2 * 8;                // GroupNorm scratch: 8 waves x {sum, sumsq} doubles
+constexpr int NTAPS = 48;
+#ifndef ESTD_W2LDS_TAPS
+#define ESTD_W2LDS_TAPS 16
+#endif
+constexpr int WLDS_TAPS = ESTD_W2LDS_TAPS;           // weights of the first taps of every tile come from LDS (even)
+constexpr int WLDS_BYTES = WLDS_TAPS * 4096;         // [tap][2 halves][2 quads][64 lanes][4]
+constexpr int LDS_BYTES = 4 * SLICE_BYTES + RED_BYTES + WLDS_BYTES;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;        // beyond num_records of any descriptor: loads return 0, stores are dropped
+
+__device__ __forceinline__ float4 as_float4(u32x4 v)
+{
+    float4 f;
+    __builtin_memcpy(&f, &v, 16);
+    return f;
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, size_t elems)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(elems * 4), 0x00020000);
+}
+
+// workgroup barrier that only orders LDS traffic (no vmcnt drain: prefetches and output stores stay in flight)
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__device__ __forceinline__ int lds_chunk_off(int v, int c) { return v * 128 + ((c ^ ((v >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ float act_apply(float v, int act)
+{
+    if (act == ESTD_ACT_RELU) return v > 0.0f ? v : 0.0f;
+    if (act == ESTD_ACT_TANH) return tanhf(v);
+    return v;
+}
+
+__device__ __forceinline__ float4 f4_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+__global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino2_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int dpairs, int total_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rp = wave & 3;            // tile rows 2rp, 2rp+1 (halo rows 2rp .. 2rp+3)
+    const int nh = wave >> 2;           // output channels 16nh .. 16nh+15
+    const int g = lane >> 4;            // k index inside an MFMA
+    const int i = lane & 15;            // M row (A) / N column (B, D)
+    // MFMA row <-> voxel of a tile row (conflict-free ds_read_b128 for every tap; see csrc/conv3d_wino.hip)
+    const int pi = i < 4 ? 2 * i : i < 12 ? 2 * i - 7 : 2 * i - 16;
+    const int D = p.D, H = p.H, W = p.W;
+    const int HW = H * W;
+    const size_t vol = (size_t)D * HW;
+
+    // ---- range of the flattened tile list (column-major: the d pairs of one (n, h-tile, w-tile) column are consecutive) ----
+    int u, u_end;
+    {
+        const int G = gridDim.x, bid = blockIdx.x;
+        const int r = ((G & 7) == 0) ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;       // XCD x owns a contiguous block of ranges
+        u = (int)((long long)total_tiles * r / G);
+        u_end = (int)((long long)total_tiles * (r + 1) / G);
+    }
+    if (u >= u_end) return;
+
+    char* lds_w = smem + 4 * SLICE_BYTES + RED_BYTES;                             // weights of taps 0 .. WLDS_TAPS-1
+    for (int e = tid; e < WLDS_BYTES / 16; e += NTHREADS)                         // (visible after the first tile's barriers)
+        reinterpret_cast<float4*>(lds_w)[e] = reinterpret_cast<const float4*>(p.w_wino2)[e];
+
+    const int ch = 16 * nh + i;                     // this lane's output channel
+    const float sc = p.scale[ch], sh = p.shift[ch];
+    const int act0 = ch < p.act_split ? p.act_a : p.act_b;
+    // packed weights: [48 taps][2 halves][2 quads][64 lanes][4]
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w_wino2, (size_t)NTAPS * 2 * 2 * 256);
+    const int wlane = lane * 16 + nh * 2048;
+    const int row0 = 2 * rp;
+
+    while (u < u_end) {
+        // ---- column segment [u, seg_end): same (n, h-tile, w-tile), consecutive depth pairs ----
+        const int col = u / dpairs;
+        int dp = u - col * dpairs;
+        const int twi = col % tiles_w, c2 = col / tiles_w;
+        const int thi = c2 % tiles_h, n = c2 / tiles_h;
+        const int tw0 = twi * TW, th0 = thi * TH;
+        const int seg_end = min(u_end, (col + 1) * dpairs);
+
+        const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in_main + (size_t)n * vol * p.in_stride, vol * p.in_stride);
+        __amdgpu_buffer_rsrc_t rs_out = rs_in, rs_res = rs_in, rs_res2 = rs_in;
+        rs_out = make_rsrc(p.out_main + (size_t)n * vol * p.out_stride, vol * p.out_stride);
+        if (p.residual) rs_res = make_rsrc(p.residual + (size_t)n * vol * p.out_stride, vol * p.out_stride);
+        if (p.residual2) rs_res2 = make_rsrc(p.residual2 + (size_t)n * vol * p.out_stride, vol * p.out_stride);
+        const int in_slice_bytes = HW * p.in_stride * 4;
+        const int out_plane_bytes = HW * p.out_stride * 4;
+
+        // per-thread slice elements (validity in y / x does not depend on d)
+        unsigned voff[SIT];
+        int loff[SIT];
+#pragma unroll
+        for (int it = 0; it < SIT; ++it) {
+            const int e = tid + it * NTHREADS;
+            const int vs = e >> 3, c = e & 7;
+            const int zy = vs / IN_W, zx = vs % IN_W;
+            const int gy = th0 - 1 + zy, gx = tw0 - 1 + zx;
+            const bool ok = e < SL_CHUNKS && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            voff[it] = ok ? (unsigned)((gy * W + gx) * p.in_stride + c * 4) * 4u : OOB_OFFSET;
+            loff[it] = e < SL_CHUNKS ? lds_chunk_off(vs, c) : -1;
+        }
+        auto load_plane = [&](int pd, float4 (&dst)[SIT]) {
+            const bool pv = (unsigned)pd < (unsigned)D;        // wave-uniform; planes outside the volume are zero padding
+#pragma unroll
+            for (int it = 0; it < SIT; ++it)
+                dst[it] = pv ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[it], pd * in_slice_bytes, 0))
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+
+        // epilogue lane offsets (bytes inside one depth plane): rows row0, row0+1; D rows 4g + r of lane group g are the voxels
+        // pi(4g + r): 2r, 2r + 1, 2r + 9, 2r + 8 for g = 0..3
+        const int ey0 = th0 + row0;
+        const int ex0 = tw0 + (g == 0 ? 0 : g == 1 ? 1 : g == 2 ? 9 : 8);
+        auto eoff_of = [&](int m, int r) {
+            const int y = ey0 + m, x = ex0 + 2 * r;
+            return (y < H && x < W) ? (unsigned)((y * W + x) * p.out_stride + ch) * 4u : OOB_OFFSET;
+        };
+
+        // epilogue of one plane: the 2 x 4 voxels (tile row m, D row r) of channel ch this lane holds.  Every read-back stream
+        // (residuals, the running sum) issues its eight loads back to back and is waited for ONCE.
+        auto epi_plane = [&](const f32x4 (&a)[2], int dd) {
+            const int so = dd * out_plane_bytes;
+            unsigned eo[2][4];
+            float r1[2][4], r2[2][4], ro[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) eo[m][r] = eoff_of(m, r);
+            if (p.residual) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) r1[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, eo[m][r], so, 0));
+            }
+            if (p.residual2) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) r2[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res2, eo[m][r], so, 0));
+            }
+            if (p.accumulate) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ro[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_out, eo[m][r], so, 0));
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = act_apply(a[m][r] * sc + sh, act0);
+                    if (p.residual) v += r1[m][r];
+                    if (p.residual2) v += r2[m][r];
+                    v *= p.out_scale;
+                    if (p.accumulate) v += ro[m][r];
+                    if (!(ESTD_W2ABL & 1)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, eo[m][r], so, 0);
+                }
+        };
+        // GroupNorm(1 group) partial sums of the raw outputs of one plane: group = channel half nh.  Fixed-order reduction
+        // (lanes by butterfly, the four row-pair waves of a half through LDS) -> deterministic.  Workgroup-uniform call.
+        auto plane_stats = [&](const f32x4 (&a)[2], int dd) {
+            double s_sum = 0.0, s_sq = 0.0;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (eoff_of(m, r) != OOB_OFFSET) { const double v = (double)(a[m][r] * sc + sh); s_sum += v; s_sq += v * v; }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { s_sum += __shfl_xor(s_sum, o); s_sq += __shfl_xor(s_sq, o); }
+            double* red = reinterpret_cast<double*>(smem + 4 * SLICE_BYTES);
+            __syncthreads();                                     // the previous plane's scratch has been consumed
+            if (lane == 0) { red[wave * 2] = s_sum; red[wave * 2 + 1] = s_sq; }
+            __syncthreads();
+            if (tid < 4) {
+                const int grp = tid >> 1, q = tid & 1;
+                const double tot = red[(grp * 4 + 0) * 2 + q] + red[(grp * 4 + 1) * 2 + q] + red[(grp * 4 + 2) * 2 + q] + red[(grp * 4 + 3) * 2 + q];
+                // partial index = canonical tile id (n, d, thi, twi), as the direct kernel writes it
+                const size_t tile_id = (((size_t)n * D + dd) * tiles_h + thi) * tiles_w + twi;
+                p.stats_partials[tile_id * 4 + tid] = tot;
+            }
+        };
+
+        // raw planes in registers: xa = x[d0-1], xb = x[d0], xc = x[d0+1], xd = x[d0+2]
+        float4 xa[SIT], xb[SIT], xc[SIT], xd[SIT];
+        {
+            const int d0 = 2 * dp;
+            load_plane(d0 - 1, xa);
+            load_plane(d0, xb);
+            load_plane(d0 + 1, xc);
+            load_plane(d0 + 2, xd);
+        }
+
+        // depth transform B^T x of the planes in (xa, xb, xc, xd), straight into LDS slice sl
+        auto write_slice = [&](int sl) {
+#pragma unroll
+            for (int it = 0; it < SIT; ++it) {
+                if ((it < SIT - 1 || loff[it] >= 0) && !(ESTD_W2ABL & 2)) {
+                    const float4 v = sl == 0 ? f4_sub(xa[it], xc[it]) : sl == 1 ? f4_add(xb[it], xc[it])
+                                   : sl == 2 ? f4_sub(xc[it], xb[it]) : f4_sub(xb[it], xd[it]);
+                    *reinterpret_cast<float4*>(smem + sl * SLICE_BYTES + loff[it]) = v;
+                }
+            }
+        };
+        auto shift_planes = [&]() {                      // planes d0+1, d0+2 are planes d0'-1, d0' of the next tile
+#pragma unroll
+            for (int it = 0; it < SIT; ++it) { xa[it] = xc[it]; xb[it] = xd[it]; }
+        };
+        bool first = true;
+
+        for (; u < seg_end; ++u, ++dp) {
+            const int d0 = 2 * dp;
+            if (first) {
+                lds_barrier();                          // every wave is done reading the previous tile's slices
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) write_slice(sl);
+                shift_planes();
+                lds_barrier();
+                first = false;
+            }
+
+            const bool has_next = (u + 1 < seg_end);     // wave-uniform
+            const int nd = d0 + 3;                       // new planes of the next tile: nd, nd + 1
+            const bool v0 = nd < D, v1 = nd + 1 < D;
+
+            f32x4 acc[4][4];                             // m[sd][sh]
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[s][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+            auto load_w = [&](int t, int q) {               // t is a compile-time constant after unrolling
+                if (t < WLDS_TAPS) return *reinterpret_cast<const float4*>(lds_w + t * 4096 + q * 1024 + wlane);
+                return as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, t * 4096 + q * 1024, 0));
+            };
+            // 16-byte chunk c (channels 4g.. for c = 0, 16+4g.. for c = 1) of halo row 2rp + r at column shift kw of depth slice sd
+            auto load_row = [&](int sd, int kw, int c, int r) {
+                const int vs = (row0 + r) * IN_W + kw + pi;
+                const int off0 = sd * SLICE_BYTES + lds_chunk_off(vs, g);
+                return *reinterpret_cast<const float4*>(smem + (c ? (off0 ^ 64) : off0));
+            };
+
+            float4 bcur[4], bnext[4];                    // [sh]: this step's quad of the four taps of the group
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bcur[t] = load_w(t, 0);
+            float4 R[4], Rn[4];                          // raw rows of this step / of the next one
+#pragma unroll
+            for (int r = 0; r < 4; ++r) R[r] = load_row(0, 0, 0, r);
+
+#pragma clang loop unroll(full)
+            for (int step = 0; step < 24; ++step) {      // step = (group gi = 3 sd + kw, channel chunk c)
+                const int gi = step >> 1, c = step & 1;
+                const int sd = gi / 3;
+                if (has_next && step == 18) {
+                    lds_barrier();                       // slices 0..2 have been read for the last time by every wave
+                    write_slice(0);
+                    write_slice(1);
+                    write_slice(2);
+                }
+                // next step's weights and raw rows
+                if (step + 1 < 24) {
+                    const int ns = step + 1, ng = ns >> 1, nc = ns & 1;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (ESTD_W2ABL & 8) { bnext[t] = bcur[t]; asm volatile("" : "+v"(bnext[t].x)); }
+                        else bnext[t] = load_w(4 * ng + t, nc);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Rn[r] = load_row(ng / 3, ng % 3, nc, r);
+                }
+                // one 16-byte chunk of the NEXT tile's two new planes per step
+                if (has_next && step < 2 * SIT && !(ESTD_W2ABL & 16)) {
+                    const int it = step % SIT;
+                    if (step < SIT) xc[it] = v0 ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[it], nd * in_slice_bytes, 0))
+                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+                    else            xd[it] = v1 ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[it], (nd + 1) * in_slice_bytes, 0))
+                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                // row transform: the four fragments of this chunk
+                float4 T[4];
+                if (ESTD_W2ABL & 128) { T[0] = R[0]; T[1] = R[1]; T[2] = R[2]; T[3] = R[3]; }
+                else { T[0] = f4_sub(R[0], R[2]); T[1] = f4_add(R[1], R[2]); T[2] = f4_sub(R[2], R[1]); T[3] = f4_sub(R[1], R[3]); }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)           // the four products rotate: no MFMA waits for its own predecessor
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float a = ks == 0 ? T[t].x : ks == 1 ? T[t].y : ks == 2 ? T[t].z : T[t].w;
+                        const float b = ks == 0 ? bcur[t].x : ks == 1 ? bcur[t].y : ks == 2 ? bcur[t].z : bcur[t].w;
+                        acc[sd][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[sd][t], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { bcur[t] = bnext[t]; R[t] = Rn[t]; }
+                __builtin_amdgcn_sched_barrier(0);       // keep each step's loads inside the step (bounds live registers)
+            }
+
+            if (has_next) {                               // slice 3 of the next tile
+                lds_barrier();
+                write_slice(3);
+                shift_planes();
+                lds_barrier();
+            }
+
+            // ---- output transform A^T m A and the epilogue of the two planes ----
+            f32x4 y0[2], y1[2];
+            {
+                f32x4 z[4][2];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    z[s][0] = acc[s][0] + acc[s][1] + acc[s][2];
+                    z[s][1] = acc[s][1] - acc[s][2] - acc[s][3];
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    y0[m] = z[0][m] + z[1][m] + z[2][m];
+                    y1[m] = z[1][m] - z[2][m] - z[3][m];
+                }
+            }
+            if (p.stats_partials) {                      // uniform; the GRU gate convolution (one volume per launch)
+                plane_stats(y0, d0);
+                if (d0 + 1 < D) plane_stats(y1, d0 + 1);              // (odd D: the last pair has one plane)
+            }
+            epi_plane(y0, d0);
+            if (d0 + 1 < D) epi_plane(y1, d0 + 1);
+        }
+    }
+}
+
+constexpr int PERSISTENT_WGS = 256;     // one 512-thread workgroup per CU (LDS-limited)
+
+}  // namespace
+
+extern "C" int estd_conv3d_k3_wino2(const estd_conv3d_desc* dp, estd_stream_t s)
+{
+    if (!dp) return ESTD_ERR_ARG;
+    const estd_conv3d_desc& d = *dp;
+    if (d.N <= 0 || d.D <= 0 || d.H <= 0 || d.W <= 0) return ESTD_ERR_ARG;
+    if (!d.in_main || !d.w_wino2 || !d.scale || !d.shift || !d.out_main) return ESTD_ERR_ARG;
+    // the plain instance only: 32 -> 32 on the MFMA, no scalar 33rd input / output channel, no fused head
+    if (d.cin_main != 32 || d.n_tiles != 2 || d.out_head || d.in_extra || d.w_extra || d.out_extra) return ESTD_ERR_UNSUPPORTED;
+    if (d.in_stride < 32 || (d.in_stride & 3) || d.out_stride < 32 || (d.act_split & 1)) return ESTD_ERR_ARG;
+    const int tiles_w = (d.W + TW - 1) / TW, tiles_h = (d.H + TH - 1) / TH, dpairs = (d.D + 1) / 2;
+    const long long total = (long long)d.N * dpairs * tiles_h * tiles_w;
+    if (total > 0x7fffffffLL) return ESTD_ERR_ARG;
+    {   // buffer descriptors address one volume of the batch with 32-bit byte offsets
+        const long long vox = (long long)d.D * d.H * d.W;
+        const int widest = d.in_stride > d.out_stride ? d.in_stride : d.out_stride;
+        if (vox * widest * 4 >= 0x7fffff00LL) return ESTD_ERR_UNSUPPORTED;
+    }
+    const int slots = estd_persistent_wgs(PERSISTENT_WGS / 256);
+    int grid = total < slots ? (int)total : slots;
+    if (grid >= 8) grid &= ~7;
+    estd_allow_dynamic_lds<conv3d_wino2_kernel>(LDS_BYTES);
+    hipLaunchKernelGGL(conv3d_wino2_kernel, dim3(grid), dim3(NTHREADS), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h, dpairs, (int)total);
+    return ESTD_LAUNCH_CHECK();
+}

@@ -152,7 +152,7 @@ void conv3d_k3(const Tensor& x, const OptTensor& x_extra, const Tensor& w_main, 
         d.stats_partials = stats_partials->data_ptr<double>();
     }
     // variant: 0 = direct fp32 MFMA; 1 = exact 3 x bf16 operand split (w_alt = split weights); 2 = fp32 MFMA with the depth
-    // axis in Winograd F(2,3) form (w_alt = transformed filters)
+    // axis in Winograd F(2,3) form (w_alt = transformed filters); 3 = depth and row axis in Winograd form (plain 32 -> 32 only)
     if (variant != 0) TORCH_CHECK(w_alt.has_value() && w_alt->defined() && w_alt->is_cuda(), "conv3d_k3: this variant needs its packed weights");
     if (variant == 1) {
         d.w_split = w_alt->data_ptr();
@@ -160,6 +160,9 @@ void conv3d_k3(const Tensor& x, const OptTensor& x_extra, const Tensor& w_main, 
     } else if (variant == 2) {
         d.w_wino = fptr(*w_alt, "Winograd-packed weights");
         check_status(estd_conv3d_k3_wino(&d, cur_stream()), "estd_conv3d_k3_wino");
+    } else if (variant == 3) {
+        d.w_wino2 = fptr(*w_alt, "2-axis Winograd-packed weights");
+        check_status(estd_conv3d_k3_wino2(&d, cur_stream()), "estd_conv3d_k3_wino2");
     } else {
         TORCH_CHECK(variant == 0, "conv3d_k3: unknown variant ", variant);
         check_status(estd_conv3d_k3(&d, cur_stream()), "estd_conv3d_k3");

@@ -74,7 +74,9 @@ class _Prof:
 CONV3D_ARITH = os.environ.get("ESTD_CONV3D_ARITH", "f32")
 CONV2D_ARITH = os.environ.get("ESTD_CONV2D_ARITH", "f32")     # same choice for the 3x3 / dilation-1 NHWC convolutions
 # Algorithm of the plain 32->32 3x3x3 convolutions under CONV3D_ARITH == "f32" (every product an fp32 MFMA either way):
-# "wino" = depth axis in Winograd F(2,3) form, 2/3 of the products (csrc/conv3d_wino.hip); "direct" = 27 taps (csrc/conv3d_mfma.hip)
+# "wino2" = depth AND row axis in Winograd F(2,3) form for the plain 32 -> 32 instance, 0.444 of the products
+# (csrc/conv3d_wino2.hip; the 33-channel instances take the "wino" kernel); "wino" = depth axis only, 2/3 of the products
+# (csrc/conv3d_wino.hip); "direct" = 27 taps (csrc/conv3d_mfma.hip)
 CONV3D_ALGO = os.environ.get("ESTD_CONV3D_ALGO", "wino")
 # same choice for the 3x3 / dilation-1 NHWC convolutions: row axis in Winograd F(2,3) form (csrc/conv2d_wino.hip) or direct
 CONV2D_ALGO = os.environ.get("ESTD_CONV2D_ALGO", "wino")
@@ -201,6 +203,7 @@ class Conv3dPlan:
         self.w_wino = packing.pack_conv3d_wino(weight, main_idx, out_idx[:32]).to(device) if wino_ok else None
         self.w_wino_extra = packing.pack_conv3d_wino_extra(weight, extra_idx, out_idx[:32]).to(device) if (wino_ok and extra_idx is not None) else None
         self.w_wino_xout = packing.pack_conv3d_wino_xout(weight, main_idx, extra_idx, out_idx[32]).to(device) if (wino_ok and n_tiles == 3) else None
+        self.w_wino2 = packing.pack_conv3d_wino2(weight, main_idx, out_idx[:32]).to(device) if (wino_ok and n_tiles == 2 and extra_idx is None) else None
         self.w_main = wm.to(device)
         self.w_extra = wx.to(device) if wx is not None else None
         self.scale = scale.float().contiguous().to(device)
@@ -243,12 +246,13 @@ class Conv3dPlan:
         else:
             inst = not tanh
         split = CONV3D_ARITH == "bf16x3" and self.w_split is not None and out is not None and inst
-        if CONV3D_ALGO not in ("wino", "direct"):
-            raise RuntimeError("ESTD_CONV3D_ALGO must be wino or direct, got %r" % (CONV3D_ALGO,))
-        wino = (not split) and CONV3D_ALGO == "wino" and self.w_wino is not None and out is not None \
+        if CONV3D_ALGO not in ("wino2", "wino", "direct"):
+            raise RuntimeError("ESTD_CONV3D_ALGO must be wino2, wino or direct, got %r" % (CONV3D_ALGO,))
+        wino = (not split) and CONV3D_ALGO in ("wino", "wino2") and self.w_wino is not None and out is not None \
             and (out_extra is not None) == (self.n_tiles == 3) and out_head is None and out_channels == 32 \
             and (stats_partials is None or self.w_extra is None)
-        variant, w_alt = (1, self.w_split) if split else (2, self.w_wino) if wino else (0, None)
+        wino2 = wino and CONV3D_ALGO == "wino2" and self.w_wino2 is not None and in_extra is None
+        variant, w_alt = (1, self.w_split) if split else (3, self.w_wino2) if wino2 else (2, self.w_wino) if wino else (0, None)
         cin = self.cin_main + (1 if self.w_extra is not None else 0)
         with _Prof("conv3d:%d->%d" % (cin, self.n_out), 2.0 * 27 * cin * self.n_out * Nn * D * H * W):
             if _use_torch():
@@ -281,6 +285,9 @@ class Conv3dPlan:
             if split:
                 d.w_split = self.w_split.data_ptr()
                 N.check(N.lib().estd_conv3d_k3_split(ctypes.byref(d), _stream()), "estd_conv3d_k3_split")
+            elif wino2:
+                d.w_wino2 = self.w_wino2.data_ptr()
+                N.check(N.lib().estd_conv3d_k3_wino2(ctypes.byref(d), _stream()), "estd_conv3d_k3_wino2")
             elif wino:
                 d.w_wino = self.w_wino.data_ptr()
                 d.w_extra = self.w_wino_extra.data_ptr() if self.w_wino_extra is not None else None

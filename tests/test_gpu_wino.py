@@ -41,8 +41,12 @@ def _run(plan, algo, x, dims, **kw):
         ops.CONV3D_ALGO = old
 
 
+ALGOS = ("wino", "wino2")      # depth axis / depth and row axis in Winograd form
+
+
+@pytest.mark.parametrize("algo", ALGOS)
 @pytest.mark.parametrize("dims,scale", [((1, 6, 19, 45), 1.0), ((2, 3, 8, 32), 100.0), ((1, 1, 5, 7), 1e-3), ((1, 64, 24, 32), 1.0)])
-def test_wino_error_vs_fp64_is_at_the_direct_kernels_level(dims, scale):
+def test_wino_error_vs_fp64_is_at_the_direct_kernels_level(dims, scale, algo):
     mod, plan = _plan(11, act=None)
     N, D, H, W = dims
     x = torch.randn(N, D, H, W, 32, generator=torch.Generator().manual_seed(5)) * scale
@@ -54,15 +58,16 @@ def test_wino_error_vs_fp64_is_at_the_direct_kernels_level(dims, scale):
     ref = (ref * sc[None, :, None, None, None] + sh[None, :, None, None, None]).permute(0, 2, 3, 4, 1)
     xd = x.to(DEV)
     e_dir = (_run(plan, "direct", xd, dims).double().cpu() - ref).abs().max().item()
-    e_win = (_run(plan, "wino", xd, dims).double().cpu() - ref).abs().max().item()
+    e_win = (_run(plan, algo, xd, dims).double().cpu() - ref).abs().max().item()
     mag = ref.abs().max().item()
-    print("fp64 check dims=%s scale=%g: |ref|max %.3g  err direct %.3g  err wino %.3g" % (dims, scale, mag, e_dir, e_win))
+    print("fp64 check dims=%s scale=%g: |ref|max %.3g  err direct %.3g  err %s %.3g" % (dims, scale, mag, e_dir, algo, e_win))
     assert e_win <= 3.0 * e_dir + 1e-7 * mag, (e_win, e_dir)
     assert e_win < 3e-6 * mag
 
 
+@pytest.mark.parametrize("algo", ALGOS)
 @pytest.mark.parametrize("dims", [(1, 4, 8, 32), (3, 5, 13, 50), (1, 2, 120, 160), (2, 1, 9, 33), (1, 7, 8, 16), (1, 70, 8, 32)])
-def test_wino_matches_direct_kernel_all_epilogues(dims):
+def test_wino_matches_direct_kernel_all_epilogues(dims, algo):
     """ReLU / none, residual, two residuals + scale, running accumulation, strided output, GroupNorm partial sums."""
     from estdepth_amd import ops
     N, D, H, W = dims
@@ -75,13 +80,13 @@ def test_wino_matches_direct_kernel_all_epilogues(dims):
         cases = [dict(), dict(residual=r1), dict(residual=r1, residual2=r2, out_scale=0.5)]
         for kw in cases:
             a = _run(plan, "direct", x, dims, **kw)
-            b = _run(plan, "wino", x, dims, **kw)
+            b = _run(plan, algo, x, dims, **kw)
             tol = 5e-6 * max(1.0, float(a.abs().max()))
             assert float((a - b).abs().max()) < tol, (act, sorted(kw), float((a - b).abs().max()))
         # running accumulation (mean over source views): out += result
         base = torch.randn(N, D, H, W, 32, generator=g).to(DEV)
         a = _run(plan, "direct", x, dims, out=base.clone(), accumulate=True, out_scale=0.5)
-        b = _run(plan, "wino", x, dims, out=base.clone(), accumulate=True, out_scale=0.5)
+        b = _run(plan, algo, x, dims, out=base.clone(), accumulate=True, out_scale=0.5)
         assert float((a - b).abs().max()) < 5e-6 * max(1.0, float(a.abs().max()))
     # GroupNorm partial sums (the GRU gate convolution: bias, no activation, N = 1 volume at a time)
     _, plan = _plan(9, act=None)
@@ -89,7 +94,7 @@ def test_wino_matches_direct_kernel_all_epilogues(dims):
     pa = torch.zeros(nblk * 4, device=DEV, dtype=torch.float64)
     pb = torch.zeros(nblk * 4, device=DEV, dtype=torch.float64)
     a = _run(plan, "direct", x, dims, stats_partials=pa)
-    b = _run(plan, "wino", x, dims, stats_partials=pb)
+    b = _run(plan, algo, x, dims, stats_partials=pb)
     assert float((a - b).abs().max()) < 5e-6 * max(1.0, float(a.abs().max()))
     sa = ops.groupnorm_finalize(pa, nblk, 16.0 * N * D * H * W).cpu()
     sb = ops.groupnorm_finalize(pb, nblk, 16.0 * N * D * H * W).cpu()
@@ -98,7 +103,8 @@ def test_wino_matches_direct_kernel_all_epilogues(dims):
     assert int((pb.view(-1, 4)[:, 1] == 0).sum()) == 0
 
 
-def test_wino_vs_oracle_ragged():
+@pytest.mark.parametrize("algo", ALGOS)
+def test_wino_vs_oracle_ragged(algo):
     from oracle import ref_ops as O
     mod, plan = _plan(21, act="relu")
     dims = (2, 5, 11, 19)
@@ -107,21 +113,22 @@ def test_wino_vs_oracle_ragged():
     ref = O.bn_act(O.conv3d(x.permute(0, 4, 1, 2, 3).numpy(), mod[0].weight.detach().cpu().numpy()),
                    (bn.weight.detach().cpu().numpy(), bn.bias.detach().cpu().numpy(), bn.running_mean.cpu().numpy(),
                     bn.running_var.cpu().numpy()), "relu")
-    out = _run(plan, "wino", x.to(DEV), dims).cpu().numpy()
+    out = _run(plan, algo, x.to(DEV), dims).cpu().numpy()
     assert np.abs(np.moveaxis(out, -1, 1) - ref).max() < 2e-5
 
 
-def test_wino_full_size_linearity_and_match():
+@pytest.mark.parametrize("algo", ALGOS)
+def test_wino_full_size_linearity_and_match(algo):
     """BASELINE configs[1] size (3 volumes of 64x120x160): against the direct kernel and a linearity property."""
     _, plan = _plan(5, act=None)
     dims = (3, 64, 120, 160)
     x = torch.randn(*dims, 32, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
     a = _run(plan, "direct", x, dims)
-    b = _run(plan, "wino", x, dims)
+    b = _run(plan, algo, x, dims)
     assert float((a - b).abs().max()) < 5e-6 * float(a.abs().max())
     del a
-    zero = _run(plan, "wino", torch.zeros_like(x), dims)              # = folded shift
-    c = _run(plan, "wino", x * -2.0, dims)
+    zero = _run(plan, algo, torch.zeros_like(x), dims)              # = folded shift
+    c = _run(plan, algo, x * -2.0, dims)
     assert float((c - zero + 2.0 * (b - zero)).abs().max()) < 2e-5 * float(b.abs().max())
 
 
