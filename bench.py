@@ -54,9 +54,10 @@ def parse():
     ap.add_argument("--conv3d-arith", default=os.environ.get("ESTD_CONV3D_ARITH", "f32"), choices=["f32", "bf16x3"],
                     help="products of the plain 32->32 3D convolutions: native fp32 MFMA (default) or the exact 3-way bf16 "
                          "operand split with six bf16 MFMAs per product block (fp32-level error, opt-in)")
-    ap.add_argument("--conv3d-algo", default=os.environ.get("ESTD_CONV3D_ALGO", "wino"), choices=["wino", "direct"],
-                    help="plain 32->32 3D convolutions under f32 arithmetic: depth axis in Winograd F(2,3) form (2/3 of the fp32 MFMA "
-                         "products, csrc/conv3d_wino.hip; default) or the direct 27-tap implicit GEMM (csrc/conv3d_mfma.hip)")
+    ap.add_argument("--conv3d-algo", default=os.environ.get("ESTD_CONV3D_ALGO", "wino2"), choices=["wino2", "wino", "direct"],
+                    help="3D convolutions under f32 arithmetic: wino2 = depth and row axis of the plain 32->32 instance in Winograd F(2,3) "
+                         "form (0.444 of the fp32 MFMA products, csrc/conv3d_wino2.hip; the 33-channel instances take wino; default), "
+                         "wino = depth axis only (2/3 of the products, csrc/conv3d_wino.hip), direct = 27-tap implicit GEMM (csrc/conv3d_mfma.hip)")
     ap.add_argument("--no-alt", action="store_true", help="skip the second timed loop with the other convolution arithmetic")
     ap.add_argument("--conv2d-arith", default=os.environ.get("ESTD_CONV2D_ARITH", "f32"), choices=["f32", "bf16x3"],
                     help="same choice for the 3x3 NHWC convolutions of the PSM extractor / 2D decoder (opt-in)")

@@ -28,6 +28,7 @@
 //     (two taps) ahead; tap = (3 sd + kw) * 4 + sh.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "estd_hip.h"
 #include "estd_common.h"
@@ -39,23 +40,23 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
 
 constexpr int TH = 8, TW = 16;
 constexpr int IN_H = TH + 2, IN_W = TW + 2;
 constexpr int SL_VOX = IN_H * IN_W;                 // 180 voxels per input slice (with halo)
 constexpr int SLICE_BYTES = SL_VOX * 128;           // 32 channels
-constexpr int NTHREADS = 512;
 constexpr int SL_CHUNKS = SL_VOX * 8;               // 16-byte chunks per slice: 1440
-constexpr int SIT = (SL_CHUNKS + NTHREADS - 1) / NTHREADS;     // chunks per thread per slice: 3
-constexpr int RED_BYTES = 8 * 2 * 8;                // GroupNorm scratch: 8 waves x {sum, sumsq} doubles
+constexpr int RED_BYTES = 8 * 2 * 8;                // GroupNorm scratch: 8 (row pair, channel half) x {sum, sumsq} doubles
 constexpr int NTAPS = 48;
 #ifndef ESTD_W2LDS_TAPS
 #define ESTD_W2LDS_TAPS 16
 #endif
-constexpr int WLDS_TAPS = ESTD_W2LDS_TAPS;           // weights of the first taps of every tile come from LDS (even)
+constexpr int WLDS_TAPS = ESTD_W2LDS_TAPS;           // weights of the first taps of every tile come from LDS
 constexpr int WLDS_BYTES = WLDS_TAPS * 4096;         // [tap][2 halves][2 quads][64 lanes][4]
-constexpr int LDS_BYTES = 4 * SLICE_BYTES + RED_BYTES + WLDS_BYTES;
+constexpr int SS_BYTES = 2 * 32 * 4;                 // folded BN scale | shift of the 32 output channels
+constexpr int LDS_BYTES = 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + WLDS_BYTES;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;        // beyond num_records of any descriptor: loads return 0, stores are dropped
 
@@ -89,18 +90,28 @@ __device__ __forceinline__ float act_apply(float v, int act)
 __device__ __forceinline__ float4 f4_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-__global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino2_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int dpairs, int total_tiles)
+// NW = 8: 512 threads, two waves per SIMD (256 registers each), wave = (row pair rp, channel half nh).
+// NW = 4: 256 threads, ONE wave per SIMD (512 registers: the accumulators of both channel halves), wave = row pair rp: every
+//         fragment read and every row transform serves 2 x 16 output channels -- half the VALU instructions per MFMA -- and
+//         no second wave competes for the SIMD's VALU issue.  Measured cost of one VALU instruction in the 8-wave form:
+//         ~6.5 SIMD cycles, NOT hidden behind the MFMAs (time is linear in the VALU count, profiles/r3_wino2_*).
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int dpairs, int total_tiles)
 {
+    constexpr int NTHREADS = 64 * NW;
+    constexpr int NHW = 8 / NW;                          // channel halves per wave
+    constexpr int SIT = (SL_CHUNKS + NTHREADS - 1) / NTHREADS;     // chunks per thread per slice: 3 | 6
+    constexpr bool HOLD = NW == 4;                       // per-thread offsets held in registers (there is room) or re-formed at each use
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rp = wave & 3;            // tile rows 2rp, 2rp+1 (halo rows 2rp .. 2rp+3)
-    const int nh = wave >> 2;           // output channels 16nh .. 16nh+15
+    const int nh0 = NW == 8 ? wave >> 2 : 0;            // first channel half of this wave
     const int g = lane >> 4;            // k index inside an MFMA
-    const int i = lane & 15;            // M row (A) / N column (B, D)
-    // MFMA row <-> voxel of a tile row (conflict-free ds_read_b128 for every tap; see csrc/conv3d_wino.hip)
+    const int i = lane & 15;            // voxel column of the (transposed) MFMA
+    // MFMA column <-> voxel of a tile row (conflict-free ds_read_b128 for every tap; see csrc/conv3d_wino.hip)
     const int pi = i < 4 ? 2 * i : i < 12 ? 2 * i - 7 : 2 * i - 16;
     const int D = p.D, H = p.H, W = p.W;
     const int HW = H * W;
@@ -116,16 +127,15 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino2_kernel(const estd_co
     }
     if (u >= u_end) return;
 
-    char* lds_w = smem + 4 * SLICE_BYTES + RED_BYTES;                             // weights of taps 0 .. WLDS_TAPS-1
+    float* lds_ss = reinterpret_cast<float*>(smem + 4 * SLICE_BYTES + RED_BYTES);  // scale[32] | shift[32]: read in the epilogue
+    if (tid < 64) lds_ss[tid] = tid < 32 ? p.scale[tid] : p.shift[tid - 32];     // (a global load there is an exposed L2 round trip)
+    char* lds_w = smem + 4 * SLICE_BYTES + RED_BYTES + SS_BYTES;                  // weights of taps 0 .. WLDS_TAPS-1
     for (int e = tid; e < WLDS_BYTES / 16; e += NTHREADS)                         // (visible after the first tile's barriers)
         reinterpret_cast<float4*>(lds_w)[e] = reinterpret_cast<const float4*>(p.w_wino2)[e];
 
-    const int ch = 16 * nh + i;                     // this lane's output channel
-    const float sc = p.scale[ch], sh = p.shift[ch];
-    const int act0 = ch < p.act_split ? p.act_a : p.act_b;
     // packed weights: [48 taps][2 halves][2 quads][64 lanes][4]
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w_wino2, (size_t)NTAPS * 2 * 2 * 256);
-    const int wlane = lane * 16 + nh * 2048;
+    const int wlane = lane * 16 + nh0 * 2048;
     const int row0 = 2 * rp;
 
     while (u < u_end) {
@@ -145,90 +155,127 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino2_kernel(const estd_co
         const int in_slice_bytes = HW * p.in_stride * 4;
         const int out_plane_bytes = HW * p.out_stride * 4;
 
-        // per-thread slice elements (validity in y / x does not depend on d)
-        unsigned voff[SIT];
-        int loff[SIT];
-#pragma unroll
-        for (int it = 0; it < SIT; ++it) {
-            const int e = tid + it * NTHREADS;
+        // per-thread slice elements (validity in y / x does not depend on d).  8-wave form: global offset and LDS offset of chunk
+        // `it` are re-formed at every use from an opaque copy of the thread index (a dozen VALU operations) -- held across the tap
+        // loop they are the registers that spill, and a scratch reload in front of a prefetch waits for every weight load before it.
+        auto chunk_voff_f = [&](int it) {
+            int t = tid;
+            if (!HOLD) asm volatile("" : "+v"(t));
+            const int e = t + it * NTHREADS;
             const int vs = e >> 3, c = e & 7;
             const int zy = vs / IN_W, zx = vs % IN_W;
             const int gy = th0 - 1 + zy, gx = tw0 - 1 + zx;
             const bool ok = e < SL_CHUNKS && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-            voff[it] = ok ? (unsigned)((gy * W + gx) * p.in_stride + c * 4) * 4u : OOB_OFFSET;
-            loff[it] = e < SL_CHUNKS ? lds_chunk_off(vs, c) : -1;
+            return ok ? (unsigned)((gy * W + gx) * p.in_stride + c * 4) * 4u : OOB_OFFSET;
+        };
+        auto chunk_loff_f = [&](int it) {
+            int t = tid;
+            if (!HOLD) asm volatile("" : "+v"(t));
+            const int e = t + it * NTHREADS;
+            return e < SL_CHUNKS ? lds_chunk_off(e >> 3, e & 7) : -1;
+        };
+        unsigned voff_h[SIT];
+        int loff_h[SIT];
+        if (HOLD) {
+#pragma unroll
+            for (int it = 0; it < SIT; ++it) { voff_h[it] = chunk_voff_f(it); loff_h[it] = chunk_loff_f(it); }
         }
+        auto chunk_voff = [&](int it) { return HOLD ? voff_h[it] : chunk_voff_f(it); };
+        auto chunk_loff = [&](int it) { return HOLD ? loff_h[it] : chunk_loff_f(it); };
         auto load_plane = [&](int pd, float4 (&dst)[SIT]) {
             const bool pv = (unsigned)pd < (unsigned)D;        // wave-uniform; planes outside the volume are zero padding
 #pragma unroll
             for (int it = 0; it < SIT; ++it)
-                dst[it] = pv ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[it], pd * in_slice_bytes, 0))
+                dst[it] = pv ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, chunk_voff(it), pd * in_slice_bytes, 0))
                              : make_float4(0.f, 0.f, 0.f, 0.f);
         };
 
-        // epilogue lane offsets (bytes inside one depth plane): rows row0, row0+1; D rows 4g + r of lane group g are the voxels
-        // pi(4g + r): 2r, 2r + 1, 2r + 9, 2r + 8 for g = 0..3
-        const int ey0 = th0 + row0;
-        const int ex0 = tw0 + (g == 0 ? 0 : g == 1 ? 1 : g == 2 ? 9 : 8);
-        auto eoff_of = [&](int m, int r) {
-            const int y = ey0 + m, x = ex0 + 2 * r;
-            return (y < H && x < W) ? (unsigned)((y * W + x) * p.out_stride + ch) * 4u : OOB_OFFSET;
+        // The MFMAs run TRANSPOSED (weights as the A operand, voxels as B): D row = output channel, D column = voxel, so lane
+        // (g, i) holds the four consecutive channels 16nh + 4g .. +3 of voxel pi(i) of a tile row -- one 16-byte store (and one
+        // 16-byte read per residual stream) per plane, row and channel half instead of four 4-byte ones.
+        auto eoff_f = [&](int m) {                     // channel half nh0; the second half of a 4-wave lane is 64 bytes further
+            int l = lane;
+            if (!HOLD) asm volatile("" : "+v"(l));
+            const int ii = l & 15;
+            const int y = th0 + row0 + m, x = tw0 + (ii < 4 ? 2 * ii : ii < 12 ? 2 * ii - 7 : 2 * ii - 16);
+            return (y < H && x < W) ? (unsigned)((y * W + x) * p.out_stride + 16 * nh0 + 4 * (l >> 4)) * 4u : OOB_OFFSET;
         };
-
-        // epilogue of one plane: the 2 x 4 voxels (tile row m, D row r) of channel ch this lane holds.  Every read-back stream
-        // (residuals, the running sum) issues its eight loads back to back and is waited for ONCE.
-        auto epi_plane = [&](const f32x4 (&a)[2], int dd) {
+        unsigned eoff_h[2];
+        if (HOLD) { eoff_h[0] = eoff_f(0); eoff_h[1] = eoff_f(1); }
+        auto eoff_of = [&](int m) { return HOLD ? eoff_h[m] : eoff_f(m); };
+        auto bn_act = [&](const f32x4& a, int cb, float4& v) {
+            const float4 sc4 = *reinterpret_cast<const float4*>(lds_ss + cb), sh4 = *reinterpret_cast<const float4*>(lds_ss + 32 + cb);
+            v.x = act_apply(a[0] * sc4.x + sh4.x, cb + 0 < p.act_split ? p.act_a : p.act_b);
+            v.y = act_apply(a[1] * sc4.y + sh4.y, cb + 1 < p.act_split ? p.act_a : p.act_b);
+            v.z = act_apply(a[2] * sc4.z + sh4.z, cb + 2 < p.act_split ? p.act_a : p.act_b);
+            v.w = act_apply(a[3] * sc4.w + sh4.w, cb + 3 < p.act_split ? p.act_a : p.act_b);
+        };
+        // epilogue of one plane: tile rows row0, row0 + 1 (m), channel halves (x).  Every read-back stream (residuals, the running
+        // sum) issues its loads back to back and is waited for ONCE.
+        auto epi_plane = [&](const f32x4 (&a)[2][NHW], int dd) {
             const int so = dd * out_plane_bytes;
-            unsigned eo[2][4];
-            float r1[2][4], r2[2][4], ro[2][4];
+            unsigned eo[2];
+            float4 r1[2][NHW], r2[2][NHW], ro[2][NHW];
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) eo[m][r] = eoff_of(m, r);
+            for (int m = 0; m < 2; ++m) eo[m] = eoff_of(m);
             if (p.residual) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) r1[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res, eo[m][r], so, 0));
+                    for (int x = 0; x < NHW; ++x) r1[m][x] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_res, eo[m], so + 64 * x, 0));
             }
             if (p.residual2) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) r2[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_res2, eo[m][r], so, 0));
+                    for (int x = 0; x < NHW; ++x) r2[m][x] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_res2, eo[m], so + 64 * x, 0));
             }
             if (p.accumulate) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ro[m][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_out, eo[m][r], so, 0));
+                    for (int x = 0; x < NHW; ++x) ro[m][x] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_out, eo[m], so + 64 * x, 0));
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = act_apply(a[m][r] * sc + sh, act0);
-                    if (p.residual) v += r1[m][r];
-                    if (p.residual2) v += r2[m][r];
-                    v *= p.out_scale;
-                    if (p.accumulate) v += ro[m][r];
-                    if (!(ESTD_W2ABL & 1)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, eo[m][r], so, 0);
+                for (int x = 0; x < NHW; ++x) {
+                    float4 v;
+                    bn_act(a[m][x], 16 * (nh0 + x) + 4 * g, v);
+                    if (p.residual) v = f4_add(v, r1[m][x]);
+                    if (p.residual2) v = f4_add(v, r2[m][x]);
+                    v = make_float4(v.x * p.out_scale, v.y * p.out_scale, v.z * p.out_scale, v.w * p.out_scale);
+                    if (p.accumulate) v = f4_add(v, ro[m][x]);
+                    u32x4 bits;
+                    __builtin_memcpy(&bits, &v, 16);
+                    if (!(ESTD_W2ABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(bits, rs_out, eo[m], so + 64 * x, 0);
                 }
         };
-        // GroupNorm(1 group) partial sums of the raw outputs of one plane: group = channel half nh.  Fixed-order reduction
-        // (lanes by butterfly, the four row-pair waves of a half through LDS) -> deterministic.  Workgroup-uniform call.
-        auto plane_stats = [&](const f32x4 (&a)[2], int dd) {
-            double s_sum = 0.0, s_sq = 0.0;
+        // GroupNorm(1 group) partial sums of the raw outputs of one plane: group = channel half.  Fixed-order reduction
+        // (lanes by butterfly, the four row pairs of a half through LDS) -> deterministic.  Workgroup-uniform call.
+        auto plane_stats = [&](const f32x4 (&a)[2][NHW], int dd) {
+            double s_sum[NHW], s_sq[NHW];
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int x = 0; x < NHW; ++x) {
+                s_sum[x] = 0.0; s_sq[x] = 0.0;
+                const int cb = 16 * (nh0 + x) + 4 * g;
+                const float4 sc4 = *reinterpret_cast<const float4*>(lds_ss + cb), sh4 = *reinterpret_cast<const float4*>(lds_ss + 32 + cb);
+                const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (eoff_of(m, r) != OOB_OFFSET) { const double v = (double)(a[m][r] * sc + sh); s_sum += v; s_sq += v * v; }
+                for (int m = 0; m < 2; ++m)
+                    if (eoff_of(m) != OOB_OFFSET) {
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) { s_sum += __shfl_xor(s_sum, o); s_sq += __shfl_xor(s_sq, o); }
-            double* red = reinterpret_cast<double*>(smem + 4 * SLICE_BYTES);
+                        for (int r = 0; r < 4; ++r) { const double v = (double)(a[m][x][r] * scv[r] + shv[r]); s_sum[x] += v; s_sq[x] += v * v; }
+                    }
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) { s_sum[x] += __shfl_xor(s_sum[x], o); s_sq[x] += __shfl_xor(s_sq[x], o); }
+            }
+            double* red = reinterpret_cast<double*>(smem + 4 * SLICE_BYTES);       // [channel half][row pair][sum, sumsq]
             __syncthreads();                                     // the previous plane's scratch has been consumed
-            if (lane == 0) { red[wave * 2] = s_sum; red[wave * 2 + 1] = s_sq; }
+            if (lane == 0) {
+#pragma unroll
+                for (int x = 0; x < NHW; ++x) { red[((nh0 + x) * 4 + rp) * 2] = s_sum[x]; red[((nh0 + x) * 4 + rp) * 2 + 1] = s_sq[x]; }
+            }
             __syncthreads();
             if (tid < 4) {
                 const int grp = tid >> 1, q = tid & 1;
@@ -253,10 +300,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino2_kernel(const estd_co
         auto write_slice = [&](int sl) {
 #pragma unroll
             for (int it = 0; it < SIT; ++it) {
-                if ((it < SIT - 1 || loff[it] >= 0) && !(ESTD_W2ABL & 2)) {
+                const int lo = chunk_loff(it);
+                if ((it < SIT - 1 || lo >= 0) && !(ESTD_W2ABL & 2)) {
                     const float4 v = sl == 0 ? f4_sub(xa[it], xc[it]) : sl == 1 ? f4_add(xb[it], xc[it])
                                    : sl == 2 ? f4_sub(xc[it], xb[it]) : f4_sub(xb[it], xd[it]);
-                    *reinterpret_cast<float4*>(smem + sl * SLICE_BYTES + loff[it]) = v;
+                    *reinterpret_cast<float4*>(smem + sl * SLICE_BYTES + lo) = v;
                 }
             }
         };
@@ -281,33 +329,67 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino2_kernel(const estd_co
             const int nd = d0 + 3;                       // new planes of the next tile: nd, nd + 1
             const bool v0 = nd < D, v1 = nd + 1 < D;
 
-            f32x4 acc[4][4];                             // m[sd][sh]
+            f32x4 acc[4][4][NHW];                        // m[sd][sh] per channel half
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[s][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int x = 0; x < NHW; ++x) acc[s][t][x] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-            auto load_w = [&](int t, int q) {               // t is a compile-time constant after unrolling
-                if (t < WLDS_TAPS) return *reinterpret_cast<const float4*>(lds_w + t * 4096 + q * 1024 + wlane);
-                return as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, t * 4096 + q * 1024, 0));
+            auto load_w = [&](int t, int q, int x) {        // t, q, x are compile-time constants after unrolling
+                if (t < WLDS_TAPS) return *reinterpret_cast<const float4*>(lds_w + t * 4096 + x * 2048 + q * 1024 + wlane);
+                return as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, t * 4096 + x * 2048 + q * 1024, 0));
             };
             // 16-byte chunk c (channels 4g.. for c = 0, 16+4g.. for c = 1) of halo row 2rp + r at column shift kw of depth slice sd
             auto load_row = [&](int sd, int kw, int c, int r) {
                 const int vs = (row0 + r) * IN_W + kw + pi;
-                const int off0 = sd * SLICE_BYTES + lds_chunk_off(vs, g);
-                return *reinterpret_cast<const float4*>(smem + (c ? (off0 ^ 64) : off0));
+                int off = sd * SLICE_BYTES + lds_chunk_off(vs, g);
+                if (c) off ^= 64;
+                return *reinterpret_cast<const float4*>(smem + off);
+            };
+            // transform components 2h, 2h+1 of the four row fragments from the raw rows: PACKED adds (v_pk_add_f32).  The fp32 MFMA
+            // runs at the f32 vector rate on the same lanes, so VALU work is not hidden behind it -- measured: kernel time is linear
+            // in the VALU instruction count, ~7 SIMD cycles per instruction -- and a packed add transforms two operands per slot.
+            auto xform2 = [&](const float4 (&Rr)[4], int h, f32x2 (&o)[4]) {
+                f32x2 r[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) r[k] = h == 0 ? (f32x2){Rr[k].x, Rr[k].y} : (f32x2){Rr[k].z, Rr[k].w};
+                if (ESTD_W2ABL & 128) { o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3]; }
+                else { o[0] = r[0] - r[2]; o[1] = r[1] + r[2]; o[2] = r[2] - r[1]; o[3] = r[1] - r[3]; }
+            };
+            auto load_rows = [&](int st, float4 (&Rr)[4]) {
+                const int ng = st >> 1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Rr[r] = load_row(ng / 3, ng % 3, st & 1, r);
+            };
+            auto load_b = [&](int st, float4 (&bq)[4][NHW]) {
+                const int ng = st >> 1, nc = st & 1;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int x = 0; x < NHW; ++x) bq[t][x] = load_w(4 * ng + t, nc, x);
             };
 
-            float4 bcur[4], bnext[4];                    // [sh]: this step's quad of the four taps of the group
-#pragma unroll
-            for (int t = 0; t < 4; ++t) bcur[t] = load_w(t, 0);
-            float4 R[4], Rn[4];                          // raw rows of this step / of the next one
-#pragma unroll
-            for (int r = 0; r < 4; ++r) R[r] = load_row(0, 0, 0, r);
+            // software pipeline inside the wave: step s multiplies the fragments T (transformed during step s-1) while the VALU
+            // transforms the raw rows of step s+1 (read during step s-1) two components at a time -- T's registers are recycled as
+            // the MFMAs consume them -- and then reads the raw rows of step s+2.  Weights: one step ahead (8 waves), two steps ahead
+            // with one wave per SIMD (nobody covers an L2 round trip there, and the registers are free).
+            constexpr int BD = NW == 4 ? 3 : 2;          // weight buffers in flight
+            float4 bq[BD][4][NHW];                       // [buffer][sh][channel half]: one step's quad of the four taps of a group
+            f32x2 T[2][4];                               // [component pair][sh]
+            float4 R[4];
+            load_b(0, bq[0]);
+            if (BD == 3) load_b(1, bq[1]);
+            load_rows(0, R);
+            xform2(R, 0, T[0]);
+            xform2(R, 1, T[1]);
+            load_rows(1, R);
+            __builtin_amdgcn_sched_barrier(0);
 
 #pragma clang loop unroll(full)
             for (int step = 0; step < 24; ++step) {      // step = (group gi = 3 sd + kw, channel chunk c)
-                const int gi = step >> 1, c = step & 1;
+                const int gi = step >> 1;
                 const int sd = gi / 3;
                 if (has_next && step == 18) {
                     lds_barrier();                       // slices 0..2 have been read for the last time by every wave
@@ -315,40 +397,55 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino2_kernel(const estd_co
                     write_slice(1);
                     write_slice(2);
                 }
-                // next step's weights and raw rows
+                // weights of step + BD - 1
+                if (step + BD - 1 < 24 && !(ESTD_W2ABL & 8)) load_b(step + BD - 1, bq[(step + BD - 1) % BD]);
+                // chunks of the NEXT tile's two new planes: spread over the first steps
+                if (has_next && !(ESTD_W2ABL & 16)) {
+                    constexpr int PER = SIT / 3;         // chunks per step: the 2 x SIT chunks go out in steps 0..5
+                    if (step < 6) {
+#pragma unroll
+                        for (int k = 0; k < PER; ++k) {
+                            const int idx = step * PER + k, it = idx % SIT;
+                            const unsigned vo = chunk_voff(it);
+                            if (idx < SIT) xc[it] = v0 ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, nd * in_slice_bytes, 0))
+                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                            else           xd[it] = v1 ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, (nd + 1) * in_slice_bytes, 0))
+                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);       // the loads above are issued BEFORE this step's MFMAs (left alone, the
+                                                         // scheduler sinks them to the end of the step: no prefetch at all)
+                const int cur = (ESTD_W2ABL & 8) ? 0 : step % BD;
+                f32x2 Tn[2][4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {            // the products rotate: no MFMA waits for its own predecessor
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int x = 0; x < NHW; ++x) {
+                                const float4 b4 = bq[cur][t][x];
+                                const float b = h == 0 ? (e == 0 ? b4.x : b4.y) : (e == 0 ? b4.z : b4.w);
+                                acc[sd][t][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, T[h][t][e], acc[sd][t][x], 0, 0, 0);
+                            }
+                    if (step + 1 < 24) xform2(R, h, Tn[h]);
+                }
+                if (step + 2 < 24) load_rows(step + 2, R);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {            // order of the region: the MFMAs of two components, then the next step's 4 packed transforms
+                    __builtin_amdgcn_sched_group_barrier(0x008, 8 * NHW, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
                 if (step + 1 < 24) {
-                    const int ns = step + 1, ng = ns >> 1, nc = ns & 1;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        if (ESTD_W2ABL & 8) { bnext[t] = bcur[t]; asm volatile("" : "+v"(bnext[t].x)); }
-                        else bnext[t] = load_w(4 * ng + t, nc);
-                    }
+                    for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) Rn[r] = load_row(ng / 3, ng % 3, nc, r);
+                        for (int t = 0; t < 4; ++t) T[h][t] = Tn[h][t];
                 }
-                // one 16-byte chunk of the NEXT tile's two new planes per step
-                if (has_next && step < 2 * SIT && !(ESTD_W2ABL & 16)) {
-                    const int it = step % SIT;
-                    if (step < SIT) xc[it] = v0 ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[it], nd * in_slice_bytes, 0))
-                                                : make_float4(0.f, 0.f, 0.f, 0.f);
-                    else            xd[it] = v1 ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[it], (nd + 1) * in_slice_bytes, 0))
-                                                : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-                // row transform: the four fragments of this chunk
-                float4 T[4];
-                if (ESTD_W2ABL & 128) { T[0] = R[0]; T[1] = R[1]; T[2] = R[2]; T[3] = R[3]; }
-                else { T[0] = f4_sub(R[0], R[2]); T[1] = f4_add(R[1], R[2]); T[2] = f4_sub(R[2], R[1]); T[3] = f4_sub(R[1], R[3]); }
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)           // the four products rotate: no MFMA waits for its own predecessor
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const float a = ks == 0 ? T[t].x : ks == 1 ? T[t].y : ks == 2 ? T[t].z : T[t].w;
-                        const float b = ks == 0 ? bcur[t].x : ks == 1 ? bcur[t].y : ks == 2 ? bcur[t].z : bcur[t].w;
-                        acc[sd][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[sd][t], 0, 0, 0);
-                    }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) { bcur[t] = bnext[t]; R[t] = Rn[t]; }
-                __builtin_amdgcn_sched_barrier(0);       // keep each step's loads inside the step (bounds live registers)
+                __builtin_amdgcn_sched_barrier(0);
             }
 
             if (has_next) {                               // slice 3 of the next tile
@@ -359,18 +456,19 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino2_kernel(const estd_co
             }
 
             // ---- output transform A^T m A and the epilogue of the two planes ----
-            f32x4 y0[2], y1[2];
-            {
+            f32x4 y0[2][NHW], y1[2][NHW];
+#pragma unroll
+            for (int x = 0; x < NHW; ++x) {
                 f32x4 z[4][2];
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    z[s][0] = acc[s][0] + acc[s][1] + acc[s][2];
-                    z[s][1] = acc[s][1] - acc[s][2] - acc[s][3];
+                    z[s][0] = acc[s][0][x] + acc[s][1][x] + acc[s][2][x];
+                    z[s][1] = acc[s][1][x] - acc[s][2][x] - acc[s][3][x];
                 }
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    y0[m] = z[0][m] + z[1][m] + z[2][m];
-                    y1[m] = z[1][m] - z[2][m] - z[3][m];
+                    y0[m][x] = z[0][m] + z[1][m] + z[2][m];
+                    y1[m][x] = z[1][m] - z[2][m] - z[3][m];
                 }
             }
             if (p.stats_partials) {                      // uniform; the GRU gate convolution (one volume per launch)
@@ -407,7 +505,13 @@ extern "C" int estd_conv3d_k3_wino2(const estd_conv3d_desc* dp, estd_stream_t s)
     const int slots = estd_persistent_wgs(PERSISTENT_WGS / 256);
     int grid = total < slots ? (int)total : slots;
     if (grid >= 8) grid &= ~7;
-    estd_allow_dynamic_lds<conv3d_wino2_kernel>(LDS_BYTES);
-    hipLaunchKernelGGL(conv3d_wino2_kernel, dim3(grid), dim3(NTHREADS), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h, dpairs, (int)total);
+    static const int nw = [] { const char* e = getenv("ESTD_WINO2_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
+    if (nw == 8) {
+        estd_allow_dynamic_lds<conv3d_wino2_kernel<8>>(LDS_BYTES);
+        hipLaunchKernelGGL(conv3d_wino2_kernel<8>, dim3(grid), dim3(512), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h, dpairs, (int)total);
+    } else {
+        estd_allow_dynamic_lds<conv3d_wino2_kernel<4>>(LDS_BYTES);
+        hipLaunchKernelGGL(conv3d_wino2_kernel<4>, dim3(grid), dim3(256), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h, dpairs, (int)total);
+    }
     return ESTD_LAUNCH_CHECK();
 }

@@ -77,7 +77,7 @@ CONV2D_ARITH = os.environ.get("ESTD_CONV2D_ARITH", "f32")     # same choice for 
 # "wino2" = depth AND row axis in Winograd F(2,3) form for the plain 32 -> 32 instance, 0.444 of the products
 # (csrc/conv3d_wino2.hip; the 33-channel instances take the "wino" kernel); "wino" = depth axis only, 2/3 of the products
 # (csrc/conv3d_wino.hip); "direct" = 27 taps (csrc/conv3d_mfma.hip)
-CONV3D_ALGO = os.environ.get("ESTD_CONV3D_ALGO", "wino")
+CONV3D_ALGO = os.environ.get("ESTD_CONV3D_ALGO", "wino2")
 # same choice for the 3x3 / dilation-1 NHWC convolutions: row axis in Winograd F(2,3) form (csrc/conv2d_wino.hip) or direct
 CONV2D_ALGO = os.environ.get("ESTD_CONV2D_ALGO", "wino")
 
