@@ -51,12 +51,13 @@ constexpr int SL_CHUNKS = SL_VOX * 8;               // 16-byte chunks per slice:
 constexpr int RED_BYTES = 8 * 2 * 8;                // GroupNorm scratch: 8 (row pair, channel half) x {sum, sumsq} doubles
 constexpr int NTAPS = 48;
 #ifndef ESTD_W2LDS_TAPS
-#define ESTD_W2LDS_TAPS 16
+#define ESTD_W2LDS_TAPS 14
 #endif
 constexpr int WLDS_TAPS = ESTD_W2LDS_TAPS;           // weights of the first taps of every tile come from LDS
 constexpr int WLDS_BYTES = WLDS_TAPS * 4096;         // [tap][2 halves][2 quads][64 lanes][4]
 constexpr int SS_BYTES = 2 * 32 * 4;                 // folded BN scale | shift of the 32 output channels
-constexpr int LDS_BYTES = 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + WLDS_BYTES;
+constexpr int VTAB_BYTES = 6 * 256 * 4;               // per-thread global offsets of the slice chunks (3 x 512 or 6 x 256 threads)
+constexpr int LDS_BYTES = 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + WLDS_BYTES;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;        // beyond num_records of any descriptor: loads return 0, stores are dropped
 
@@ -129,7 +130,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
 
     float* lds_ss = reinterpret_cast<float*>(smem + 4 * SLICE_BYTES + RED_BYTES);  // scale[32] | shift[32]: read in the epilogue
     if (tid < 64) lds_ss[tid] = tid < 32 ? p.scale[tid] : p.shift[tid - 32];     // (a global load there is an exposed L2 round trip)
-    char* lds_w = smem + 4 * SLICE_BYTES + RED_BYTES + SS_BYTES;                  // weights of taps 0 .. WLDS_TAPS-1
+    unsigned* lds_vt = reinterpret_cast<unsigned*>(smem + 4 * SLICE_BYTES + RED_BYTES + SS_BYTES);     // [it][thread]
+    char* lds_w = smem + 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES;     // weights of taps 0 .. WLDS_TAPS-1
     for (int e = tid; e < WLDS_BYTES / 16; e += NTHREADS)                         // (visible after the first tile's barriers)
         reinterpret_cast<float4*>(lds_w)[e] = reinterpret_cast<const float4*>(p.w_wino2)[e];
 
@@ -155,33 +157,27 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
         const int in_slice_bytes = HW * p.in_stride * 4;
         const int out_plane_bytes = HW * p.out_stride * 4;
 
-        // per-thread slice elements (validity in y / x does not depend on d).  8-wave form: global offset and LDS offset of chunk
-        // `it` are re-formed at every use from an opaque copy of the thread index (a dozen VALU operations) -- held across the tap
-        // loop they are the registers that spill, and a scratch reload in front of a prefetch waits for every weight load before it.
-        auto chunk_voff_f = [&](int it) {
-            int t = tid;
-            if (!HOLD) asm volatile("" : "+v"(t));
-            const int e = t + it * NTHREADS;
+        // per-thread slice elements (validity in y / x does not depend on d): chunk it of a slice = chunk tid + it * NTHREADS.
+        // Global offsets are held per column segment; the LDS offset of chunk it is loff0 + it * NTHREADS * 16 exactly (the
+        // swizzle key (voxel >> 1) & 7 does not change when the voxel advances by NTHREADS / 8), i.e. one register + immediates.
+        // Global offsets: a per-thread table in LDS, rewritten per column segment (own entries only: no barrier needed) -- held in
+        // registers across the tap loop they spill, and a scratch reload in front of a prefetch waits for every weight load before it.
+#pragma unroll
+        for (int it = 0; it < SIT; ++it) {
+            const int e = tid + it * NTHREADS;
             const int vs = e >> 3, c = e & 7;
             const int zy = vs / IN_W, zx = vs % IN_W;
             const int gy = th0 - 1 + zy, gx = tw0 - 1 + zx;
             const bool ok = e < SL_CHUNKS && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-            return ok ? (unsigned)((gy * W + gx) * p.in_stride + c * 4) * 4u : OOB_OFFSET;
-        };
-        auto chunk_loff_f = [&](int it) {
-            int t = tid;
-            if (!HOLD) asm volatile("" : "+v"(t));
-            const int e = t + it * NTHREADS;
-            return e < SL_CHUNKS ? lds_chunk_off(e >> 3, e & 7) : -1;
-        };
-        unsigned voff_h[SIT];
-        int loff_h[SIT];
-        if (HOLD) {
-#pragma unroll
-            for (int it = 0; it < SIT; ++it) { voff_h[it] = chunk_voff_f(it); loff_h[it] = chunk_loff_f(it); }
+            lds_vt[it * NTHREADS + tid] = ok ? (unsigned)((gy * W + gx) * p.in_stride + c * 4) * 4u : OOB_OFFSET;
         }
-        auto chunk_voff = [&](int it) { return HOLD ? voff_h[it] : chunk_voff_f(it); };
-        auto chunk_loff = [&](int it) { return HOLD ? loff_h[it] : chunk_loff_f(it); };
+        // (the thread's table slot is re-formed from the lane id where it is read: nothing is held across the tap loop)
+        auto chunk_voff = [&](int it) {
+            const int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            return lds_vt[it * NTHREADS + wave * 64 + l];
+        };
+        const int loff0 = lds_chunk_off(tid >> 3, tid & 7);
+        const bool last_ok = tid + (SIT - 1) * NTHREADS < SL_CHUNKS;      // the last chunk of a slice exists for this thread
         auto load_plane = [&](int pd, float4 (&dst)[SIT]) {
             const bool pv = (unsigned)pd < (unsigned)D;        // wave-uniform; planes outside the volume are zero padding
 #pragma unroll
@@ -194,15 +190,15 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
         // (g, i) holds the four consecutive channels 16nh + 4g .. +3 of voxel pi(i) of a tile row -- one 16-byte store (and one
         // 16-byte read per residual stream) per plane, row and channel half instead of four 4-byte ones.
         auto eoff_f = [&](int m) {                     // channel half nh0; the second half of a 4-wave lane is 64 bytes further
-            int l = lane;
-            if (!HOLD) asm volatile("" : "+v"(l));
+            const int l = lane;
             const int ii = l & 15;
             const int y = th0 + row0 + m, x = tw0 + (ii < 4 ? 2 * ii : ii < 12 ? 2 * ii - 7 : 2 * ii - 16);
             return (y < H && x < W) ? (unsigned)((y * W + x) * p.out_stride + 16 * nh0 + 4 * (l >> 4)) * 4u : OOB_OFFSET;
         };
-        unsigned eoff_h[2];
-        if (HOLD) { eoff_h[0] = eoff_f(0); eoff_h[1] = eoff_f(1); }
-        auto eoff_of = [&](int m) { return HOLD ? eoff_h[m] : eoff_f(m); };
+        unsigned eoff_h[2];                            // segment constants
+        eoff_h[0] = eoff_f(0);
+        eoff_h[1] = eoff_f(1);
+        auto eoff_of = [&](int m) { return eoff_h[m]; };
         auto bn_act = [&](const f32x4& a, int cb, float4& v) {
             const float4 sc4 = *reinterpret_cast<const float4*>(lds_ss + cb), sh4 = *reinterpret_cast<const float4*>(lds_ss + 32 + cb);
             v.x = act_apply(a[0] * sc4.x + sh4.x, cb + 0 < p.act_split ? p.act_a : p.act_b);
@@ -300,11 +296,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
         auto write_slice = [&](int sl) {
 #pragma unroll
             for (int it = 0; it < SIT; ++it) {
-                const int lo = chunk_loff(it);
-                if ((it < SIT - 1 || lo >= 0) && !(ESTD_W2ABL & 2)) {
+                if ((it < SIT - 1 || last_ok) && !(ESTD_W2ABL & 2)) {
                     const float4 v = sl == 0 ? f4_sub(xa[it], xc[it]) : sl == 1 ? f4_add(xb[it], xc[it])
                                    : sl == 2 ? f4_sub(xc[it], xb[it]) : f4_sub(xb[it], xd[it]);
-                    *reinterpret_cast<float4*>(smem + sl * SLICE_BYTES + lo) = v;
+                    *reinterpret_cast<float4*>(smem + loff0 + sl * SLICE_BYTES + it * NTHREADS * 16) = v;
                 }
             }
         };
@@ -385,6 +380,12 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
             xform2(R, 0, T[0]);
             xform2(R, 1, T[1]);
             load_rows(1, R);
+            constexpr int PER = SIT / 3;                 // plane chunks per step: the 2 x SIT chunks go out in steps 0..5
+            unsigned vo_next[PER];
+            if (has_next && !(ESTD_W2ABL & 16)) {
+#pragma unroll
+                for (int k = 0; k < PER; ++k) vo_next[k] = chunk_voff(k % SIT);
+            }
             __builtin_amdgcn_sched_barrier(0);
 
 #pragma clang loop unroll(full)
@@ -399,14 +400,14 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                 }
                 // weights of step + BD - 1
                 if (step + BD - 1 < 24 && !(ESTD_W2ABL & 8)) load_b(step + BD - 1, bq[(step + BD - 1) % BD]);
-                // chunks of the NEXT tile's two new planes: spread over the first steps
+                // chunks of the NEXT tile's two new planes: spread over the first steps (their offsets were read from the LDS table
+                // at the end of the previous step)
                 if (has_next && !(ESTD_W2ABL & 16)) {
-                    constexpr int PER = SIT / 3;         // chunks per step: the 2 x SIT chunks go out in steps 0..5
                     if (step < 6) {
 #pragma unroll
                         for (int k = 0; k < PER; ++k) {
                             const int idx = step * PER + k, it = idx % SIT;
-                            const unsigned vo = chunk_voff(it);
+                            const unsigned vo = vo_next[k];
                             if (idx < SIT) xc[it] = v0 ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, nd * in_slice_bytes, 0))
                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
                             else           xd[it] = v1 ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, (nd + 1) * in_slice_bytes, 0))
@@ -433,6 +434,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                     if (step + 1 < 24) xform2(R, h, Tn[h]);
                 }
                 if (step + 2 < 24) load_rows(step + 2, R);
+                if (has_next && step + 1 < 6 && !(ESTD_W2ABL & 16)) {
+#pragma unroll
+                    for (int k = 0; k < PER; ++k) vo_next[k] = chunk_voff(((step + 1) * PER + k) % SIT);
+                }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {            // order of the region: the MFMAs of two components, then the next step's 4 packed transforms
                     __builtin_amdgcn_sched_group_barrier(0x008, 8 * NHW, 0);

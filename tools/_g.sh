@@ -1,11 +1,3 @@
-mkdir -p gpurun_out/r3
-python bench.py --steps 20 --warmup 5 --no-alt --conv3d-algo wino2 > gpurun_out/r3/bench_wino2.json 2> gpurun_out/r3/bench_wino2.err; tail -c 1500 gpurun_out/r3/bench_wino2.json | cut -c1-300
-python bench.py --steps 20 --warmup 5 --no-alt --no-cpu-baseline --conv3d-algo wino > gpurun_out/r3/bench_wino.json 2>/dev/null
-python - <<'PY'
-import json
-for f in ("gpurun_out/r3/bench_wino2.json","gpurun_out/r3/bench_wino.json"):
-    try:
-        l=json.loads(open(f).read().strip().split("\n")[-1])
-        print(f, l["value"], l["ms_per_step"], l.get("parity",{}).get("max_abs_depth_diff_vs_oracle_m"), {k:(v["avg_launch_ms"],v["launches"]) for k,v in l["roofline"]["mfma_kernels"].items()})
-    except Exception as e: print(f, "ERR", e)
-PY
+for nw in 8 4; do echo "== NW=$nw"; ESTD_WINO2_WAVES=$nw python -m pytest tests/test_gpu_wino.py -x -q -k "wino2 or fuzz" 2>&1 | tail -2
+ESTD_WINO2_WAVES=$nw ESTD_CONV3D_ALGO=wino2 CB_EPI=1 python tools/conv_bench.py 3 30 2>&1 | grep -v amdgpu.ids
+ESTD_WINO2_WAVES=$nw ESTD_CONV3D_ALGO=wino2 python tools/conv_bench.py 1 30 2>&1 | grep conv3d; done
