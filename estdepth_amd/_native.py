@@ -34,6 +34,13 @@ class Conv3dDesc(ctypes.Structure):
     ]
 
 
+class WarpVolumeOpts(ctypes.Structure):
+    """Mirror of struct estd_warp_volume_opts (include/estd_hip.h)."""
+    _fields_ = [("depth_per_voxel", ctypes.c_int), ("use_disp", ctypes.c_int), ("border", ctypes.c_int),
+                ("depth_min", ctypes.c_float), ("depth_interval", ctypes.c_float),
+                ("disp_min", ctypes.c_float), ("disp_interval", ctypes.c_float), ("padding_value", ctypes.c_float)]
+
+
 class Conv2dDesc(ctypes.Structure):
     """Mirror of struct estd_conv2d_desc (include/estd_hip.h)."""
     _fields_ = [
@@ -56,6 +63,10 @@ _SIGNATURES = {
     "estd_cam_volume_mats": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_stream]),
     "estd_homo_warping": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
+    "estd_homo_warping_px": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p,
+                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
+    "estd_warp_volume_ex": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, ctypes.POINTER(WarpVolumeOpts), c_float_p,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
     "estd_mix1x1_chw_to_hwc": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p,
                                               ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
     "estd_homo_warp_costvol": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,

@@ -145,7 +145,17 @@ def finish(p):
     poses = flat[:V * 16].reshape(1, V, 4, 4)
     K = flat[V * 16:V * 16 + 9].reshape(1, 3, 3)
     pre_cpu = [flat[V * 16 + 9 + 16 * i:V * 16 + 25 + 16 * i].reshape(1, 4, 4) for i in range(p.n_pre)]
-    sweep, vol = ops.T().camera_matrices_host(poses, K, pre_cpu, p.with_volume)
+    if ops.BINDING == "torch":
+        sweep, vol = ops.T().camera_matrices_host(poses, K, pre_cpu, p.with_volume)
+    else:
+        # torch-free binding (ESTD_BINDING=ctypes): the same ATen CPU calls from Python -- bit-identical to the C++ operator
+        # (tests/test_camera_host.py), ~40 dispatcher trips slower, and libestd_torch_ops.so is not needed
+        sweep = torch.stack([_sweep_set(poses, K, t + 1, (t, t + 2)) for t in range(V - 2)])
+        if p.with_volume:
+            plist = [poses[:, t + 1] for t in range(V - 2)] + pre_cpu
+            vol = volume_matrices(plist, V - 2, K, "cpu")
+        else:
+            vol = torch.empty(0, dtype=torch.float32)
     n_sweep, n = sweep.numel(), sweep.numel() + vol.numel()
     if torch.device(p.device).type == "cuda":
         stage = _pinned.get(n)

@@ -111,6 +111,75 @@ __global__ __launch_bounds__(256) void warp_volume_kernel(const float* __restric
     }
 }
 
+// Level-1 operator, every branch of the reference's signature (homo_utils.py:240-279): per-VOXEL depth (:246,:253), disparity
+// planes (:187-190), padding_mode='border' on the volume whose outermost voxel layer holds padding_value (:271-274,:305-319).
+// Same rounding sequence as volume_coords_base; the masks stay on in border mode (normalize_pixel_coords_volume is called with
+// its own default padding_mode, :262-269).  Off the hot path: one thread per target voxel, loop over channels.
+__global__ __launch_bounds__(256) void warp_volume_ex_kernel(const float* __restrict__ vol, const float* __restrict__ M,
+                                                             const float* __restrict__ depth, estd_warp_volume_opts o,
+                                                             float* __restrict__ out, int C, int D, int H, int W)
+{
+#pragma clang fp contract(off)
+    const long long HW = (long long)H * W, S = (long long)D * HW;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < S; idx += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W);
+        const int y = (int)((idx / W) % H);
+        const int d = (int)(idx / HW);
+        const float dep = o.depth_per_voxel ? depth[idx] : depth[d];
+        const float fx = (float)x, fy = (float)y;
+        const float c0 = (fmaf(M[1], fy, M[0] * fx) + M[2]) * dep;
+        const float c1 = (fmaf(M[4], fy, M[3] * fx) + M[5]) * dep;
+        const float c2 = (fmaf(M[7], fy, M[6] * fx) + M[8]) * dep;
+        const float s0 = fmaf(M[11], c2, fmaf(M[10], c1, M[9] * c0)) + M[12];
+        const float s1 = fmaf(M[15], c2, fmaf(M[14], c1, M[13] * c0)) + M[16];
+        const float s2 = fmaf(M[19], c2, fmaf(M[18], c1, M[17] * c0)) + M[20];
+        const float q0 = fmaf(M[23], s2, fmaf(M[22], s1, M[21] * s0));
+        const float q1 = fmaf(M[26], s2, fmaf(M[25], s1, M[24] * s0));
+        const float q2 = fmaf(M[29], s2, fmaf(M[28], s1, M[27] * s0));
+        const float den = q2 + 1e-10f;
+        const float X = q0 / den, Y = q1 / den, Z = q2;
+        float xn = 2.0f * X / (float)(W - 1) - 1.0f;
+        float yn = 2.0f * Y / (float)(H - 1) - 1.0f;
+        float zn = o.use_disp ? 2.0f * ((1.0f / (Z + 1e-10f) - o.disp_min) / o.disp_interval) / (float)(D - 1) - 1.0f
+                              : 2.0f * ((Z - o.depth_min) / o.depth_interval) / (float)(D - 1) - 1.0f;
+        if (xn > 1.0f || xn < -1.0f) xn = 2.0f;
+        if (yn > 1.0f || yn < -1.0f) yn = 2.0f;
+        if (zn > 1.0f || zn < -1.0f) zn = 2.0f;
+        float ix = ((xn + 1.0f) * (float)W - 1.0f) * 0.5f;
+        float iy = ((yn + 1.0f) * (float)H - 1.0f) * 0.5f;
+        float iz = ((zn + 1.0f) * (float)D - 1.0f) * 0.5f;
+        if (o.border) {                                     // ATen clip_coordinates: min(size - 1, max(i, 0))
+            ix = fminf((float)(W - 1), fmaxf(ix, 0.0f));
+            iy = fminf((float)(H - 1), fmaxf(iy, 0.0f));
+            iz = fminf((float)(D - 1), fmaxf(iz, 0.0f));
+        }
+        const float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
+        const bool finite = (ix == ix) && (iy == iy) && (iz == iz);
+        const float tx = ix - fx0, ty = iy - fy0, tz = iz - fz0;
+        const int x0 = finite ? (int)fx0 : -2, y0 = finite ? (int)fy0 : -2, z0 = finite ? (int)fz0 : -2;
+        float wgt[8];
+        long long off[8];
+        bool edge[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int dx = k & 1, dy = (k >> 1) & 1, dz = (k >> 2) & 1;
+            const int xx = x0 + dx, yy = y0 + dy, zz = z0 + dz;
+            const bool ok = xx >= 0 && xx < W && yy >= 0 && yy < H && zz >= 0 && zz < D;
+            const float w = (dx ? tx : 1.0f - tx) * (dy ? ty : 1.0f - ty) * (dz ? tz : 1.0f - tz);
+            wgt[k] = ok ? w : 0.0f;
+            off[k] = ok ? ((long long)zz * H + yy) * W + xx : 0;
+            edge[k] = o.border && (xx == 0 || xx == W - 1 || yy == 0 || yy == H - 1 || zz == 0 || zz == D - 1);
+        }
+        for (int c = 0; c < C; ++c) {
+            const float* s = vol + (long long)c * S;
+            float v = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v += (edge[k] ? o.padding_value : s[off[k]]) * wgt[k];
+            out[(long long)c * S + idx] = v;
+        }
+    }
+}
+
 // Fused warp(K_j), warp(V_j) + attention.  4 lanes per target voxel; lane c owns float4 chunk c of
 // the 16 value channels and chunk c of the 16 key channels (kv record = [V(16) | K(16)] = 128 B).
 #ifndef WA_TD
@@ -434,6 +503,18 @@ extern "C" int estd_warp_volume(const float* vol, const float* mats30, const flo
     const long long nb = (S + 255) / 256;
     hipLaunchKernelGGL(warp_volume_kernel, dim3((unsigned)(nb > 1048576 ? 1048576 : nb)), dim3(256), 0, estd_stream(s),
                        vol, mats30, dvals, depth_min, depth_interval, out, C, D, H, W);
+    return ESTD_LAUNCH_CHECK();
+}
+
+extern "C" int estd_warp_volume_ex(const float* vol, const float* mats30, const float* depth, const estd_warp_volume_opts* opts,
+                                   float* out, int C, int D, int H, int W, estd_stream_t s)
+{
+    if (!vol || !mats30 || !depth || !opts || !out || C <= 0 || D <= 1 || H <= 1 || W <= 1) return ESTD_ERR_ARG;
+    if (opts->use_disp ? !(opts->disp_interval != 0.0f) : !(opts->depth_interval != 0.0f)) return ESTD_ERR_ARG;
+    const long long S = (long long)D * H * W;
+    const long long nb = (S + 255) / 256;
+    hipLaunchKernelGGL(warp_volume_ex_kernel, dim3((unsigned)(nb > 1048576 ? 1048576 : nb)), dim3(256), 0, estd_stream(s),
+                       vol, mats30, depth, *opts, out, C, D, H, W);
     return ESTD_LAUNCH_CHECK();
 }
 

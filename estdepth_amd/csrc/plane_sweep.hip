@@ -173,16 +173,17 @@ __device__ __forceinline__ Bilin sweep_coords(const float* __restrict__ P, float
 
 // Level-1 operator: NCHW in, NCDHW out.  One thread per (d,y,x), loop over channels.
 __global__ __launch_bounds__(256) void homo_warping_kernel(const float* __restrict__ src, const float* __restrict__ P,
-                                                           const float* __restrict__ dvals, float* __restrict__ out,
+                                                           const float* __restrict__ dvals, int per_pixel, float* __restrict__ out,
                                                            int C, int D, int H, int W)
 {
+    // per_pixel: dvals = [D][H][W] depth hypotheses per pixel (homo_utils.py:462: "depth_values: [B, Ndepth] o [B, Ndepth, H, W]")
     const long long HW = (long long)H * W;
     const long long total = (long long)D * HW;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int x = (int)(idx % W);
         const int y = (int)((idx / W) % H);
         const int d = (int)(idx / HW);
-        const Bilin b = sweep_coords(P, dvals[d], x, y, H, W);
+        const Bilin b = sweep_coords(P, per_pixel ? dvals[idx] : dvals[d], x, y, H, W);
         for (int c = 0; c < C; ++c) {
             const float* s = src + (long long)c * HW;
             const float v = s[b.o00] * b.w00 + s[b.o01] * b.w01 + s[b.o10] * b.w10 + s[b.o11] * b.w11;
@@ -318,7 +319,17 @@ extern "C" int estd_homo_warping(const float* src, const float* P, const float* 
     if (!src || !P || !dvals || !out || C <= 0 || D <= 0 || H <= 0 || W <= 0) return ESTD_ERR_ARG;
     const long long total = (long long)D * H * W;
     const int grid = (int)((total + 255) / 256 > 65535 * 8 ? 65535 * 8 : (total + 255) / 256);
-    hipLaunchKernelGGL(homo_warping_kernel, dim3(grid), dim3(256), 0, estd_stream(s), src, P, dvals, out, C, D, H, W);
+    hipLaunchKernelGGL(homo_warping_kernel, dim3(grid), dim3(256), 0, estd_stream(s), src, P, dvals, 0, out, C, D, H, W);
+    return ESTD_LAUNCH_CHECK();
+}
+
+extern "C" int estd_homo_warping_px(const float* src, const float* P, const float* depth_dhw, float* out,
+                                    int C, int D, int H, int W, estd_stream_t s)
+{
+    if (!src || !P || !depth_dhw || !out || C <= 0 || D <= 0 || H <= 0 || W <= 0) return ESTD_ERR_ARG;
+    const long long total = (long long)D * H * W;
+    const int grid = (int)((total + 255) / 256 > 65535 * 8 ? 65535 * 8 : (total + 255) / 256);
+    hipLaunchKernelGGL(homo_warping_kernel, dim3(grid), dim3(256), 0, estd_stream(s), src, P, depth_dhw, 1, out, C, D, H, W);
     return ESTD_LAUNCH_CHECK();
 }
 

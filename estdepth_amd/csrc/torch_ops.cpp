@@ -13,6 +13,7 @@
 // Built by estdepth_amd/build.py into estdepth_amd/lib/libestd_torch_ops.so; loaded with torch.ops.load_library().
 #include <ATen/ATen.h>
 #include <ATen/hip/HIPContext.h>
+#include <ATen/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -27,6 +28,20 @@ using OptTensor = std::optional<Tensor>;
 
 inline estd_stream_t cur_stream() { return static_cast<estd_stream_t>(c10::hip::getCurrentHIPStream().stream()); }
 
+// Every operator opens an OpScope on its first tensor argument: a device guard (the kernels are enqueued on the current stream
+// of THAT tensor's device, not of whatever device happens to be current), and every further tensor checked through fptr() must
+// live on the same device.
+struct OpScope {
+    static inline thread_local const c10::Device* cur = nullptr;
+    c10::OptionalDeviceGuard guard;
+    c10::Device dev;
+    const c10::Device* prev;
+    explicit OpScope(const Tensor& t) : guard(at::device_of(t)), dev(t.defined() ? t.device() : c10::Device(c10::kCPU)), prev(cur) { cur = &dev; }
+    ~OpScope() { cur = prev; }
+    OpScope(const OpScope&) = delete;
+    OpScope& operator=(const OpScope&) = delete;
+};
+
 inline void check_status(int st, const char* what)
 {
     TORCH_CHECK(st == ESTD_OK, what, " failed: ", estd_status_string(st), " (estd_status ", st, ")");
@@ -36,6 +51,7 @@ inline const float* fptr(const Tensor& t, const char* name, bool need_contiguous
 {
     TORCH_CHECK(t.defined(), name, " must be a tensor");
     TORCH_CHECK(t.is_cuda(), name, " must live on a ROCm device (estdepth_hip has no CPU path); got ", t.device());
+    if (OpScope::cur) TORCH_CHECK(t.device() == *OpScope::cur, name, " is on ", t.device(), " but the operator runs on ", *OpScope::cur);
     TORCH_CHECK(t.scalar_type() == at::kFloat, name, " must be float32, got ", t.scalar_type());
     if (need_contiguous) TORCH_CHECK(t.is_contiguous(), name, " must be contiguous");
     return t.data_ptr<float>();
@@ -50,6 +66,7 @@ inline Tensor new_f32(at::IntArrayRef shape, const Tensor& like) { return at::em
 // ------------------------------------------------------------------------------------------------ camera algebra
 Tensor cam_pair_proj(const Tensor& src_proj, const Tensor& ref_proj)
 {
+    const OpScope scope(src_proj);
     TORCH_CHECK(src_proj.numel() == 16 && ref_proj.numel() == 16, "cam_pair_proj: 4x4 projection matrices expected");
     Tensor out = new_f32({12}, src_proj);
     check_status(estd_cam_pair_proj(fptr(src_proj, "src_proj"), fptr(ref_proj, "ref_proj"), out.data_ptr<float>(), cur_stream()),
@@ -59,6 +76,7 @@ Tensor cam_pair_proj(const Tensor& src_proj, const Tensor& ref_proj)
 
 Tensor cam_sweep_proj(const Tensor& ref_pose, const Tensor& src_pose, const Tensor& intr)
 {
+    const OpScope scope(ref_pose);
     TORCH_CHECK(ref_pose.numel() == 16 && src_pose.numel() == 16 && intr.numel() == 9, "cam_sweep_proj: 4x4 poses and 3x3 intrinsics expected");
     Tensor out = new_f32({12}, ref_pose);
     check_status(estd_cam_sweep_proj(fptr(ref_pose, "ref_pose"), fptr(src_pose, "src_pose"), fptr(intr, "cam_intr"),
@@ -68,6 +86,7 @@ Tensor cam_sweep_proj(const Tensor& ref_pose, const Tensor& src_pose, const Tens
 
 void cam_volume_mats(const Tensor& pose_j, const OptTensor& pose_i, const Tensor& intr, Tensor out)
 {
+    const OpScope scope(pose_j);
     TORCH_CHECK(pose_j.numel() == 16 && intr.numel() == 9, "cam_volume_mats: 4x4 pose and 3x3 intrinsics expected");
     TORCH_CHECK(out.numel() == 30, "cam_volume_mats: out must hold 30 floats");
     check_status(estd_cam_volume_mats(fptr(pose_j, "pose_j"), opt_fptr(pose_i, "pose_i"), fptr(intr, "cam_intr"),
@@ -77,6 +96,7 @@ void cam_volume_mats(const Tensor& pose_j, const OptTensor& pose_i, const Tensor
 // ------------------------------------------------------------------------------------------------ plane sweep
 Tensor homo_warping(const Tensor& src_chw, const Tensor& proj12, const Tensor& depth_values, int64_t D)
 {
+    const OpScope scope(src_chw);
     TORCH_CHECK(src_chw.dim() == 3, "homo_warping: src_fea must be [C,H,W]");
     TORCH_CHECK(depth_values.numel() >= D && proj12.numel() == 12, "homo_warping: depth_values / proj12 size");
     const int64_t C = src_chw.size(0), H = src_chw.size(1), W = src_chw.size(2);
@@ -86,8 +106,21 @@ Tensor homo_warping(const Tensor& src_chw, const Tensor& proj12, const Tensor& d
     return out;
 }
 
+Tensor homo_warping_px(const Tensor& src_chw, const Tensor& proj12, const Tensor& depth_dhw)
+{
+    const OpScope scope(src_chw);
+    TORCH_CHECK(src_chw.dim() == 3 && depth_dhw.dim() == 3, "homo_warping_px: src_fea [C,H,W], depth [D,H,W]");
+    const int64_t C = src_chw.size(0), H = src_chw.size(1), W = src_chw.size(2), D = depth_dhw.size(0);
+    TORCH_CHECK(depth_dhw.size(1) == H && depth_dhw.size(2) == W && proj12.numel() == 12, "homo_warping_px: depth / proj12 size");
+    Tensor out = new_f32({C, D, H, W}, src_chw);
+    check_status(estd_homo_warping_px(fptr(src_chw, "src_fea"), fptr(proj12, "proj12"), fptr(depth_dhw, "depth_values"),
+                                      out.data_ptr<float>(), (int)C, (int)D, (int)H, (int)W, cur_stream()), "estd_homo_warping_px");
+    return out;
+}
+
 Tensor mix1x1(const Tensor& in_chw, const Tensor& w, const OptTensor& bias)
 {
+    const OpScope scope(in_chw);
     TORCH_CHECK(in_chw.dim() == 3 && w.dim() == 2 && w.size(1) == in_chw.size(0), "mix1x1: in [Cin,H,W], w [Cout,Cin]");
     const int64_t Cin = in_chw.size(0), H = in_chw.size(1), W = in_chw.size(2), Cout = w.size(0);
     Tensor out = new_f32({H, W, Cout}, in_chw);
@@ -99,6 +132,7 @@ Tensor mix1x1(const Tensor& in_chw, const Tensor& w, const OptTensor& bias)
 void homo_warp_costvol(const Tensor& src_mix, const Tensor& ref_mix, const Tensor& proj12, const Tensor& depth_values,
                        int64_t D, Tensor out)
 {
+    const OpScope scope(src_mix);
     TORCH_CHECK(src_mix.dim() == 3 && src_mix.size(2) == 32 && ref_mix.sizes() == src_mix.sizes(),
                 "homo_warp_costvol: src_mix / ref_mix must be [H,W,32] of one shape");
     TORCH_CHECK(depth_values.numel() >= D && D >= 1 && proj12.numel() == 12, "homo_warp_costvol: depth_values / proj12 size");
@@ -119,6 +153,7 @@ void conv3d_k3(const Tensor& x, const OptTensor& x_extra, const Tensor& w_main, 
                bool accumulate, const OptTensor& out_extra, const OptTensor& head_w, const OptTensor& head_b, const OptTensor& out_head,
                const OptTensor& stats_partials, int64_t variant)
 {
+    const OpScope scope(x);
     TORCH_CHECK(dims.size() == 4, "conv3d_k3: dims = (N, D, H, W)");
     estd_conv3d_desc d{};
     d.N = (int)dims[0]; d.D = (int)dims[1]; d.H = (int)dims[2]; d.W = (int)dims[3];
@@ -173,6 +208,7 @@ Tensor conv2d_k3(const Tensor& x_nhwc, const Tensor& w, const OptTensor& w_alt, 
                  int64_t cout, int64_t dilation, int64_t group_tiles, bool relu_before_residual, bool relu_after_residual,
                  const OptTensor& residual, int64_t variant)
 {
+    const OpScope scope(x_nhwc);
     TORCH_CHECK(x_nhwc.dim() == 4, "conv2d_k3: input must be [N,H,W,Cin] (NHWC, contiguous)");
     estd_conv2d_desc d{};
     d.N = (int)x_nhwc.size(0); d.H = (int)x_nhwc.size(1); d.W = (int)x_nhwc.size(2); d.cin = (int)x_nhwc.size(3);
@@ -203,6 +239,7 @@ Tensor conv2d_k3(const Tensor& x_nhwc, const Tensor& w, const OptTensor& w_alt, 
 
 Tensor groupnorm_finalize(const Tensor& partials, int64_t n_blocks, double count, double eps)
 {
+    const OpScope scope(partials);
     TORCH_CHECK(partials.is_cuda() && partials.scalar_type() == at::kDouble && partials.is_contiguous() && partials.numel() >= n_blocks * 4,
                 "groupnorm_finalize: partials must be a contiguous float64 ROCm tensor with 4 doubles per block");
     Tensor out = at::empty({4}, partials.options().dtype(at::kFloat));
@@ -214,6 +251,7 @@ Tensor groupnorm_finalize(const Tensor& partials, int64_t n_blocks, double count
 // ------------------------------------------------------------------------------------------------ soft-argmin
 std::tuple<Tensor, Tensor> softargmin_up(const Tensor& logits, const Tensor& depth_values, int64_t scale)
 {
+    const OpScope scope(logits);
     TORCH_CHECK(logits.dim() == 4, "softargmin_up: logits must be [N,D,H,W]");
     const int64_t N = logits.size(0), D = logits.size(1), H = logits.size(2), W = logits.size(3);
     TORCH_CHECK(depth_values.numel() >= D, "softargmin_up: one depth value per plane expected");
@@ -227,6 +265,7 @@ std::tuple<Tensor, Tensor> softargmin_up(const Tensor& logits, const Tensor& dep
 // ------------------------------------------------------------------------------------------------ EST fusion
 Tensor warp_volume(const Tensor& vol, const Tensor& mats30, const Tensor& depth_values, double depth_min, double depth_interval)
 {
+    const OpScope scope(vol);
     TORCH_CHECK(vol.dim() == 4 && mats30.numel() == 30, "warp_volume: vol [C,D,H,W], mats30 [30]");
     TORCH_CHECK(depth_values.numel() >= vol.size(1), "warp_volume: one depth value per plane expected");
     Tensor out = at::empty_like(vol);
@@ -236,9 +275,28 @@ Tensor warp_volume(const Tensor& vol, const Tensor& mats30, const Tensor& depth_
     return out;
 }
 
+Tensor warp_volume_ex(const Tensor& vol, const Tensor& mats30, const Tensor& depth, bool depth_per_voxel, double depth_min,
+                      double depth_interval, bool use_disp, double disp_min, double disp_interval, bool border, double padding_value)
+{
+    const OpScope scope(vol);
+    TORCH_CHECK(vol.dim() == 4 && mats30.numel() == 30, "warp_volume: vol [C,D,H,W], mats30 [30]");
+    const int64_t need = depth_per_voxel ? vol.size(1) * vol.size(2) * vol.size(3) : vol.size(1);
+    TORCH_CHECK(depth.numel() >= need, "warp_volume: depth must hold ", need, " values");
+    estd_warp_volume_opts o{};
+    o.depth_per_voxel = depth_per_voxel; o.use_disp = use_disp; o.border = border;
+    o.depth_min = (float)depth_min; o.depth_interval = (float)depth_interval;
+    o.disp_min = (float)disp_min; o.disp_interval = (float)disp_interval; o.padding_value = (float)padding_value;
+    Tensor out = at::empty_like(vol);
+    check_status(estd_warp_volume_ex(fptr(vol, "feat_volume"), fptr(mats30, "mats30"), fptr(depth, "depth"), &o, out.data_ptr<float>(),
+                                     (int)vol.size(0), (int)vol.size(1), (int)vol.size(2), (int)vol.size(3), cur_stream()),
+                 "estd_warp_volume_ex");
+    return out;
+}
+
 Tensor warp_attention(const Tensor& kv_target, at::TensorList kv_sources, const Tensor& mats, const Tensor& depth_values,
                       double depth_min, double depth_interval)
 {
+    const OpScope scope(kv_target);
     TORCH_CHECK(kv_target.dim() == 4 && kv_target.size(3) == 32, "warp_attention: kv volumes must be [D,H,W,32]");
     const int64_t D = kv_target.size(0), H = kv_target.size(1), W = kv_target.size(2);
     const int n = (int)kv_sources.size();
@@ -260,6 +318,7 @@ Tensor warp_attention(const Tensor& kv_target, at::TensorList kv_sources, const 
 
 Tensor attention_prewarped(const Tensor& kv_target, at::TensorList kv_sources)
 {
+    const OpScope scope(kv_target);
     const int n = (int)kv_sources.size();
     TORCH_CHECK(n >= 1 && n <= 8, "attention_prewarped: 1..8 pre-warped source volumes");
     TORCH_CHECK(kv_target.numel() % 32 == 0, "attention_prewarped: kv volumes hold 32 floats per voxel");
@@ -276,6 +335,7 @@ Tensor attention_prewarped(const Tensor& kv_target, at::TensorList kv_sources)
 
 Tensor gru_reset_apply(const Tensor& xh, const Tensor& ru, const Tensor& stats4, const Tensor& gamma_r, const Tensor& beta_r)
 {
+    const OpScope scope(xh);
     TORCH_CHECK(xh.numel() == ru.numel() && xh.numel() % 32 == 0, "gru_reset_apply: xh and ru are [D,H,W,32] volumes");
     TORCH_CHECK(stats4.numel() == 4 && gamma_r.numel() == 16 && beta_r.numel() == 16, "gru_reset_apply: stats [4], affine [16]");
     Tensor xrh = at::empty_like(xh);
@@ -287,6 +347,7 @@ Tensor gru_reset_apply(const Tensor& xh, const Tensor& ru, const Tensor& stats4,
 void gru_blend(const Tensor& xh, const Tensor& ru, const Tensor& o_raw, const Tensor& stats_ru, const Tensor& stats_o,
                const Tensor& gamma_u, const Tensor& beta_u, const Tensor& gamma_o, const Tensor& beta_o, Tensor out_value, int64_t out_stride)
 {
+    const OpScope scope(xh);
     const int64_t n_vox = xh.numel() / 32;
     TORCH_CHECK(xh.numel() == ru.numel() && o_raw.numel() == n_vox * 16, "gru_blend: xh, ru [D,H,W,32]; o_raw [D,H,W,16]");
     TORCH_CHECK(stats_ru.numel() == 4 && stats_o.numel() == 4 && gamma_u.numel() == 16 && beta_u.numel() == 16 &&
@@ -299,6 +360,7 @@ void gru_blend(const Tensor& xh, const Tensor& ru, const Tensor& o_raw, const Te
 // ------------------------------------------------------------------------------------------------ 2D backbone epilogues, layouts
 Tensor bn_act_nhwc_(Tensor x, const Tensor& scale, const Tensor& shift, bool relu, const OptTensor& residual)
 {
+    const OpScope scope(x);
     TORCH_CHECK(x.dim() == 4 && x.is_cuda() && x.scalar_type() == at::kFloat && x.is_contiguous(at::MemoryFormat::ChannelsLast),
                 "bn_act_nhwc_: expected a float32 ROCm tensor in channels_last memory (no CPU path)");
     const int64_t n = x.size(0), c = x.size(1), h = x.size(2), w = x.size(3);
@@ -316,6 +378,7 @@ Tensor bn_act_nhwc_(Tensor x, const Tensor& scale, const Tensor& shift, bool rel
 
 Tensor spp_upsample_cat(const Tensor& raw, const Tensor& skip, at::TensorList branches)
 {
+    const OpScope scope(raw);
     const int nb = (int)branches.size();
     TORCH_CHECK(raw.dim() == 4 && skip.dim() == 4 && nb >= 1 && nb <= 4, "spp_upsample_cat: NHWC raw/skip and 1..4 branches");
     const int64_t n = raw.size(0), h = raw.size(1), w = raw.size(2), cr = raw.size(3), cs = skip.size(3), cb = branches[0].size(3);
@@ -333,6 +396,7 @@ Tensor spp_upsample_cat(const Tensor& raw, const Tensor& skip, at::TensorList br
 
 Tensor conv2d_k3_to16_nhwc(const Tensor& x, const Tensor& w_packed, const Tensor& scale, const Tensor& shift, bool upsample)
 {
+    const OpScope scope(x);
     TORCH_CHECK(x.dim() == 4 && (x.size(3) == 16 || x.size(3) == 32), "conv2d_k3_to16_nhwc: NHWC x with 16 or 32 channels expected");
     const int64_t n = x.size(0), c = x.size(3), h = (upsample ? 2 : 1) * x.size(1), w = (upsample ? 2 : 1) * x.size(2);
     TORCH_CHECK(w_packed.numel() == 9 * (c / 16) * 64 * 4 && scale.numel() == 16 && shift.numel() == 16,
@@ -346,6 +410,7 @@ Tensor conv2d_k3_to16_nhwc(const Tensor& x, const Tensor& w_packed, const Tensor
 
 Tensor normalise_nhwc(const Tensor& imgs)
 {
+    const OpScope scope(imgs);
     TORCH_CHECK(imgs.dim() == 4 && imgs.size(1) == 3, "normalise_nhwc: [N,3,H,W] images expected");
     const int64_t n = imgs.size(0), h = imgs.size(2), w = imgs.size(3);
     Tensor out = new_f32({n, h, w, 3}, imgs);
@@ -355,6 +420,7 @@ Tensor normalise_nhwc(const Tensor& imgs)
 
 Tensor stem3x3s2_nhwc(const Tensor& x, const Tensor& weight, const Tensor& scale, const Tensor& shift)
 {
+    const OpScope scope(x);
     TORCH_CHECK(x.dim() == 4 && x.size(3) == 3 && weight.dim() == 4 && weight.size(0) == 32 && weight.size(1) == 3 && weight.size(2) == 3 &&
                 weight.size(3) == 3 && scale.numel() == 32 && shift.numel() == 32,
                 "stem3x3s2_nhwc: NHWC x [N,H,W,3], weight [32,3,3,3], scale/shift [32] expected");
@@ -367,6 +433,7 @@ Tensor stem3x3s2_nhwc(const Tensor& x, const Tensor& weight, const Tensor& scale
 
 Tensor planes_cat_nhwc(const Tensor& a, const Tensor& b, bool relu_b)
 {
+    const OpScope scope(a);
     TORCH_CHECK(a.dim() == 4 && b.dim() == 4 && a.size(0) == b.size(0) && a.size(2) == b.size(2) && a.size(3) == b.size(3),
                 "planes_cat_nhwc: two NCHW stacks of the same N, H, W expected");
     const int64_t n = a.size(0), ca = a.size(1), cb = b.size(1), h = a.size(2), w = a.size(3);
@@ -378,6 +445,7 @@ Tensor planes_cat_nhwc(const Tensor& a, const Tensor& b, bool relu_b)
 
 Tensor upsample2_cat_nhwc(const Tensor& x, const Tensor& skip)
 {
+    const OpScope scope(x);
     TORCH_CHECK(x.dim() == 4 && skip.dim() == 4 && x.size(0) == skip.size(0) && 2 * x.size(1) == skip.size(1) && 2 * x.size(2) == skip.size(2),
                 "upsample2_cat_nhwc: NHWC x [N,H/2,W/2,Cx] and skip [N,H,W,Cs] expected");
     const int64_t n = skip.size(0), h = skip.size(1), w = skip.size(2), cx = x.size(3), cs = skip.size(3);
@@ -389,6 +457,7 @@ Tensor upsample2_cat_nhwc(const Tensor& x, const Tensor& skip)
 
 Tensor disp_head_nhwc(const Tensor& x, const Tensor& weight, const Tensor& bias, double depth_max, int64_t upscale)
 {
+    const OpScope scope(x);
     TORCH_CHECK(x.dim() == 4 && weight.dim() == 4 && weight.size(0) == 1 && weight.size(1) == x.size(3) && weight.size(2) == 3 &&
                 weight.size(3) == 3 && bias.numel() == 1, "disp_head_nhwc: NHWC x [N,H,W,C], weight [1,C,3,3], bias [1] expected");
     TORCH_CHECK(upscale == 1 || upscale == 2, "disp_head_nhwc: upscale must be 1 or 2");
@@ -401,6 +470,7 @@ Tensor disp_head_nhwc(const Tensor& x, const Tensor& weight, const Tensor& bias,
 
 void cdhw_to_vol(const Tensor& src, Tensor dst, int64_t dst_stride, int64_t dst_off)
 {
+    const OpScope scope(src);
     TORCH_CHECK(src.dim() >= 2, "cdhw_to_vol: src must be [C, ...]");
     const int64_t C = src.size(0), S = src.numel() / C;
     TORCH_CHECK(dst.numel() >= S * dst_stride, "cdhw_to_vol: destination too small");
@@ -410,6 +480,7 @@ void cdhw_to_vol(const Tensor& src, Tensor dst, int64_t dst_stride, int64_t dst_
 
 Tensor vol_to_cdhw(const Tensor& src, int64_t C, at::IntArrayRef dims, int64_t src_stride, int64_t src_off)
 {
+    const OpScope scope(src);
     TORCH_CHECK(dims.size() == 3, "vol_to_cdhw: dims = (D, H, W)");
     const int64_t S = dims[0] * dims[1] * dims[2];
     TORCH_CHECK(src.numel() >= S * src_stride, "vol_to_cdhw: source too small");
@@ -500,6 +571,7 @@ TORCH_LIBRARY(estdepth_hip, m)
     m.def("cam_sweep_proj(Tensor ref_pose, Tensor src_pose, Tensor cam_intr) -> Tensor");
     m.def("cam_volume_mats(Tensor pose_j, Tensor? pose_i, Tensor cam_intr, Tensor(a!) out) -> ()");
     m.def("homo_warping(Tensor src_fea, Tensor proj12, Tensor depth_values, int D) -> Tensor");
+    m.def("homo_warping_px(Tensor src_fea, Tensor proj12, Tensor depth_dhw) -> Tensor");
     m.def("mix1x1(Tensor feature, Tensor weight, Tensor? bias) -> Tensor");
     m.def("homo_warp_costvol(Tensor src_mix, Tensor ref_mix, Tensor proj12, Tensor depth_values, int D, Tensor(a!) out) -> ()");
     m.def("conv3d_k3(Tensor x, Tensor? x_extra, Tensor w_main, Tensor? w_extra, Tensor? w_xout, Tensor? w_alt, Tensor scale, Tensor shift, "
@@ -511,6 +583,8 @@ TORCH_LIBRARY(estdepth_hip, m)
     m.def("groupnorm_finalize(Tensor partials, int n_blocks, float count, float eps) -> Tensor");
     m.def("softargmin_up(Tensor logits, Tensor depth_values, int scale) -> (Tensor, Tensor)");
     m.def("warp_volume(Tensor feat_volume, Tensor mats30, Tensor depth_values, float depth_min, float depth_interval) -> Tensor");
+    m.def("warp_volume_ex(Tensor feat_volume, Tensor mats30, Tensor depth, bool depth_per_voxel, float depth_min, float depth_interval, "
+          "bool use_disp, float disp_min, float disp_interval, bool border, float padding_value) -> Tensor");
     m.def("warp_attention(Tensor kv_target, Tensor[] kv_sources, Tensor mats, Tensor depth_values, float depth_min, float depth_interval) -> Tensor");
     m.def("attention_prewarped(Tensor kv_target, Tensor[] kv_sources) -> Tensor");
     m.def("gru_reset_apply(Tensor xh, Tensor ru, Tensor stats4, Tensor gamma_r, Tensor beta_r) -> Tensor");
@@ -541,6 +615,7 @@ TORCH_LIBRARY_IMPL(estdepth_hip, CUDA, m)
     m.impl("cam_sweep_proj", cam_sweep_proj);
     m.impl("cam_volume_mats", cam_volume_mats);
     m.impl("homo_warping", homo_warping);
+    m.impl("homo_warping_px", homo_warping_px);
     m.impl("mix1x1", mix1x1);
     m.impl("homo_warp_costvol", homo_warp_costvol);
     m.impl("conv3d_k3", conv3d_k3);
@@ -548,6 +623,7 @@ TORCH_LIBRARY_IMPL(estdepth_hip, CUDA, m)
     m.impl("groupnorm_finalize", groupnorm_finalize);
     m.impl("softargmin_up", softargmin_up);
     m.impl("warp_volume", warp_volume);
+    m.impl("warp_volume_ex", warp_volume_ex);
     m.impl("warp_attention", warp_attention);
     m.impl("attention_prewarped", attention_prewarped);
     m.impl("gru_reset_apply", gru_reset_apply);

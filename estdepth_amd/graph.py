@@ -11,7 +11,7 @@ every inference call site of the reference (``eval_hybrid.py:229-243``, ``eval_h
 Contract differences from the eager call (documented, not hidden):
   * the tensors of the returned ``outputs`` dict are the graph's static output buffers: they are overwritten by
     the next call with the same signature -- consume or clone them first (the reference's eval loops copy results
-    to the host right after each call, eval_hybrid_seq.py:210-236);
+    to the host right after each call, eval_hybrid_seq.py:210-236), or construct with ``clone_outputs=True``;
   * the returned memory ``(costs, cam_poses)`` ARE fresh tensors (one 157 MB device copy at cfg2 size): callers
     keep them across calls (memory_size = 2 windows in the ESTM protocol), so they must not alias each other;
   * memory volumes handed in as ``pre_costs`` are copied into static input buffers (one device copy per volume);
@@ -29,13 +29,16 @@ from .layers_op import PlanCache
 
 
 class GraphedForward:
-    def __init__(self, model, warmup=2):
+    def __init__(self, model, warmup=2, clone_outputs=False):
+        """``clone_outputs=True``: the returned ``outputs`` dict holds fresh tensors (18 device copies of [1,1,Hi,Wi] maps per
+        Joint call) instead of the graph's static output buffers -- a true drop-in for callers that keep outputs across calls."""
         self.model = model
         self.warmup = warmup
+        self.clone_outputs = clone_outputs
         self._graphs = {}
 
     def __getattr__(self, name):                 # normalise_images, matchingFeature, ndepths, ... of the wrapped model
-        if name in ("model", "warmup", "_graphs"):
+        if name in ("model", "warmup", "_graphs", "clone_outputs"):
             raise AttributeError(name)
         return getattr(self.model, name)
 
@@ -142,6 +145,8 @@ class GraphedForward:
                     st["cam"][name].copy_(t)
         st["graph_b"].replay()
         outputs, costs, cposes = st["out"]
+        if self.clone_outputs:
+            outputs = {k: v.clone() for k, v in outputs.items()}
         # memory handed back to the caller: fresh tensors (they outlive the next replay)
         key_t, value_t = costs["keys"][0], costs["values"][0]
         kv = getattr(value_t, "_estd_kv", None)
@@ -154,15 +159,24 @@ class GraphedForward:
 
 class GraphedModule:
     """hipGraph replay of a single-tensor-in / single-tensor-out module call with a static input shape (used for the
-    per-frame PSM matching-feature extraction of the streaming harness).  The returned tensor is a fresh clone."""
+    per-frame PSM matching-feature extraction of the streaming harness).  The returned tensor is a fresh clone.
+    ``owner``: the model whose weights the module reads -- a capture is keyed on its weights epoch (``load_state_dict`` /
+    ``.to()`` bump it and force a re-capture, as in GraphedForward) and keeps the packed-plan buffers of ``owner`` alive;
+    call ``invalidate()`` after editing parameters in place."""
 
-    def __init__(self, fn, warmup=2):
+    def __init__(self, fn, warmup=2, owner=None):
         self.fn = fn
         self.warmup = warmup
+        self.owner = owner
         self._graphs = {}
 
+    def invalidate(self):
+        self._graphs.clear()
+
     def __call__(self, x):
-        key = (tuple(x.shape), x.is_contiguous(memory_format=torch.channels_last))
+        from . import ops
+        key = (tuple(x.shape), x.is_contiguous(memory_format=torch.channels_last), ops.CONV2D_ARITH, ops.CONV2D_ALGO,
+               getattr(self.owner, "_estd_weights_epoch", 0))
         st = self._graphs.get(key)
         if st is None:
             st = {"x": x.clone(memory_format=torch.preserve_format)}
@@ -177,6 +191,10 @@ class GraphedModule:
             with torch.no_grad(), torch.cuda.graph(g, capture_error_mode="thread_local"):
                 st["y"] = self.fn(st["x"])
             st["graph"] = g
+            mods = self.owner.modules() if self.owner is not None else (self.fn.modules() if hasattr(self.fn, "modules") else [])
+            st["keepalive"] = [c._plans for c in (getattr(mod, "_cache", None) for mod in mods) if isinstance(c, PlanCache)]
+            for k in [k for k in self._graphs if k[:-1] == key[:-1]]:      # same call shape, older weights epoch
+                del self._graphs[k]
             self._graphs[key] = st
         st["x"].copy_(x)
         st["graph"].replay()

@@ -20,6 +20,9 @@ Align_Corners_Range = False
 
 
 # A/B switches, read once at import
+# ESTD_FAST_PATH=0: a model moved to a ROCm device keeps the plain module path (NCHW MIOpen 2D networks, one stream) instead of
+# switching the accelerators on by itself; the individual switches below / the use_*() methods still apply
+FAST_PATH = os.environ.get("ESTD_FAST_PATH", "1") == "1"
 FUSED_NORM = os.environ.get("ESTD_FUSED_NORM", "1") == "1"     # image normalisation + NHWC layout in one kernel
 MIX_GEMM = os.environ.get("ESTD_MIX_GEMM", "1") == "1"         # pre0 halves as two library GEMMs on NHWC features
 R50_HIP = os.environ.get("ESTD_R50_HIP", "1") == "1"           # ResNet stride-1 3x3 convolutions on the MFMA conv2d kernel
@@ -49,7 +52,8 @@ class DepthNetHybrid(nn.Module):
         self._cache = PlanCache()
         # "host" (default): camera matrices with the reference's own torch-CPU calls, bit-identical (estdepth_amd/camera.py);
         # "device": estd_cam_* kernels, no host synchronisation, boundary samples may flip vs the reference
-        self.camera_algebra = "host"
+        self._camera_algebra = "host"
+        self.CostRegNet.camera_algebra = "host"
         # weights epoch: bumped whenever parameters are replaced wholesale (load_state_dict, .to()/.cuda()); captured
         # hipGraphs (estdepth_amd.graph) bake packed-weight addresses in and re-capture when it changes
         self._estd_weights_epoch = 0
@@ -58,10 +62,41 @@ class DepthNetHybrid(nn.Module):
     def _bump_weights_epoch(self):
         self._estd_weights_epoch += 1
 
+    @property
+    def camera_algebra(self):
+        return self._camera_algebra
+
+    @camera_algebra.setter
+    def camera_algebra(self, mode):
+        if mode not in ("host", "device"):
+            raise RuntimeError("camera_algebra must be 'host' or 'device', got %r" % (mode,))
+        self._camera_algebra = mode
+        self.CostRegNet.camera_algebra = mode            # the decoder's stand-alone fallback follows the model
+
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
         self._estd_weights_epoch = getattr(self, "_estd_weights_epoch", 0) + 1
+        # A model that lands on a ROCm device runs the benchmarked configuration by default: NHWC 2D networks, PSM / ResNet
+        # stride-1 3x3 convolutions on the MFMA conv2d kernels, fused BN epilogues, semantic branch and stereo heads on a side
+        # stream.  Every one of them passes the same golden / oracle parity tests as the plain path (tests/test_gpu_*).
+        if FAST_PATH and not getattr(self, "_estd_accel_decided", False) and self.pre0[0].weight.is_cuda:
+            self._estd_accel_decided = True
+            self.accelerate()
         return out
+
+    def accelerate(self, enable=True):
+        """switch every accelerator of the 2D networks / stream layout on (the default on a ROCm device) or off (``plain_path()``)."""
+        self._estd_accel_decided = True
+        self.use_hip_psm(enable)
+        self.fuse_bn_2d(enable)
+        self.overlap_semantic_branch(enable)
+        self.use_channels_last_2d(enable)
+        return self
+
+    def plain_path(self):
+        """the plain module path: NCHW library convolutions for the 2D networks, separate BatchNorm passes, one stream (what
+        ``ESTD_FAST_PATH=0`` keeps).  The 3D hot path is the HIP library either way."""
+        return self.accelerate(False)
 
     # ------------------------------------------------------------------------------ packed weights
     def _plans(self):
@@ -86,8 +121,6 @@ class DepthNetHybrid(nn.Module):
         if self.camera_algebra == "device":
             return {"sweep": camera.sweep_projections_device(cam_poses.to(dev), cam_intr_stage1.to(dev)),
                     "vol": camera.volume_matrices_device([p.to(dev) for p in plist], T, cam_intr_stage1.to(dev)) if est else None}
-        if self.camera_algebra != "host":
-            raise RuntimeError("camera_algebra must be 'host' or 'device', got %r" % (self.camera_algebra,))
         return camera.forward_matrices(cam_poses, cam_intr_stage1, pre_cam_poses, est, dev)
 
     def _costvolumes(self, ref_mixes, src_mix_pairs, sweep, depth_values, P=None):

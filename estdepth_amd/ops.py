@@ -157,6 +157,18 @@ def homo_warping_chw(src_chw, proj12, depth_values, D):
     return out
 
 
+def homo_warping_px_chw(src_chw, proj12, depth_dhw):
+    """per-pixel depth hypotheses [D,H,W] (homo_utils.py:462)."""
+    if _use_torch():
+        return T().homo_warping_px(src_chw, proj12, depth_dhw)
+    C, H, W = src_chw.shape
+    D = depth_dhw.shape[0]
+    out = torch.empty((C, D, H, W), device=src_chw.device, dtype=torch.float32)
+    N.check(N.lib().estd_homo_warping_px(_p(_chk(src_chw, "src_fea")), _p(proj12), _p(_chk(depth_dhw, "depth_values")),
+                                         _p(out), C, D, H, W, _stream()), "estd_homo_warping_px")
+    return out
+
+
 def mix1x1(in_chw, w, bias):
     """[Cin,H,W] -> [H,W,Cout] channel mix."""
     if _use_torch():
@@ -407,6 +419,22 @@ def warp_volume_cdhw(vol, mats30, depth_values, depth_min, depth_interval):
     N.check(N.lib().estd_warp_volume(_p(_chk(vol, "feat_volume")), _p(mats30), _p(_chk(depth_values, "depth")),
                                      float(depth_min), float(depth_interval), _p(out), C, D, H, W, _stream()),
             "estd_warp_volume")
+    return out
+
+
+def warp_volume_ex_cdhw(vol, mats30, depth, depth_per_voxel, depth_min, depth_interval, disp_min=None, disp_interval=None,
+                        border=False, padding_value=0.0):
+    """every branch of the reference's warp_volume() signature (include/estd_hip.h::estd_warp_volume_ex)."""
+    use_disp = disp_min is not None
+    if _use_torch():
+        return T().warp_volume_ex(vol, mats30, depth, bool(depth_per_voxel), float(depth_min), float(depth_interval), use_disp,
+                                  float(disp_min or 0.0), float(disp_interval or 1.0), bool(border), float(padding_value))
+    C, D, H, W = vol.shape
+    out = torch.empty_like(vol)
+    o = N.WarpVolumeOpts(int(bool(depth_per_voxel)), int(use_disp), int(bool(border)), float(depth_min), float(depth_interval),
+                         float(disp_min or 0.0), float(disp_interval or 1.0), float(padding_value))
+    N.check(N.lib().estd_warp_volume_ex(_p(_chk(vol, "feat_volume")), _p(mats30), _p(_chk(depth, "depth")), ctypes.byref(o),
+                                        _p(out), C, D, H, W, _stream()), "estd_warp_volume_ex")
     return out
 
 

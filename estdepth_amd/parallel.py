@@ -61,9 +61,9 @@ def allgather_memory_bank_async(costs, cam_poses, group=None, stage=True):
         n, m = flat.numel(), psend.numel()
         recv_kv = torch.empty(world * n, device=flat.device, dtype=flat.dtype)
         recv_p = torch.empty(world * m, device=flat.device, dtype=flat.dtype)
-        dist.all_gather_into_tensor(recv_p, psend, group=group, async_op=True)          # same communicator: runs before the big one
+        work_p = dist.all_gather_into_tensor(recv_p, psend, group=group, async_op=True)
         work = dist.all_gather_into_tensor(recv_kv, flat, group=group, async_op=True)
-        pend = _PendingBank2(work, recv_kv.view(world, n), recv_p.view(world, m), meta)
+        pend = _PendingBank2((work_p, work), recv_kv.view(world, n), recv_p.view(world, m), meta)
         pend._send = (flat, psend, kv)  # keep the source alive until the collective has run
         return pend
     flat = kv.reshape(-1) if channels_last else torch.cat([value.reshape(-1), key.reshape(-1)])
@@ -78,12 +78,16 @@ def allgather_memory_bank_async(costs, cam_poses, group=None, stage=True):
 class _PendingBank2:
     """in-flight memory-bank all-gather without a staging copy: records and poses arrive in two receive buffers."""
 
-    def __init__(self, work, recv_kv, recv_p, meta):
-        self.work, self.recv_kv, self.recv_p, self.meta = work, recv_kv, recv_p, meta
+    def __init__(self, works, recv_kv, recv_p, meta):
+        self.work, self.recv_kv, self.recv_p, self.meta = works, recv_kv, recv_p, meta
 
     def wait(self):
         if self.work is not None:
-            self.work.wait()            # collectives of one communicator complete in order: the pose gather is done as well
+            # BOTH handles: RCCL completes the collectives of one communicator in order on one stream, but gloo runs async
+            # works on several threads with no completion order (and only a work's own wait() orders its copy-back with
+            # the current stream).  Waiting on the pose gather as well costs nothing on RCCL and is correct everywhere.
+            for w in self.work:
+                w.wait()
             self.work = None
         world, kv_shape, key_shape, value_shape, pose_shape, _ = self.meta
         from .hybrid_depth_decoder import kv_views

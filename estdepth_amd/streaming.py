@@ -24,7 +24,7 @@ class ESTMStream:
             from .graph import GraphedForward, GraphedModule
             if not isinstance(model, GraphedForward):
                 model = GraphedForward(model)
-            self._psm = GraphedModule(model.matchingFeature)
+            self._psm = GraphedModule(model.matchingFeature, owner=model.model)     # keyed on the model's weights epoch
         self.model = model
         self.lwindow = lwindow
         self.memory_size = memory_size

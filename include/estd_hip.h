@@ -75,6 +75,11 @@ int estd_cam_volume_mats(const float* pose_j16, const float* pose_i16, const flo
 int estd_homo_warping(const float* src_chw, const float* proj12, const float* depth_values,
                       float* out_cdhw, int C, int D, int H, int W, estd_stream_t stream);
 
+/* Same operator with PER-PIXEL depth hypotheses depth_dhw [D][H][W] (the reference's second accepted shape of depth_values,
+ * utils/homo_utils.py:462 "[B, Ndepth] o [B, Ndepth, H, W]", :480-481). */
+int estd_homo_warping_px(const float* src_chw, const float* proj12, const float* depth_dhw,
+                         float* out_cdhw, int C, int D, int H, int W, estd_stream_t stream);
+
 /* 1x1 channel mix of a 2D feature map, NCHW in -> HWC out: out[p][o] = sum_c w[o][c]*in[c][p] + b[o].
  * Used to push pre0 (model_hybrid.py:58,:93-94: 1x1x1 conv 64->32 + BN over cat[ref, warped]) in
  * front of the warp: pre0(cat[ref,warp(src)]) = mix_ref(ref)+shift + warp(mix_src(src)). Cin,Cout<=64 */
@@ -203,13 +208,29 @@ int estd_warp_volume(const float* vol_cdhw, const float* mats30, const float* de
                      float depth_min, float depth_interval, float* out_cdhw,
                      int C, int D, int H, int W, estd_stream_t stream);
 
+/* Every branch of the reference's warp_volume() signature (utils/homo_utils.py:240-279): depth per plane [D] or per VOXEL
+ * [D][H*W] (:246,:253), depth or disparity planes for the z normalisation (:187-190), padding_mode 'zeros' or 'border' -- the
+ * latter samples the volume whose outermost voxel layer is replaced by padding_value (:271-274, _set_vol_border :305-319). */
+typedef struct estd_warp_volume_opts {
+    int depth_per_voxel;      /* 0: depth[D], 1: depth[D][H*W] */
+    int use_disp;             /* 0: depth planes (depth_min, depth_interval), 1: disparity planes (disp_min, disp_interval) */
+    int border;               /* 0: padding_mode='zeros', 1: padding_mode='border' with padding_value */
+    float depth_min, depth_interval;
+    float disp_min, disp_interval;
+    float padding_value;
+} estd_warp_volume_opts;
+int estd_warp_volume_ex(const float* vol_cdhw, const float* mats30, const float* depth, const estd_warp_volume_opts* opts,
+                        float* out_cdhw, int C, int D, int H, int W, estd_stream_t stream);
+
 /* Fused warp_volume(K_j), warp_volume(V_j) for all sources j + epipolar attention
  * (hybrid_depth_decoder.py:233-246 + transformer/epipolar_transformer.py:62-73):
  *   xh[vox][0:16] = V_t ; xh[vox][16:32] = h = mean_j( softmax_j(K_t . warp(K_j)) * warp(V_j) ).
  * kv_src: HOST array of n_src device pointers to kv volumes (copied into the launch arguments);
  * mats_dev: device [n_src][30] from estd_cam_volume_mats.  n_src in 1..ESTD_MAX_ATTENTION_SOURCES
- * (more: ESTD_ERR_UNSUPPORTED).  The source boxes a 2x8x16 target brick samples are staged in LDS; the softmax over
- * the sources is evaluated in running (max-rescaled) form. */
+ * (more: ESTD_ERR_UNSUPPORTED).  Global gather of the eight corner records per source (LDS staging of the source boxes
+ * was measured slower and dropped, csrc/est_fusion.hip), 2x4x8 target bricks in XCD-contiguous order, 4 lanes per target
+ * voxel; instances specialised for 1..4 sources and generic ones for up to 8 / 16 (per-source correlation held in registers,
+ * max-subtracted softmax as the reference's). */
 int estd_warp_attention(const float* kv_target, const float* const* kv_src, const float* mats_dev,
                         int n_src, const float* depth_values, float depth_min, float depth_interval,
                         float* xh_out, int D, int H, int W, estd_stream_t stream);

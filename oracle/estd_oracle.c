@@ -50,7 +50,7 @@ void orc_set_num_threads(int n) {
 /*   the wrapper computes with LAPACK in fp32 exactly like torch.inverse.      */
 /* ------------------------------------------------------------------------- */
 void orc_homo_warping(const float* src, const float* rot /*3x3*/, const float* trans /*3*/,
-                      const float* depth_values /*D*/, int C, int H, int W, int D,
+                      const float* depth_values /*D, or [D][H*W] when per_pixel (:462)*/, int per_pixel, int C, int H, int W, int D,
                       float* out /*[C][D][H][W]*/)
 {
     const long HW = (long)H * W;
@@ -66,7 +66,7 @@ void orc_homo_warping(const float* src, const float* rot /*3x3*/, const float* t
                 float r1 = fmaf(rot[4], fy, rot[3] * fx) + rot[5];
                 float r2 = fmaf(rot[7], fy, rot[6] * fx) + rot[8];
                 /* * depth + trans  (:480-482) */
-                const float dv = depth_values[d];
+                const float dv = per_pixel ? depth_values[(long)d * HW + (long)y * W + x] : depth_values[d];
                 float p0 = r0 * dv + trans[0];
                 float p1 = r1 * dv + trans[1];
                 float p2 = r2 * dv + trans[2];
@@ -114,6 +114,8 @@ void orc_homo_warping(const float* src, const float* rot /*3x3*/, const float* t
 void orc_warp_volume(const float* vol /*[C][D][H][W]*/, const float* depth /*[D][H*W]*/,
                      const float* kinv /*3x3*/, const float* m /*4x4*/, const float* kmat /*3x3*/,
                      float depth_min, float depth_interval,
+                     int use_disp, float disp_min, float disp_interval,      /* :187-190 disparity planes */
+                     int border, float padding_value,                        /* :271-274 padding_mode='border' on _set_vol_border(vol) (:305-319) */
                      int C, int D, int H, int W, float* out /*[C][D][H][W]*/)
 {
     const long HW = (long)H * W;
@@ -144,33 +146,44 @@ void orc_warp_volume(const float* vol /*[C][D][H][W]*/, const float* depth /*[D]
                 /* normalize_pixel_coords_volume (:183-198) */
                 float xn = 2.0f * X / (float)(W - 1) - 1.0f;
                 float yn = 2.0f * Y / (float)(H - 1) - 1.0f;
-                float zn = 2.0f * ((Z - depth_min) / depth_interval) / (float)(D - 1) - 1.0f;
+                float zn = use_disp ? 2.0f * ((1.0f / (Z + 1e-10f) - disp_min) / disp_interval) / (float)(D - 1) - 1.0f   /* :190 */
+                                    : 2.0f * ((Z - depth_min) / depth_interval) / (float)(D - 1) - 1.0f;                  /* :187 */
+                /* the masks are applied whatever warp_volume's padding_mode is: normalize_pixel_coords_volume is called with
+                 * its own default padding_mode='zeros' (:262-269) */
                 if (xn > 1.0f || xn < -1.0f) xn = 2.0f;
                 if (yn > 1.0f || yn < -1.0f) yn = 2.0f;
                 if (zn > 1.0f || zn < -1.0f) zn = 2.0f;
-                /* 5-D grid_sample, 'bilinear' (= trilinear), zeros, align_corners=False */
+                /* 5-D grid_sample, 'bilinear' (= trilinear), align_corners=False; zeros, or border = ATen clip_coordinates
+                 * min(size - 1, max(i, 0)) after the un-normalisation */
                 float ix = ((xn + 1.0f) * (float)W - 1.0f) / 2.0f;
                 float iy = ((yn + 1.0f) * (float)H - 1.0f) / 2.0f;
                 float iz = ((zn + 1.0f) * (float)D - 1.0f) / 2.0f;
+                if (border) {
+                    ix = fminf((float)(W - 1), fmaxf(ix, 0.0f));
+                    iy = fminf((float)(H - 1), fmaxf(iy, 0.0f));
+                    iz = fminf((float)(D - 1), fmaxf(iz, 0.0f));
+                }
                 float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
                 int x0 = (int)fx0, y0 = (int)fy0, z0 = (int)fz0;
                 float tx = ix - fx0, ty = iy - fy0, tz = iz - fz0;
                 int nanc = !(ix == ix) || !(iy == iy) || !(iz == iz);
                 float wgt[8];
                 long off[8];
-                int ok[8];
+                int ok[8], edge[8];
                 for (int k = 0; k < 8; ++k) {
                     int dx = k & 1, dy = (k >> 1) & 1, dz = (k >> 2) & 1;
                     int xx = x0 + dx, yy = y0 + dy, zz = z0 + dz;
                     ok[k] = !nanc && xx >= 0 && xx < W && yy >= 0 && yy < H && zz >= 0 && zz < D;
                     wgt[k] = (dx ? tx : 1.0f - tx) * (dy ? ty : 1.0f - ty) * (dz ? tz : 1.0f - tz);
                     off[k] = ok[k] ? ((long)zz * HW + (long)yy * W + xx) : 0;
+                    /* _set_vol_border: the outermost voxel layer of the volume holds padding_value (:311-317) */
+                    edge[k] = border && (xx == 0 || xx == W - 1 || yy == 0 || yy == H - 1 || zz == 0 || zz == D - 1);
                 }
                 for (int c = 0; c < C; ++c) {
                     const float* s = vol + (long)c * DHW;
                     float v = 0.0f;
                     for (int k = 0; k < 8; ++k)
-                        if (ok[k]) v += s[off[k]] * wgt[k];
+                        if (ok[k]) v += (edge[k] ? padding_value : s[off[k]]) * wgt[k];
                     out[(long)c * DHW + (long)d * HW + (long)y * W + x] = v;
                 }
             }

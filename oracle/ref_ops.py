@@ -91,11 +91,14 @@ def sweep_proj(cam_poses, cam_intr, ref, src):
 
 # ----------------------------------------------------------------------------- ops
 def homo_warping_proj(src_fea, proj, depth_values):
-    """utils/homo_utils.py:470-504 given proj = src_proj @ inverse(ref_proj) [B,4,4]."""
+    """utils/homo_utils.py:470-504 given proj = src_proj @ inverse(ref_proj) [B,4,4]; depth_values [B,D], [B,D,1,1] or per-pixel
+    hypotheses [B,D,H,W] (:462)."""
     src_fea = np.asarray(src_fea, np.float32)
     B, C, H, W = src_fea.shape
-    dv = np.asarray(depth_values, np.float32).reshape(B, -1)
-    D = dv.shape[1]
+    depth_values = np.asarray(depth_values, np.float32)
+    D = depth_values.shape[1]
+    dv = depth_values.reshape(B, -1)
+    per_pixel = int(dv.shape[1] == D * H * W and H * W > 1)
     out = np.empty((B, C, D, H, W), np.float32)
     for b in range(B):
         rot, rp = _c(proj[b][:3, :3])
@@ -103,7 +106,7 @@ def homo_warping_proj(src_fea, proj, depth_values):
         s, sp = _c(src_fea[b])
         d, dp = _c(dv[b])
         o = out[b]
-        lib().orc_homo_warping(sp, rp, tp, dp, C, H, W, D, o.ctypes.data_as(_f))
+        lib().orc_homo_warping(sp, rp, tp, dp, per_pixel, C, H, W, D, o.ctypes.data_as(_f))
     return out
 
 
@@ -120,10 +123,12 @@ def set_id_grid(h, w):
     return np.stack([j, i, np.ones((h, w), np.float32)], 0)[None]
 
 
-def warp_volume(feat_volume, depth, pose, cam_intr, pixel_coords, depth_min, depth_interval):
-    """utils/homo_utils.py:240-279 (padding zeros, trilinear).  feat_volume [N,C,D,H,W];
-    depth [N,1,D,H*W]; pose [N,4,4]; cam_intr [N,3,3].  pixel_coords is the reference's cached
-    (x,y,1) grid (set_id_grid); the restatement regenerates it from indices."""
+def warp_volume(feat_volume, depth, pose, cam_intr, pixel_coords, depth_min, depth_interval, padding_mode="zeros", padding_value=0.0,
+                disp_min=None, disp_interval=None):
+    """utils/homo_utils.py:240-279 (trilinear; padding zeros or border + padding value; depth or disparity planes).
+    feat_volume [N,C,D,H,W]; depth [N,1,D,H*W] (per voxel); pose [N,4,4]; cam_intr [N,3,3].  pixel_coords is the reference's
+    cached (x,y,1) grid (set_id_grid); the restatement regenerates it from indices."""
+    assert padding_mode in ("zeros", "border")
     feat_volume = np.asarray(feat_volume, np.float32)
     N, C, D, H, W = feat_volume.shape
     depth = np.asarray(depth, np.float32).reshape(N, D, H * W)
@@ -135,6 +140,8 @@ def warp_volume(feat_volume, depth, pose, cam_intr, pixel_coords, depth_min, dep
         v, vp = _c(feat_volume[b])
         dd, ddp = _c(depth[b])
         lib().orc_warp_volume(vp, ddp, kinvp, mp, kp, ctypes.c_float(depth_min), ctypes.c_float(depth_interval),
+                              int(disp_min is not None), ctypes.c_float(disp_min or 0.0), ctypes.c_float(disp_interval or 1.0),
+                              int(padding_mode == "border"), ctypes.c_float(padding_value),
                               C, D, H, W, out[b].ctypes.data_as(_f))
     return out
 

@@ -51,6 +51,48 @@ def g3_case():
     return vol, depth, rel, K[None], depth_min, interval
 
 
+# ---------------------------------------------------------------- G12 level-1 signatures the hybrid callers do not use
+def g12_homo_case():
+    """homo_warping with PER-PIXEL depth hypotheses [B, Ndepth, H, W] (homo_utils.py:462,:480-481)."""
+    C, H, W, D = 4, 12, 16, 8
+    name, src, sp, rp, dv = g1_cases()[0][0], _t(121, 1, C, H, W), None, None, None
+    K = torch.from_numpy(synth.intrinsics(H * 4, W * 4)).clone()
+    K[:2] *= 0.25
+    def proj(v):
+        e = torch.inverse(torch.from_numpy(synth.camera_pose(v, motion=2.0)))
+        p = e.clone()
+        p[:3, :4] = K @ e[:3, :4]
+        return p[None]
+    planes = (torch.arange(D, dtype=torch.float32) * ((10.0 - 0.1) / (D - 1)) + 0.1).view(1, D, 1, 1)
+    depth = planes * (1.0 + 0.05 * torch.tanh(_t(122, 1, D, H, W)))
+    return src, proj(0), proj(1), depth.contiguous()
+
+
+def g12_volume_cases():
+    """warp_volume (homo_utils.py:240-279) beyond the hybrid path's call: per-VOXEL depth (:246,:253), padding_mode='border' with a
+    padding value (:271-274, :305-319), disparity planes (:187-190).  D = 64: the reference reads depth[:, 0, 62] (Q6)."""
+    C, D, H, W = 4, 64, 12, 16
+    vol = _t(131, 1, C, D, H, W)
+    K = torch.from_numpy(synth.intrinsics(H * 4, W * 4)).clone()
+    K[:2] *= 0.25
+    pi = torch.from_numpy(synth.camera_pose(1, motion=1.5))
+    pj = torch.from_numpy(synth.camera_pose(3, motion=1.5))
+    rel = (pj @ torch.inverse(pi))[None]
+    dmin, dmax = 0.1, 10.0
+    dint = (dmax - dmin) / (D - 1)
+    planes = (torch.arange(D, dtype=torch.float32) * dint + dmin).view(1, D, 1, 1)
+    per_plane = planes.repeat(1, 1, H, W).view(1, 1, D, H * W)
+    per_voxel = (planes * (1.0 + 0.03 * torch.tanh(_t(132, 1, D, H, W)))).reshape(1, 1, D, H * W).contiguous()
+    disp_min, disp_max = 1.0 / 10.0, 1.0 / 0.5
+    disp_int = (disp_max - disp_min) / (D - 1)
+    disp_depth = (1.0 / (torch.arange(D, dtype=torch.float32) * disp_int + disp_min)).view(1, D, 1, 1).repeat(1, 1, H, W).view(1, 1, D, H * W)
+    base = dict(feat_volume=vol, pose=rel, cam_intr=K[None], depth_min=dmin, depth_interval=dint)
+    return {"per_voxel": dict(base, depth=per_voxel),
+            "border": dict(base, depth=per_plane, padding_mode="border", padding_value=0.5),
+            "border_per_voxel": dict(base, depth=per_voxel, padding_mode="border", padding_value=-1.25),
+            "disp": dict(base, depth=disp_depth, disp_min=disp_min, disp_interval=disp_int)}
+
+
 # ---------------------------------------------------------------- G4 EpipolarTransformer
 def g4_case(n_views):
     C, D, H, W = 16, 8, 12, 16

@@ -1,0 +1,99 @@
+"""GPU, two ranks on the one test device (gloo): the gathered memory bank is CONSUMED (the protocol of
+eval_hybrid_seq.py:102-115,185-193).  Rank 0 runs windows 0 and 1 of the G8 stream, rank 1 windows 0 and 1 of another stream;
+after every window the ranks all-gather {K, V_fused, pose}.  Rank 1 then CONTINUES RANK 0's STREAM: window 2 from the gathered
+bank only.  Its outputs must equal the single-rank run's window 2 (the G8 golden vectors of the reference), and on every rank
+the received shard of the rank itself must equal the tensors it sent bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    import sys
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fixtures_spec as S
+        from estdepth_amd import DepthNetHybrid, parallel, synth
+        torch.backends.cudnn.allow_tf32 = False
+        torch.backends.cuda.matmul.allow_tf32 = False
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        m = DepthNetHybrid(ndepths=64, depth_min=0.1, depth_max=10.0, resnet=18, IF_EST_transformer=True).eval()
+        synth.fill_state_dict(m, seed=2, head_gain=1.0)
+        m = m.to(dev)
+        # every rank owns a stream: rank 0 the G8 stream, rank 1 another one (as the 8 sequences of configs[3])
+        imgs, poses, intr, sample = S.e2e_inputs(6, S.E2E_HI, S.E2E_WI, seed=1003 + 10 * rank)
+        imgs, poses, intr = imgs.to(dev), poses.to(dev), intr.to(dev)
+        smp = lambda sample_, sl: {k: v[:, sl] for k, v in sample_.items()}
+        own, banks, ok = [], [], True
+        for w in range(2):
+            sl = slice(w, w + 3)
+            pre_costs = {"keys": [c["keys"][0] for c, _ in own], "values": [c["values"][0] for c, _ in own]} if own else None
+            pre_poses = [p[0] for _, p in own] if own else None
+            with torch.no_grad():
+                _, costs, cposes = m(imgs[:, sl], poses[:, sl], intr, smp(sample, sl), pre_costs, pre_poses, mode="val")
+            own.append((costs, cposes))
+            bank = parallel.allgather_memory_bank_async(costs, cposes, stage=(w == 0)).wait()        # both flavours of the collective
+            torch.cuda.synchronize()
+            ok = ok and len(bank) == world
+            ok = ok and torch.equal(bank[rank][0]["keys"][0], costs["keys"][0]) and torch.equal(bank[rank][0]["values"][0], costs["values"][0])
+            ok = ok and torch.equal(bank[rank][1][0], cposes[0])
+            banks.append(bank)
+        res = {"own_shard_bit_equal": bool(ok)}
+        if rank == 1:
+            # continue RANK 0's stream: window 2 = frames 2..4 of the G8 sequence, memory = rank 0's windows 0 and 1 as gathered
+            g_imgs, g_poses, g_intr, g_sample = S.e2e_inputs(6, S.E2E_HI, S.E2E_WI, seed=1003)
+            g_imgs, g_poses, g_intr = g_imgs.to(dev), g_poses.to(dev), g_intr.to(dev)
+            pre_costs = {"keys": [banks[0][0][0]["keys"][0], banks[1][0][0]["keys"][0]],
+                         "values": [banks[0][0][0]["values"][0], banks[1][0][0]["values"][0]]}
+            pre_poses = [banks[0][0][1][0], banks[1][0][1][0]]
+            with torch.no_grad():
+                out, costs, cposes = m(g_imgs[:, 2:5], g_poses[:, 2:5], g_intr, smp(g_sample, slice(2, 5)), pre_costs, pre_poses, mode="val")
+            g = np.load(os.path.join(ROOT, "tests", "golden", "g8_estm_stream.npz"))
+            worst = 0.0
+            for k, v in out.items():
+                name = "w2|" + "|".join(str(x) for x in k)
+                if name in g.files:
+                    worst = max(worst, float(np.abs(v.cpu().numpy() - g[name]).max()))
+                    res["compared"] = res.get("compared", 0) + 1
+            res["worst_vs_g8_window2"] = worst
+            res["pose_equal"] = bool(np.array_equal(cposes[0].cpu().numpy(), g["w2|pose"]))
+        ret[rank] = res
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_rank1_continues_rank0_stream_from_the_gathered_bank():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a ROCm device")
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert ret[0]["own_shard_bit_equal"] and ret[1]["own_shard_bit_equal"], dict(ret)
+    r1 = ret[1]
+    assert r1["compared"] >= 4 and r1["pose_equal"], r1
+    assert r1["worst_vs_g8_window2"] < 1e-4, r1                 # the tolerance of test_estm_stream (depth within 1e-4 of the reference)

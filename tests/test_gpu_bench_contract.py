@@ -34,13 +34,48 @@ def test_bench_single_gpu_line():
     d = _last_json(out.stdout)
     assert REQUIRED <= set(d) and "cpu_baseline" in d
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["workload"].startswith("cfg1")
-    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] <= 1
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    runs = d["cpu_baseline"]["all_runs"]                 # 8 threads and the box's default; the headline entry is the faster one
+    assert len(runs) == 2 and d["cpu_baseline"]["value"] == max(r["value"] for r in runs)
     assert d["parity"]["within_tolerance"] and max(d["parity"]["max_abs_depth_diff_vs_oracle_m"].values()) <= 1e-4
     assert {"homo_warp_costvol", "softargmin"} <= set(d["roofline"]["hbm_kernels"])
     assert "conv3d:32->32" in d["roofline"]["mfma_kernels"]
     assert d["dtype"] == "f32" and d["config"]["conv3d_arith"] == "f32"          # the headline is native fp32 MFMA
     assert d["alt_arith"]["conv3d_arith"] == "bf16x3" and d["alt_arith"]["value"] > 0
+
+
+def test_bench_headline_workload_roofline_fields_are_hardware_fractions():
+    """BASELINE configs[1] (the workload `value` is quoted on), 3 steps: `frac` is the EXECUTED fraction of the fp32 MFMA peak
+    (<= 1 -- the algorithmic rate of a Winograd kernel is above the peak and lives in its own field), the dominant kernel's
+    launches fit inside the step, the stand-alone HBM-kernel figures are present."""
+    out = subprocess.run([sys.executable, "bench.py", "--workload", "joint", "--steps", "3", "--warmup", "1", "--no-alt", "--no-cpu-baseline"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900)
+    d = _last_json(out.stdout)
+    r = d["roofline"]
+    assert REQUIRED <= set(d) and d["config"]["workload"].startswith("cfg2")
+    assert 0 < r["frac"] <= 1 and r["achieved"] <= r["peak"] and abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3
+    assert r["algorithmic_tflops"] >= r["achieved"] and abs(r["achieved"] - r["algorithmic_tflops"] * r["executed_factor"]) < 0.05
+    assert r["launches_per_step"] * r["avg_launch_ms"] <= d["ms_per_step"]
+    for k in r["mfma_kernels"].values():
+        assert 0 < k["frac"] <= 1 and k["achieved_tflops"] <= r["peak"]
+    alone = r["hbm_kernels_standalone"]
+    assert {"homo_warp_costvol", "warp_attention N=3", "gru_blend", "softargmin_up (T=3)"} <= set(alone)
+    assert all(0 < v["frac"] <= 1 for v in alone.values())
+    assert d["value"] > 50.0                               # north_star: >= 50 depth frames/s on one MI355X
+
+
+def test_bench_world_size_one_rccl_communicator():
+    """ESTD_FORCE_DIST=1: the N > 1 code against real RCCL on the one GPU of the test box -- nccl process group with device_id,
+    channel cap, CU reserve, the asynchronous all-gather overlapped with the next step, the own-shard bit-equality check."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["ESTD_FORCE_DIST"] = "1"
+    out = subprocess.run([sys.executable, "bench.py", "--workload", "cfg1", "--steps", "3", "--warmup", "1", "--no-alt", "--no-cpu-baseline"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    d = _last_json(out.stdout)
+    ag = d["config"]["allgather"]
+    assert d["n_gpus"] == 1 and ag["backend"].startswith("RCCL") and ag["own_shard_bit_equal"] is True
+    assert ag["ms_alone"] > 0 and ag["ms_per_step_without_collective"] > 0 and "CUs left free" in d["config"]["parallelism"]
 
 
 def _check_two_ranks(d):
@@ -49,6 +84,7 @@ def _check_two_ranks(d):
     assert len(d["config"]["per_rank_ms_per_step"]) == 2
     ag = d["config"]["allgather"]
     assert ag["bytes_sent_per_rank"] == 4 * (2 * 16 * 16 * 32 * 40 + 16) and ag["bus_gbs_per_rank"] > 0
+    assert ag["own_shard_bit_equal"] is True             # the gathered bank equals the owner's tensors bit for bit
 
 
 def test_bench_gpus_flag_launches_the_ranks_itself():

@@ -5,6 +5,7 @@ BASELINE.json configs[1] (cfg2): seq_len=5, 480x640, D=64, ResNet-50, Joint-mode
       side-stream semantic branch and heads, hipGraph replay) vs the plain eager path: all outputs within 5e-5;
   (b) plain path and accelerated path vs the CPU ORACLE on the same inputs: every ("depth", t, s) within 1e-4 abs
       (north_star tolerance) -- one oracle forward at full size, ~1 min on the box's host cores.
+BASELINE.json configs[2] (cfg3): the steady-state ESTM window at 480x640, D=64, ResNet-50 vs the oracle (1e-4).
 BASELINE.json configs[4] (cfg5): 960x1280, D=128 ESTM steady-state window (2 memory volumes)
   (d) the whole window vs the oracle (1e-4), the fused warp+attention identity / permutation properties and the
       GroupNorm statistics of the ConvGRU against fp64 torch at 128x240x320 (157 M-element reductions).
@@ -62,7 +63,7 @@ def cfg2_joint():
     dev = torch.device(DEV)
     plain = DepthNetHybrid(ndepths=64, depth_min=0.1, depth_max=10.0, resnet=50, IF_EST_transformer=True)
     synth.fill_state_dict(plain, seed=0, head_gain=1.0)
-    plain = plain.eval().to(dev)
+    plain = plain.eval().to(dev).plain_path()                        # NCHW library 2D networks, one stream: no accelerator
     imgs, poses, intr, sample = B.make_inputs("joint", 0, dev)
     sl, frames, pre_costs, pre_poses = B.steady_state(plain, "joint", imgs, poses, intr, sample)      # call 1, plain path
     x_imgs, x_poses = imgs[:, sl].contiguous(), poses[:, sl].contiguous()
@@ -113,7 +114,34 @@ def test_semantic_encoder_resnet50_fused_path_vs_torch_cpu():
     for r, o in zip(ref, got):
         assert tuple(r.shape) == tuple(o.shape)
         scale = float(r.abs().max())
-        assert float((o.cpu() - r).abs().max()) < 2e-4 * max(scale, 1.0), (tuple(r.shape), scale)
+        # 2e-5 x the map's range: the fused path re-associates BN into the GEMM weights and runs ~50 fp32 convolutions of K up to
+        # 4608 on a different kernel than torch's CPU oneDNN -- both sides are fp32 roundoff, neither is the reference value
+        assert float((o.cpu() - r).abs().max()) < 2e-5 * max(scale, 1.0), (tuple(r.shape), scale, float((o.cpu() - r).abs().max()))
+
+
+def test_cfg3_estm_window_matches_the_oracle():
+    """BASELINE.json configs[2] at FULL size: the steady-state ESTM window (3 frames, 2 memory volumes, 480x640, D=64, ResNet-50)
+    through every accelerator + hipGraph replay vs the CPU oracle on the same inputs and the same carried memory."""
+    import bench as B
+    from estdepth_amd.graph import GraphedForward
+    dev = torch.device(DEV)
+    model = B.build_model("estm", dev)
+    imgs, poses, intr, sample = B.make_inputs("estm", 0, dev)
+    sl, frames, pre_costs, pre_poses = B.steady_state(model, "estm", imgs, poses, intr, sample)
+    assert frames == 1 and len(pre_costs["keys"]) == 2
+    x_imgs, x_poses = imgs[:, sl].contiguous(), poses[:, sl].contiguous()
+    x_sample = {k: v[:, sl] for k, v in sample.items()}
+    fwd = GraphedForward(model)
+    with torch.no_grad():
+        for _ in range(2):                                          # capture, then a pure replay
+            out, costs, cposes = fwd(x_imgs, x_poses, intr, x_sample, pre_costs, list(pre_poses), mode="val")
+    out = {k: v.clone() for k, v in out.items()}
+    torch.cuda.synchronize()
+    ref = _oracle_forward("estm", x_imgs, x_poses, intr, pre_costs, pre_poses)
+    assert len(out) == 6 and tuple(out[("depth", 0, 0)].shape) == (1, 1, 480, 640)
+    for k, v in out.items():
+        d = float(np.abs(_np(v) - ref[k]).max())
+        assert np.isfinite(d) and d < (TOL_DEPTH if k[0] == "depth" else 5e-5), (k, d)
 
 
 @pytest.fixture(scope="module")

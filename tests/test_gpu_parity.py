@@ -34,9 +34,13 @@ def _g(golden_dir, name):
     return np.load(os.path.join(golden_dir, name))
 
 
-def _vol_close(out, ref, flip_frac=5e-4, med=5e-6, big=1e-4):
+def _vol_close(out, ref, flip_frac=0.0, med=5e-6, big=5e-5):
+    """Sample coordinates are bit-identical to the reference's (host camera algebra + the reference's rounding sequence in the
+    kernels), so NO sample may flip across the |norm| > 1 mask: EVERY element within `big` (a flipped sample moves
+    a value by a texel's worth, 0.1 .. 1 on these unit-variance volumes; what remains is the interpolation-weight rounding of the
+    two implementations on |values| up to ~4.5: measured max 2.2e-5)."""
     d = np.abs(np.asarray(out, np.float64) - np.asarray(ref, np.float64))
-    assert (d > big).mean() < flip_frac, ("flipped fraction", float((d > big).mean()), float(d.max()))
+    assert (d > big).mean() <= flip_frac, ("flipped fraction", float((d > big).mean()), float(d.max()))
     assert np.median(d) < med, float(np.median(d))
 
 
@@ -75,6 +79,28 @@ def test_warp_volume_vs_reference_and_oracle(golden_dir):
     _vol_close(out, g["out"])
     assert abs((out == 0).mean() - float(g["zero_frac"])) < 1e-3
     _vol_close(out, O.warp_volume(vol.numpy(), depth.numpy(), rel.numpy(), K.numpy(), None, dmin, dint))
+
+
+def test_level1_signatures_the_hybrid_callers_do_not_use(golden_dir):
+    """G12: per-pixel depth hypotheses in homo_warping (homo_utils.py:462,:480-481); per-voxel depth, padding_mode='border' with a
+    padding value and disparity planes in warp_volume (:246,:253,:187-190,:271-274) -- against the reference's outputs AND the
+    oracle, zero flipped samples."""
+    from estdepth_amd import homo_warping, warp_volume
+    from oracle import ref_ops as O
+    g = _g(golden_dir, "g12_level1_signatures.npz")
+    src, sp, rp, depth = S.g12_homo_case()
+    out = homo_warping(src.to(DEV), sp.to(DEV), rp.to(DEV), depth.to(DEV)).cpu().numpy()
+    _vol_close(out, g["homo_per_pixel"])
+    _vol_close(out, O.homo_warping(src.numpy(), sp.numpy(), rp.numpy(), depth.numpy()))
+    for name, kw in S.g12_volume_cases().items():
+        a = dict(kw)
+        dev = lambda t: t.to(DEV) if isinstance(t, torch.Tensor) else t
+        out = warp_volume(dev(a.pop("feat_volume")), dev(a.pop("depth")), dev(a.pop("pose")), dev(a.pop("cam_intr")), None,
+                          a.pop("depth_min"), a.pop("depth_interval"), **a).cpu().numpy()
+        _vol_close(out, g["vol_" + name])
+    with pytest.raises(RuntimeError, match="padding_mode"):
+        warp_volume(kw["feat_volume"].to(DEV), kw["depth"].to(DEV), kw["pose"].to(DEV), kw["cam_intr"].to(DEV), None, 0.1, 0.1,
+                    padding_mode="reflection")
 
 
 def test_warp_volume_small_depth_count():
@@ -246,11 +272,17 @@ def _stream_model():
     return m.to(DEV)
 
 
-def test_estm_stream(golden_dir):
-    """eval_hybrid_seq.py:160-193: sliding windows of 3 frames, memory of 2 (configs[2] protocol, small size)."""
+@pytest.mark.parametrize("path", ["default", "plain"])
+def test_estm_stream(golden_dir, path):
+    """eval_hybrid_seq.py:160-193: sliding windows of 3 frames, memory of 2 (configs[2] protocol, small size).
+    ``default`` = what DepthNetHybrid(...).to(device) runs (every accelerator on), ``plain`` = plain_path() (ESTD_FAST_PATH=0)."""
     g = _g(golden_dir, "g8_estm_stream.npz")
     g11 = _g(golden_dir, "g11_estm_logits.npz")
     m = _stream_model()
+    assert m._channels_last_2d and m._overlap_semantic          # the fast path is the default on a ROCm device
+    if path == "plain":
+        m.plain_path()
+        assert not m._channels_last_2d and not m._overlap_semantic
     m.CostRegNet.keep_logits = True
     imgs, poses, intr, sample = S.e2e_inputs(6, S.E2E_HI, S.E2E_WI, seed=1003)
     imgs, poses, intr = imgs.to(DEV), poses.to(DEV), intr.to(DEV)
@@ -339,7 +371,7 @@ def test_graph_replay_matches_eager():
 def test_channels_last_2d_backbones_keep_parity(golden_dir):
     """use_channels_last_2d() only changes the MIOpen layout of the 2D backbones: golden parity must hold."""
     g = _g(golden_dir, "g8_estm_stream.npz")
-    m = _stream_model().use_channels_last_2d()
+    m = _stream_model().plain_path().use_channels_last_2d()
     imgs, poses, intr, sample = S.e2e_inputs(6, S.E2E_HI, S.E2E_WI, seed=1003)
     imgs, poses, intr = imgs.to(DEV), poses.to(DEV), intr.to(DEV)
     mem_costs, mem_poses = [], []

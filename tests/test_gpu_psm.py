@@ -113,7 +113,8 @@ def test_overlapped_semantic_branch_and_all_accelerators_match_plain_path():
         m = DepthNetHybrid(ndepths=64, depth_min=0.1, depth_max=10.0, resnet=18, IF_EST_transformer=True).eval()
         synth.fill_state_dict(m, seed=2, head_gain=1.0)
         return m.to(DEV)
-    plain, fast = make(), make().use_hip_psm().fuse_bn_2d().overlap_semantic_branch()
+    plain, fast = make().plain_path(), make()            # a model on a ROCm device runs every accelerator by default
+    assert fast._channels_last_2d and fast._overlap_semantic and not plain._channels_last_2d and not plain._overlap_semantic
     gf = GraphedForward(fast)
     imgs, poses, intr, sample = S.e2e_inputs(8, S.E2E_HI, S.E2E_WI, seed=1004)
     imgs, poses, intr = imgs.to(DEV), poses.to(DEV), intr.to(DEV)

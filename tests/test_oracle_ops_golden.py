@@ -36,6 +36,24 @@ def test_g3_warp_volume(golden_dir):
     assert abs((out == 0).mean() - float(g["zero_frac"])) < 1e-3
 
 
+def test_g12_level1_signatures_the_hybrid_path_does_not_use(golden_dir):
+    """per-pixel depth hypotheses in homo_warping (homo_utils.py:462,:480-481); per-voxel depth, padding_mode='border' with a
+    padding value and disparity planes in warp_volume (:246,:253,:187-190,:271-274,:305-319) against the reference's outputs."""
+    g = _load(golden_dir, "g12_level1_signatures.npz")
+    src, sp, rp, depth = S.g12_homo_case()
+    out = O.homo_warping(src.numpy(), sp.numpy(), rp.numpy(), depth.numpy())
+    d = np.abs(out - g["homo_per_pixel"])
+    assert d.max() < 2e-5 and (g["homo_per_pixel"] != 0).mean() > 0.2, float(d.max())
+    for name, kw in S.g12_volume_cases().items():
+        a = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in kw.items()}
+        out = O.warp_volume(a.pop("feat_volume"), a.pop("depth"), a.pop("pose"), a.pop("cam_intr"), None, a.pop("depth_min"),
+                            a.pop("depth_interval"), **a)
+        ref = g["vol_" + name]
+        d = np.abs(out - ref)
+        assert d.max() < 2e-5, (name, float(d.max()), float((d > 1e-4).mean()))
+        assert (ref != 0).mean() > 0.1, name
+
+
 def test_g4_epipolar_transformer(golden_dir):
     from estdepth_amd import synth
     from estdepth_amd.epipolar_transformer import EpipolarTransformer

@@ -80,6 +80,23 @@ def gen_metrics():
     print("G10 done")
 
 
+def gen_g12(hu):
+    """G12: the level-1 signatures the hybrid callers never use -- per-pixel depth hypotheses in homo_warping, per-voxel depth /
+    border padding / disparity planes in warp_volume."""
+    out = {}
+    src, sp, rp, depth = S.g12_homo_case()
+    out["homo_per_pixel"] = npy(hu.homo_warping(src, sp, rp, depth))
+    for name, kw in S.g12_volume_cases().items():
+        vol = kw["feat_volume"]
+        D, H, W = vol.shape[2:]
+        grid = hu.set_id_grid(H, W).view(1, 3, 1, H * W).repeat(1, 1, D, 1)
+        args = dict(kw)
+        out["vol_" + name] = npy(hu.warp_volume(args.pop("feat_volume"), args.pop("depth"), args.pop("pose"), args.pop("cam_intr"), grid,
+                                                args.pop("depth_min"), args.pop("depth_interval"), **args))
+    np.savez(os.path.join(OUT, "g12_level1_signatures.npz"), **out)
+    print("G12 done", {k: float(np.abs(v).mean()) for k, v in out.items()})
+
+
 def main():
     if "--metrics-only" in sys.argv:
         os.makedirs(OUT, exist_ok=True)
@@ -88,6 +105,9 @@ def main():
     torch.manual_seed(0)
     hu, et, hd, mh = import_reference()
     os.makedirs(OUT, exist_ok=True)
+    if "--g12-only" in sys.argv:
+        return gen_g12(hu)
+    gen_g12(hu)
 
     # G1 homo_warping
     out = {}
