@@ -149,6 +149,9 @@ def _cpu_model_name():
     return "unknown"
 
 
+_DEFAULT_TORCH_THREADS = [0]        # torch's own default (= the physical cores of the box), recorded before anything changes it
+
+
 def cpu_baseline(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses, gpu_outputs, frames):
     """The CPU oracle (C/OpenMP restatement of the reference + the product's plain 2D nn.Modules on torch-CPU = a
     "port") timed on ONE full step of the same workload on the box's host cores: the whole DepthNetHybrid.forward of the
@@ -160,7 +163,7 @@ def cpu_baseline(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses,
     from oracle import ref_model as M, ref_ops as O
     from oracle.nets2d import Nets2D, sd_numpy
     ncores = os.cpu_count() or 1
-    threads = torch.get_num_threads() if threads <= 0 else min(threads, ncores)
+    threads = _DEFAULT_TORCH_THREADS[0] if threads <= 0 else min(threads, ncores)
     O.set_num_threads(threads)
     torch.set_num_threads(threads)
     D = WORKLOADS[workload][3]
@@ -269,6 +272,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    _DEFAULT_TORCH_THREADS[0] = torch.get_num_threads()
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
     oversub = int(os.environ.get("ESTD_OVERSUBSCRIBED", "0"))
@@ -552,6 +556,11 @@ def main():
             line["cpu_baseline"] = dict(best)
             line["cpu_baseline"]["all_runs"] = [{"cores": b["cores"], "value": b["value"], "wall_s": b["wall_s"]} for b in runs]
             line["parity"] = parity
+        try:                               # RCCL's banner sits in the C stdio buffer of a redirected stdout: flush it so that the JSON
+            import ctypes                  # line is the LAST line of the output
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(line), flush=True)
     if dist_on:
         dist.barrier()

@@ -33,9 +33,24 @@
 #include "estd_hip.h"
 #include "estd_common.h"
 
+#ifndef ESTD_W2PRIO
+#define ESTD_W2PRIO 0   // 1: per-step alternating s_setprio between the two waves of a SIMD; 2: static priority 1 for waves 4..7
+#endif
 #ifndef ESTD_W2ABL
 #define ESTD_W2ABL 0    // timing ablations only (results are wrong): 1 no output stores, 2 no slice writes, 8 no weight stream,
 #endif                  // 16 no next-plane prefetch, 128 no row transform (raw rows as operands)
+
+#ifdef ESTD_W2TIME
+// debug build only: s_memtime stamps of waves 0 and 4 of workgroup 0 at fixed points of its first tiles, written over the
+// GroupNorm partial-sum buffer (tools/wino2_timeline.py); perturbs the timing a little (every stamp drains lgkmcnt)
+#define W2STAMP(pt)                                                                                                         \
+    do {                                                                                                                    \
+        if (blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && p.stats_partials && tl_tile < 8)                             \
+            p.stats_partials[((wave >> 2) * 8 + tl_tile) * 16 + (pt)] = (double)__builtin_amdgcn_s_memtime();               \
+    } while (0)
+#else
+#define W2STAMP(pt) do { } while (0)
+#endif
 
 namespace {
 
@@ -140,6 +155,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
     const int wlane = lane * 16 + nh0 * 2048;
     const int row0 = 2 * rp;
 
+    int tl_tile = 0;        // (timeline builds) tiles done by this workgroup
+#if ESTD_W2PRIO == 2
+    if (NW == 8 && nh0 != 0) __builtin_amdgcn_s_setprio(1);
+#endif
     while (u < u_end) {
         // ---- column segment [u, seg_end): same (n, h-tile, w-tile), consecutive depth pairs ----
         const int col = u / dpairs;
@@ -309,8 +328,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
         };
         bool first = true;
 
-        for (; u < seg_end; ++u, ++dp) {
+        for (; u < seg_end; ++u, ++dp, ++tl_tile) {
             const int d0 = 2 * dp;
+            W2STAMP(0);
             if (first) {
                 lds_barrier();                          // every wave is done reading the previous tile's slices
 #pragma unroll
@@ -387,11 +407,16 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                 for (int k = 0; k < PER; ++k) vo_next[k] = chunk_voff(k % SIT);
             }
             __builtin_amdgcn_sched_barrier(0);
+            W2STAMP(1);
 
 #pragma clang loop unroll(full)
             for (int step = 0; step < 24; ++step) {      // step = (group gi = 3 sd + kw, channel chunk c)
                 const int gi = step >> 1;
                 const int sd = gi / 3;
+                if (step == 6) W2STAMP(2);
+                if (step == 12) W2STAMP(3);
+                if (step == 18) W2STAMP(4);
+                if (step == 19) W2STAMP(5);
                 if (has_next && step == 18) {
                     lds_barrier();                       // slices 0..2 have been read for the last time by every wave
                     write_slice(0);
@@ -417,6 +442,11 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                 }
                 __builtin_amdgcn_sched_barrier(0);       // the loads above are issued BEFORE this step's MFMAs (left alone, the
                                                          // scheduler sinks them to the end of the step: no prefetch at all)
+#if ESTD_W2PRIO == 1
+                // the two waves of a SIMD take turns at priority 1, a step each: left to age-based arbitration the older wave
+                // runs ahead and then idles at the step-18 barrier while the younger one, alone, cannot keep the matrix pipe busy
+                if (NW == 8) { if (((step & 1) ^ nh0) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#endif
                 const int cur = (ESTD_W2ABL & 8) ? 0 : step % BD;
                 f32x2 Tn[2][4];
 #pragma unroll
@@ -453,6 +483,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                 __builtin_amdgcn_sched_barrier(0);
             }
 
+            W2STAMP(6);
             if (has_next) {                               // slice 3 of the next tile
                 lds_barrier();
                 write_slice(3);
@@ -460,6 +491,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                 lds_barrier();
             }
 
+            W2STAMP(7);
             // ---- output transform A^T m A and the epilogue of the two planes ----
             f32x4 y0[2][NHW], y1[2][NHW];
 #pragma unroll
@@ -476,12 +508,15 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                     y1[m][x] = z[1][m] - z[2][m] - z[3][m];
                 }
             }
+#ifndef ESTD_W2TIME
             if (p.stats_partials) {                      // uniform; the GRU gate convolution (one volume per launch)
                 plane_stats(y0, d0);
                 if (d0 + 1 < D) plane_stats(y1, d0 + 1);              // (odd D: the last pair has one plane)
             }
+#endif
             epi_plane(y0, d0);
             if (d0 + 1 < D) epi_plane(y1, d0 + 1);
+            W2STAMP(8);
         }
     }
 }
