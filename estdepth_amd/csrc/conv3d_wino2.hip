@@ -36,6 +36,12 @@
 #ifndef ESTD_W2PRIO
 #define ESTD_W2PRIO 0   // 1: per-step alternating s_setprio between the two waves of a SIMD; 2: static priority 1 for waves 4..7
 #endif
+#ifndef ESTD_W2PK
+#define ESTD_W2PK 0     // row transforms: 0 vector arithmetic (the compiler packs some, unpacks others next to MFMAs), 1 inline-assembly
+#endif                  // v_pk_add_f32 fenced between the MFMA halves, 2 inline assembly without inner fences
+#ifndef ESTD_W2DEFER
+#define ESTD_W2DEFER 1  // 1: epilogue of tile k inside the first steps of tile k+1, two barriers per tile; 0: epilogue between the tiles
+#endif
 #ifndef ESTD_W2ABL
 #define ESTD_W2ABL 0    // timing ablations only (results are wrong): 1 no output stores, 2 no slice writes, 8 no weight stream,
 #endif                  // 16 no next-plane prefetch, 128 no row transform (raw rows as operands)
@@ -70,7 +76,7 @@ constexpr int NTAPS = 48;
 #endif
 constexpr int WLDS_TAPS = ESTD_W2LDS_TAPS;           // weights of the first taps of every tile come from LDS
 constexpr int WLDS_BYTES = WLDS_TAPS * 4096;         // [tap][2 halves][2 quads][64 lanes][4]
-constexpr int SS_BYTES = 2 * 32 * 4;                 // folded BN scale | shift of the 32 output channels
+constexpr int SS_BYTES = 3 * 32 * 4;                 // folded BN scale | shift | activation floor of the 32 output channels
 constexpr int VTAB_BYTES = 6 * 256 * 4;               // per-thread global offsets of the slice chunks (3 x 512 or 6 x 256 threads)
 constexpr int LDS_BYTES = 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + WLDS_BYTES;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
@@ -111,7 +117,9 @@ __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float
 //         fragment read and every row transform serves 2 x 16 output channels -- half the VALU instructions per MFMA -- and
 //         no second wave competes for the SIMD's VALU issue.  Measured cost of one VALU instruction in the 8-wave form:
 //         ~6.5 SIMD cycles, NOT hidden behind the MFMAs (time is linear in the VALU count, profiles/r3_wino2_*).
-template <int NW>
+// RB: the launch has read-back streams in its epilogue (residual, residual2 or a running sum); the instance without them
+// (conv + BN + activation only) carries no registers for them.
+template <int NW, bool RB>
 __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int dpairs, int total_tiles)
 {
     constexpr int NTHREADS = 64 * NW;
@@ -145,6 +153,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
 
     float* lds_ss = reinterpret_cast<float*>(smem + 4 * SLICE_BYTES + RED_BYTES);  // scale[32] | shift[32]: read in the epilogue
     if (tid < 64) lds_ss[tid] = tid < 32 ? p.scale[tid] : p.shift[tid - 32];     // (a global load there is an exposed L2 round trip)
+    // activation as a per-channel floor: ReLU = max(v, 0), none = max(v, -inf) -- two VALU operations per value in the epilogue
+    // (fp32 MFMAs hide no VALU work: every epilogue instruction is paid in matrix-pipe time); tanh takes the generic path
+    if (tid >= 64 && tid < 96) lds_ss[tid] = ((tid - 64) < p.act_split ? p.act_a : p.act_b) == ESTD_ACT_RELU ? 0.0f : -__builtin_inff();
+    const bool any_tanh = p.act_a == ESTD_ACT_TANH || p.act_b == ESTD_ACT_TANH;                     // uniform
     unsigned* lds_vt = reinterpret_cast<unsigned*>(smem + 4 * SLICE_BYTES + RED_BYTES + SS_BYTES);     // [it][thread]
     char* lds_w = smem + 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES;     // weights of taps 0 .. WLDS_TAPS-1
     for (int e = tid; e < WLDS_BYTES / 16; e += NTHREADS)                         // (visible after the first tile's barriers)
@@ -220,6 +232,14 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
         auto eoff_of = [&](int m) { return eoff_h[m]; };
         auto bn_act = [&](const f32x4& a, int cb, float4& v) {
             const float4 sc4 = *reinterpret_cast<const float4*>(lds_ss + cb), sh4 = *reinterpret_cast<const float4*>(lds_ss + 32 + cb);
+            if (!any_tanh) {
+                const float4 lo = *reinterpret_cast<const float4*>(lds_ss + 64 + cb);
+                v.x = fmaxf(a[0] * sc4.x + sh4.x, lo.x);
+                v.y = fmaxf(a[1] * sc4.y + sh4.y, lo.y);
+                v.z = fmaxf(a[2] * sc4.z + sh4.z, lo.z);
+                v.w = fmaxf(a[3] * sc4.w + sh4.w, lo.w);
+                return;
+            }
             v.x = act_apply(a[0] * sc4.x + sh4.x, cb + 0 < p.act_split ? p.act_a : p.act_b);
             v.y = act_apply(a[1] * sc4.y + sh4.y, cb + 1 < p.act_split ? p.act_a : p.act_b);
             v.z = act_apply(a[2] * sc4.z + sh4.z, cb + 2 < p.act_split ? p.act_a : p.act_b);
@@ -227,44 +247,51 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
         };
         // epilogue of one plane: tile rows row0, row0 + 1 (m), channel halves (x).  Every read-back stream (residuals, the running
         // sum) issues its loads back to back and is waited for ONCE.
-        auto epi_plane = [&](const f32x4 (&a)[2][NHW], int dd) {
+        struct EpiLoads { float4 r1[2][NHW], r2[2][NHW], ro[2][NHW]; };
+        auto epi_issue = [&](int dd, EpiLoads& L) {       // the read-back streams of one plane, all loads back to back
             const int so = dd * out_plane_bytes;
-            unsigned eo[2];
-            float4 r1[2][NHW], r2[2][NHW], ro[2][NHW];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) eo[m] = eoff_of(m);
-            if (p.residual) {
+            if (RB && p.residual) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int x = 0; x < NHW; ++x) r1[m][x] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_res, eo[m], so + 64 * x, 0));
+                    for (int x = 0; x < NHW; ++x) L.r1[m][x] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_res, eoff_of(m), so + 64 * x, 0));
             }
-            if (p.residual2) {
+            if (RB && p.residual2) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int x = 0; x < NHW; ++x) r2[m][x] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_res2, eo[m], so + 64 * x, 0));
+                    for (int x = 0; x < NHW; ++x) L.r2[m][x] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_res2, eoff_of(m), so + 64 * x, 0));
             }
-            if (p.accumulate) {
+            if (RB && p.accumulate) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int x = 0; x < NHW; ++x) ro[m][x] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_out, eo[m], so + 64 * x, 0));
+                    for (int x = 0; x < NHW; ++x) L.ro[m][x] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_out, eoff_of(m), so + 64 * x, 0));
             }
+        };
+        auto epi_finish = [&](const f32x4 (&a)[2][NHW], int dd, const EpiLoads& L) {
+            const int so = dd * out_plane_bytes;
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int x = 0; x < NHW; ++x) {
                     float4 v;
                     bn_act(a[m][x], 16 * (nh0 + x) + 4 * g, v);
-                    if (p.residual) v = f4_add(v, r1[m][x]);
-                    if (p.residual2) v = f4_add(v, r2[m][x]);
-                    v = make_float4(v.x * p.out_scale, v.y * p.out_scale, v.z * p.out_scale, v.w * p.out_scale);
-                    if (p.accumulate) v = f4_add(v, ro[m][x]);
+                    if (RB && p.residual) v = f4_add(v, L.r1[m][x]);
+                    if (RB && p.residual2) v = f4_add(v, L.r2[m][x]);
+                    if (RB) v = make_float4(v.x * p.out_scale, v.y * p.out_scale, v.z * p.out_scale, v.w * p.out_scale);
+                    if (RB && p.accumulate) v = f4_add(v, L.ro[m][x]);
                     u32x4 bits;
                     __builtin_memcpy(&bits, &v, 16);
-                    if (!(ESTD_W2ABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(bits, rs_out, eo[m], so + 64 * x, 0);
+                    if (!(ESTD_W2ABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(bits, rs_out, eoff_of(m), so + 64 * x, 0);
                 }
+        };
+        // epilogue of one plane: tile rows row0, row0 + 1 (m), channel halves (x).  Every read-back stream (residuals, the running
+        // sum) issues its loads back to back and is waited for ONCE.
+        auto epi_plane = [&](const f32x4 (&a)[2][NHW], int dd) {
+            EpiLoads L;
+            epi_issue(dd, L);
+            epi_finish(a, dd, L);
         };
         // GroupNorm(1 group) partial sums of the raw outputs of one plane: group = channel half.  Fixed-order reduction
         // (lanes by butterfly, the four row pairs of a half through LDS) -> deterministic.  Workgroup-uniform call.
@@ -327,6 +354,20 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
             for (int it = 0; it < SIT; ++it) { xa[it] = xc[it]; xb[it] = xd[it]; }
         };
         bool first = true;
+        // DEFER: the outputs of the previous tile of this column segment, stored inside the first steps of the current one -- between
+        // the last MFMA of a tile and the first of the next there is then ONE barrier and the prologue (measured before: ~6 000 of
+        // 35 500 cycles per tile without a single MFMA: two barriers, the slice-3 rewrite and the epilogue of all eight waves at once,
+        // profiles/r3_wino2_tile_timeline.txt).  Their registers are the ones the next-plane prefetch occupies later in the loop.
+        constexpr bool DEFER = ESTD_W2DEFER != 0 && !RB;        // (with read-back streams the deferred form spills inside the tap loop)
+        constexpr int RB_STEP = DEFER ? 16 : 18;         // step in front of which slices 0..2 are rewritten
+        constexpr int PF_STEP = DEFER ? 4 : 0;           // first step of the next-plane prefetch
+        f32x4 py0[2][NHW], py1[2][NHW];
+        int pd0 = 0;
+        bool have_prev = false;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int x = 0; x < NHW; ++x) { py0[m][x] = (f32x4){0.f, 0.f, 0.f, 0.f}; py1[m][x] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
         for (; u < seg_end; ++u, ++dp, ++tl_tile) {
             const int d0 = 2 * dp;
@@ -371,7 +412,16 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
 #pragma unroll
                 for (int k = 0; k < 4; ++k) r[k] = h == 0 ? (f32x2){Rr[k].x, Rr[k].y} : (f32x2){Rr[k].z, Rr[k].w};
                 if (ESTD_W2ABL & 128) { o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3]; }
-                else { o[0] = r[0] - r[2]; o[1] = r[1] + r[2]; o[2] = r[2] - r[1]; o[3] = r[1] - r[3]; }
+                else if (ESTD_W2PK == 0) { o[0] = r[0] - r[2]; o[1] = r[1] + r[2]; o[2] = r[2] - r[1]; o[3] = r[1] - r[3]; }
+                else {
+                    // inline assembly: left to itself the compiler UNPACKS packed adds next to MFMAs into two plain ones (a
+                    // heuristic for the bf16 matrix pipe, which overlaps plain VALU work).  Measured: forcing them packed is
+                    // SLOWER (0.938 vs 0.913 ms), with or without fences -- kept as an A/B switch.
+                    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o[0]) : "v"(r[0]), "v"(r[2]));
+                    asm("v_pk_add_f32 %0, %1, %2" : "=v"(o[1]) : "v"(r[1]), "v"(r[2]));
+                    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o[2]) : "v"(r[2]), "v"(r[1]));
+                    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o[3]) : "v"(r[1]), "v"(r[3]));
+                }
             };
             auto load_rows = [&](int st, float4 (&Rr)[4]) {
                 const int ng = st >> 1;
@@ -400,12 +450,13 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
             xform2(R, 0, T[0]);
             xform2(R, 1, T[1]);
             load_rows(1, R);
-            constexpr int PER = SIT / 3;                 // plane chunks per step: the 2 x SIT chunks go out in steps 0..5
+            constexpr int PER = SIT / 3;                 // plane chunks per step: the 2 x SIT chunks go out in six steps
             unsigned vo_next[PER];
-            if (has_next && !(ESTD_W2ABL & 16)) {
+            if (has_next && PF_STEP == 0 && !(ESTD_W2ABL & 16)) {
 #pragma unroll
                 for (int k = 0; k < PER; ++k) vo_next[k] = chunk_voff(k % SIT);
             }
+            EpiLoads pl;                                 // read-back loads of the deferred epilogue (issued one step before use)
             __builtin_amdgcn_sched_barrier(0);
             W2STAMP(1);
 
@@ -417,8 +468,11 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                 if (step == 12) W2STAMP(3);
                 if (step == 18) W2STAMP(4);
                 if (step == 19) W2STAMP(5);
-                if (has_next && step == 18) {
-                    lds_barrier();                       // slices 0..2 have been read for the last time by every wave
+                if (has_next && step == RB_STEP) {
+                    // slices 0..2 have been read for the last time by every wave (the rows of step 17 are fetched at the end of step
+                    // 15); DEFER: this barrier also publishes slice 3, rewritten at the top of this tile and first read at the end of
+                    // step 16
+                    lds_barrier();
                     write_slice(0);
                     write_slice(1);
                     write_slice(2);
@@ -428,10 +482,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                 // chunks of the NEXT tile's two new planes: spread over the first steps (their offsets were read from the LDS table
                 // at the end of the previous step)
                 if (has_next && !(ESTD_W2ABL & 16)) {
-                    if (step < 6) {
+                    if (step >= PF_STEP && step < PF_STEP + 6) {
 #pragma unroll
                         for (int k = 0; k < PER; ++k) {
-                            const int idx = step * PER + k, it = idx % SIT;
+                            const int idx = (step - PF_STEP) * PER + k, it = idx % SIT;
                             const unsigned vo = vo_next[k];
                             if (idx < SIT) xc[it] = v0 ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, nd * in_slice_bytes, 0))
                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -461,19 +515,30 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                                 const float b = h == 0 ? (e == 0 ? b4.x : b4.y) : (e == 0 ? b4.z : b4.w);
                                 acc[sd][t][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, T[h][t][e], acc[sd][t][x], 0, 0, 0);
                             }
+                    if (ESTD_W2PK == 1) __builtin_amdgcn_sched_barrier(0);   // the MFMAs of two components, then the next step's 4 packed transforms
                     if (step + 1 < 24) xform2(R, h, Tn[h]);
+                    if (ESTD_W2PK == 1 && h == 0) __builtin_amdgcn_sched_barrier(0);
                 }
                 if (step + 2 < 24) load_rows(step + 2, R);
-                if (has_next && step + 1 < 6 && !(ESTD_W2ABL & 16)) {
+                if (has_next && step + 1 >= PF_STEP && step + 1 < PF_STEP + 6 && !(ESTD_W2ABL & 16)) {
 #pragma unroll
-                    for (int k = 0; k < PER; ++k) vo_next[k] = chunk_voff(((step + 1) * PER + k) % SIT);
+                    for (int k = 0; k < PER; ++k) vo_next[k] = chunk_voff(((step + 1 - PF_STEP) * PER + k) % SIT);
                 }
+                if (DEFER && have_prev && step < 4) {     // the previous tile's epilogue: plane d0 in steps 0-1, plane d0 + 1 in steps 2-3
+                    const bool second = step >= 2;
+                    if (!second || pd0 + 1 < D) {
+                        if ((step & 1) == 0) epi_issue(pd0 + (second ? 1 : 0), pl);
+                        else epi_finish(second ? py1 : py0, pd0 + (second ? 1 : 0), pl);
+                    }
+                }
+                if (ESTD_W2PK == 0) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {            // order of the region: the MFMAs of two components, then the next step's 4 packed transforms
-                    __builtin_amdgcn_sched_group_barrier(0x008, 8 * NHW, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    for (int h = 0; h < 2; ++h) {        // order of the region: the MFMAs of two components, then the next step's 4 transforms
+                        __builtin_amdgcn_sched_group_barrier(0x008, 8 * NHW, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
                 if (step + 1 < 24) {
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
@@ -484,15 +549,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
             }
 
             W2STAMP(6);
-            if (has_next) {                               // slice 3 of the next tile
-                lds_barrier();
-                write_slice(3);
-                shift_planes();
-                lds_barrier();
-            }
-
-            W2STAMP(7);
-            // ---- output transform A^T m A and the epilogue of the two planes ----
+            // ---- output transform A^T m A ----
             f32x4 y0[2][NHW], y1[2][NHW];
 #pragma unroll
             for (int x = 0; x < NHW; ++x) {
@@ -508,14 +565,35 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                     y1[m][x] = z[1][m] - z[2][m] - z[3][m];
                 }
             }
+            if (has_next) {                               // slice 3 of the next tile
+                lds_barrier();                            // every wave has read slice 3 for the last time; slices 0..2 (rewritten in the loop) are visible
+                write_slice(3);
+                shift_planes();
+                if (!DEFER) lds_barrier();                // DEFER: slice 3 is published by the next tile's in-loop barrier
+            }
+            W2STAMP(7);
+#ifdef ESTD_W2TIME
+            const bool defer_this = DEFER && has_next;
+#else
+            const bool defer_this = DEFER && has_next && !p.stats_partials;      // uniform
+#endif
 #ifndef ESTD_W2TIME
             if (p.stats_partials) {                      // uniform; the GRU gate convolution (one volume per launch)
                 plane_stats(y0, d0);
                 if (d0 + 1 < D) plane_stats(y1, d0 + 1);              // (odd D: the last pair has one plane)
             }
 #endif
-            epi_plane(y0, d0);
-            if (d0 + 1 < D) epi_plane(y1, d0 + 1);
+            if (!defer_this) {
+                epi_plane(y0, d0);
+                if (d0 + 1 < D) epi_plane(y1, d0 + 1);
+            }
+            // (assigned on both paths: a value that survives only on the non-deferred path would stay live through the whole loop)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int x = 0; x < NHW; ++x) { py0[m][x] = y0[m][x]; py1[m][x] = y1[m][x]; }
+            pd0 = d0;
+            have_prev = defer_this;
             W2STAMP(8);
         }
     }
@@ -546,12 +624,15 @@ extern "C" int estd_conv3d_k3_wino2(const estd_conv3d_desc* dp, estd_stream_t s)
     int grid = total < slots ? (int)total : slots;
     if (grid >= 8) grid &= ~7;
     static const int nw = [] { const char* e = getenv("ESTD_WINO2_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
-    if (nw == 8) {
-        estd_allow_dynamic_lds<conv3d_wino2_kernel<8>>(LDS_BYTES);
-        hipLaunchKernelGGL(conv3d_wino2_kernel<8>, dim3(grid), dim3(512), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h, dpairs, (int)total);
-    } else {
-        estd_allow_dynamic_lds<conv3d_wino2_kernel<4>>(LDS_BYTES);
-        hipLaunchKernelGGL(conv3d_wino2_kernel<4>, dim3(grid), dim3(256), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h, dpairs, (int)total);
-    }
+    const bool rb = d.residual || d.residual2 || d.accumulate || d.out_scale != 1.0f;      // (the scale multiply lives in that instance)
+#define ESTD_W2_LAUNCH(NWV, RBV)                                                                                                     \
+    do {                                                                                                                             \
+        estd_allow_dynamic_lds<conv3d_wino2_kernel<NWV, RBV>>(LDS_BYTES);                                                            \
+        hipLaunchKernelGGL((conv3d_wino2_kernel<NWV, RBV>), dim3(grid), dim3(64 * NWV), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h, \
+                           dpairs, (int)total);                                                                                      \
+    } while (0)
+    if (nw == 8) { if (rb) ESTD_W2_LAUNCH(8, true); else ESTD_W2_LAUNCH(8, false); }
+    else { if (rb) ESTD_W2_LAUNCH(4, true); else ESTD_W2_LAUNCH(4, false); }
+#undef ESTD_W2_LAUNCH
     return ESTD_LAUNCH_CHECK();
 }
