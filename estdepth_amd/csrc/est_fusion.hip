@@ -182,6 +182,9 @@ __global__ __launch_bounds__(256) void warp_volume_ex_kernel(const float* __rest
 
 // Fused warp(K_j), warp(V_j) + attention.  4 lanes per target voxel; lane c owns float4 chunk c of
 // the 16 value channels and chunk c of the 16 key channels (kv record = [V(16) | K(16)] = 128 B).
+#ifndef WA_SHARE
+#define WA_SHARE 0   // 1: dx = 1 corner records from the x-neighbour's registers (DPP) instead of a second gather -- measured SLOWER (348 vs 255 us at N = 3, profiles/r3_warp_attention_share_pmc.csv): A/B switch only
+#endif
 #ifndef WA_TD
 #define WA_TD 2      // target brick of one 256-thread workgroup (64 voxels x 4 lanes): depth x rows x columns
 #define WA_TY 4
@@ -234,11 +237,47 @@ __global__ __launch_bounds__(256) void warp_attention_kernel(const float* __rest
             const Tri t = volume_coords(mats + j * 30, dep, x, y, depth_min, depth_interval, D, H, W);
             const float4* s4 = reinterpret_cast<const float4*>(srcs.kv_src[j]) + sub;
             float4 cv[8], ck[8];
+#if WA_SHARE
+            // Corner sharing across x-neighbours: the texture-address path, not HBM, bounds this kernel (TA busy 90 % of the CU-busy
+            // cycles, 31 TA cycles per 64-lane 16-byte gather, profiles/r2_warp_attention_ta_pmc.csv).  The voxel one step further
+            // in x (the next 4-lane group of the wave) samples one record further in x for small relative motion: its dx = 0 corner
+            // IS this voxel's dx = 1 corner.  Every group gathers its four dx = 0 corners; a dx = 1 corner is taken from the
+            // neighbour's registers (ds_bpermute: the LDS crossbar, 4x the TA's bytes per clock) when the neighbour loaded that very
+            // record, and gathered directly otherwise (row ends, large motion, volume border).  Same records, same arithmetic.
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {          // the 8 gathers of the dx = 0 corners, issued before anything is used
+                cv[2 * c] = s4[(long long)t.off[2 * c] * 8];
+                ck[2 * c] = s4[(long long)t.off[2 * c] * 8 + 4];
+            }
+            // neighbour = the next 4-lane group of the same 16-lane DPP row (v_mov_b32_dpp row_shl:4: VALU, idle in this kernel; a
+            // ds_bpermute through the LDS crossbar costs more than the gather it replaces: measured 362 vs 255 us)
+            const bool has_nb = (v & 3) != 3 && x + 1 < W;
+            auto shl4 = [](float f) {
+                return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x104, 0xf, 0xf, true));
+            };
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int k0 = 2 * c, k1 = 2 * c + 1;
+                const int nb_off = __builtin_amdgcn_update_dpp(-1, t.off[k0], 0x104, 0xf, 0xf, false);
+                const bool need = t.w[k1] != 0.0f;                       // out-of-volume corners carry weight 0: their data is never used
+                const bool share = has_nb && nb_off == t.off[k1];
+                float4 nv, nk;
+                nv.x = shl4(cv[k0].x); nv.y = shl4(cv[k0].y); nv.z = shl4(cv[k0].z); nv.w = shl4(cv[k0].w);
+                nk.x = shl4(ck[k0].x); nk.y = shl4(ck[k0].y); nk.z = shl4(ck[k0].z); nk.w = shl4(ck[k0].w);
+                cv[k1] = nv;
+                ck[k1] = nk;
+                if (need && !share) {
+                    cv[k1] = s4[(long long)t.off[k1] * 8];
+                    ck[k1] = s4[(long long)t.off[k1] * 8 + 4];
+                }
+            }
+#else
 #pragma unroll
             for (int k = 0; k < 8; ++k) {          // issue all 16 gathers of this source before using any
                 cv[k] = s4[(long long)t.off[k] * 8];
                 ck[k] = s4[(long long)t.off[k] * 8 + 4];
             }
+#endif
             float4 av = make_float4(0.f, 0.f, 0.f, 0.f), ak = av;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
