@@ -94,6 +94,7 @@ _SIGNATURES = {
                                             ctypes.c_int64, c_stream]),
     "estd_gru_blend": (ctypes.c_int, [c_float_p] * 10 + [ctypes.c_int, ctypes.c_int64, c_stream]),
     "estd_bn_act_nhwc": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_stream]),
+    "estd_conv2d_small_nhwc": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p] + [ctypes.c_int] * 8 + [c_stream]),
     "estd_conv2d_k3_to16_nhwc": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int, c_stream]),
     "estd_normalise_nhwc": (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_int64, c_stream]),

@@ -148,6 +148,33 @@ def conv_bn_act(conv, bn, x, relu, residual=None):
     return ops.bn_act_nhwc_(y, sc, sh, relu, residual)
 
 
+HIP_SMALL = os.environ.get("ESTD_HIP_SMALL_CONVS", "1") == "1"     # A/B switch: the PSM extractor's stride-2 / 1x1 convolutions on csrc/refine2d.hip
+
+
+def small_conv_nhwc(conv, bn, x_nhwc, relu):
+    """Conv2d (3x3 stride 2 or 1x1) [+ BatchNorm2d(eval)] [+ ReLU] of the PSM extractor on csrc/refine2d.hip::conv2d_small_kernel
+    (psm_submodule.py:52,:72-74,:78-83,:100-110), NHWC in -> NHWC out; None when the shape has no instance (the caller then
+    takes the library path)."""
+    from . import ops, packing
+    k, s = conv.kernel_size[0], conv.stride[0]
+    if not HIP_SMALL or conv.bias is not None or conv.groups != 1 or conv.dilation != (1, 1) or conv.kernel_size != (k, k) \
+            or conv.stride != (s, s) or conv.padding != (k // 2, k // 2) or (conv.in_channels, k, s) not in ops.SMALL_CONV_SHAPES \
+            or conv.out_channels % 16 or not x_nhwc.is_cuda:
+        return None
+    key = (conv.weight.device, conv.weight._version, conv.weight.data_ptr()) + \
+        ((bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version) if bn is not None else ())
+    c = conv.__dict__.get("_estd_small")
+    if c is None or c[0] != key:
+        dev = conv.weight.device
+        if bn is not None:
+            sc, sh = _folded(bn)
+        else:
+            sc, sh = torch.ones(conv.out_channels, device=dev), torch.zeros(conv.out_channels, device=dev)
+        c = (key, packing.pack_conv2d_small(conv.weight).to(dev), sc.float().contiguous(), sh.float().contiguous())
+        conv.__dict__["_estd_small"] = c
+    return ops.conv2d_small_nhwc(x_nhwc.contiguous(), c[1], c[2], c[3], conv.out_channels, k, s, relu)
+
+
 def enable_fused_bn(root, enable=True):
     """Opt-in for every 2D block under ``root``: BatchNorm2d -> (add) -> ReLU after a library convolution become
     one estd_bn_act_nhwc launch.  Needs channels_last activations (DepthNetHybrid.use_channels_last_2d)."""
@@ -272,9 +299,17 @@ class PSMFeatures(nn.Module):
             for bi, blk in enumerate(getattr(self, lname)):
                 if (lname, bi, 1) in P:
                     y = P[(lname, bi, 1)].run(x)
-                else:                                                             # stride-2 conv1 (layer2.0): MIOpen
-                    y = self._nhwc(blk.first(self._nchw(x)))
-                res = x if blk.downsample is None else self._nhwc(blk.shortcut(self._nchw(x)))
+                else:                                                             # stride-2 conv1 (layer2.0)
+                    c1 = blk.conv1[0]
+                    y = small_conv_nhwc(c1[0], c1[1], x, relu=True)
+                    if y is None:
+                        y = self._nhwc(blk.first(self._nchw(x)))                  # library path
+                if blk.downsample is None:
+                    res = x
+                else:
+                    res = small_conv_nhwc(blk.downsample[0], blk.downsample[1], x, relu=False)
+                    if res is None:
+                        res = self._nhwc(blk.shortcut(self._nchw(x)))
                 x = P[(lname, bi, 2)].run(y, residual=res)
             if lname == "layer2":
                 raw = x
@@ -297,11 +332,19 @@ class PSMFeatures(nn.Module):
             cat_nhwc = self._nhwc(torch.cat([self._nchw(raw), skip_nchw] + ups, 1))
         y = P["last"].run(cat_nhwc)
         last = self.lastconv[2]                                                   # 1x1, 128 -> 32, no BN
+        z = small_conv_nhwc(last, None, y, relu=False)
+        if z is not None:
+            return self._nchw(z)
         return conv1x1_gemm(last, self._nchw(y)) if fused_on(self, y) else last(self._nchw(y))
 
     def _branch(self, i, skip, pooled=None):
         """SPP branch: AvgPool -> 1x1 conv -> BN -> ReLU (psm_submodule.py:100-110)."""
         br = getattr(self, "branch%d" % i)
+        if getattr(self, "_hip", False) and skip.is_cuda:
+            p = br[0](skip) if pooled is None else pooled[i]
+            z = small_conv_nhwc(br[1][0], br[1][1], self._nhwc(p), relu=True)
+            if z is not None:
+                return self._nchw(z)
         if fused_on(self, skip):
             return conv_bn_act(br[1][0], br[1][1], br[0](skip) if pooled is None else pooled[i], relu=True)
         return br(skip)

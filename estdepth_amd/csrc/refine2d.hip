@@ -193,6 +193,95 @@ __global__ __launch_bounds__(256) void conv2d_k3_to16_kernel(const float* __rest
     }
 }
 
+// ---- the small convolutions of the PSM extractor that are neither 3x3 / stride 1 nor wide enough for the tiled kernels:
+//      3x3 stride 2 (layer2[0].conv1, psm_submodule.py:52), 1x1 stride 1 | 2 (the downsample paths :78-83, the SPP branch
+//      convolutions :100-110, lastconv's 1x1 :72-74).  Same scheme as conv2d_k3_to16_kernel: a wave owns 16 output pixels of a row x
+//      one 16-channel output tile, weights of that tile in registers, operands straight from L1/L2 with one 16-byte load per tap and
+//      16 input channels, transposed MFMAs (a lane stores 16 bytes), folded BN (+ ReLU) epilogue.  NHWC in / out.
+template <int CIN, int KS, int STRIDE, int NTW>
+__global__ __launch_bounds__(256) void conv2d_small_kernel(const float* __restrict__ in, const float4* __restrict__ wpk, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, float* __restrict__ out, int N, int Hin, int Win,
+                                                           int Ho, int Wo, int cout, int relu, int strips_y, int segs_x, int rows)
+{
+    // NTW = 16-channel output tiles per wave: every operand fetched serves NTW tiles (the 3x3 stride-2 layer re-reads its taps per
+    // tile otherwise and is bound by the L1 / texture-address path)
+    constexpr int Q = CIN / 16, TAPS = KS * KS, PAD = KS / 2;
+    const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15;
+    const int ngroups = cout / (16 * NTW);
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);          // wave id -> (n, strip, segment, channel group)
+    const long long nwaves = (long long)N * strips_y * segs_x * ngroups;
+    if (wid >= nwaves) return;
+    const int ng = (int)(wid % ngroups);
+    const int seg = (int)((wid / ngroups) % segs_x);
+    const int strip = (int)((wid / ((long long)ngroups * segs_x)) % strips_y);
+    const int n = (int)(wid / ((long long)ngroups * segs_x * strips_y));
+
+    float4 wr[NTW][TAPS][Q];                                  // this lane's weights: [tile][tap][16-channel group] x 4 k-steps
+    float4 sc[NTW], sh[NTW];
+#pragma unroll
+    for (int u = 0; u < NTW; ++u) {
+        const int nt = ng * NTW + u;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) wr[u][t][q] = wpk[((nt * TAPS + t) * Q + q) * 64 + lane];
+        sc[u] = reinterpret_cast<const float4*>(scale + 16 * nt)[g];
+        sh[u] = reinterpret_cast<const float4*>(shift + 16 * nt)[g];
+    }
+
+    const __amdgpu_buffer_rsrc_t rs_in =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + (size_t)n * Hin * Win * CIN), 0, (int)((size_t)Hin * Win * CIN * 4), 0x00020000);
+    const int x = seg * 16 + i;
+    unsigned coloff[KS];                                      // byte offset of the source column of tap kx (OOB: beyond the buffer)
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx) {
+        const int xx = x * STRIDE + kx - PAD;
+        coloff[kx] = (x < Wo && (unsigned)xx < (unsigned)Win) ? (unsigned)(xx * CIN + 4 * g) * 4u : 0xFFFFFF00u;
+    }
+    for (int r = 0; r < rows; ++r) {
+        const int y = strip * rows + r;
+        if (y >= Ho) break;                                   // wave-uniform
+        f32x4_t acc[NTW][2];                                  // two chains per tile: no MFMA waits for its own predecessor
+#pragma unroll
+        for (int u = 0; u < NTW; ++u) { acc[u][0] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; acc[u][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            const int yy = y * STRIDE + ky - PAD;
+            if ((unsigned)yy >= (unsigned)Hin) continue;      // wave-uniform: zero padding rows
+            const int rowoff = yy * Win * CIN * 4;
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(rs_in, coloff[kx], rowoff + q * 64, 0);
+                    float4 a;
+                    __builtin_memcpy(&a, &raw, 16);
+#pragma unroll
+                    for (int u = 0; u < NTW; ++u) {
+                        const float4 wq = wr[u][ky * KS + kx][q];
+                        acc[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq.x, a.x, acc[u][0], 0, 0, 0);
+                        acc[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq.y, a.y, acc[u][1], 0, 0, 0);
+                        acc[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq.z, a.z, acc[u][0], 0, 0, 0);
+                        acc[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq.w, a.w, acc[u][1], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (x < Wo) {
+#pragma unroll
+            for (int u = 0; u < NTW; ++u) {
+                float4 o;
+                o.x = (acc[u][0][0] + acc[u][1][0]) * sc[u].x + sh[u].x;
+                o.y = (acc[u][0][1] + acc[u][1][1]) * sc[u].y + sh[u].y;
+                o.z = (acc[u][0][2] + acc[u][1][2]) * sc[u].z + sh[u].z;
+                o.w = (acc[u][0][3] + acc[u][1][3]) * sc[u].w + sh[u].w;
+                if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                *reinterpret_cast<float4*>(out + (((size_t)n * Ho + y) * Wo + x) * cout + 16 * (ng * NTW + u) + 4 * g) = o;
+            }
+        }
+    }
+}
+
 // ---- [N][3][HW] image planes in 0..255 -> [N][HW][3] records in -1..1 ----
 __global__ __launch_bounds__(256) void normalise_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, long long HW, long long total)
 {
@@ -294,6 +383,39 @@ extern "C" int estd_conv2d_k3_to16_nhwc(const float* in, const float* w_packed, 
     if (cin == 16) { if (upsample) ESTD_TO16(16, true); else ESTD_TO16(16, false); }
     else { if (upsample) ESTD_TO16(32, true); else ESTD_TO16(32, false); }
 #undef ESTD_TO16
+    return ESTD_LAUNCH_CHECK();
+}
+
+extern "C" int estd_conv2d_small_nhwc(const float* in, const float* w_packed, const float* scale, const float* shift, float* out, int N, int Hin,
+                                      int Win, int cin, int cout, int ksize, int stride, int relu, estd_stream_t s)
+{
+    if (!in || !w_packed || !scale || !shift || !out || N <= 0 || Hin <= 0 || Win <= 0) return ESTD_ERR_ARG;
+    if (cout <= 0 || (cout & 15) || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return ESTD_ERR_ARG;
+    if ((long long)Hin * Win * cin * 4 >= 0x7fffff00LL) return ESTD_ERR_UNSUPPORTED;
+    const int pad = ksize / 2;
+    const int Ho = (Hin + 2 * pad - ksize) / stride + 1, Wo = (Win + 2 * pad - ksize) / stride + 1;
+    // channel tiles per wave: 2 where the register budget allows and the layer has an even tile count (3x3: 144 weight registers)
+    const int ntw = ((cout & 31) == 0 && cin <= 64) ? 2 : 1;
+    // rows of 16 pixels per wave: 8 amortise the weight fetch; fewer when the map is small, so that every SIMD has several waves to
+    // cover the load latency with (these kernels are latency / bandwidth bound)
+    const int segs_x = (Wo + 15) / 16, ngroups = cout / (16 * ntw);
+    int rows = TO16_ROWS;
+    while (rows > 1 && (long long)N * ((Ho + rows - 1) / rows) * segs_x * ngroups < 8192) rows >>= 1;
+    const int strips_y = (Ho + rows - 1) / rows;
+    const long long waves = (long long)N * strips_y * segs_x * ngroups;
+    const long long blocks = (waves + 3) / 4;
+    if (blocks > 0x7fffffffLL) return ESTD_ERR_ARG;
+    const float4* wp = reinterpret_cast<const float4*>(w_packed);
+#define ESTD_SMALL(C, K, S, T)                                                                                                                    \
+    hipLaunchKernelGGL((conv2d_small_kernel<C, K, S, T>), dim3((unsigned)blocks), dim3(256), 0, estd_stream(s), in, wp, scale, shift, out, N, Hin, \
+                       Win, Ho, Wo, cout, relu, strips_y, segs_x, rows)
+    if (ksize == 3 && stride == 2 && cin == 32) { if (ntw == 2) ESTD_SMALL(32, 3, 2, 2); else ESTD_SMALL(32, 3, 2, 1); }
+    else if (ksize == 1 && stride == 2 && cin == 32) { if (ntw == 2) ESTD_SMALL(32, 1, 2, 2); else ESTD_SMALL(32, 1, 2, 1); }
+    else if (ksize == 1 && stride == 1 && cin == 32) { if (ntw == 2) ESTD_SMALL(32, 1, 1, 2); else ESTD_SMALL(32, 1, 1, 1); }
+    else if (ksize == 1 && stride == 1 && cin == 64) { if (ntw == 2) ESTD_SMALL(64, 1, 1, 2); else ESTD_SMALL(64, 1, 1, 1); }
+    else if (ksize == 1 && stride == 1 && cin == 128) ESTD_SMALL(128, 1, 1, 1);
+    else return ESTD_ERR_UNSUPPORTED;
+#undef ESTD_SMALL
     return ESTD_LAUNCH_CHECK();
 }
 

@@ -394,6 +394,24 @@ Tensor spp_upsample_cat(const Tensor& raw, const Tensor& skip, at::TensorList br
     return out;
 }
 
+Tensor conv2d_small_nhwc(const Tensor& x, const Tensor& w_packed, const Tensor& scale, const Tensor& shift, int64_t cout, int64_t ksize,
+                         int64_t stride, bool relu)
+{
+    const OpScope scope(x);
+    TORCH_CHECK(x.dim() == 4, "conv2d_small_nhwc: NHWC x expected");
+    const int64_t n = x.size(0), h = x.size(1), w = x.size(2), cin = x.size(3);
+    TORCH_CHECK((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2) && cout > 0 && cout % 16 == 0 && cin % 16 == 0,
+                "conv2d_small_nhwc: ksize 1|3, stride 1|2, channel counts multiples of 16");
+    TORCH_CHECK(w_packed.numel() == cout / 16 * ksize * ksize * (cin / 16) * 256 && scale.numel() == cout && shift.numel() == cout,
+                "conv2d_small_nhwc: packed weights [cout/16][taps][cin/16][64][4] and scale/shift [cout] expected");
+    const int64_t pad = ksize / 2, ho = (h + 2 * pad - ksize) / stride + 1, wo = (w + 2 * pad - ksize) / stride + 1;
+    Tensor out = new_f32({n, ho, wo, cout}, x);
+    check_status(estd_conv2d_small_nhwc(fptr(x, "x"), fptr(w_packed, "packed weights"), fptr(scale, "scale"), fptr(shift, "shift"),
+                                        out.data_ptr<float>(), (int)n, (int)h, (int)w, (int)cin, (int)cout, (int)ksize, (int)stride, relu ? 1 : 0,
+                                        cur_stream()), "estd_conv2d_small_nhwc");
+    return out;
+}
+
 Tensor conv2d_k3_to16_nhwc(const Tensor& x, const Tensor& w_packed, const Tensor& scale, const Tensor& shift, bool upsample)
 {
     const OpScope scope(x);
@@ -592,6 +610,7 @@ TORCH_LIBRARY(estdepth_hip, m)
           "Tensor beta_o, Tensor(a!) out_value, int out_stride) -> ()");
     m.def("bn_act_nhwc_(Tensor(a!) x, Tensor scale, Tensor shift, bool relu, Tensor? residual) -> Tensor(a!)");
     m.def("spp_upsample_cat(Tensor raw, Tensor skip, Tensor[] branches) -> Tensor");
+    m.def("conv2d_small_nhwc(Tensor x, Tensor w_packed, Tensor scale, Tensor shift, int cout, int ksize, int stride, bool relu) -> Tensor");
     m.def("conv2d_k3_to16_nhwc(Tensor x, Tensor w_packed, Tensor scale, Tensor shift, bool upsample) -> Tensor");
     m.def("normalise_nhwc(Tensor imgs) -> Tensor");
     m.def("stem3x3s2_nhwc(Tensor x, Tensor weight, Tensor scale, Tensor shift) -> Tensor");
@@ -630,6 +649,7 @@ TORCH_LIBRARY_IMPL(estdepth_hip, CUDA, m)
     m.impl("gru_blend", gru_blend);
     m.impl("bn_act_nhwc_", bn_act_nhwc_);
     m.impl("spp_upsample_cat", spp_upsample_cat);
+    m.impl("conv2d_small_nhwc", conv2d_small_nhwc);
     m.impl("conv2d_k3_to16_nhwc", conv2d_k3_to16_nhwc);
     m.impl("normalise_nhwc", normalise_nhwc);
     m.impl("stem3x3s2_nhwc", stem3x3s2_nhwc);

@@ -520,6 +520,23 @@ def conv2d_k3_to16_nhwc(x, w_packed, scale, shift, upsample=False):
     return out
 
 
+SMALL_CONV_SHAPES = {(32, 3, 2), (32, 1, 2), (32, 1, 1), (64, 1, 1), (128, 1, 1)}      # (cin, ksize, stride) instances of estd_conv2d_small_nhwc
+
+
+def conv2d_small_nhwc(x, w_packed, scale, shift, cout, ksize, stride, relu):
+    """small PSM convolutions (3x3 stride 2, 1x1 stride 1|2) + folded BN [+ ReLU] on an NHWC map -> NHWC [N,Ho,Wo,cout]."""
+    if _use_torch():
+        return T().conv2d_small_nhwc(x, w_packed, scale, shift, int(cout), int(ksize), int(stride), bool(relu))
+    _need_f32_cuda("conv2d_small_nhwc", x, w_packed, scale, shift)
+    n, h, w, c = x.shape
+    pad = ksize // 2
+    ho, wo = (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
+    out = torch.empty((n, ho, wo, cout), device=x.device, dtype=torch.float32)
+    N.check(N.lib().estd_conv2d_small_nhwc(_p(x), _p(w_packed), _p(scale), _p(shift), _p(out), n, h, w, c, int(cout), int(ksize), int(stride),
+                                           int(bool(relu)), _stream()), "estd_conv2d_small_nhwc")
+    return out
+
+
 def normalise_nhwc(imgs):
     """[N,3,H,W] images in 0..255 -> 2 * (imgs / 255) - 1 as an NHWC batch [N,H,W,3] (model_hybrid.py:119)."""
     if _use_torch():

@@ -309,6 +309,24 @@ def pack_conv2d_to16(weight):
     return torch.from_numpy(out)
 
 
+def pack_conv2d_small(weight):
+    """Conv2d weight [cout, cin, k, k] (k = 1 | 3; cin, cout multiples of 16) for csrc/refine2d.hip conv2d_small_kernel: float32
+    [cout/16 tiles][k*k taps][cin/16][64 lanes][4]; element ks of lane (g, i) of (tile nt, tap, group q) =
+    weight[16 nt + i][16 q + 4 g + ks][ky][kx] -- output channel i of the tile as the MFMA's M row, the four consecutive input
+    channels a lane loads as its four k-steps."""
+    w = weight.detach().float().cpu().numpy()
+    cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+    assert cout % 16 == 0 and cin % 16 == 0 and k in (1, 3) and w.shape[3] == k
+    out = np.zeros((cout // 16, k * k, cin // 16, 64, 4), np.float32)
+    for lane in range(64):
+        g, i = lane >> 4, lane & 15
+        for nt in range(cout // 16):
+            for q in range(cin // 16):
+                for ks in range(4):
+                    out[nt, :, q, lane, ks] = w[16 * nt + i, 16 * q + 4 * g + ks].reshape(k * k)
+    return torch.from_numpy(out)
+
+
 def pack_conv2d_wino(weight, group_tiles):
     """3x3 Conv2d weight [Cout, Cin, 3, 3] for csrc/conv2d_wino.hip: the row taps g0, g1, g2 of every kw column in Winograd
     F(2,3) form U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2 (float64, rounded once to float32), packed as

@@ -286,6 +286,13 @@ int estd_spp_upsample_cat(const float* raw, int c_raw, const float* skip, int c_
  * of the decoder (hybrid_models/hybrid_depth_decoder.py:17-30 ConvBlock; :276 upconv_0_0, :277-278 upconv_0_1(upsample(x))):
  * in [N][Hin][Win][cin], cin = 16 | 32; upsample = 1: the convolution reads the nearest-x2 upsampled map (Hin = H/2, Win = W/2,
  * :11-14) without materialising it; out [N][H][W][16].  w_packed: packing.pack_conv2d_to16 ([9 taps][cin/16][64 lanes][4]). */
+/* The small convolutions of the PSM extractor outside the tiled 3x3 / stride-1 kernels (networks/psm_submodule.py): 3x3 stride 2
+ * (:52 layer2[0].conv1), 1x1 stride 1 | 2 (:78-83 downsample, :100-110 SPP branches, :72-74 lastconv's 1x1) + folded BatchNorm2d
+ * (scale 1 / shift 0 where the reference has none) [+ ReLU] on NHWC maps: in [N][Hin][Win][cin] -> out [N][Ho][Wo][cout], padding
+ * ksize / 2.  Instances: (cin, ksize, stride) = (32,3,2), (32,1,2), (32,1,1), (64,1,1), (128,1,1); cout a multiple of 16;
+ * w_packed: packing.pack_conv2d_small ([cout/16][ksize^2 taps][cin/16][64 lanes][4]).  Other shapes: ESTD_ERR_UNSUPPORTED. */
+int estd_conv2d_small_nhwc(const float* in, const float* w_packed, const float* scale, const float* shift, float* out, int N, int Hin,
+                           int Win, int cin, int cout, int ksize, int stride, int relu, estd_stream_t stream);
 int estd_conv2d_k3_to16_nhwc(const float* in, const float* w_packed, const float* scale, const float* shift, float* out, int N,
                              int H, int W, int cin, int upsample, estd_stream_t stream);
 /* image normalisation of DepthNetHybrid.forward (hybrid_models/model_hybrid.py:119: imgs = 2 * (imgs / 255.) - 1.):

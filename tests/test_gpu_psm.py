@@ -261,3 +261,57 @@ def test_spp_upsample_cat_matches_torch():
     assert out.shape == ref.shape
     assert torch.equal(out[..., :192], ref[..., :192])
     assert (out - ref).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("cin,cout,k,s,hw,relu,with_bn", [(32, 64, 3, 2, (120, 160), True, True), (32, 64, 1, 2, (120, 160), False, True),
+                                                           (64, 128, 1, 1, (60, 80), False, True), (128, 32, 1, 1, (30, 40), True, True),
+                                                           (128, 32, 1, 1, (3, 5), True, True), (128, 32, 1, 1, (60, 80), False, False),
+                                                           (32, 64, 3, 2, (37, 51), True, True), (32, 32, 1, 1, (9, 17), False, True)])
+def test_small_psm_convolutions_vs_torch_fp64(cin, cout, k, s, hw, relu, with_bn):
+    """csrc/refine2d.hip::conv2d_small_kernel -- the PSM extractor's 3x3 stride-2 and 1x1 (stride 1 | 2) convolutions + folded BN
+    [+ ReLU] (psm_submodule.py:52,:72-74,:78-83,:100-110), NHWC, ragged sizes -- against torch's float64 convolution."""
+    from estdepth_amd.backbones import small_conv_nhwc
+    g = torch.Generator().manual_seed(cin + cout + k + s)
+    conv = torch.nn.Conv2d(cin, cout, k, s, k // 2, bias=False)
+    bn = torch.nn.BatchNorm2d(cout).eval() if with_bn else None
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.1)
+        if bn is not None:
+            bn.weight.copy_(torch.rand(cout, generator=g) + 0.5); bn.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+            bn.running_mean.copy_(torch.randn(cout, generator=g) * 0.1); bn.running_var.copy_(torch.rand(cout, generator=g) + 0.5)
+    x = torch.randn(2, cin, hw[0], hw[1], generator=g)
+    with torch.no_grad():
+        ref = conv.double()(x.double())
+        if bn is not None:
+            ref = bn.double()(ref)
+        if relu:
+            ref = torch.relu(ref)
+    conv, bn = conv.float().to(DEV), (bn.float().to(DEV) if bn is not None else None)
+    out = small_conv_nhwc(conv, bn, x.to(DEV).permute(0, 2, 3, 1).contiguous(), relu)
+    assert out is not None and tuple(out.shape) == (2, ref.shape[2], ref.shape[3], cout)
+    err = float((out.permute(0, 3, 1, 2).double().cpu() - ref).abs().max())
+    assert err < 2e-6 * max(1.0, float(ref.abs().max())) * (cin * k * k) ** 0.5, err
+
+
+def test_psm_extractor_runs_no_library_convolution():
+    """the matching branch on a ROCm device launches no MIOpen / hipBLASLt kernel: every convolution of PSMFeatures is one of
+    the in-house kernels (only ATen's pooling remains)."""
+    from torch.profiler import profile, ProfilerActivity
+    from estdepth_amd import synth
+    from estdepth_amd.backbones import PSMFeatures, enable_fused_bn
+    m = PSMFeatures().eval()
+    synth.fill_state_dict(m, seed=5)
+    m = m.to(DEV).use_hip_convs()
+    enable_fused_bn(m, True)
+    x = synth.smooth_images(2, 128, 160, seed=3)[0].to(DEV) / 255.0 * 2 - 1
+    x = x.contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        m(x)
+        torch.cuda.synchronize()
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            y = m(x)
+            torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages()]
+    lib = [n for n in names if any(t in n for t in ("Cijk_", "igemm", "miopen", "MIOpen", "gemm", "xdl", "naive_conv", "Conv"))]
+    assert not lib, lib
+    assert tuple(y.shape) == (2, 32, 32, 40)

@@ -1,5 +1,4 @@
-mkdir -p gpurun_out/r3
-C="TA_TA_BUSY_sum SQ_BUSY_CU_CYCLES SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU TCP_TOTAL_CACHE_ACCESSES_sum"
-R=$PWD
-bash tools/pmc_collect.sh "$C" $R/gpurun_out/r3/wa_base_pmc.csv -- python $R/tools/hbm_bench.py | grep "kernel,\|warp_attention_kernel<3>"
-ESTD_BINDING=ctypes ESTD_LIB=$R/estdepth_amd/lib/libestd_hip_share.so bash tools/pmc_collect.sh "$C" $R/gpurun_out/r3/wa_share_pmc.csv -- python $R/tools/hbm_bench.py | grep "warp_attention_kernel<3>"
+python -m pytest tests/test_gpu_psm.py tests/test_gpu_parity.py -x -q 2>&1 | tail -3
+for v in 1 0 1 0; do echo "== ESTD_HIP_SMALL_CONVS=$v"; ESTD_HIP_SMALL_CONVS=$v python bench.py --steps 20 --warmup 5 --no-alt --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print(d['value'], d['ms_per_step'])"; done
