@@ -323,10 +323,10 @@ __global__ __launch_bounds__(256) void attention_prewarped_kernel(const float* _
     const float4* t4 = reinterpret_cast<const float4*>(kv_t) + idx * 8;
     const float4 vt = t4[sub];
     const float4 kt = t4[4 + sub];
-    float corr[8];
-    float4 wv[8];
+    float corr[ESTD_MAX_ATTENTION_SOURCES];
+    float4 wv[ESTD_MAX_ATTENTION_SOURCES];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < ESTD_MAX_ATTENTION_SOURCES; ++j) {
         if (j < n_src) {
             const float4* s4 = reinterpret_cast<const float4*>(srcs.kv_src[j]) + idx * 8;
             wv[j] = s4[sub];
@@ -339,13 +339,13 @@ __global__ __launch_bounds__(256) void attention_prewarped_kernel(const float* _
     }
     float mx = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) if (j < n_src) mx = fmaxf(mx, corr[j]);
+    for (int j = 0; j < ESTD_MAX_ATTENTION_SOURCES; ++j) if (j < n_src) mx = fmaxf(mx, corr[j]);
     float den = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) if (j < n_src) { corr[j] = expf(corr[j] - mx); den += corr[j]; }
+    for (int j = 0; j < ESTD_MAX_ATTENTION_SOURCES; ++j) if (j < n_src) { corr[j] = expf(corr[j] - mx); den += corr[j]; }
     float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) if (j < n_src) {
+    for (int j = 0; j < ESTD_MAX_ATTENTION_SOURCES; ++j) if (j < n_src) {
         const float a = corr[j] / den;
         h.x += wv[j].x * a; h.y += wv[j].y * a; h.z += wv[j].z * a; h.w += wv[j].w * a;
     }
@@ -585,10 +585,11 @@ extern "C" int estd_warp_attention(const float* kv_target, const float* const* k
 extern "C" int estd_attention_prewarped(const float* kv_target, const float* const* kv_src, int n_src,
                                         float* xh_out, int64_t n_vox, estd_stream_t s)
 {
-    if (!kv_target || !kv_src || !xh_out || n_src < 1 || n_src > 8 || n_vox <= 0) return ESTD_ERR_ARG;
+    if (!kv_target || !kv_src || !xh_out || n_src < 1 || n_vox <= 0) return ESTD_ERR_ARG;
+    if (n_src > ESTD_MAX_ATTENTION_SOURCES) return ESTD_ERR_UNSUPPORTED;
     WarpAttnArgs a;
     for (int j = 0; j < n_src; ++j) if (!kv_src[j]) return ESTD_ERR_ARG;
-    for (int j = 0; j < 8; ++j) a.kv_src[j] = j < n_src ? kv_src[j] : kv_src[0];
+    for (int j = 0; j < ESTD_MAX_ATTENTION_SOURCES; ++j) a.kv_src[j] = j < n_src ? kv_src[j] : kv_src[0];
     hipLaunchKernelGGL(attention_prewarped_kernel, dim3((unsigned)((n_vox + 63) / 64)), dim3(256), 0, estd_stream(s),
                        kv_target, a, n_src, xh_out, (long long)n_vox);
     return ESTD_LAUNCH_CHECK();

@@ -10,9 +10,28 @@
 
 static inline hipStream_t estd_stream(estd_stream_t s) { return static_cast<hipStream_t>(s); }
 
-// persistent-grid size of a kernel with `per_cu` resident workgroups per CU (256 CUs, minus the reserve of estd_set_reserved_cus)
+// persistent-grid size of a kernel with `per_cu` resident workgroups per CU: the compute units of the CURRENT device (256 on an
+// MI355X; queried once per device ordinal -- partitioned / other gfx950 parts report their own count) minus the reserve of
+// estd_set_reserved_cus
 extern "C" int estd_get_reserved_cus(void);
-static inline int estd_persistent_wgs(int per_cu) { return (256 - estd_get_reserved_cus()) * per_cu; }
+static inline int estd_device_cus(void)
+{
+    static int cus[64] = {0};                   // 0 = not queried yet (a benign race: every thread writes the same value)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    dev &= 63;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+static inline int estd_persistent_wgs(int per_cu)
+{
+    const int cus = estd_device_cus() - estd_get_reserved_cus();
+    return (cus > 8 ? cus : 8) * per_cu;
+}
 
 static inline int estd_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -320,7 +320,7 @@ Tensor attention_prewarped(const Tensor& kv_target, at::TensorList kv_sources)
 {
     const OpScope scope(kv_target);
     const int n = (int)kv_sources.size();
-    TORCH_CHECK(n >= 1 && n <= 8, "attention_prewarped: 1..8 pre-warped source volumes");
+    TORCH_CHECK(n >= 1 && n <= ESTD_MAX_ATTENTION_SOURCES, "attention_prewarped: 1..", ESTD_MAX_ATTENTION_SOURCES, " pre-warped source volumes");
     TORCH_CHECK(kv_target.numel() % 32 == 0, "attention_prewarped: kv volumes hold 32 floats per voxel");
     std::vector<const float*> ptrs(n);
     for (int j = 0; j < n; ++j) {

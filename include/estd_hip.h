@@ -236,7 +236,8 @@ int estd_warp_attention(const float* kv_target, const float* const* kv_src, cons
                         float* xh_out, int D, int H, int W, estd_stream_t stream);
 
 /* Attention over already-warped kv volumes (the level-1 EpipolarTransformer.forward signature,
- * transformer/epipolar_transformer.py:56-73): same output as estd_warp_attention without the gather. */
+ * transformer/epipolar_transformer.py:56-73): same output as estd_warp_attention without the gather; n_src in
+ * 1..ESTD_MAX_ATTENTION_SOURCES like it (more: ESTD_ERR_UNSUPPORTED). */
 int estd_attention_prewarped(const float* kv_target, const float* const* kv_src, int n_src,
                              float* xh_out, int64_t n_vox, estd_stream_t stream);
 

@@ -212,6 +212,24 @@ def test_epipolar_transformer(golden_dir):
         assert np.abs(out.cpu().numpy() - g["n%d" % n]).max() < 3e-5, n
 
 
+@pytest.mark.parametrize("n_src", [9, 16])
+def test_attention_over_prewarped_volumes_up_to_16_sources(n_src):
+    """the level-1 attention (epipolar_transformer.py:62-73) takes as many pre-warped views as the fused kernel: vs the oracle."""
+    from estdepth_amd import ops
+    from oracle import ref_ops as O
+    D, H, W = 5, 9, 13
+    g = torch.Generator().manual_seed(n_src)
+    kv_t = torch.randn(D, H, W, 32, generator=g)
+    kvs = [torch.randn(D, H, W, 32, generator=g) for _ in range(n_src)]
+    to_c = lambda kv, sl: np.ascontiguousarray(np.moveaxis(kv.numpy()[..., sl], -1, 0))[None]
+    ref = O.epipolar_attention(to_c(kv_t, slice(16, 32)), [to_c(k, slice(16, 32)) for k in kvs], [to_c(k, slice(0, 16)) for k in kvs])[0]
+    xh = ops.attention_prewarped(kv_t.to(DEV), [k.to(DEV) for k in kvs]).cpu().numpy()
+    assert np.array_equal(xh[..., :16], kv_t.numpy()[..., :16])
+    assert np.abs(np.moveaxis(xh[..., 16:], -1, 0) - ref).max() < 2e-6
+    with pytest.raises(RuntimeError):
+        ops.attention_prewarped(kv_t.to(DEV), [kvs[0].to(DEV)] * 17)
+
+
 def _cmp_outputs(outputs, g, prefix="", tol=TOL_DEPTH, optional=()):
     worst = 0.0
     for k, v in outputs.items():
