@@ -224,13 +224,13 @@ def stream_bench(args, device, rank, world):
 
 
 def conv3d_algo_of(group, algo, arith):
-    """which kernel a profiled conv3d group ran on: the plain 32->32 instance follows --conv3d-algo, the 33-channel instances
-    take the depth-only Winograd kernel under wino / wino2, the 16-output-channel instances are always direct."""
+    """which kernel a profiled conv3d group ran on: the 32->32 and 33->32 instances follow --conv3d-algo, the 33->33 instance (dres2)
+    takes the depth-only Winograd kernel under wino / wino2, the 16-output-channel instances are always direct."""
     if arith != "f32":
         return "direct"
-    if group == "conv3d:32->32":
+    if group in ("conv3d:32->32", "conv3d:33->32"):      # the key || value convolution (33 -> 32) has a wino2 instance as well
         return algo
-    if group in ("conv3d:33->32", "conv3d:33->33"):
+    if group == "conv3d:33->33":
         return "wino" if algo in ("wino", "wino2") else "direct"
     return "direct"
 

@@ -77,8 +77,9 @@ constexpr int NTAPS = 48;
 constexpr int WLDS_TAPS = ESTD_W2LDS_TAPS;           // weights of the first taps of every tile come from LDS
 constexpr int WLDS_BYTES = WLDS_TAPS * 4096;         // [tap][2 halves][2 quads][64 lanes][4]
 constexpr int SS_BYTES = 3 * 32 * 4;                 // folded BN scale | shift | activation floor of the 32 output channels
-constexpr int VTAB_BYTES = 6 * 256 * 4;               // per-thread global offsets of the slice chunks (3 x 512 or 6 x 256 threads)
-constexpr int LDS_BYTES = 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + WLDS_BYTES;
+constexpr int VTAB_BYTES = 6 * 256 * 4 + 512 * 4;     // per-thread global offsets of the slice chunks (3 x 512 or 6 x 256 threads) + of the scalar channel's voxel
+constexpr int XSL_BYTES = 4 * SL_VOX * 4;             // EXTRA: the four depth-transformed slices of the scalar 33rd input channel
+constexpr int LDS_BYTES = 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + XSL_BYTES + WLDS_BYTES;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;        // beyond num_records of any descriptor: loads return 0, stores are dropped
 
@@ -119,7 +120,10 @@ __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float
 //         ~6.5 SIMD cycles, NOT hidden behind the MFMAs (time is linear in the VALU count, profiles/r3_wino2_*).
 // RB: the launch has read-back streams in its epilogue (residual, residual2 or a running sum); the instance without them
 // (conv + BN + activation only) carries no registers for them.
-template <int NW, bool RB>
+// EXTRA: a scalar 33rd INPUT channel (the key || value convolution, hybrid_depth_decoder.py:190-191 on cat[dres2 output]): its own
+// four depth-transformed slices in LDS (2.9 KB); after the tap loop ONE more k-step per product m[sd][sh] -- lane group g multiplies
+// column tap kw = g of the row-transformed scalar rows (g = 3: zero weight) -- i.e. 16 more MFMAs per tile and wave.
+template <int NW, bool RB, bool EXTRA>
 __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int dpairs, int total_tiles)
 {
     constexpr int NTHREADS = 64 * NW;
@@ -158,7 +162,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
     if (tid >= 64 && tid < 96) lds_ss[tid] = ((tid - 64) < p.act_split ? p.act_a : p.act_b) == ESTD_ACT_RELU ? 0.0f : -__builtin_inff();
     const bool any_tanh = p.act_a == ESTD_ACT_TANH || p.act_b == ESTD_ACT_TANH;                     // uniform
     unsigned* lds_vt = reinterpret_cast<unsigned*>(smem + 4 * SLICE_BYTES + RED_BYTES + SS_BYTES);     // [it][thread]
-    char* lds_w = smem + 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES;     // weights of taps 0 .. WLDS_TAPS-1
+    float* lds_x = reinterpret_cast<float*>(smem + 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES);          // [4][SL_VOX]
+    char* lds_w = smem + 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + XSL_BYTES;     // weights of taps 0 .. WLDS_TAPS-1
     for (int e = tid; e < WLDS_BYTES / 16; e += NTHREADS)                         // (visible after the first tile's barriers)
         reinterpret_cast<float4*>(lds_w)[e] = reinterpret_cast<const float4*>(p.w_wino2)[e];
 
@@ -187,6 +192,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
         if (p.residual2) rs_res2 = make_rsrc(p.residual2 + (size_t)n * vol * p.out_stride, vol * p.out_stride);
         const int in_slice_bytes = HW * p.in_stride * 4;
         const int out_plane_bytes = HW * p.out_stride * 4;
+        __amdgpu_buffer_rsrc_t rs_ex = rs_in;
+        if (EXTRA) rs_ex = make_rsrc(p.in_extra + (size_t)n * vol, vol);
 
         // per-thread slice elements (validity in y / x does not depend on d): chunk it of a slice = chunk tid + it * NTHREADS.
         // Global offsets are held per column segment; the LDS offset of chunk it is loff0 + it * NTHREADS * 16 exactly (the
@@ -202,6 +209,18 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
             const bool ok = e < SL_CHUNKS && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
             lds_vt[it * NTHREADS + tid] = ok ? (unsigned)((gy * W + gx) * p.in_stride + c * 4) * 4u : OOB_OFFSET;
         }
+        if (EXTRA) {                                     // the scalar channel: thread t < 180 owns voxel t of its haloed slices
+            const int zy = tid / IN_W, zx = tid % IN_W;
+            const int gy = th0 - 1 + zy, gx = tw0 - 1 + zx;
+            if (tid < 512) lds_vt[6 * 256 + tid] = (tid < SL_VOX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? (unsigned)(gy * W + gx) * 4u : OOB_OFFSET;
+        }
+        auto x_voff = [&]() {
+            const int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            return lds_vt[6 * 256 + wave * 64 + l];
+        };
+        auto load_x = [&](int pd, unsigned vo) {
+            return (unsigned)pd < (unsigned)D ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ex, vo, pd * HW * 4, 0)) : 0.0f;
+        };
         // (the thread's table slot is re-formed from the lane id where it is read: nothing is held across the tap loop)
         auto chunk_voff = [&](int it) {
             const int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -337,6 +356,20 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
             load_plane(d0 + 1, xc);
             load_plane(d0 + 2, xd);
         }
+        float ea = 0.f, eb = 0.f, ec = 0.f, ed = 0.f;    // EXTRA: the scalar channel's four planes at this thread's voxel
+        if (EXTRA) {
+            const int d0 = 2 * dp;
+            const unsigned vo = x_voff();
+            ea = load_x(d0 - 1, vo); eb = load_x(d0, vo); ec = load_x(d0 + 1, vo); ed = load_x(d0 + 2, vo);
+        }
+        auto write_x_slices = [&]() {
+            if (EXTRA && tid < SL_VOX) {
+                lds_x[0 * SL_VOX + tid] = ea - ec;
+                lds_x[1 * SL_VOX + tid] = eb + ec;
+                lds_x[2 * SL_VOX + tid] = ec - eb;
+                lds_x[3 * SL_VOX + tid] = eb - ed;
+            }
+        };
 
         // depth transform B^T x of the planes in (xa, xb, xc, xd), straight into LDS slice sl
         auto write_slice = [&](int sl) {
@@ -352,6 +385,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
         auto shift_planes = [&]() {                      // planes d0+1, d0+2 are planes d0'-1, d0' of the next tile
 #pragma unroll
             for (int it = 0; it < SIT; ++it) { xa[it] = xc[it]; xb[it] = xd[it]; }
+            if (EXTRA) { ea = ec; eb = ed; }
         };
         bool first = true;
         // DEFER: the outputs of the previous tile of this column segment, stored inside the first steps of the current one -- between
@@ -376,6 +410,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                 lds_barrier();                          // every wave is done reading the previous tile's slices
 #pragma unroll
                 for (int sl = 0; sl < 4; ++sl) write_slice(sl);
+                write_x_slices();
                 shift_planes();
                 lds_barrier();
                 first = false;
@@ -494,6 +529,11 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                         }
                     }
                 }
+                if (EXTRA && has_next && (step == PF_STEP + 6 || step == PF_STEP + 7)) {      // the scalar channel's two new planes
+                    const unsigned vo = x_voff();
+                    if (step == PF_STEP + 6) ec = v0 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ex, vo, nd * HW * 4, 0)) : 0.f;
+                    else                     ed = v1 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ex, vo, (nd + 1) * HW * 4, 0)) : 0.f;
+                }
                 __builtin_amdgcn_sched_barrier(0);       // the loads above are issued BEFORE this step's MFMAs (left alone, the
                                                          // scheduler sinks them to the end of the step: no prefetch at all)
 #if ESTD_W2PRIO == 1
@@ -549,6 +589,29 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
             }
 
             W2STAMP(6);
+            // ---- the scalar input channel: one more k-step per product (lane group g = column tap kw = g) ----
+            if (EXTRA) {
+                // weights: [4 sd][2 halves][64 lanes][4 sh] (packing.pack_conv3d_wino2_extra), L2-resident
+                const __amdgpu_buffer_rsrc_t rs_wx = make_rsrc(p.w_extra, (size_t)4 * 2 * 256);
+                const int kwc = g < 3 ? g : 2;               // (g = 3 carries zero weights: any in-slice address)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    float4 wx[NHW];
+#pragma unroll
+                    for (int x = 0; x < NHW; ++x) wx[x] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_wx, lane * 16, ((s * 2 + nh0 + x) * 64) * 16, 0));
+                    float r[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) r[k] = lds_x[s * SL_VOX + (row0 + k) * IN_W + kwc + pi];
+                    const float t[4] = {r[0] - r[2], r[1] + r[2], r[2] - r[1], r[1] - r[3]};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int x = 0; x < NHW; ++x) {
+                            const float w = q == 0 ? wx[x].x : q == 1 ? wx[x].y : q == 2 ? wx[x].z : wx[x].w;
+                            acc[s][q][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, t[q], acc[s][q][x], 0, 0, 0);
+                        }
+                }
+            }
             // ---- output transform A^T m A ----
             f32x4 y0[2][NHW], y1[2][NHW];
 #pragma unroll
@@ -568,6 +631,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
             if (has_next) {                               // slice 3 of the next tile
                 lds_barrier();                            // every wave has read slice 3 for the last time; slices 0..2 (rewritten in the loop) are visible
                 write_slice(3);
+                write_x_slices();                         // (read only after the tap loop: published by the next tile's in-loop barrier too)
                 shift_planes();
                 if (!DEFER) lds_barrier();                // DEFER: slice 3 is published by the next tile's in-loop barrier
             }
@@ -610,7 +674,10 @@ extern "C" int estd_conv3d_k3_wino2(const estd_conv3d_desc* dp, estd_stream_t s)
     if (d.N <= 0 || d.D <= 0 || d.H <= 0 || d.W <= 0) return ESTD_ERR_ARG;
     if (!d.in_main || !d.w_wino2 || !d.scale || !d.shift || !d.out_main) return ESTD_ERR_ARG;
     // the plain instance only: 32 -> 32 on the MFMA, no scalar 33rd input / output channel, no fused head
-    if (d.cin_main != 32 || d.n_tiles != 2 || d.out_head || d.in_extra || d.w_extra || d.out_extra) return ESTD_ERR_UNSUPPORTED;
+    if (d.cin_main != 32 || d.n_tiles != 2 || d.out_head || d.out_extra) return ESTD_ERR_UNSUPPORTED;
+    const bool extra = d.in_extra != nullptr;
+    if (extra != (d.w_extra != nullptr)) return ESTD_ERR_ARG;
+    if (extra && d.stats_partials) return ESTD_ERR_UNSUPPORTED;
     if (d.in_stride < 32 || (d.in_stride & 3) || d.out_stride < 32 || (d.act_split & 1)) return ESTD_ERR_ARG;
     const int tiles_w = (d.W + TW - 1) / TW, tiles_h = (d.H + TH - 1) / TH, dpairs = (d.D + 1) / 2;
     const long long total = (long long)d.N * dpairs * tiles_h * tiles_w;
@@ -625,14 +692,16 @@ extern "C" int estd_conv3d_k3_wino2(const estd_conv3d_desc* dp, estd_stream_t s)
     if (grid >= 8) grid &= ~7;
     static const int nw = [] { const char* e = getenv("ESTD_WINO2_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
     const bool rb = d.residual || d.residual2 || d.accumulate || d.out_scale != 1.0f;      // (the scale multiply lives in that instance)
-#define ESTD_W2_LAUNCH(NWV, RBV)                                                                                                     \
+#define ESTD_W2_LAUNCH(NWV, RBV, EXV)                                                                                                \
     do {                                                                                                                             \
-        estd_allow_dynamic_lds<conv3d_wino2_kernel<NWV, RBV>>(LDS_BYTES);                                                            \
-        hipLaunchKernelGGL((conv3d_wino2_kernel<NWV, RBV>), dim3(grid), dim3(64 * NWV), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h, \
-                           dpairs, (int)total);                                                                                      \
+        estd_allow_dynamic_lds<conv3d_wino2_kernel<NWV, RBV, EXV>>(LDS_BYTES);                                                       \
+        hipLaunchKernelGGL((conv3d_wino2_kernel<NWV, RBV, EXV>), dim3(grid), dim3(64 * NWV), LDS_BYTES, estd_stream(s), d, tiles_w,  \
+                           tiles_h, dpairs, (int)total);                                                                             \
     } while (0)
-    if (nw == 8) { if (rb) ESTD_W2_LAUNCH(8, true); else ESTD_W2_LAUNCH(8, false); }
-    else { if (rb) ESTD_W2_LAUNCH(4, true); else ESTD_W2_LAUNCH(4, false); }
+    if (extra) {                                     // 8-wave form only (the key || value convolution)
+        if (rb) ESTD_W2_LAUNCH(8, true, true); else ESTD_W2_LAUNCH(8, false, true);
+    } else if (nw == 8) { if (rb) ESTD_W2_LAUNCH(8, true, false); else ESTD_W2_LAUNCH(8, false, false); }
+    else { if (rb) ESTD_W2_LAUNCH(4, true, false); else ESTD_W2_LAUNCH(4, false, false); }
 #undef ESTD_W2_LAUNCH
     return ESTD_LAUNCH_CHECK();
 }

@@ -215,7 +215,9 @@ class Conv3dPlan:
         self.w_wino = packing.pack_conv3d_wino(weight, main_idx, out_idx[:32]).to(device) if wino_ok else None
         self.w_wino_extra = packing.pack_conv3d_wino_extra(weight, extra_idx, out_idx[:32]).to(device) if (wino_ok and extra_idx is not None) else None
         self.w_wino_xout = packing.pack_conv3d_wino_xout(weight, main_idx, extra_idx, out_idx[32]).to(device) if (wino_ok and n_tiles == 3) else None
-        self.w_wino2 = packing.pack_conv3d_wino2(weight, main_idx, out_idx[:32]).to(device) if (wino_ok and n_tiles == 2 and extra_idx is None) else None
+        self.w_wino2 = packing.pack_conv3d_wino2(weight, main_idx, out_idx[:32]).to(device) if (wino_ok and n_tiles == 2) else None
+        self.w_wino2_extra = packing.pack_conv3d_wino2_extra(weight, extra_idx, out_idx[:32]).to(device) \
+            if (wino_ok and n_tiles == 2 and extra_idx is not None) else None
         self.w_main = wm.to(device)
         self.w_extra = wx.to(device) if wx is not None else None
         self.scale = scale.float().contiguous().to(device)
@@ -263,12 +265,13 @@ class Conv3dPlan:
         wino = (not split) and CONV3D_ALGO in ("wino", "wino2") and self.w_wino is not None and out is not None \
             and (out_extra is not None) == (self.n_tiles == 3) and out_head is None and out_channels == 32 \
             and (stats_partials is None or self.w_extra is None)
-        wino2 = wino and CONV3D_ALGO == "wino2" and self.w_wino2 is not None and in_extra is None
+        wino2 = wino and CONV3D_ALGO == "wino2" and self.w_wino2 is not None and (in_extra is None or stats_partials is None)
         variant, w_alt = (1, self.w_split) if split else (3, self.w_wino2) if wino2 else (2, self.w_wino) if wino else (0, None)
         cin = self.cin_main + (1 if self.w_extra is not None else 0)
         with _Prof("conv3d:%d->%d" % (cin, self.n_out), 2.0 * 27 * cin * self.n_out * Nn * D * H * W):
             if _use_torch():
-                T().conv3d_k3(x, in_extra, self.w_main, self.w_wino_extra if wino else self.w_extra, self.w_wino_xout if wino else self.w_xout, w_alt, self.scale, self.shift,
+                T().conv3d_k3(x, in_extra, self.w_main, self.w_wino2_extra if wino2 else self.w_wino_extra if wino else self.w_extra,
+                              self.w_wino_xout if wino else self.w_xout, w_alt, self.scale, self.shift,
                               (Nn, D, H, W), self.cin_main, in_stride, self.n_tiles, self.act_a, self.act_b, self.act_split, out,
                               out_stride, out_channels, residual, residual2, float(out_scale), bool(accumulate), out_extra, head_w, head_b,
                               out_head, stats_partials, variant)
@@ -299,6 +302,7 @@ class Conv3dPlan:
                 N.check(N.lib().estd_conv3d_k3_split(ctypes.byref(d), _stream()), "estd_conv3d_k3_split")
             elif wino2:
                 d.w_wino2 = self.w_wino2.data_ptr()
+                d.w_extra = self.w_wino2_extra.data_ptr() if self.w_wino2_extra is not None else None
                 N.check(N.lib().estd_conv3d_k3_wino2(ctypes.byref(d), _stream()), "estd_conv3d_k3_wino2")
             elif wino:
                 d.w_wino = self.w_wino.data_ptr()

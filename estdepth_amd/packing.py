@@ -293,6 +293,23 @@ def pack_conv3d_wino2(weight, main_idx, out_idx):
     return torch.from_numpy(out.reshape(48, 2, 2, 64, 4))
 
 
+def pack_conv3d_wino2_extra(weight, extra_idx, out_idx):
+    """the scalar 33rd input channel of a 33 -> 32 convolution for csrc/conv3d_wino2.hip<EXTRA>: float32
+    [4 sd][2 channel halves][64 lanes][4 sh]; element sh of lane (g, j) of (sd, half nh) = U[sd][sh][out_idx[16 nh + j]][extra_idx]
+    at column tap kw = g (g = 3: zero), U = G g G^T over (kd, kh) as in pack_conv3d_wino2."""
+    w = weight.detach().double().cpu().numpy()[:, extra_idx]         # [Cout, kd, kh, kw]
+    G = np.array([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
+    U = np.einsum("sd,th,odhw->stow", G, G, w).astype(np.float32)    # [4 sd, 4 sh, Cout, 3 kw]
+    out = np.zeros((4, 2, 64, 4), np.float32)
+    oi = np.asarray(out_idx)
+    for lane in range(64):
+        g, j = lane >> 4, lane & 15
+        if g < 3:
+            for nh in range(2):
+                out[:, nh, lane, :] = U[:, :, oi[16 * nh + j], g]
+    return torch.from_numpy(out)
+
+
 def pack_conv2d_to16(weight):
     """Conv2d weight [16, cin, 3, 3] (cin = 16 | 32) for csrc/refine2d.hip conv2d_k3_to16_kernel: float32 [9 taps][cin/16][64 lanes][4];
     element ks of lane (g, i) of (tap, half q) = weight[i][16 q + 4 g + ks][ky][kx] -- output channel i as the MFMA's M row, the

@@ -132,8 +132,9 @@ def test_wino_full_size_linearity_and_match(algo):
     assert float((c - zero + 2.0 * (b - zero)).abs().max()) < 2e-5 * float(b.abs().max())
 
 
+@pytest.mark.parametrize("algo", ALGOS)
 @pytest.mark.parametrize("dims", [(1, 4, 8, 32), (3, 5, 13, 50), (2, 1, 9, 33), (1, 64, 24, 32)])
-def test_wino_extra_input_channel_matches_direct_kernel_and_fp64(dims):
+def test_wino_extra_input_channel_matches_direct_kernel_and_fp64(dims, algo):
     """the key || value convolution's shape: 32 channels-last inputs + a scalar 33rd input volume -> 32 outputs (ReLU)."""
     from estdepth_amd import ops
     N, D, H, W = dims
@@ -141,11 +142,11 @@ def test_wino_extra_input_channel_matches_direct_kernel_and_fp64(dims):
     w = torch.randn(32, 33, 3, 3, 3, generator=g) * 0.05
     sc, sh = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.1
     plan = ops.Conv3dPlan(w, list(range(32)), 32, list(range(32)), 2, sc, sh, act_a="relu", device=DEV)
-    assert plan.w_wino_extra is not None
+    assert plan.w_wino_extra is not None and plan.w_wino2_extra is not None
     x = torch.randn(N, D, H, W, 32, generator=g)
     e = torch.randn(N, D, H, W, generator=g)
     a = _run(plan, "direct", x.to(DEV), dims, in_extra=e.to(DEV))
-    b = _run(plan, "wino", x.to(DEV), dims, in_extra=e.to(DEV))
+    b = _run(plan, algo, x.to(DEV), dims, in_extra=e.to(DEV))
     full = torch.cat([x.permute(0, 4, 1, 2, 3), e[:, None]], 1).double()
     ref = torch.nn.functional.conv3d(full, w.double(), padding=1) * sc.double()[None, :, None, None, None] + sh.double()[None, :, None, None, None]
     ref = torch.relu(ref).permute(0, 2, 3, 4, 1)

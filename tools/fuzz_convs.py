@@ -69,6 +69,10 @@ def case_conv3d():
                               act_a="tanh", act_b="relu", act_split=16, device=DEV)
         a = run3d(plan, "direct", x, dims, in_extra=e, out=torch.empty_like(x))
         b = run3d(plan, "wino", x, dims, in_extra=e, out=torch.empty_like(x))
+        b2 = run3d(plan, "wino2", x, dims, in_extra=e, out=torch.empty_like(x))
+        d2 = float((a - b2).abs().max())
+        if not ((d2 == d2) and d2 < 4e-5 * max(1.0, float(a.abs().max()))):
+            return False, ("conv3d", "extra/wino2", dims, d2)
     else:
         w = rnd(33, 33, 3, 3, 3, scale=0.06).cpu()
         plan = ops.Conv3dPlan(w, list(range(1, 33)), 0, list(range(33)), 3, torch.rand(33, generator=g) + 0.5, torch.randn(33, generator=g) * 0.1,

@@ -9,7 +9,7 @@ g = torch.Generator().manual_seed(1)
 w = torch.randn(32, 33, 3, 3, 3, generator=g) * 0.05
 plan = ops.Conv3dPlan(w, list(range(32)), 32, list(range(32)), 2, torch.ones(32), torch.zeros(32), act_a="relu", device=dev)
 x = torch.randn(N, D, H, W, 32, device=dev); e = torch.randn(N, D, H, W, device=dev); y = torch.empty_like(x)
-for algo in ("direct", "wino", "direct", "wino"):
+for algo in ("direct", "wino", "wino2", "wino", "wino2"):
     ops.CONV3D_ALGO = algo
     for _ in range(3): plan.run(x, (N, D, H, W), in_extra=e, out=y)
     torch.cuda.synchronize()
