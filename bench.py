@@ -225,13 +225,15 @@ def stream_bench(args, device, rank, world):
 
 def conv3d_algo_of(group, algo, arith):
     """which kernel a profiled conv3d group ran on: the 32->32 and 33->32 instances follow --conv3d-algo, the 33->33 instance (dres2)
-    takes the depth-only Winograd kernel under wino / wino2, the 16-output-channel instances are always direct."""
+    takes the depth-only Winograd kernel under wino / wino2, 32->16 has a wino2 instance, the 16->16 heads are always direct."""
     if arith != "f32":
         return "direct"
     if group in ("conv3d:32->32", "conv3d:33->32"):      # the key || value convolution (33 -> 32) has a wino2 instance as well
         return algo
     if group == "conv3d:33->33":
         return "wino" if algo in ("wino", "wino2") else "direct"
+    if group == "conv3d:32->16":                     # the GRU output convolution: 16-output-channel instance of the wino2 kernel
+        return "wino2" if algo == "wino2" else "direct"
     return "direct"
 
 

@@ -81,6 +81,11 @@ constexpr int VTAB_BYTES = 6 * 256 * 4 + 512 * 4;     // per-thread global offse
 constexpr int XSL_BYTES = 4 * SL_VOX * 4;             // EXTRA: the four depth-transformed slices of the scalar 33rd input channel
 constexpr int LDS_BYTES = 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + XSL_BYTES + WLDS_BYTES;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+// O16 (16 output channels): a tap's weights are 2 KB; 20 taps in LDS + the 16 KB exchange buffer of the cross-wave reduction
+constexpr int O16_WLDS_TAPS = 20;
+constexpr int O16_XCH_BYTES = 8 * 2 * 64 * 16;
+constexpr int O16_LDS_BYTES = 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + O16_XCH_BYTES + O16_WLDS_TAPS * 2048;
+static_assert(O16_LDS_BYTES <= 160 * 1024, "LDS budget (O16)");
 constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;        // beyond num_records of any descriptor: loads return 0, stores are dropped
 
 __device__ __forceinline__ float4 as_float4(u32x4 v)
@@ -123,7 +128,11 @@ __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float
 // EXTRA: a scalar 33rd INPUT channel (the key || value convolution, hybrid_depth_decoder.py:190-191 on cat[dres2 output]): its own
 // four depth-transformed slices in LDS (2.9 KB); after the tap loop ONE more k-step per product m[sd][sh] -- lane group g multiplies
 // column tap kw = g of the row-transformed scalar rows (g = 3: zero weight) -- i.e. 16 more MFMAs per tile and wave.
-template <int NW, bool RB, bool EXTRA>
+// O16: 32 -> 16 output channels (the GRU output convolution, transformer/epipolar_transformer.py:26): one 16-channel tile per product, so
+// the two waves of a SIMD split the INPUT channels instead -- wave (rp, cw) multiplies chunk cw (16 of the 32 channels) in 12 steps of
+// 16 MFMAs -- and sum their outputs through a 16 KB LDS exchange after the output transform: wave cw keeps plane d0 + cw, sends the
+// other one to its partner, and runs the epilogue of its plane only.
+template <int NW, bool RB, bool EXTRA, bool O16>
 __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int dpairs, int total_tiles)
 {
     constexpr int NTHREADS = 64 * NW;
@@ -136,7 +145,12 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rp = wave & 3;            // tile rows 2rp, 2rp+1 (halo rows 2rp .. 2rp+3)
-    const int nh0 = NW == 8 ? wave >> 2 : 0;            // first channel half of this wave
+    static_assert(!O16 || (NW == 8 && !EXTRA), "O16: 8-wave form without the scalar channel");
+    const int cw = wave >> 2;                           // O16: this wave's input-channel chunk and the output plane (d0 + cw) it finishes
+    const int nh0 = (NW == 8 && !O16) ? wave >> 2 : 0;  // first channel half of this wave
+    constexpr int NSTEPS = O16 ? 12 : 24;
+    constexpr int TAP_BYTES = O16 ? 2048 : 4096;
+    constexpr int WTAPS = O16 ? O16_WLDS_TAPS : WLDS_TAPS;
     const int g = lane >> 4;            // k index inside an MFMA
     const int i = lane & 15;            // voxel column of the (transposed) MFMA
     // MFMA column <-> voxel of a tile row (conflict-free ds_read_b128 for every tap; see csrc/conv3d_wino.hip)
@@ -156,19 +170,24 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
     if (u >= u_end) return;
 
     float* lds_ss = reinterpret_cast<float*>(smem + 4 * SLICE_BYTES + RED_BYTES);  // scale[32] | shift[32]: read in the epilogue
-    if (tid < 64) lds_ss[tid] = tid < 32 ? p.scale[tid] : p.shift[tid - 32];     // (a global load there is an exposed L2 round trip)
+    if (tid < 64) {                                                               // (a global load there is an exposed L2 round trip)
+        const int c = tid & 31;
+        lds_ss[tid] = (O16 && c >= 16) ? 0.0f : (tid < 32 ? p.scale[c] : p.shift[c]);
+    }
     // activation as a per-channel floor: ReLU = max(v, 0), none = max(v, -inf) -- two VALU operations per value in the epilogue
     // (fp32 MFMAs hide no VALU work: every epilogue instruction is paid in matrix-pipe time); tanh takes the generic path
     if (tid >= 64 && tid < 96) lds_ss[tid] = ((tid - 64) < p.act_split ? p.act_a : p.act_b) == ESTD_ACT_RELU ? 0.0f : -__builtin_inff();
+    // (O16: scale / shift hold 16 entries; lanes read channels 0..15 only)
     const bool any_tanh = p.act_a == ESTD_ACT_TANH || p.act_b == ESTD_ACT_TANH;                     // uniform
     unsigned* lds_vt = reinterpret_cast<unsigned*>(smem + 4 * SLICE_BYTES + RED_BYTES + SS_BYTES);     // [it][thread]
-    float* lds_x = reinterpret_cast<float*>(smem + 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES);          // [4][SL_VOX]
-    char* lds_w = smem + 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + XSL_BYTES;     // weights of taps 0 .. WLDS_TAPS-1
-    for (int e = tid; e < WLDS_BYTES / 16; e += NTHREADS)                         // (visible after the first tile's barriers)
+    float* lds_x = reinterpret_cast<float*>(smem + 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES);          // [4][SL_VOX] (EXTRA)
+    char* lds_xch = smem + 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES;               // O16: [8 waves][2 rows][64 lanes] float4
+    char* lds_w = smem + 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + (O16 ? O16_XCH_BYTES : XSL_BYTES);     // weights of the first taps
+    for (int e = tid; e < WTAPS * TAP_BYTES / 16; e += NTHREADS)                  // (visible after the first tile's barriers)
         reinterpret_cast<float4*>(lds_w)[e] = reinterpret_cast<const float4*>(p.w_wino2)[e];
 
     // packed weights: [48 taps][2 halves][2 quads][64 lanes][4]
-    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w_wino2, (size_t)NTAPS * 2 * 2 * 256);
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w_wino2, (size_t)NTAPS * (O16 ? 1 : 2) * 2 * 256);
     const int wlane = lane * 16 + nh0 * 2048;
     const int row0 = 2 * rp;
 
@@ -347,6 +366,36 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
             }
         };
 
+        // O16: one 16-channel group; wave (rp, cw) holds plane d0 + cw -> both planes of the tile in ONE reduction: group slot 0 of
+        // the plane's canonical tile id receives {sum, sumsq}, slot 1 zeros (estd_groupnorm_finalize reads both groups).
+        auto plane_stats_o16 = [&](const f32x4 (&a)[2][NHW], int d0_) {
+            double s_sum = 0.0, s_sq = 0.0;
+            const int cb = 4 * g;
+            const float4 sc4 = *reinterpret_cast<const float4*>(lds_ss + cb), sh4 = *reinterpret_cast<const float4*>(lds_ss + 32 + cb);
+            const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                if (eoff_of(m) != OOB_OFFSET) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const double v = (double)(a[m][0][r] * scv[r] + shv[r]); s_sum += v; s_sq += v * v; }
+                }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { s_sum += __shfl_xor(s_sum, o); s_sq += __shfl_xor(s_sq, o); }
+            double* red = reinterpret_cast<double*>(smem + 4 * SLICE_BYTES);       // [plane cw][row pair][sum, sumsq]
+            __syncthreads();
+            if (lane == 0) { red[(cw * 4 + rp) * 2] = s_sum; red[(cw * 4 + rp) * 2 + 1] = s_sq; }
+            __syncthreads();
+            if (tid < 4) {
+                const int pl_ = tid >> 1, q = tid & 1;
+                if (d0_ + pl_ < D) {
+                    const double tot = red[(pl_ * 4 + 0) * 2 + q] + red[(pl_ * 4 + 1) * 2 + q] + red[(pl_ * 4 + 2) * 2 + q] + red[(pl_ * 4 + 3) * 2 + q];
+                    const size_t tile_id = (((size_t)n * D + d0_ + pl_) * tiles_h + thi) * tiles_w + twi;
+                    p.stats_partials[tile_id * 4 + q] = tot;
+                    p.stats_partials[tile_id * 4 + 2 + q] = 0.0;
+                }
+            }
+        };
+
         // raw planes in registers: xa = x[d0-1], xb = x[d0], xc = x[d0+1], xd = x[d0+2]
         float4 xa[SIT], xb[SIT], xc[SIT], xd[SIT];
         {
@@ -393,8 +442,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
         // 35 500 cycles per tile without a single MFMA: two barriers, the slice-3 rewrite and the epilogue of all eight waves at once,
         // profiles/r3_wino2_tile_timeline.txt).  Their registers are the ones the next-plane prefetch occupies later in the loop.
         constexpr bool DEFER = ESTD_W2DEFER != 0 && !RB;        // (with read-back streams the deferred form spills inside the tap loop)
-        constexpr int RB_STEP = DEFER ? 16 : 18;         // step in front of which slices 0..2 are rewritten
-        constexpr int PF_STEP = DEFER ? 4 : 0;           // first step of the next-plane prefetch
+        // step in front of which slices 0..2 are rewritten (every read of them has been issued: rows are fetched two steps ahead)
+        constexpr int RB_STEP = O16 ? (DEFER ? 7 : 9) : (DEFER ? 16 : 18);
+        constexpr int PF_STEP = (DEFER && !O16) ? 4 : 0; // first step of the next-plane prefetch
         f32x4 py0[2][NHW], py1[2][NHW];
         int pd0 = 0;
         bool have_prev = false;
@@ -428,9 +478,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
 #pragma unroll
                     for (int x = 0; x < NHW; ++x) acc[s][t][x] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-            auto load_w = [&](int t, int q, int x) {        // t, q, x are compile-time constants after unrolling
-                if (t < WLDS_TAPS) return *reinterpret_cast<const float4*>(lds_w + t * 4096 + x * 2048 + q * 1024 + wlane);
-                return as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, t * 4096 + x * 2048 + q * 1024, 0));
+            auto load_w = [&](int t, int q, int x) {        // t, x are compile-time constants after unrolling (q too, except O16: q = cw)
+                if (t < WTAPS) return *reinterpret_cast<const float4*>(lds_w + t * TAP_BYTES + x * 2048 + q * 1024 + wlane);
+                return as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane + (O16 ? q * 1024 : 0), t * TAP_BYTES + x * 2048 + (O16 ? 0 : q * 1024), 0));
             };
             // 16-byte chunk c (channels 4g.. for c = 0, 16+4g.. for c = 1) of halo row 2rp + r at column shift kw of depth slice sd
             auto load_row = [&](int sd, int kw, int c, int r) {
@@ -459,12 +509,12 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                 }
             };
             auto load_rows = [&](int st, float4 (&Rr)[4]) {
-                const int ng = st >> 1;
+                const int ng = O16 ? st : st >> 1;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Rr[r] = load_row(ng / 3, ng % 3, st & 1, r);
+                for (int r = 0; r < 4; ++r) Rr[r] = load_row(ng / 3, ng % 3, O16 ? cw : (st & 1), r);
             };
             auto load_b = [&](int st, float4 (&bq)[4][NHW]) {
-                const int ng = st >> 1, nc = st & 1;
+                const int ng = O16 ? st : st >> 1, nc = O16 ? cw : (st & 1);
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -496,13 +546,13 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
             W2STAMP(1);
 
 #pragma clang loop unroll(full)
-            for (int step = 0; step < 24; ++step) {      // step = (group gi = 3 sd + kw, channel chunk c)
-                const int gi = step >> 1;
+            for (int step = 0; step < NSTEPS; ++step) {  // step = (group gi = 3 sd + kw, channel chunk c); O16: the chunk is the wave's
+                const int gi = O16 ? step : step >> 1;
                 const int sd = gi / 3;
-                if (step == 6) W2STAMP(2);
-                if (step == 12) W2STAMP(3);
-                if (step == 18) W2STAMP(4);
-                if (step == 19) W2STAMP(5);
+                if (step == NSTEPS / 4) W2STAMP(2);
+                if (step == NSTEPS / 2) W2STAMP(3);
+                if (step == 3 * NSTEPS / 4) W2STAMP(4);
+                if (step == 3 * NSTEPS / 4 + 1) W2STAMP(5);
                 if (has_next && step == RB_STEP) {
                     // slices 0..2 have been read for the last time by every wave (the rows of step 17 are fetched at the end of step
                     // 15); DEFER: this barrier also publishes slice 3, rewritten at the top of this tile and first read at the end of
@@ -513,7 +563,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                     write_slice(2);
                 }
                 // weights of step + BD - 1
-                if (step + BD - 1 < 24 && !(ESTD_W2ABL & 8)) load_b(step + BD - 1, bq[(step + BD - 1) % BD]);
+                if (step + BD - 1 < NSTEPS && !(ESTD_W2ABL & 8)) load_b(step + BD - 1, bq[(step + BD - 1) % BD]);
                 // chunks of the NEXT tile's two new planes: spread over the first steps (their offsets were read from the LDS table
                 // at the end of the previous step)
                 if (has_next && !(ESTD_W2ABL & 16)) {
@@ -556,20 +606,24 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                                 acc[sd][t][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, T[h][t][e], acc[sd][t][x], 0, 0, 0);
                             }
                     if (ESTD_W2PK == 1) __builtin_amdgcn_sched_barrier(0);   // the MFMAs of two components, then the next step's 4 packed transforms
-                    if (step + 1 < 24) xform2(R, h, Tn[h]);
+                    if (step + 1 < NSTEPS) xform2(R, h, Tn[h]);
                     if (ESTD_W2PK == 1 && h == 0) __builtin_amdgcn_sched_barrier(0);
                 }
-                if (step + 2 < 24) load_rows(step + 2, R);
+                if (step + 2 < NSTEPS) load_rows(step + 2, R);
                 if (has_next && step + 1 >= PF_STEP && step + 1 < PF_STEP + 6 && !(ESTD_W2ABL & 16)) {
 #pragma unroll
                     for (int k = 0; k < PER; ++k) vo_next[k] = chunk_voff(((step + 1 - PF_STEP) * PER + k) % SIT);
                 }
-                if (DEFER && have_prev && step < 4) {     // the previous tile's epilogue: plane d0 in steps 0-1, plane d0 + 1 in steps 2-3
+                if (DEFER && !O16 && have_prev && step < 4) {     // the previous tile's epilogue: plane d0 in steps 0-1, plane d0 + 1 in steps 2-3
                     const bool second = step >= 2;
                     if (!second || pd0 + 1 < D) {
                         if ((step & 1) == 0) epi_issue(pd0 + (second ? 1 : 0), pl);
                         else epi_finish(second ? py1 : py0, pd0 + (second ? 1 : 0), pl);
                     }
+                }
+                if (DEFER && O16 && have_prev && step < 2 && pd0 + cw < D) {   // O16: this wave's ONE plane of the previous tile
+                    if (step == 0) epi_issue(pd0 + cw, pl);
+                    else epi_finish(py0, pd0 + cw, pl);
                 }
                 if (ESTD_W2PK == 0) {
 #pragma unroll
@@ -579,7 +633,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                     }
                     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
                 }
-                if (step + 1 < 24) {
+                if (step + 1 < NSTEPS) {
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -628,8 +682,29 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                     y1[m][x] = z[1][m] - z[2][m] - z[3][m];
                 }
             }
-            if (has_next) {                               // slice 3 of the next tile
+            if (O16) {
+                // cross-wave reduction over the two input-channel chunks: wave cw keeps plane d0 + cw and hands the other plane's
+                // partial sums to its partner (wave ^ 4, same rows) through LDS; the barrier below is the tile's post-loop barrier
+                float4* xw = reinterpret_cast<float4*>(lds_xch) + (wave * 2) * 64 + lane;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const f32x4 snd = cw == 0 ? y1[m][0] : y0[m][0];
+                    xw[m * 64] = make_float4(snd[0], snd[1], snd[2], snd[3]);
+                }
+            }
+            if (has_next || O16) {
                 lds_barrier();                            // every wave has read slice 3 for the last time; slices 0..2 (rewritten in the loop) are visible
+            }
+            if (O16) {
+                const float4* xr = reinterpret_cast<const float4*>(lds_xch) + ((wave ^ 4) * 2) * 64 + lane;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const float4 o = xr[m * 64];
+                    const f32x4 own = cw == 0 ? y0[m][0] : y1[m][0];
+                    y0[m][0] = own + (f32x4){o.x, o.y, o.z, o.w};          // y0 now = the finished outputs of plane d0 + cw
+                }
+            }
+            if (has_next) {                               // slice 3 of the next tile
                 write_slice(3);
                 write_x_slices();                         // (read only after the tap loop: published by the next tile's in-loop barrier too)
                 shift_planes();
@@ -642,20 +717,26 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
             const bool defer_this = DEFER && has_next && !p.stats_partials;      // uniform
 #endif
 #ifndef ESTD_W2TIME
-            if (p.stats_partials) {                      // uniform; the GRU gate convolution (one volume per launch)
-                plane_stats(y0, d0);
-                if (d0 + 1 < D) plane_stats(y1, d0 + 1);              // (odd D: the last pair has one plane)
+            if (p.stats_partials) {                      // uniform; the GRU convolutions (one volume per launch)
+                if (O16) plane_stats_o16(y0, d0);
+                else {
+                    plane_stats(y0, d0);
+                    if (d0 + 1 < D) plane_stats(y1, d0 + 1);          // (odd D: the last pair has one plane)
+                }
             }
 #endif
             if (!defer_this) {
-                epi_plane(y0, d0);
-                if (d0 + 1 < D) epi_plane(y1, d0 + 1);
+                if (O16) { if (d0 + cw < D) epi_plane(y0, d0 + cw); }
+                else {
+                    epi_plane(y0, d0);
+                    if (d0 + 1 < D) epi_plane(y1, d0 + 1);
+                }
             }
             // (assigned on both paths: a value that survives only on the non-deferred path would stay live through the whole loop)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int x = 0; x < NHW; ++x) { py0[m][x] = y0[m][x]; py1[m][x] = y1[m][x]; }
+                for (int x = 0; x < NHW; ++x) { py0[m][x] = y0[m][x]; if (!O16) py1[m][x] = y1[m][x]; }
             pd0 = d0;
             have_prev = defer_this;
             W2STAMP(8);
@@ -674,11 +755,13 @@ extern "C" int estd_conv3d_k3_wino2(const estd_conv3d_desc* dp, estd_stream_t s)
     if (d.N <= 0 || d.D <= 0 || d.H <= 0 || d.W <= 0) return ESTD_ERR_ARG;
     if (!d.in_main || !d.w_wino2 || !d.scale || !d.shift || !d.out_main) return ESTD_ERR_ARG;
     // the plain instance only: 32 -> 32 on the MFMA, no scalar 33rd input / output channel, no fused head
-    if (d.cin_main != 32 || d.n_tiles != 2 || d.out_head || d.out_extra) return ESTD_ERR_UNSUPPORTED;
+    if (d.cin_main != 32 || (d.n_tiles != 2 && d.n_tiles != 1) || d.out_head || d.out_extra) return ESTD_ERR_UNSUPPORTED;
+    const bool o16 = d.n_tiles == 1;                 // 32 -> 16 (the GRU output convolution)
     const bool extra = d.in_extra != nullptr;
+    if (o16 && (extra || d.out_stride < 16)) return ESTD_ERR_UNSUPPORTED;
     if (extra != (d.w_extra != nullptr)) return ESTD_ERR_ARG;
     if (extra && d.stats_partials) return ESTD_ERR_UNSUPPORTED;
-    if (d.in_stride < 32 || (d.in_stride & 3) || d.out_stride < 32 || (d.act_split & 1)) return ESTD_ERR_ARG;
+    if (d.in_stride < 32 || (d.in_stride & 3) || d.out_stride < (o16 ? 16 : 32) || (d.out_stride & 3) || (d.act_split & 1)) return ESTD_ERR_ARG;
     const int tiles_w = (d.W + TW - 1) / TW, tiles_h = (d.H + TH - 1) / TH, dpairs = (d.D + 1) / 2;
     const long long total = (long long)d.N * dpairs * tiles_h * tiles_w;
     if (total > 0x7fffffffLL) return ESTD_ERR_ARG;
@@ -692,16 +775,19 @@ extern "C" int estd_conv3d_k3_wino2(const estd_conv3d_desc* dp, estd_stream_t s)
     if (grid >= 8) grid &= ~7;
     static const int nw = [] { const char* e = getenv("ESTD_WINO2_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
     const bool rb = d.residual || d.residual2 || d.accumulate || d.out_scale != 1.0f;      // (the scale multiply lives in that instance)
-#define ESTD_W2_LAUNCH(NWV, RBV, EXV)                                                                                                \
+#define ESTD_W2_LAUNCH(NWV, RBV, EXV, OV)                                                                                            \
     do {                                                                                                                             \
-        estd_allow_dynamic_lds<conv3d_wino2_kernel<NWV, RBV, EXV>>(LDS_BYTES);                                                       \
-        hipLaunchKernelGGL((conv3d_wino2_kernel<NWV, RBV, EXV>), dim3(grid), dim3(64 * NWV), LDS_BYTES, estd_stream(s), d, tiles_w,  \
-                           tiles_h, dpairs, (int)total);                                                                             \
+        const int lds_bytes = OV ? O16_LDS_BYTES : LDS_BYTES;                                                                        \
+        estd_allow_dynamic_lds<conv3d_wino2_kernel<NWV, RBV, EXV, OV>>(lds_bytes);                                                   \
+        hipLaunchKernelGGL((conv3d_wino2_kernel<NWV, RBV, EXV, OV>), dim3(grid), dim3(64 * NWV), lds_bytes, estd_stream(s), d,       \
+                           tiles_w, tiles_h, dpairs, (int)total);                                                                    \
     } while (0)
-    if (extra) {                                     // 8-wave form only (the key || value convolution)
-        if (rb) ESTD_W2_LAUNCH(8, true, true); else ESTD_W2_LAUNCH(8, false, true);
-    } else if (nw == 8) { if (rb) ESTD_W2_LAUNCH(8, true, false); else ESTD_W2_LAUNCH(8, false, false); }
-    else { if (rb) ESTD_W2_LAUNCH(4, true, false); else ESTD_W2_LAUNCH(4, false, false); }
+    if (o16) {                                       // 8-wave form only
+        if (rb) ESTD_W2_LAUNCH(8, true, false, true); else ESTD_W2_LAUNCH(8, false, false, true);
+    } else if (extra) {                              // 8-wave form only (the key || value convolution)
+        if (rb) ESTD_W2_LAUNCH(8, true, true, false); else ESTD_W2_LAUNCH(8, false, true, false);
+    } else if (nw == 8) { if (rb) ESTD_W2_LAUNCH(8, true, false, false); else ESTD_W2_LAUNCH(8, false, false, false); }
+    else { if (rb) ESTD_W2_LAUNCH(4, true, false, false); else ESTD_W2_LAUNCH(4, false, false, false); }
 #undef ESTD_W2_LAUNCH
     return ESTD_LAUNCH_CHECK();
 }

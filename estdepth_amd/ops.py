@@ -218,6 +218,9 @@ class Conv3dPlan:
         self.w_wino2 = packing.pack_conv3d_wino2(weight, main_idx, out_idx[:32]).to(device) if (wino_ok and n_tiles == 2) else None
         self.w_wino2_extra = packing.pack_conv3d_wino2_extra(weight, extra_idx, out_idx[:32]).to(device) \
             if (wino_ok and n_tiles == 2 and extra_idx is not None) else None
+        # 32 -> 16 (the GRU output convolution): the wino2 kernel's 16-output-channel instance
+        self.w_wino2_o16 = packing.pack_conv3d_wino2(weight, main_idx, out_idx[:16]).to(device) \
+            if (len(main_idx) == 32 and n_tiles == 1 and len(out_idx) == 16 and extra_idx is None and head_w is None) else None
         self.w_main = wm.to(device)
         self.w_extra = wx.to(device) if wx is not None else None
         self.scale = scale.float().contiguous().to(device)
@@ -266,7 +269,9 @@ class Conv3dPlan:
             and (out_extra is not None) == (self.n_tiles == 3) and out_head is None and out_channels == 32 \
             and (stats_partials is None or self.w_extra is None)
         wino2 = wino and CONV3D_ALGO == "wino2" and self.w_wino2 is not None and (in_extra is None or stats_partials is None)
-        variant, w_alt = (1, self.w_split) if split else (3, self.w_wino2) if wino2 else (2, self.w_wino) if wino else (0, None)
+        o16 = (not split) and CONV3D_ALGO == "wino2" and self.w_wino2_o16 is not None and out is not None and out_head is None \
+            and in_extra is None and out_channels == 16 and out_extra is None
+        variant, w_alt = (1, self.w_split) if split else (3, self.w_wino2_o16) if o16 else (3, self.w_wino2) if wino2 else (2, self.w_wino) if wino else (0, None)
         cin = self.cin_main + (1 if self.w_extra is not None else 0)
         with _Prof("conv3d:%d->%d" % (cin, self.n_out), 2.0 * 27 * cin * self.n_out * Nn * D * H * W):
             if _use_torch():
@@ -300,6 +305,9 @@ class Conv3dPlan:
             if split:
                 d.w_split = self.w_split.data_ptr()
                 N.check(N.lib().estd_conv3d_k3_split(ctypes.byref(d), _stream()), "estd_conv3d_k3_split")
+            elif o16:
+                d.w_wino2 = self.w_wino2_o16.data_ptr()
+                N.check(N.lib().estd_conv3d_k3_wino2(ctypes.byref(d), _stream()), "estd_conv3d_k3_wino2")
             elif wino2:
                 d.w_wino2 = self.w_wino2.data_ptr()
                 d.w_extra = self.w_wino2_extra.data_ptr() if self.w_wino2_extra is not None else None

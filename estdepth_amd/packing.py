@@ -274,23 +274,24 @@ def pack_conv3d_wino(weight, main_idx, out_idx):
 
 
 def pack_conv3d_wino2(weight, main_idx, out_idx):
-    """32 -> 32 filters for csrc/conv3d_wino2.hip: depth AND row taps in Winograd F(2,3) form, U = G g G^T with
+    """32 -> 32 (or 32 -> 16) filters for csrc/conv3d_wino2.hip: depth AND row taps in Winograd F(2,3) form, U = G g G^T with
     G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]] applied on kd and on kh (float64, rounded once to float32), packed as float32
-    [48 taps][2 channel halves][2 quads][64 lanes][4]: tap = (3 sd + kw) * 4 + sh (sd / sh = depth / row transform index); lane
-    (g, j) of half nh holds, at k-step t = 4 q + e, U[sd][sh][out_idx[16 nh + j]][main_idx[ch(g, t)]][kw]."""
-    assert len(main_idx) == 32 and len(out_idx) == 32
+    [48 taps][NH channel halves][2 quads][64 lanes][4] (NH = len(out_idx) / 16 = 2 | 1): tap = (3 sd + kw) * 4 + sh (sd / sh = depth /
+    row transform index); lane (g, j) of half nh holds, at k-step t = 4 q + e, U[sd][sh][out_idx[16 nh + j]][main_idx[ch(g, t)]][kw]."""
+    assert len(main_idx) == 32 and len(out_idx) in (16, 32)
+    nhalf = len(out_idx) // 16
     w = weight.detach().double().cpu().numpy()                       # [Cout, Cin, kd, kh, kw]
     G = np.array([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
     U = np.einsum("sd,th,oidhw->stoiw", G, G, w).astype(np.float32)  # [4 sd, 4 sh, Cout, Cin, 3 kw]
-    out = np.zeros((4, 3, 4, 2, 2, 64, 4), np.float32)               # [sd][kw][sh][nh][q][lane][e]
+    out = np.zeros((4, 3, 4, nhalf, 2, 64, 4), np.float32)           # [sd][kw][sh][nh][q][lane][e]
     oi, mi = np.asarray(out_idx), np.asarray(main_idx)
     for lane in range(64):
         g, j = lane >> 4, lane & 15
         for t in range(8):
             ci = mi[_ch(32, g, t)]
-            for nh in range(2):
+            for nh in range(nhalf):
                 out[:, :, :, nh, t // 4, lane, t % 4] = U[:, :, oi[16 * nh + j], ci, :].transpose(0, 2, 1)
-    return torch.from_numpy(out.reshape(48, 2, 2, 64, 4))
+    return torch.from_numpy(out.reshape(48, nhalf, 2, 64, 4))
 
 
 def pack_conv3d_wino2_extra(weight, extra_idx, out_idx):

@@ -226,3 +226,38 @@ def test_wino_rejects_other_shapes():
     d.in_main = d.out_main = d.w_wino = d.scale = d.shift = x.data_ptr()
     d.cin_main, d.n_tiles, d.in_stride, d.out_stride = 16, 1, 32, 32
     assert _native.lib().estd_conv3d_k3_wino(d, None) == -3                 # not the plain 32 -> 32 instance
+
+
+@pytest.mark.parametrize("dims", [(1, 4, 8, 32), (2, 5, 13, 50), (1, 1, 9, 33), (1, 64, 24, 32), (1, 7, 120, 160)])
+def test_wino2_16_output_channels_matches_direct_kernel_and_fp64(dims):
+    """the GRU output convolution's shape (32 -> 16, bias, no activation, GroupNorm partial sums; epipolar_transformer.py:26): the
+    16-output-channel instance of the 2-axis Winograd kernel (input channels split over the two waves of a SIMD, cross-wave
+    reduction through LDS) against the direct kernel and an fp64 convolution, incl. odd D and partial tiles."""
+    from estdepth_amd import ops
+    N, D, H, W = dims
+    g = torch.Generator().manual_seed(11 + sum(dims))
+    w = torch.randn(16, 32, 3, 3, 3, generator=g) * 0.05
+    sc, sh = torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.1
+    plan = ops.Conv3dPlan(w, list(range(32)), None, list(range(16)), 1, sc, sh, device=DEV)
+    assert plan.w_wino2_o16 is not None
+    x = torch.randn(N, D, H, W, 32, generator=g)
+    nblk = ops.conv3d_grid(N, D, H, W)
+    outs, parts = {}, {}
+    for algo in ("direct", "wino2"):
+        for with_stats in (False, True):
+            part = torch.zeros(nblk * 4, device=DEV, dtype=torch.float64) if with_stats else None
+            o = torch.full((N, D, H, W, 16), float("nan"), device=DEV)
+            _run(plan, algo, x.to(DEV), dims, out=o, out_stride=16, stats_partials=part)
+            outs[(algo, with_stats)], parts[algo] = o, part
+    ref = torch.nn.functional.conv3d(x.permute(0, 4, 1, 2, 3).double(), w.double(), padding=1) * sc.double()[None, :, None, None, None] \
+        + sh.double()[None, :, None, None, None]
+    ref = ref.permute(0, 2, 3, 4, 1)
+    mag = float(ref.abs().max())
+    e_dir = float((outs[("direct", False)].double().cpu() - ref).abs().max())
+    for with_stats in (False, True):
+        e_win = float((outs[("wino2", with_stats)].double().cpu() - ref).abs().max())
+        assert e_win <= 3.0 * e_dir + 1e-7 * mag and e_win < 3e-6 * mag, (with_stats, e_dir, e_win, mag)
+    if N == 1:      # GroupNorm statistics (one volume per launch, as the ConvGRU calls it)
+        sa = ops.groupnorm_finalize(parts["direct"], nblk, 16.0 * N * D * H * W).cpu()
+        sb = ops.groupnorm_finalize(parts["wino2"], nblk, 16.0 * N * D * H * W).cpu()
+        assert float((sa[:2] - sb[:2]).abs().max()) < 1e-5 * max(1.0, float(sa[:2].abs().max())), (sa, sb)
