@@ -80,6 +80,7 @@ CONV2D_ARITH = os.environ.get("ESTD_CONV2D_ARITH", "f32")     # same choice for 
 CONV3D_ALGO = os.environ.get("ESTD_CONV3D_ALGO", "wino2")
 # same choice for the 3x3 / dilation-1 NHWC convolutions: row axis in Winograd F(2,3) form (csrc/conv2d_wino.hip) or direct
 CONV2D_ALGO = os.environ.get("ESTD_CONV2D_ALGO", "wino")
+CONV2D_NT = os.environ.get("ESTD_CONV2D_NT", "auto")
 
 
 def _stream():
@@ -348,6 +349,8 @@ class Conv2dPlan:
     def _pick_nt(self, n, h, w):
         if 4 not in self.w_nt:
             return 2
+        if CONV2D_NT in ("2", "4"):               # A/B switch (ESTD_CONV2D_NT): force the work-item width
+            return int(CONV2D_NT)
         tiles = n * ((h + 7) // 8) * ((w + 15) // 16)
         def balance(items):                       # fraction of the persistent grid's rounds that does useful work
             return items / (512.0 * ((items + 511) // 512))
