@@ -23,12 +23,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "estd_hip.h"
 #include "estd_common.h"
 
 #ifndef ESTD_W2ABL
 #define ESTD_W2ABL 0    // timing ablations only (wrong results when != 0): 1 no output stores, 2 no transform writes, 8 no weight stream,
 #endif                  // 16 no brick prefetch
+#ifndef ESTD_C2SCHED
+#define ESTD_C2SCHED 1   // explicit issue order inside a tap (A/B switch)
+#endif
 
 namespace {
 
@@ -103,12 +108,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(const estd_conv2d_d
         th0 = thi * TH; tw0 = twi * TW;
     };
     // per-thread source offsets (bytes inside one image, chunk 0) of the ten brick rows of a tile; OOB -> zeros
-    auto brick_offsets = [&](int th0, int tw0, unsigned (&voff)[IN_H]) {
+    auto brick_offsets = [&](int th0, int tw0, unsigned (&voff)[IN_H], bool enable) {
         const int gx = tw0 - DIL + lzx;
 #pragma unroll
         for (int zy = 0; zy < IN_H; ++zy) {
             const int gy = th0 - DIL + zy;
-            const bool ok = loader && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            const bool ok = enable && loader && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
             voff[zy] = ok ? (unsigned)((gy * W + gx) * Cin + lc * 4) * 4u : OOB_OFFSET;
         }
     };
@@ -122,15 +127,30 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(const estd_conv2d_d
     int grp, n, th0, tw0;
     decode(u, grp, n, th0, tw0);
     unsigned voff[IN_H];
-    brick_offsets(th0, tw0, voff);
+    brick_offsets(th0, tw0, voff, true);
     __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in + (size_t)n * img_in, img_in);
     float4 pf[IN_H];
 #pragma unroll
     for (int zy = 0; zy < IN_H; ++zy) pf[zy] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[zy], 0, 0));
 
+    // Weight stream: WD taps ahead of the MFMAs through a ring of WD + 1 register sets, CONTINUOUS across chunks and work items -- the
+    // first WD taps of the next chunk (or of the next item's first chunk) are requested during the last WD taps of this one, so no
+    // chunk starts by waiting for an L2 round trip.  One tap = 8 NT MFMAs = 256 NT matrix cycles: NT = 2 needs two taps of cover.
+    constexpr int WD = (NT == 2) ? 2 : 1, WR = WD + 1;
+    const size_t wgrp_elems = (size_t)nchunks * 13 * QN * 256;          // packed floats per output group (12 taps + 1 pad)
+    float4 bq[WR][QN];
+    {
+        const __amdgpu_buffer_rsrc_t rs_w0 = make_rsrc(p.w_wino + (size_t)grp * wgrp_elems, wgrp_elems);
+#pragma unroll
+        for (int t = 0; t < WD; ++t)
+#pragma unroll
+            for (int q = 0; q < QN; ++q) bq[t][q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w0, wlane, (t * QN + q) * 1024, 0));
+    }
+    const float floor_b = p.relu_before_residual ? 0.f : -__builtin_inff();
+    const float floor_a = p.relu_after_residual ? 0.f : -__builtin_inff();
+
     int k = 0;                                              // global chunk counter -> LDS slot
     while (true) {
-        const size_t wgrp_elems = (size_t)nchunks * 13 * QN * 256;          // packed floats per output group (12 taps + 1 pad)
         const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w_wino + (size_t)grp * wgrp_elems, wgrp_elems);
 
         f32x4 acc[4][NT];                                   // m0..m3 of this wave's row pair, summed over the input chunks
@@ -142,6 +162,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(const estd_conv2d_d
         const bool has_next_item = (u + 1 < u_end);
         int ngrp = grp, nn_ = n, nth0 = th0, ntw0 = tw0;
         if (has_next_item) decode(u + 1, ngrp, nn_, nth0, ntw0);
+        const __amdgpu_buffer_rsrc_t rs_wni = make_rsrc(p.w_wino + (size_t)ngrp * wgrp_elems, wgrp_elems);
 
         for (int c = 0; c < nchunks; ++c, ++k) {
             char* slot = smem + (k & 1) * SLOT_BYTES;
@@ -159,20 +180,18 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(const estd_conv2d_d
             }
             lds_barrier();
 
-            // what to prefetch while this chunk computes: the next 32-channel chunk of the same pixels, or chunk 0 of the next item
+            // what to prefetch while this chunk computes: the next 32-channel chunk of the same pixels, or chunk 0 of the next item.
+            // Branch-free: with nothing left to fetch every offset is out of bounds (the loads return zeros without touching memory).
             const bool last_chunk = (c + 1 == nchunks);
-            const bool do_pf = !last_chunk || has_next_item;
             int pf_soff = (c + 1) * 128;
-            if (last_chunk && has_next_item) {
-                brick_offsets(nth0, ntw0, voff);
+            if (last_chunk) {
+                brick_offsets(nth0, ntw0, voff, has_next_item);
                 if (nn_ != n) rs_in = make_rsrc(p.in + (size_t)nn_ * img_in, img_in);
                 pf_soff = 0;
             }
-
-            float4 bcur[QN], bnext[QN];
             const int wbase = c * 13 * QN;                                 // quads of this chunk's first tap
-#pragma unroll
-            for (int q = 0; q < QN; ++q) bcur[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, (wbase + q) * 1024, 0));
+            const __amdgpu_buffer_rsrc_t rs_wx = last_chunk ? rs_wni : rs_w;     // where the stream goes on after tap 11
+            const int wnext = last_chunk ? 0 : wbase + 13 * QN;
 
             // A fragment of (transformed row i, column tap kw): two 16-byte LDS reads (channels 4g.., 16+4g..)
             auto load_a = [&](int tap, float4& a0, float4& a1) {
@@ -181,106 +200,117 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(const estd_conv2d_d
                 a0 = *reinterpret_cast<const float4*>(slot + off0);
                 a1 = *reinterpret_cast<const float4*>(slot + (off0 ^ 64));
             };
-            float4 a0c, a1c, a0n, a1n;
-            load_a(0, a0c, a1c);
+            float4 af[2][2];
+            load_a(0, af[0][0], af[0][1]);
 
 #pragma clang loop unroll(full)
             for (int tap = 0; tap < 12; ++tap) {
                 const int i = tap / 3;
+                const int tgt = tap + WD;
 #pragma unroll
                 for (int q = 0; q < QN; ++q) {
-                    if (ESTD_W2ABL & 8) { bnext[q] = bcur[q]; asm volatile("" : "+v"(bnext[q].x)); }
-                    else bnext[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, (wbase + (tap + 1) * QN + q) * 1024, 0));
+                    if (ESTD_W2ABL & 8) continue;
+                    bq[tgt % WR][q] = tgt < 12
+                        ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, (wbase + tgt * QN + q) * 1024, 0))
+                        : as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_wx, wlane, (wnext + (tgt - 12) * QN + q) * 1024, 0));
                 }
-                if (do_pf && tap < IN_H && !(ESTD_W2ABL & 16))
+                if (tap < IN_H && !(ESTD_W2ABL & 16))
                     pf[tap] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[tap], pf_soff, 0));
-                if (tap + 1 < 12) load_a(tap + 1, a0n, a1n);           // next tap's A fragment: LDS latency under this tap's MFMAs
+                if (tap + 1 < 12) load_a(tap + 1, af[(tap + 1) & 1][0], af[(tap + 1) & 1][1]);   // LDS latency under this tap's MFMAs
+                const float4 a0c = af[tap & 1][0], a1c = af[tap & 1][1];
                 const float av[8] = {a0c.x, a0c.y, a0c.z, a0c.w, a1c.x, a1c.y, a1c.z, a1c.w};
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
                     for (int nn = 0; nn < NT; ++nn) {
                         const int idx = ks * NT + nn;
-                        const float4 bq = bcur[idx >> 2];
-                        const float b = (idx & 3) == 0 ? bq.x : (idx & 3) == 1 ? bq.y : (idx & 3) == 2 ? bq.z : bq.w;
+                        const float4 bv = bq[tap % WR][idx >> 2];
+                        const float b = (idx & 3) == 0 ? bv.x : (idx & 3) == 1 ? bv.y : (idx & 3) == 2 ? bv.z : bv.w;
                         acc[i][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], b, acc[i][nn], 0, 0, 0);
                     }
                 }
+#if ESTD_C2SCHED
+                // issue order of a tap: the next tap's two LDS reads first, then one memory request per two MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
-                for (int q = 0; q < QN; ++q) bcur[q] = bnext[q];
-                a0c = a0n; a1c = a1n;
+                for (int q = 0; q < QN + 1; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 8 * NT - 2 * (QN + 1), 0);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
 
         // ---- output transform A^T m, then the direct kernel's epilogue: lane = column j (N index) x pixels 4g..4g+3 of the two
-        //      output rows; its channels are grp*16*NT + NT*j .. +NT-1 ----
-        {
+        //      output rows; its channels are grp*16*NT + NT*j .. +NT-1.  Two instances (with / without residual), the activations as
+        //      floors (0 or -inf): no branch per pixel ----
+        auto epilogue = [&](auto has_res_c) {
+            constexpr bool HAS_RES = decltype(has_res_c)::value;
             const int cb = grp * 16 * NT + NT * col;
             float sc[NT], sh[NT];
 #pragma unroll
             for (int nn = 0; nn < NT; ++nn) { sc[nn] = p.scale[cb + nn]; sh[nn] = p.shift[cb + nn]; }
             const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(p.out + (size_t)n * img_out, img_out);
-            const __amdgpu_buffer_rsrc_t rs_res = make_rsrc((p.residual ? p.residual : p.out) + (size_t)n * img_out, img_out);
-            // the residual pixels: loads issued back to back and waited for once per batch (one load -> wait -> store per pixel
-            // serialises eight memory round trips per tile).  NT = 2: both rows in one batch; NT = 4: a row at a time (registers).
-            float rres[2][4][NT];
-            auto load_res_row = [&](int m) {
+            const __amdgpu_buffer_rsrc_t rs_res = make_rsrc((HAS_RES ? p.residual : p.out) + (size_t)n * img_out, img_out);
+            const float floor_1 = HAS_RES ? floor_b : fmaxf(floor_b, floor_a);
+            unsigned eo[2][4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
                 const int y = th0 + a_w + m * DIL;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int x = tw0 + px0 + pxs * r;
-                    const unsigned eo = (y < H && x < W) ? (unsigned)((y * W + x) * Cout + cb) * 4u : OOB_OFFSET;
+                    eo[m][r] = (y < H && x < W) ? (unsigned)((y * W + x) * Cout + cb) * 4u : OOB_OFFSET;
+                }
+            }
+            // the residual pixels: loads issued back to back and waited for once per batch (one load -> wait -> store per pixel
+            // serialises eight memory round trips per tile).  NT = 2: both rows in one batch; NT = 4: a row at a time (registers).
+            float rres[2][4][NT];
+            auto load_res_row = [&](int m) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
                     if (NT == 4) {
-                        const float4 rr = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_res, eo, 0, 0));
+                        const float4 rr = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_res, eo[m][r], 0, 0));
                         rres[m][r][0] = rr.x; rres[m][r][1] = rr.y; rres[m][r][NT - 2] = rr.z; rres[m][r][NT - 1] = rr.w;
                     } else {
-                        const u32x2 rv = __builtin_amdgcn_raw_buffer_load_b64(rs_res, eo, 0, 0);
+                        const u32x2 rv = __builtin_amdgcn_raw_buffer_load_b64(rs_res, eo[m][r], 0, 0);
                         float2 rr; __builtin_memcpy(&rr, &rv, 8);
                         rres[m][r][0] = rr.x; rres[m][r][1] = rr.y;
                     }
                 }
             };
-            if (NT == 2 && p.residual) { load_res_row(0); load_res_row(1); }
+            if (NT == 2 && HAS_RES) { load_res_row(0); load_res_row(1); }
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                const int y = th0 + a_w + m * DIL;
-                if (NT == 4 && p.residual) load_res_row(m);
+                if (NT == 4 && HAS_RES) load_res_row(m);
                 f32x4 yv[NT];
 #pragma unroll
                 for (int nn = 0; nn < NT; ++nn)
                     yv[nn] = m == 0 ? acc[0][nn] + acc[1][nn] + acc[2][nn] : acc[1][nn] - acc[2][nn] - acc[3][nn];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int x = tw0 + px0 + pxs * r;
-                    const unsigned eo = (y < H && x < W) ? (unsigned)((y * W + x) * Cout + cb) * 4u : OOB_OFFSET;
                     float v[NT];
 #pragma unroll
-                    for (int nn = 0; nn < NT; ++nn) v[nn] = yv[nn][r] * sc[nn] + sh[nn];
-                    if (p.relu_before_residual) {
-#pragma unroll
-                        for (int nn = 0; nn < NT; ++nn) v[nn] = v[nn] > 0.f ? v[nn] : 0.f;
-                    }
-                    if (p.residual) {
-#pragma unroll
-                        for (int nn = 0; nn < NT; ++nn) v[nn] += rres[m][r][nn];
-                    }
-                    if (p.relu_after_residual) {
-#pragma unroll
-                        for (int nn = 0; nn < NT; ++nn) v[nn] = v[nn] > 0.f ? v[nn] : 0.f;
+                    for (int nn = 0; nn < NT; ++nn) {
+                        v[nn] = __builtin_fmaxf(__builtin_fmaf(yv[nn][r], sc[nn], sh[nn]), floor_1);
+                        if (HAS_RES) v[nn] = __builtin_fmaxf(v[nn] + rres[m][r][nn], floor_a);
                     }
                     if (ESTD_W2ABL & 1) {
                         asm volatile("" :: "v"(v[0]), "v"(v[NT - 1]));
                     } else if (NT == 4) {
-                        __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(make_float4(v[0], v[1], v[2], v[3])), rs_out, eo, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(as_u32x4(make_float4(v[0], v[1], v[2], v[3])), rs_out, eo[m][r], 0, 0);
                     } else {
                         const float2 ov = make_float2(v[0], v[1]);
                         u32x2 od; __builtin_memcpy(&od, &ov, 8);
-                        __builtin_amdgcn_raw_buffer_store_b64(od, rs_out, eo, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(od, rs_out, eo[m][r], 0, 0);
                     }
                 }
             }
-        }
+        };
+        if (p.residual) epilogue(std::true_type{}); else epilogue(std::false_type{});
 
         if (!has_next_item) break;
         ++u;
