@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
 #include <type_traits>
 
 #include "estd_hip.h"
@@ -325,7 +326,8 @@ int launch2d(const estd_conv2d_desc& d, hipStream_t stream)
     const int groups = d.cout / (16 * NT);
     const int total = groups * d.N * tiles_h * tiles_w;
     const size_t lds = (size_t)2 * TROWS * (TW + 2 * DIL) * 128;      // two slots: 72 KB / 80 KB -> two workgroups per CU
-    const int slots = estd_persistent_wgs(2);
+    static const int grid_mult = [] { const char* e = getenv("ESTD_C2_GRID_MULT"); const int v = e ? atoi(e) : 1; return v >= 1 ? v : 1; }();
+    const int slots = estd_persistent_wgs(2) * grid_mult;   // > 1: more workgroups than fit at once, the hardware dispatcher balances
     int grid = total < slots ? total : slots;
     if (grid >= 8) grid &= ~7;
     estd_allow_dynamic_lds<conv2d_wino_kernel<NT, DIL>>((int)lds);
