@@ -54,6 +54,21 @@ constexpr int IN_D = 3, IN_H = TH + 2, IN_W = TW + 2;
 constexpr int NVOX_IN = IN_D * IN_H * IN_W;   // 540
 constexpr int MT = 2;    // M tiles (rows) per wave: 4 waves x 2 = 8 rows
 
+// sum over the 16 lanes of a DPP row (every lane gets the total): two quad permutations + two row rotations, all folded into v_add_f32
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v)
+{
+    v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add<0x124>(v);     // row_ror:4
+    v = dpp_add<0x128>(v);     // row_ror:8
+    return v;
+}
+
 __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == ESTD_ACT_RELU) return v > 0.0f ? v : 0.0f;
     if (act == ESTD_ACT_TANH) return tanhf(v);
@@ -149,8 +164,23 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
     if (XOUT) { sc2 = p.scale[32]; sh2 = p.shift[32]; }
     float hw = 0.f, hb = 0.f;
     if (NT == 1 && p.head_w) { hw = p.head_w[i]; hb = p.head_b[0]; }
+    // stereo heads (the only NT = 1 callers with a head): nothing but the 1x1x1 head leaves the kernel and the activation is one of
+    // none / ReLU for all 16 channels -> a straight-line epilogue (the generic one below branches per output element)
+    const bool act_uniform = p.act_split <= 0 || p.act_split >= 16 || p.act_a == p.act_b;
+    const int act_u = p.act_split <= 0 ? p.act_b : p.act_a;
+    const bool head_only = NT == 1 && !XOUT && p.head_w && !p.out_main && !(ESTD_STATS_ON && p.stats_partials) && act_uniform &&
+                           act_u != ESTD_ACT_TANH && !(ESTD_ABL & 128);
+    const float head_floor = act_u == ESTD_ACT_RELU ? 0.f : -__builtin_inff();
 
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w_main, (size_t)28 * QN * 256);
+    // 16 -> 16 (stereo heads): one weight quad per lane and tap, 27 quads = 108 registers -- the whole filter stays in registers, no
+    // weight stream at all (a tap is only 8 MFMAs = 256 matrix cycles, less than an L2 round trip next to another stream's kernels)
+    constexpr bool WREG = (CM == 16 && NT == 1 && !EXTRA && !XOUT && !(ESTD_ABL & 64));
+    float4 wreg[WREG ? 27 : 1];
+    if (WREG) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t) wreg[t] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, t * 1024, 0));
+    }
     // 33rd OUTPUT channel (dres2): a GEMV, 1/16 efficient on MFMA -> computed on the VALU in the MFMA shadow from the
     // A fragments already in registers: w_xout = [28 taps][2 quads][64 lanes][4] + [2][64][4] extra-input taps
     const __amdgpu_buffer_rsrc_t rs_wxo = make_rsrc(XOUT ? p.w_xout : p.w_main, (size_t)(28 * 2 + 2) * 256);
@@ -213,7 +243,28 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
             }
 
         // ---- epilogue of one finished tile (depth plane dd of this column) ----
+        // head-only epilogue: lane (g, i) stores element i of its row group's 8 head outputs ((m, r) = (i >> 2, i & 3))
+        __amdgpu_buffer_rsrc_t rs_head = rs_in;
+        unsigned hoff = OOB_OFFSET;
+        if (NT == 1 && head_only) {
+            rs_head = make_rsrc(p.out_head + (size_t)n * vol, vol);
+            const int y = ey0 + ((i >> 2) & 1), x = ex0 + 2 * (i & 3);
+            hoff = (i < 4 * MT && y < H && x < W) ? (unsigned)(y * W + x) * 4u : OOB_OFFSET;
+        }
         auto epilogue = [&](const f32x4 (&a)[MT][NT], const float (&ax)[MT], int dd) {
+            if (NT == 1 && head_only) {
+                float outv = 0.f;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = __builtin_fmaxf(__builtin_fmaf(a[m][0][r], sc[0], sh[0]), head_floor) * hw;
+                        const float tot = row16_sum(v) + hb;
+                        outv = (i == m * 4 + r) ? tot : outv;
+                    }
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, outv), rs_head, hoff, dd * HW * 4, 0);
+                return;
+            }
             // D layout: lane holds column j = i (N index) and rows 4g..4g+3 (M index = voxel along W).
             // channel of (tile nn, column j): NT==1 -> j ; NT>=2 -> 2j+nn for nn<2 ; nn==2 -> 32 (only j==0).
             double s_sum = 0.0, s_sq = 0.0;     // GroupNorm partials of this lane (its channels are in one group)
@@ -386,14 +437,17 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
                 for (int nn = 0; nn < NT; ++nn) acc[m][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
             float4 bcur[QN], bnext[QN];
+            if (WREG) bcur[0] = wreg[0];
             float4 xo_cur[2], xo_next[2];
             float xacc[MT] = {};
             if (XOUT) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) xo_cur[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_wxo, wlane, q * 1024, 0));
             }
+            if (!WREG) {
 #pragma unroll
-            for (int q = 0; q < QN; ++q) bcur[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, q * 1024, 0));
+                for (int q = 0; q < QN; ++q) bcur[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, q * 1024, 0));
+            }
 
 #pragma unroll
             for (int tap = 0; tap < 27; ++tap) {
@@ -402,7 +456,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
                 // next tap's weights (the packed buffer carries one padding tap)
 #pragma unroll
                 for (int q = 0; q < QN; ++q) {
-                    if (ESTD_ABL & 2) { bnext[q] = bcur[q]; asm volatile("" : "+v"(bnext[q].x)); }
+                    if (WREG) bnext[q] = wreg[tap + 1 < 27 ? tap + 1 : 26];
+                    else if (ESTD_ABL & 2) { bnext[q] = bcur[q]; asm volatile("" : "+v"(bnext[q].x)); }
                     else bnext[q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, ((tap + 1) * QN + q) * 1024, 0));
                 }
                 if (XOUT) {
