@@ -45,9 +45,14 @@
 #endif                  // 8 no weight stream, 16 no next-plane prefetch; correct A/B switches: 32 slice writes between the
                         // tiles only (no in-loop write of the next tile's slices), 64 weights one tap ahead instead of two
 
+#ifndef ESTD_XOUT_DEPTH
+#define ESTD_XOUT_DEPTH 2   // items the 33rd-output-channel pass reads ahead (registers: 16 per item)
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
 
 constexpr int TH = 8, TW = 16;
@@ -151,6 +156,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
     const int ch = 16 * nh + i;                     // this lane's output channel
     const float sc = p.scale[ch], sh = p.shift[ch];
     const int act0 = ch < p.act_split ? p.act_a : p.act_b;
+    // plain launches (no read-back stream, no tanh): the activation is a per-lane floor and the epilogue has no branch per element
+    const bool plain_epi = !p.residual && !p.residual2 && !p.accumulate && p.out_scale == 1.0f &&
+                           p.act_a != ESTD_ACT_TANH && p.act_b != ESTD_ACT_TANH && !(ESTD_WABL & 64);
+    const float act_floor = act0 == ESTD_ACT_RELU ? 0.f : -__builtin_inff();
     // packed weights: [37 taps (36 + 1 the prefetch may read)][2 halves][2 quads][64 lanes][4]
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w_wino, (size_t)37 * 2 * 2 * 256);
     const int wlane = lane * 16 + nh * 2048;
@@ -242,6 +251,16 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) eo[m][r] = EXTRA ? eoff_of(m, r) : eoff[m][r];
+            if (plain_epi) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = __builtin_fmaxf(__builtin_fmaf(a[m][r], sc, sh), act_floor);
+                        if (!(ESTD_WABL & 1)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, eo[m][r], so, 0);
+                    }
+                return;
+            }
             if (p.residual) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
@@ -491,26 +510,38 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
                 float xacc[4] = {0.f, 0.f, 0.f, 0.f};
                 int ix = pi, gx_ = g;                          // opaque copies: this pass's LDS addresses are formed HERE, not hoisted
                 asm volatile("" : "+v"(ix), "+v"(gx_));       // over the tap loop above, whose register budget is spent
+                // 36 (transform s, tap) items of 4 LDS reads each, software-pipelined XD items ahead by hand: fully unrolled with a
+                // scheduling barrier per item (left to itself the scheduler hoists all 144 reads and spills 360 registers; rolled, every
+                // filter row waited for its own reads -- 10 000 cycles per tile with both waves of a SIMD in this pass at the same time)
+                constexpr int XD = ESTD_XOUT_DEPTH;
+                float4 xb_[XD + 1][4];
+                auto x_issue = [&](int it, float4 (&buf)[4]) {
+                    const int s_ = it / 9, kh = (it / 3) % 3, kw = it % 3;
+                    const char* wrow = lds_wxo + ((s_ * 9 + kh * 3) * 2) * 64 + gx_ * 16;
+                    const int vs = (row0 + nh + kh) * IN_W + kw + ix;
+                    const int off0 = s_ * SLICE_BYTES + lds_chunk_off(vs, gx_);
+                    buf[0] = *reinterpret_cast<const float4*>(smem + off0);
+                    buf[1] = *reinterpret_cast<const float4*>(smem + (off0 ^ 64));
+                    buf[2] = *reinterpret_cast<const float4*>(wrow + (kw * 2 + 0) * 64);
+                    buf[3] = *reinterpret_cast<const float4*>(wrow + (kw * 2 + 1) * 64);
+                };
+                f32x2 t2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};     // two partial sums each: the products pair up into v_pk_fma_f32
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    float t = 0.f;
-#pragma clang loop unroll(disable)
-                    for (int kh = 0; kh < 3; ++kh) {             // rolled: addresses formed per row, nothing to hoist or spill
-                        const char* wrow = lds_wxo + ((s * 9 + kh * 3) * 2) * 64 + gx_ * 16;
+                for (int it = 0; it < XD; ++it) x_issue(it, xb_[it]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int kw = 0; kw < 3; ++kw) {
-                            const int vs = (row0 + nh + kh) * IN_W + kw + ix;
-                            const int off0 = s * SLICE_BYTES + lds_chunk_off(vs, gx_);
-                            const float4 a0 = *reinterpret_cast<const float4*>(smem + off0);
-                            const float4 a1 = *reinterpret_cast<const float4*>(smem + (off0 ^ 64));
-                            const float4 w0 = *reinterpret_cast<const float4*>(wrow + (kw * 2 + 0) * 64);
-                            const float4 w1 = *reinterpret_cast<const float4*>(wrow + (kw * 2 + 1) * 64);
-                            t = fmaf(a0.x, w0.x, t); t = fmaf(a0.y, w0.y, t); t = fmaf(a0.z, w0.z, t); t = fmaf(a0.w, w0.w, t);
-                            t = fmaf(a1.x, w1.x, t); t = fmaf(a1.y, w1.y, t); t = fmaf(a1.z, w1.z, t); t = fmaf(a1.w, w1.w, t);
-                        }
-                    }
-                    xacc[s] = t;
+                for (int it = 0; it < 36; ++it) {
+                    if (it + XD < 36) x_issue(it + XD, xb_[(it + XD) % (XD + 1)]);
+                    const float4 a0 = xb_[it % (XD + 1)][0], a1 = xb_[it % (XD + 1)][1], w0 = xb_[it % (XD + 1)][2], w1 = xb_[it % (XD + 1)][3];
+                    f32x2& t = t2[it / 9];
+                    t = __builtin_elementwise_fma((f32x2){a0.x, a0.y}, (f32x2){w0.x, w0.y}, t);
+                    t = __builtin_elementwise_fma((f32x2){a0.z, a0.w}, (f32x2){w0.z, w0.w}, t);
+                    t = __builtin_elementwise_fma((f32x2){a1.x, a1.y}, (f32x2){w1.x, w1.y}, t);
+                    t = __builtin_elementwise_fma((f32x2){a1.z, a1.w}, (f32x2){w1.z, w1.w}, t);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) xacc[s_] = t2[s_].x + t2[s_].y;
                 {
                     float4 wx[3];
 #pragma unroll

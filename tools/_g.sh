@@ -1,5 +1,4 @@
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_edge_cases.py -x -q -m gpu 2>&1 | tail -3
-python tools/head_bench.py 2>&1 | grep -v amdgpu | tail -4
+python -m pytest tests -x -q -m gpu 2>&1 | tail -3
 for i in 1 2; do python bench.py --steps 20 --warmup 5 --no-alt --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
 d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print(d['value'], d['ms_per_step'])"; done
