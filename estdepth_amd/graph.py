@@ -139,11 +139,24 @@ class GraphedForward:
         if pre_costs is not None:
             main.wait_stream(side)
         if pending is not None:
-            cam = camera.finish(pending)
-            for name, t in cam.items():
-                if t is not None:
-                    st["cam"][name].copy_(t)
+            # the upload of the composed matrices runs on its own stream BESIDE stage A (the host is ready long before stage A ends):
+            # ordered after the previous replay of stage B, which read these buffers; stage B waits for it
+            main = torch.cuda.current_stream()
+            up = st.get("upload_stream")
+            if up is None:
+                up = st["upload_stream"] = torch.cuda.Stream()
+            if st.get("b_done") is not None:
+                up.wait_event(st["b_done"])
+            with torch.cuda.stream(up):
+                cam = camera.finish(pending)
+                for name, t in cam.items():
+                    if t is not None:
+                        st["cam"][name].copy_(t)
+            main.wait_stream(up)
         st["graph_b"].replay()
+        if st.get("b_done") is None:
+            st["b_done"] = torch.cuda.Event()
+        st["b_done"].record()
         outputs, costs, cposes = st["out"]
         if self.clone_outputs:
             outputs = {k: v.clone() for k, v in outputs.items()}

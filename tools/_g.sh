@@ -1,6 +1,7 @@
-cd /tmp && export TMPDIR=/tmp
-R=/root/repo
-rocprofv3 --kernel-trace --output-format csv -d /tmp/pp -o p -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt > /tmp/pp.json 2>/tmp/pp.err
-f=$(find /tmp/pp -name "*kernel_trace.csv" | head -1)
-cp $f $R/gpurun_out/joint_trace.csv
-python $R/tools/prof_seq.py $f 6.5 20 | cut -c1-100
+python -m pytest tests/test_gpu_full_config.py tests/test_gpu_bench_contract.py -x -q -m gpu 2>&1 | tail -2
+for i in 1 2; do python bench.py --steps 20 --warmup 5 --no-alt --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print(d['value'], d['ms_per_step'])"; done
+python bench.py --workload estm --steps 20 --warmup 5 --no-alt --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print(d['value'], d['ms_per_step'])"
