@@ -112,11 +112,53 @@ def case_conv2d():
     return (d == d) and d < 4e-5 * max(1.0, float(a.abs().max())), ("conv2d", (N, H, W), cin, cout, dil, rb, ra, res is not None, d)
 
 
+def case_head():
+    """the 16-channel instances against a float64 torch convolution: 16 -> 16 + 1x1x1 head (head only / head + volume, ReLU / none)
+    on the direct kernel, 32 -> 16 with bias on the two-axis Winograd kernel's 16-output-channel instance"""
+    import torch.nn.functional as F
+    N, D, H, W = int(rng.integers(1, 3)), int(rng.integers(1, 10)), int(rng.integers(1, 30)), int(rng.integers(1, 50))
+    dims = (N, D, H, W)
+    x = rnd(N, D, H, W, 32)
+    xc = x.double().cpu().permute(0, 4, 1, 2, 3)                       # [N,32,D,H,W]
+    scale, shift = torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.1
+    if rng.integers(2):
+        w = rnd(16, 16, 3, 3, 3, scale=0.08).cpu()
+        lo = int(rng.choice([0, 16]))
+        act = str(rng.choice(["relu", "none"]))
+        hw, hb = torch.randn(16, generator=g) * 0.3, torch.randn(1, generator=g)
+        plan = ops.Conv3dPlan(w, list(range(16)), None, list(range(16)), 1, scale, shift, act_a=act, head_w=hw, head_b=hb, device=DEV)
+        ref = F.conv3d(xc[:, lo:lo + 16], w.double(), padding=1) * scale.double().view(1, 16, 1, 1, 1) + shift.double().view(1, 16, 1, 1, 1)
+        ref = ref.clamp_min(0) if act == "relu" else ref
+        ref_head = (ref * hw.double().view(1, 16, 1, 1, 1)).sum(1) + hb.double()
+        head = torch.full((N, D, H, W), float("nan"), device=DEV)
+        with_out = bool(rng.integers(2))
+        out = torch.full((N, D, H, W, 16), float("nan"), device=DEV) if with_out else None
+        ops.CONV3D_ALGO = "wino2"
+        plan.run(x[..., lo:], dims, in_stride=32, out=out, out_stride=16 if with_out else None, out_head=head)
+        torch.cuda.synchronize()
+        d = float((head.double().cpu() - ref_head).abs().max())
+        if with_out:
+            d = max(d, float((out.double().cpu().permute(0, 4, 1, 2, 3) - ref).abs().max()))
+        return (d == d) and d < 2e-5 * max(1.0, float(ref_head.abs().max())), ("head16", dims, lo, act, with_out, d)
+    w = rnd(16, 32, 3, 3, 3, scale=0.06).cpu()
+    plan = ops.Conv3dPlan(w, list(range(32)), None, list(range(16)), 1, torch.ones(16), shift, act_a="none", device=DEV)
+    ref = F.conv3d(xc, w.double(), padding=1) + shift.double().view(1, 16, 1, 1, 1)
+    worst = 0.0
+    for algo in ("wino2", "direct"):
+        ops.CONV3D_ALGO = algo
+        out = torch.full((N, D, H, W, 16), float("nan"), device=DEV)
+        plan.run(x, dims, out=out, out_stride=16)
+        torch.cuda.synchronize()
+        worst = max(worst, float((out.double().cpu().permute(0, 4, 1, 2, 3) - ref).abs().max()))
+    return (worst == worst) and worst < 2e-5 * max(1.0, float(ref.abs().max())), ("out16", dims, worst)
+
+
 t0, n = time.time(), 0
 while time.time() - t0 < budget:
-    ok, info = (case_conv3d if rng.integers(3) else case_conv2d)()
+    pick = int(rng.integers(4))
+    ok, info = (case_conv2d if pick == 0 else case_head if pick == 1 else case_conv3d)()
     n += 1
     if not ok:
         print("MISMATCH after %d cases:" % n, info)
         sys.exit(1)
-print("fuzz_convs: %d random cases agree (direct vs Winograd kernels)" % n)
+print("fuzz_convs: %d random cases agree (direct vs Winograd kernels, 16-channel instances vs float64)" % n)
