@@ -754,7 +754,7 @@ extern "C" int estd_conv3d_k3_wino2(const estd_conv3d_desc* dp, estd_stream_t s)
     const estd_conv3d_desc& d = *dp;
     if (d.N <= 0 || d.D <= 0 || d.H <= 0 || d.W <= 0) return ESTD_ERR_ARG;
     if (!d.in_main || !d.w_wino2 || !d.scale || !d.shift || !d.out_main) return ESTD_ERR_ARG;
-    // the plain instance only: 32 -> 32 on the MFMA, no scalar 33rd input / output channel, no fused head
+    // 32 input channels on the MFMA (+ an optional scalar 33rd input channel), 32 or 16 output channels; no 33rd output channel, no fused head
     if (d.cin_main != 32 || (d.n_tiles != 2 && d.n_tiles != 1) || d.out_head || d.out_extra) return ESTD_ERR_UNSUPPORTED;
     const bool o16 = d.n_tiles == 1;                 // 32 -> 16 (the GRU output convolution)
     const bool extra = d.in_extra != nullptr;

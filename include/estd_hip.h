@@ -147,10 +147,12 @@ int estd_conv3d_k3_split(const estd_conv3d_desc* desc, estd_stream_t stream);
  * two output planes from four transformed input planes, 36 instead of 54 tap products, every product an fp32 MFMA with
  * fp32 accumulation (csrc/conv3d_wino.hip).  Reads w_wino instead of w_main.  ESTD_ERR_UNSUPPORTED for any other shape. */
 int estd_conv3d_k3_wino(const estd_conv3d_desc* desc, estd_stream_t stream);
-/* Same operator, plain 32->32 instance only (no scalar 33rd input / output channel), with the depth AND the image-row axis in
- * Winograd form, F(2x2, 3x3): 2 x 2 outputs (two planes, two rows) from a 4 x 4 transformed input patch, 48 tap products
- * per 4 outputs = 0.444 of the direct kernel's MFMA work (csrc/conv3d_wino2.hip).  Reads w_wino2.  Epilogue features as
- * estd_conv3d_k3_wino.  ESTD_ERR_UNSUPPORTED for any other shape. */
+/* Same operator with the depth AND the image-row axis in Winograd form, F(2x2, 3x3): 2 x 2 outputs (two planes, two rows) from a
+ * 4 x 4 transformed input patch, 48 tap products per 4 outputs = 0.444 of the direct kernel's MFMA work (csrc/conv3d_wino2.hip).
+ * Instances: cin_main = 32 with n_tiles = 2 (32 -> 32; with in_extra + w_extra the 33 -> 32 key|value form; every epilogue feature of
+ * estd_conv3d_k3_wino -- GroupNorm partials not together with in_extra) and n_tiles = 1 (32 -> 16, the ConvGRU output convolution;
+ * no in_extra).  Reads w_wino2 (packing.py::pack_conv3d_wino2).  No head, no 33rd output channel:
+ * ESTD_ERR_UNSUPPORTED for any other shape. */
 int estd_conv3d_k3_wino2(const estd_conv3d_desc* desc, estd_stream_t stream);
 /* number of thread blocks estd_conv3d_k3 launches for a volume (size of stats_partials / 4 doubles) */
 int estd_conv3d_k3_grid(int N, int D, int H, int W);
