@@ -32,6 +32,12 @@
 #ifndef ESTD_W2ABL
 #define ESTD_W2ABL 0    // timing ablations only (wrong results when != 0): 1 no output stores, 2 no transform writes, 8 no weight stream,
 #endif                  // 16 no brick prefetch
+#ifndef ESTD_C2TIME
+#define ESTD_C2TIME 0    // debug build: s_memtime stamps of the first work items of the first workgroups into the RESIDUAL buffer
+#endif                   // (tools/conv2d_timeline.py; results are wrong)
+#ifndef ESTD_C2_PFR
+#define ESTD_C2_PFR 1    // brick rows requested per tap (A/B: 2 = all rows in taps 0-4: no gain alone, +0.3 ms in the step)
+#endif
 #ifndef ESTD_C2SCHED
 #define ESTD_C2SCHED 1   // explicit issue order inside a tap (A/B switch)
 #endif
@@ -58,6 +64,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, s
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+#if ESTD_C2TIME
+#define C2STAMP(slot) do { if (lane == 0 && blockIdx.x < 16 && item_no < 8)                                                       \
+        reinterpret_cast<unsigned long long*>(const_cast<float*>(p.residual))[((blockIdx.x * 8 + item_no) * 4 + wave) * 8 + (slot)] = \
+            __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define C2STAMP(slot) do { } while (0)
+#endif
+
 __device__ __forceinline__ int lds_chunk_off(int v, int c) { return v * 128 + ((c ^ ((v >> 1) & 7)) << 4); }
 
 // DIL = 2: rows of equal parity form the F(2,3) sequences -- wave w owns output rows a, a + 2 with a = (w & 1) + 4 (w >> 1),
@@ -69,7 +83,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(const estd_conv2d_d
     constexpr int IN_H = TH + 2 * DIL, IN_W = TW + 2 * DIL;      // haloed brick: 10 x 18 (dilation 1) / 12 x 20 (dilation 2)
     constexpr int SLOT_BYTES = TROWS * IN_W * 128;               // 36 864 / 40 960
     constexpr int LOADERS = IN_W * 8;                            // 144 / 160 threads hold the brick: (column, 16-byte chunk)
-    static_assert(IN_H <= 12, "one prefetch load per tap");
+    constexpr int PFR = ESTD_C2_PFR;                             // brick rows requested per tap
+    static_assert(IN_H <= 12 * PFR && 2 * (QN + PFR) <= 8 * NT, "prefetch schedule");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -110,12 +125,16 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(const estd_conv2d_d
     };
     // per-thread source offsets (bytes inside one image, chunk 0) of the ten brick rows of a tile; OOB -> zeros
     auto brick_offsets = [&](int th0, int tw0, unsigned (&voff)[IN_H], bool enable) {
+        // one vector multiply-add for the whole brick: the row term is wave-uniform (scalar unit), the row validity too
         const int gx = tw0 - DIL + lzx;
+        const bool colok = enable && loader && (unsigned)gx < (unsigned)W;
+        const unsigned base = (unsigned)(gx * Cin + lc * 4) * 4u;
+        const unsigned rowbytes = (unsigned)(W * Cin) * 4u;
 #pragma unroll
         for (int zy = 0; zy < IN_H; ++zy) {
-            const int gy = th0 - DIL + zy;
-            const bool ok = enable && loader && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-            voff[zy] = ok ? (unsigned)((gy * W + gx) * Cin + lc * 4) * 4u : OOB_OFFSET;
+            const int gy = th0 - DIL + zy;                                   // uniform
+            const bool rowok = (unsigned)gy < (unsigned)H;                   // uniform
+            voff[zy] = (colok && rowok) ? base + (unsigned)gy * rowbytes : OOB_OFFSET;
         }
     };
     // LDS byte offset of (row pair w, transformed row i) at this loader thread's (column, chunk)
@@ -151,21 +170,27 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(const estd_conv2d_d
     const float floor_a = p.relu_after_residual ? 0.f : -__builtin_inff();
 
     int k = 0;                                              // global chunk counter -> LDS slot
+    int item_no = 0;
     while (true) {
+        C2STAMP(0);
         const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w_wino + (size_t)grp * wgrp_elems, wgrp_elems);
 
-        f32x4 acc[4][NT];                                   // m0..m3 of this wave's row pair, summed over the input chunks
+        // folded BatchNorm of this lane's channels: requested HERE, a whole item ahead of the epilogue that uses it (requested there,
+        // every item ended with an exposed L2 round trip: 900 cycles alone, 4 000-7 000 next to a busy memory pipeline)
+        float sc[NT], sh[NT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int nn = 0; nn < NT; ++nn) acc[i][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nn = 0; nn < NT; ++nn) { sc[nn] = p.scale[grp * 16 * NT + NT * col + nn]; sh[nn] = p.shift[grp * 16 * NT + NT * col + nn]; }
+        // m0..m3 of this wave's row pair, summed over the input chunks.  No zero fill (8 NT register moves per item, paid in matrix
+        // time): the first chunk is a separate instance of the chunk body whose first product per accumulator takes C = 0.
+        f32x4 acc[4][NT];
 
         const bool has_next_item = (u + 1 < u_end);
         int ngrp = grp, nn_ = n, nth0 = th0, ntw0 = tw0;
         if (has_next_item) decode(u + 1, ngrp, nn_, nth0, ntw0);
         const __amdgpu_buffer_rsrc_t rs_wni = make_rsrc(p.w_wino + (size_t)ngrp * wgrp_elems, wgrp_elems);
 
-        for (int c = 0; c < nchunks; ++c, ++k) {
+        auto chunk_body = [&](auto first_c, const int c) {
+            constexpr bool FIRST = decltype(first_c)::value;
             char* slot = smem + (k & 1) * SLOT_BYTES;
             // ---- input transform B^T d along rows, from the column registers straight into the slot ----
             if (loader && !(ESTD_W2ABL & 2)) {
@@ -179,7 +204,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(const estd_conv2d_d
                     *reinterpret_cast<float4*>(slot + loff[w][3]) = f4_sub(d1, d3);
                 }
             }
+            if (c == 0) C2STAMP(1);
             lds_barrier();
+            if (c == 0) C2STAMP(2);
 
             // what to prefetch while this chunk computes: the next 32-channel chunk of the same pixels, or chunk 0 of the next item.
             // Branch-free: with nothing left to fetch every offset is out of bounds (the loads return zeros without touching memory).
@@ -215,8 +242,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(const estd_conv2d_d
                         ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, (wbase + tgt * QN + q) * 1024, 0))
                         : as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_wx, wlane, (wnext + (tgt - 12) * QN + q) * 1024, 0));
                 }
-                if (tap < IN_H && !(ESTD_W2ABL & 16))
-                    pf[tap] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[tap], pf_soff, 0));
+                // the next brick: PFR rows per tap from tap 0 on.  (tools/conv2d_timeline.py shows the transform of the next chunk waiting
+                // thousands of cycles for these rows; requesting them earlier -- PFR = 2, 4 -- only moves that wait into the tap loop or
+                // the epilogue: the two workgroups of a CU take turns on the matrix pipe and the sum per work item does not change)
+                if (tap * PFR < IN_H && !(ESTD_W2ABL & 16)) {
+#pragma unroll
+                    for (int r = 0; r < PFR; ++r)
+                        if (tap * PFR + r < IN_H)
+                            pf[tap * PFR + r] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[tap * PFR + r], pf_soff, 0));
+                }
                 if (tap + 1 < 12) load_a(tap + 1, af[(tap + 1) & 1][0], af[(tap + 1) & 1][1]);   // LDS latency under this tap's MFMAs
                 const float4 a0c = af[tap & 1][0], a1c = af[tap & 1][1];
                 const float av[8] = {a0c.x, a0c.y, a0c.z, a0c.w, a1c.x, a1c.y, a1c.z, a1c.w};
@@ -227,7 +261,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(const estd_conv2d_d
                         const int idx = ks * NT + nn;
                         const float4 bv = bq[tap % WR][idx >> 2];
                         const float b = (idx & 3) == 0 ? bv.x : (idx & 3) == 1 ? bv.y : (idx & 3) == 2 ? bv.z : bv.w;
-                        acc[i][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], b, acc[i][nn], 0, 0, 0);
+                        const f32x4 cin_ = (FIRST && tap % 3 == 0 && ks == 0) ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[i][nn];
+                        acc[i][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], b, cin_, 0, 0, 0);
                     }
                 }
 #if ESTD_C2SCHED
@@ -235,25 +270,26 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(const estd_conv2d_d
                 __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
-                for (int q = 0; q < QN + 1; ++q) {
+                for (int q = 0; q < QN + PFR; ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, 8 * NT - 2 * (QN + 1), 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 8 * NT - 2 * (QN + PFR), 0);
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
+        };
+        chunk_body(std::true_type{}, 0);
+        ++k;
+        for (int c = 1; c < nchunks; ++c, ++k) chunk_body(std::false_type{}, c);
 
+        C2STAMP(3);
         // ---- output transform A^T m, then the direct kernel's epilogue: lane = column j (N index) x pixels 4g..4g+3 of the two
         //      output rows; its channels are grp*16*NT + NT*j .. +NT-1.  Two instances (with / without residual), the activations as
         //      floors (0 or -inf): no branch per pixel ----
         auto epilogue = [&](auto has_res_c) {
             constexpr bool HAS_RES = decltype(has_res_c)::value;
             const int cb = grp * 16 * NT + NT * col;
-            float sc[NT], sh[NT];
-#pragma unroll
-            for (int nn = 0; nn < NT; ++nn) { sc[nn] = p.scale[cb + nn]; sh[nn] = p.shift[cb + nn]; }
             const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(p.out + (size_t)n * img_out, img_out);
             const __amdgpu_buffer_rsrc_t rs_res = make_rsrc((HAS_RES ? p.residual : p.out) + (size_t)n * img_out, img_out);
             const float floor_1 = HAS_RES ? floor_b : fmaxf(floor_b, floor_a);
@@ -311,7 +347,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(const estd_conv2d_d
                 }
             }
         };
-        if (p.residual) epilogue(std::true_type{}); else epilogue(std::false_type{});
+        if (p.residual && !ESTD_C2TIME) epilogue(std::true_type{}); else epilogue(std::false_type{});
+        C2STAMP(4);
+        ++item_no;
 
         if (!has_next_item) break;
         ++u;

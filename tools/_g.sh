@@ -1,2 +1,5 @@
-python tools/fuzz_convs.py 90 11 2>&1 | grep -v amdgpu | tail -3
-python tools/fuzz_convs.py 60 12 2>&1 | grep -v amdgpu | tail -3
+python -m pytest tests/test_gpu_psm.py tests/test_gpu_refine2d.py tests/test_gpu_full_config.py -x -q -m gpu 2>&1 | tail -1
+python tools/fuzz_convs.py 40 21 2>&1 | tail -1
+for i in 1 2 3; do python bench.py --steps 20 --warmup 5 --no-alt --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print(d['value'], d['ms_per_step'])"; done

@@ -7,7 +7,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((__vector_size__(16)));
 
-template <int K, int PK, int BF>
+template <int K, int PK, int BF, int NACC = 4>
 __global__ void k(float* out, int iters)
 {
     f32x4 acc[4] = {};
@@ -23,8 +23,8 @@ __global__ void k(float* out, int iters)
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                if (BF) acc[c & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[c & 3], 0, 0, 0);
-                else acc[c & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, acc[c & 3], 0, 0, 0);
+                if (BF) acc[c % NACC] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[c % NACC], 0, 0, 0);
+                else acc[c % NACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa, fb, acc[c % NACC], 0, 0, 0);
             }
 #pragma unroll
             for (int j = 0; j < K; ++j) {
@@ -41,22 +41,22 @@ __global__ void k(float* out, int iters)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-template <int K, int PK, int BF>
+template <int K, int PK, int BF, int NACC = 4>
 void run(int threads)
 {
     const int blocks = 256, iters = 200000;
     float* out;
     (void)hipMalloc(&out, blocks * threads * 4);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<K, PK, BF>), dim3(blocks), dim3(threads), 0, 0, out, 1000);
+    hipLaunchKernelGGL((k<K, PK, BF, NACC>), dim3(blocks), dim3(threads), 0, 0, out, 1000);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL((k<K, PK, BF>), dim3(blocks), dim3(threads), 0, 0, out, iters);
+    hipLaunchKernelGGL((k<K, PK, BF, NACC>), dim3(blocks), dim3(threads), 0, 0, out, iters);
     (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     const double mfma_per_simd = (double)iters * 32 * (threads / 256);
-    printf("%s waves/SIMD %d  %2d %s adds per 8 MFMAs: %7.2f ms  %6.1f ns per MFMA per SIMD (%.1f cycles at 2.4 GHz)\n", BF ? "bf16 16x16x32" : "f32 16x16x4 ",
-           threads / 256, K, PK ? "packed" : "plain ", ms, ms * 1e6 / mfma_per_simd, ms * 1e6 / mfma_per_simd * 2.4);
+    printf("%s waves/SIMD %d  %d accumulators  %2d %s adds per 8 MFMAs: %7.2f ms  %6.1f ns per MFMA per SIMD (%.1f cycles at 2.4 GHz)\n", BF ? "bf16 16x16x32" : "f32 16x16x4 ",
+           threads / 256, NACC, K, PK ? "packed" : "plain ", ms, ms * 1e6 / mfma_per_simd, ms * 1e6 / mfma_per_simd * 2.4);
     (void)hipFree(out);
 }
 
@@ -65,6 +65,7 @@ int main()
     for (int threads = 256; threads <= 512; threads += 256) {
         run<0, 0, 0>(threads); run<4, 0, 0>(threads); run<8, 0, 0>(threads); run<16, 0, 0>(threads); run<32, 0, 0>(threads);
         run<4, 1, 0>(threads); run<8, 1, 0>(threads); run<16, 1, 0>(threads);
+        run<0, 0, 0, 2>(threads); run<0, 0, 0, 1>(threads); run<8, 0, 0, 2>(threads);     // dependent chains: 2 / 1 rotating accumulators
         run<0, 0, 1>(threads); run<8, 0, 1>(threads); run<16, 0, 1>(threads); run<8, 1, 1>(threads);
     }
     return 0;
