@@ -6,10 +6,22 @@ import torch
 from . import ops, synth
 
 
-def _timeit(fn, n):
-    for _ in range(3):
-        fn()
+def warm(fn, seconds=0.3):
+    """run ``fn`` back to back for ``seconds`` so that the measurement sees SUSTAINED clocks: an idle MI355X sits at ~100 MHz and takes tens
+    of milliseconds of load to reach its working point (30 launches of a 0.9 ms kernel right after three warm-up calls measured 7 % slow:
+    0.913 ms against 0.855 ms over 400 launches, which is also what the kernel takes inside the benchmark step)."""
+    import time
+    t0 = time.time()
+    fn()
     torch.cuda.synchronize()
+    while time.time() - t0 < seconds:
+        for _ in range(8):
+            fn()
+        torch.cuda.synchronize()
+
+
+def _timeit(fn, n):
+    warm(fn, 0.2)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):

@@ -4,6 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from estdepth_amd import ops
+from estdepth_amd.microbench import warm
 dev = "cuda"
 for (h, w, cin, cout, dil) in [(240, 320, 32, 32, 1), (120, 160, 64, 64, 1), (120, 160, 128, 128, 1), (120, 160, 320, 128, 1), (120, 160, 128, 128, 2)]:
     conv = torch.nn.Conv2d(cin, cout, 3, 1, dil, dil, bias=False).to(dev)
@@ -15,8 +16,7 @@ for (h, w, cin, cout, dil) in [(240, 320, 32, 32, 1), (120, 160, 64, 64, 1), (12
     for arith in ("f32/wino", "f32/direct", "bf16x3"):
         ops.CONV2D_ARITH = arith.split("/")[0]
         ops.CONV2D_ALGO = "direct" if arith.endswith("direct") else "wino"
-        for _ in range(3): plan.run(x)
-        torch.cuda.synchronize()
+        warm(lambda: plan.run(x), 0.1)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(20): plan.run(x)
@@ -29,8 +29,7 @@ for (h, w, cin, cout, dil) in [(240, 320, 32, 32, 1), (120, 160, 64, 64, 1), (12
         line = "%3dx%-3d %3d->%-3d dil %d + residual" % (h, w, cin, cout, dil)
         for algo in ("wino", "direct"):
             ops.CONV2D_ARITH, ops.CONV2D_ALGO = "f32", algo
-            for _ in range(3): plan.run(x, residual=res)
-            torch.cuda.synchronize()
+            warm(lambda: plan.run(x, residual=res), 0.1)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(20): plan.run(x, residual=res)

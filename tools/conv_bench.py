@@ -4,6 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from estdepth_amd import synth, ops
+from estdepth_amd.microbench import warm
 from estdepth_amd.layers_op import ConvBN3d
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1
@@ -15,9 +16,7 @@ synth.fill_state_dict(mod, seed=1)
 plan = mod.to(dev).plan()
 x = torch.randn(N, D, H, W, 32, device=dev)
 y = torch.empty_like(x)
-for _ in range(3):
-    plan.run(x, (N, D, H, W), out=y, out_stride=32)
-torch.cuda.synchronize()
+warm(lambda: plan.run(x, (N, D, H, W), out=y, out_stride=32))          # sustained clocks (estdepth_amd/microbench.py)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(iters):
@@ -31,9 +30,7 @@ if os.environ.get("CB_EPI"):                               # the read-back epilo
     r1, r2 = torch.randn_like(x), torch.randn_like(x)
     for name, kw in (("accumulate", dict(accumulate=True)), ("residual", dict(residual=r1)),
                      ("2 residuals + scale", dict(residual=r1, residual2=r2, out_scale=0.5))):
-        for _ in range(3):
-            plan.run(x, (N, D, H, W), out=y, out_stride=32, **kw)
-        torch.cuda.synchronize()
+        warm(lambda: plan.run(x, (N, D, H, W), out=y, out_stride=32, **kw), 0.15)
         e0.record()
         for _ in range(iters):
             plan.run(x, (N, D, H, W), out=y, out_stride=32, **kw)

@@ -2,13 +2,13 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from estdepth_amd.microbench import warm
 import torch
 from estdepth_amd import ops
 dev = "cuda"
 D, H, W = 64, 120, 160
 def t(f, n=30):
-    for _ in range(3): f()
-    torch.cuda.synchronize()
+    warm(f, 0.15)                                   # sustained clocks (estdepth_amd/microbench.py)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n): f()

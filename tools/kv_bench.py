@@ -3,6 +3,7 @@ import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
 from estdepth_amd import ops
+from estdepth_amd.microbench import warm
 dev = torch.device("cuda:0")
 N, D, H, W = 3, 64, 120, 160
 g = torch.Generator().manual_seed(1)
@@ -11,8 +12,7 @@ plan = ops.Conv3dPlan(w, list(range(32)), 32, list(range(32)), 2, torch.ones(32)
 x = torch.randn(N, D, H, W, 32, device=dev); e = torch.randn(N, D, H, W, device=dev); y = torch.empty_like(x)
 for algo in ("direct", "wino", "wino2", "wino", "wino2"):
     ops.CONV3D_ALGO = algo
-    for _ in range(3): plan.run(x, (N, D, H, W), in_extra=e, out=y)
-    torch.cuda.synchronize()
+    warm(lambda: plan.run(x, (N, D, H, W), in_extra=e, out=y), 0.15)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20): plan.run(x, (N, D, H, W), in_extra=e, out=y)
@@ -24,8 +24,7 @@ plan = ops.Conv3dPlan(w, list(range(1, 33)), 0, list(range(33)), 3, torch.ones(3
 ex = torch.empty(N, D, H, W, device=dev)
 for algo in ("direct", "wino", "direct", "wino"):
     ops.CONV3D_ALGO = algo
-    for _ in range(3): plan.run(x, (N, D, H, W), in_extra=e, out=y, out_extra=ex)
-    torch.cuda.synchronize()
+    warm(lambda: plan.run(x, (N, D, H, W), in_extra=e, out=y, out_extra=ex), 0.15)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20): plan.run(x, (N, D, H, W), in_extra=e, out=y, out_extra=ex)

@@ -3,14 +3,14 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from estdepth_amd.microbench import warm
 import torch
 from estdepth_amd import backbones as B
 dev = "cuda"
 
 
 def t(f, n=30):
-    for _ in range(3): f()
-    torch.cuda.synchronize()
+    warm(f, 0.15)                                   # sustained clocks (estdepth_amd/microbench.py)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n): f()
