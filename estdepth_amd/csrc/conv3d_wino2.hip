@@ -39,6 +39,9 @@
 #ifndef ESTD_W2PK
 #define ESTD_W2PK 0     // row transforms: 0 vector arithmetic (the compiler packs some, unpacks others next to MFMAs), 1 inline-assembly
 #endif                  // v_pk_add_f32 fenced between the MFMA halves, 2 inline assembly without inner fences
+#ifndef ESTD_W2_STATS_DEFER
+#define ESTD_W2_STATS_DEFER 0   // A/B: deferred epilogue also for the launches that write GroupNorm partial sums
+#endif
 #ifndef ESTD_W2DEFER
 #define ESTD_W2DEFER 1  // 1: epilogue of tile k inside the first steps of tile k+1, two barriers per tile; 0: epilogue between the tiles
 #endif
@@ -69,7 +72,7 @@ constexpr int IN_H = TH + 2, IN_W = TW + 2;
 constexpr int SL_VOX = IN_H * IN_W;                 // 180 voxels per input slice (with halo)
 constexpr int SLICE_BYTES = SL_VOX * 128;           // 32 channels
 constexpr int SL_CHUNKS = SL_VOX * 8;               // 16-byte chunks per slice: 1440
-constexpr int RED_BYTES = 8 * 2 * 8;                // GroupNorm scratch: 8 (row pair, channel half) x {sum, sumsq} doubles
+constexpr int RED_BYTES = 2 * 8 * 4 * 8;            // GroupNorm scratch: 2 copies x 8 (row pair, channel half) x {sum, sumsq} x 2 planes, doubles
 constexpr int NTAPS = 48;
 #ifndef ESTD_W2LDS_TAPS
 #define ESTD_W2LDS_TAPS 14
@@ -101,6 +104,25 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, s
 }
 
 // workgroup barrier that only orders LDS traffic (no vmcnt drain: prefetches and output stores stay in flight)
+// sum of a double over the 16 lanes of a DPP row, every lane gets the total: two quad permutations + two row rotations of the two
+// dwords (v_mov_b32 with a DPP modifier: no LDS round trip) and one v_add_f64 per level
+template <int CTRL>
+__device__ __forceinline__ double dpp_add_f64(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, false);
+    return v + __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double row16_sum_f64(double v)
+{
+    v = dpp_add_f64<0xB1>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add_f64<0x4E>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add_f64<0x124>(v);     // row_ror:4
+    v = dpp_add_f64<0x128>(v);     // row_ror:8
+    return v;
+}
+
 __device__ __forceinline__ void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -331,13 +353,29 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
             epi_issue(dd, L);
             epi_finish(a, dd, L);
         };
-        // GroupNorm(1 group) partial sums of the raw outputs of one plane: group = channel half.  Fixed-order reduction
-        // (lanes by butterfly, the four row pairs of a half through LDS) -> deterministic.  Workgroup-uniform call.
-        auto plane_stats = [&](const f32x4 (&a)[2][NHW], int dd) {
-            double s_sum[NHW], s_sq[NHW];
+        // GroupNorm(1 group) partial sums of the raw outputs of BOTH planes of a tile: group = channel half.  Fixed-order reduction ->
+        // deterministic: the 16 lanes of a DPP row by four DPP-modified moves + adds (no LDS round trip), the four rows by two
+        // ds_bpermute levels, the four row pairs of a half through LDS.  One barrier pair per tile.  Workgroup-uniform call.
+        // (Round 3: one call per plane with a six-level ds_bpermute butterfly on doubles and its own barrier pair cost the gate
+        // convolution 15 %: 0.33 ms against 0.287 ms for the same launch without statistics.)
+        int stats_parity = 0;
+        auto wave_sum4 = [&](double (&v)[4]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = row16_sum_f64(v[k]);
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] += __shfl_xor(v[k], o);
+        };
+        auto tile_stats = [&](const f32x4 (&a0)[2][NHW], const f32x4 (&a1)[2][NHW], int d0_) {
+            // scratch [tile parity][channel half][row pair][sum0, sq0, sum1, sq1]: two copies, so that the only barrier is the one between
+            // the writes and the final adds (the next write to a copy is two tiles = several barriers later)
+            double* red = reinterpret_cast<double*>(smem + 4 * SLICE_BYTES) + (stats_parity ? 32 : 0);
+            stats_parity ^= 1;
+            double v[NHW][4];
 #pragma unroll
             for (int x = 0; x < NHW; ++x) {
-                s_sum[x] = 0.0; s_sq[x] = 0.0;
+                v[x][0] = v[x][1] = v[x][2] = v[x][3] = 0.0;
                 const int cb = 16 * (nh0 + x) + 4 * g;
                 const float4 sc4 = *reinterpret_cast<const float4*>(lds_ss + cb), sh4 = *reinterpret_cast<const float4*>(lds_ss + 32 + cb);
                 const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
@@ -345,31 +383,36 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                 for (int m = 0; m < 2; ++m)
                     if (eoff_of(m) != OOB_OFFSET) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { const double v = (double)(a[m][x][r] * scv[r] + shv[r]); s_sum[x] += v; s_sq[x] += v * v; }
+                        for (int r = 0; r < 4; ++r) {
+                            const double u0 = (double)(a0[m][x][r] * scv[r] + shv[r]), u1 = (double)(a1[m][x][r] * scv[r] + shv[r]);
+                            v[x][0] += u0; v[x][1] += u0 * u0; v[x][2] += u1; v[x][3] += u1 * u1;
+                        }
                     }
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) { s_sum[x] += __shfl_xor(s_sum[x], o); s_sq[x] += __shfl_xor(s_sq[x], o); }
+                wave_sum4(v[x]);
             }
-            double* red = reinterpret_cast<double*>(smem + 4 * SLICE_BYTES);       // [channel half][row pair][sum, sumsq]
-            __syncthreads();                                     // the previous plane's scratch has been consumed
             if (lane == 0) {
 #pragma unroll
-                for (int x = 0; x < NHW; ++x) { red[((nh0 + x) * 4 + rp) * 2] = s_sum[x]; red[((nh0 + x) * 4 + rp) * 2 + 1] = s_sq[x]; }
+                for (int x = 0; x < NHW; ++x)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) red[((nh0 + x) * 4 + rp) * 4 + k] = v[x][k];
             }
             __syncthreads();
-            if (tid < 4) {
-                const int grp = tid >> 1, q = tid & 1;
-                const double tot = red[(grp * 4 + 0) * 2 + q] + red[(grp * 4 + 1) * 2 + q] + red[(grp * 4 + 2) * 2 + q] + red[(grp * 4 + 3) * 2 + q];
-                // partial index = canonical tile id (n, d, thi, twi), as the direct kernel writes it
-                const size_t tile_id = (((size_t)n * D + dd) * tiles_h + thi) * tiles_w + twi;
-                p.stats_partials[tile_id * 4 + tid] = tot;
+            if (tid < 8) {                                       // (plane, channel half, {sum, sumsq})
+                const int pl_ = tid >> 2, grp = (tid >> 1) & 1, q = tid & 1;
+                if (d0_ + pl_ < D) {                             // (odd D: the last pair has one plane)
+                    const int k = pl_ * 2 + q;
+                    const double tot = red[(grp * 4 + 0) * 4 + k] + red[(grp * 4 + 1) * 4 + k] + red[(grp * 4 + 2) * 4 + k] + red[(grp * 4 + 3) * 4 + k];
+                    // partial index = canonical tile id (n, d, thi, twi), as the direct kernel writes it
+                    const size_t tile_id = (((size_t)n * D + d0_ + pl_) * tiles_h + thi) * tiles_w + twi;
+                    p.stats_partials[tile_id * 4 + grp * 2 + q] = tot;
+                }
             }
         };
 
         // O16: one 16-channel group; wave (rp, cw) holds plane d0 + cw -> both planes of the tile in ONE reduction: group slot 0 of
         // the plane's canonical tile id receives {sum, sumsq}, slot 1 zeros (estd_groupnorm_finalize reads both groups).
         auto plane_stats_o16 = [&](const f32x4 (&a)[2][NHW], int d0_) {
-            double s_sum = 0.0, s_sq = 0.0;
+            double v[4] = {0.0, 0.0, 0.0, 0.0};
             const int cb = 4 * g;
             const float4 sc4 = *reinterpret_cast<const float4*>(lds_ss + cb), sh4 = *reinterpret_cast<const float4*>(lds_ss + 32 + cb);
             const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
@@ -377,13 +420,14 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
             for (int m = 0; m < 2; ++m)
                 if (eoff_of(m) != OOB_OFFSET) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { const double v = (double)(a[m][0][r] * scv[r] + shv[r]); s_sum += v; s_sq += v * v; }
+                    for (int r = 0; r < 4; ++r) { const double u = (double)(a[m][0][r] * scv[r] + shv[r]); v[0] += u; v[1] += u * u; }
                 }
+            v[0] = row16_sum_f64(v[0]); v[1] = row16_sum_f64(v[1]);
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) { s_sum += __shfl_xor(s_sum, o); s_sq += __shfl_xor(s_sq, o); }
-            double* red = reinterpret_cast<double*>(smem + 4 * SLICE_BYTES);       // [plane cw][row pair][sum, sumsq]
-            __syncthreads();
-            if (lane == 0) { red[(cw * 4 + rp) * 2] = s_sum; red[(cw * 4 + rp) * 2 + 1] = s_sq; }
+            for (int o = 16; o <= 32; o <<= 1) { v[0] += __shfl_xor(v[0], o); v[1] += __shfl_xor(v[1], o); }
+            double* red = reinterpret_cast<double*>(smem + 4 * SLICE_BYTES) + (stats_parity ? 32 : 0);       // [tile parity][plane cw][row pair][sum, sumsq]
+            stats_parity ^= 1;
+            if (lane == 0) { red[(cw * 4 + rp) * 2] = v[0]; red[(cw * 4 + rp) * 2 + 1] = v[1]; }
             __syncthreads();
             if (tid < 4) {
                 const int pl_ = tid >> 1, q = tid & 1;
@@ -714,15 +758,12 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
 #ifdef ESTD_W2TIME
             const bool defer_this = DEFER && has_next;
 #else
-            const bool defer_this = DEFER && has_next && !p.stats_partials;      // uniform
+            const bool defer_this = DEFER && has_next && (ESTD_W2_STATS_DEFER || !p.stats_partials);      // uniform
 #endif
 #ifndef ESTD_W2TIME
             if (p.stats_partials) {                      // uniform; the GRU convolutions (one volume per launch)
                 if (O16) plane_stats_o16(y0, d0);
-                else {
-                    plane_stats(y0, d0);
-                    if (d0 + 1 < D) plane_stats(y1, d0 + 1);          // (odd D: the last pair has one plane)
-                }
+                else tile_stats(y0, y1, d0);
             }
 #endif
             if (!defer_this) {

@@ -1,7 +1,6 @@
-CB_EPI=1 python tools/conv_bench.py 3 100 2>&1 | grep -v amdgpu
-python tools/conv_bench.py 1 100 2>&1 | grep -v amdgpu
-ESTD_CONV3D_ALGO=wino python tools/conv_bench.py 3 100 2>&1 | grep -v amdgpu
-ESTD_CONV3D_ALGO=direct python tools/conv_bench.py 3 100 2>&1 | grep -v amdgpu
-python tools/head_bench.py 2>&1 | grep -v amdgpu | tail -2
-python tools/kv_bench.py 2>&1 | grep -v amdgpu | tail -4
-python tools/conv2d_bench.py 2>&1 | grep -v amdgpu | cut -c1-110
+python -m pytest tests/test_gpu_wino.py tests/test_gpu_parity.py tests/test_gpu_edge_cases.py -x -q -m gpu 2>&1 | tail -1
+python tools/_gs.py 2>&1 | grep -v amdgpu
+python tools/fuzz_convs.py 40 31 2>&1 | tail -1
+for i in 1 2 3; do python bench.py --steps 20 --warmup 5 --no-alt --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print(d['value'], d['ms_per_step'])"; done
