@@ -39,6 +39,9 @@
 #ifndef ESTD_W2PK
 #define ESTD_W2PK 0     // row transforms: 0 vector arithmetic (the compiler packs some, unpacks others next to MFMAs), 1 inline-assembly
 #endif                  // v_pk_add_f32 fenced between the MFMA halves, 2 inline assembly without inner fences
+#ifndef ESTD_W2_LIBM_TANH
+#define ESTD_W2_LIBM_TANH 0     // A/B: tanhf of the device library in the epilogue instead of tanh_fast
+#endif
 #ifndef ESTD_W2_STATS_DEFER
 #define ESTD_W2_STATS_DEFER 0   // A/B: deferred epilogue also for the launches that write GroupNorm partial sums
 #endif
@@ -130,6 +133,14 @@ __device__ __forceinline__ void lds_barrier()
 
 __device__ __forceinline__ int lds_chunk_off(int v, int c) { return v * 128 + ((c ^ ((v >> 1) & 7)) << 4); }
 
+// tanh x = 1 - 2 / (exp(2x) + 1) on the transcendental units (v_exp_f32, v_rcp_f32: 1 ulp each; five instructions instead of the device
+// library's ~30).  Absolute error <= 2e-7 over the whole range (cancellation near 0 costs relative, not absolute accuracy); +-inf -> +-1.
+__device__ __forceinline__ float tanh_fast(float x)
+{
+    const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+}
+
 __device__ __forceinline__ float act_apply(float v, int act)
 {
     if (act == ESTD_ACT_RELU) return v > 0.0f ? v : 0.0f;
@@ -201,6 +212,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
     if (tid >= 64 && tid < 96) lds_ss[tid] = ((tid - 64) < p.act_split ? p.act_a : p.act_b) == ESTD_ACT_RELU ? 0.0f : -__builtin_inff();
     // (O16: scale / shift hold 16 entries; lanes read channels 0..15 only)
     const bool any_tanh = p.act_a == ESTD_ACT_TANH || p.act_b == ESTD_ACT_TANH;                     // uniform
+    const bool tanh_quads = any_tanh && (p.act_split & 3) == 0 && !ESTD_W2_LIBM_TANH;                // uniform
     unsigned* lds_vt = reinterpret_cast<unsigned*>(smem + 4 * SLICE_BYTES + RED_BYTES + SS_BYTES);     // [it][thread]
     float* lds_x = reinterpret_cast<float*>(smem + 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES);          // [4][SL_VOX] (EXTRA)
     char* lds_xch = smem + 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES;               // O16: [8 waves][2 rows][64 lanes] float4
@@ -298,6 +310,16 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                 v.y = fmaxf(a[1] * sc4.y + sh4.y, lo.y);
                 v.z = fmaxf(a[2] * sc4.z + sh4.z, lo.z);
                 v.w = fmaxf(a[3] * sc4.w + sh4.w, lo.w);
+                return;
+            }
+            if (tanh_quads) {      // the four channels of a lane share the activation (split is a multiple of 4): tanh from the exp / rcp units
+                const float4 lo = *reinterpret_cast<const float4*>(lds_ss + 64 + cb);
+                const float u0 = a[0] * sc4.x + sh4.x, u1 = a[1] * sc4.y + sh4.y, u2 = a[2] * sc4.z + sh4.z, u3 = a[3] * sc4.w + sh4.w;
+                if ((cb < p.act_split ? p.act_a : p.act_b) == ESTD_ACT_TANH) {
+                    v.x = tanh_fast(u0); v.y = tanh_fast(u1); v.z = tanh_fast(u2); v.w = tanh_fast(u3);
+                } else {
+                    v.x = fmaxf(u0, lo.x); v.y = fmaxf(u1, lo.y); v.z = fmaxf(u2, lo.z); v.w = fmaxf(u3, lo.w);
+                }
                 return;
             }
             v.x = act_apply(a[0] * sc4.x + sh4.x, cb + 0 < p.act_split ? p.act_a : p.act_b);
