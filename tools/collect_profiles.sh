@@ -19,6 +19,7 @@ done
 for algo in wino2 wino direct; do
   ESTD_CONV3D_ALGO=$algo bash $R/tools/pmc_collect.sh "FETCH_SIZE WRITE_SIZE" $OUT/r3_conv3d_${algo}_pmc.csv -- python $R/tools/conv_bench.py 3 10 > /dev/null 2>&1
 done
+python $R/tools/pmc_json.py $OUT          # r3_conv3d_pmc.json: what bench.py reads for roofline.traffic (from profiles/)
 bash $R/tools/pmc_collect.sh "FETCH_SIZE WRITE_SIZE" $OUT/r3_hbm_kernels_pmc.csv -- python $R/tools/hbm_bench.py > /dev/null 2>&1
 # the hardware's own matrix-pipe utilisation counter of every convolution kernel, stand-alone benches
 for b in "conv_bench.py 3 10" "conv_bench.py 1 10" "kv_bench.py" "head_bench.py" "conv2d_bench.py"; do
