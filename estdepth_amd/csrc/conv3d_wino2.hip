@@ -536,13 +536,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
             const int nd = d0 + 3;                       // new planes of the next tile: nd, nd + 1
             const bool v0 = nd < D, v1 = nd + 1 < D;
 
-            f32x4 acc[4][4][NHW];                        // m[sd][sh] per channel half
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int x = 0; x < NHW; ++x) acc[s][t][x] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // m[sd][sh] per channel half.  No zero fill (64 register moves per tile and wave, paid in matrix time, §3.0 of DESIGN.md): the
+            // first product of every accumulator -- column tap 0, channel chunk 0, k-step 0 of its depth transform -- takes C = 0.
+            f32x4 acc[4][4][NHW];
 
             auto load_w = [&](int t, int q, int x) {        // t, x are compile-time constants after unrolling (q too, except O16: q = cw)
                 if (t < WTAPS) return *reinterpret_cast<const float4*>(lds_w + t * TAP_BYTES + x * 2048 + q * 1024 + wlane);
@@ -669,7 +665,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                             for (int x = 0; x < NHW; ++x) {
                                 const float4 b4 = bq[cur][t][x];
                                 const float b = h == 0 ? (e == 0 ? b4.x : b4.y) : (e == 0 ? b4.z : b4.w);
-                                acc[sd][t][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, T[h][t][e], acc[sd][t][x], 0, 0, 0);
+                                const bool first_product = gi % 3 == 0 && (O16 || (step & 1) == 0) && h == 0 && e == 0;
+                                const f32x4 c_in = first_product ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[sd][t][x];
+                                acc[sd][t][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, T[h][t][e], c_in, 0, 0, 0);
                             }
                     if (ESTD_W2PK == 1) __builtin_amdgcn_sched_barrier(0);   // the MFMAs of two components, then the next step's 4 packed transforms
                     if (step + 1 < NSTEPS) xform2(R, h, Tn[h]);

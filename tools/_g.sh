@@ -1,6 +1,8 @@
-cd /tmp && export TMPDIR=/tmp
-R=/root/repo
-rocprofv3 --kernel-trace --output-format csv -d /tmp/pp -o p -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt > /tmp/pp.json 2>/tmp/pp.err
-f=$(find /tmp/pp -name "*kernel_trace.csv" | head -1)
-cp $f $R/gpurun_out/joint_trace.csv
-python $R/tools/prof_seq.py $f 6.5 20 | grep -v "copyBuffer\|elementwise" | cut -c1-100
+python -m pytest tests/test_gpu_wino.py tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -1
+CB_EPI=1 python tools/conv_bench.py 3 100 2>&1 | grep -v amdgpu
+python tools/conv_bench.py 1 100 2>&1 | grep -v amdgpu
+python tools/head_bench.py 2>&1 | grep -v amdgpu | tail -2
+python tools/kv_bench.py 2>&1 | grep "wino2 kv" | tail -1
+for i in 1 2 3; do python bench.py --steps 20 --warmup 5 --no-alt --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); print(d['value'], d['ms_per_step'])"; done
