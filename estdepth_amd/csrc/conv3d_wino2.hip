@@ -42,6 +42,9 @@
 #ifndef ESTD_W2_LIBM_TANH
 #define ESTD_W2_LIBM_TANH 0     // A/B: tanhf of the device library in the epilogue instead of tanh_fast
 #endif
+#ifndef ESTD_W2_RB_BATCH
+#define ESTD_W2_RB_BATCH 0      // A/B: read-back loads of both planes of a tile in one batch (82 spilled registers: 0.93 -> 1.38 ms)
+#endif
 #ifndef ESTD_W2_STATS_DEFER
 #define ESTD_W2_STATS_DEFER 0   // A/B: deferred epilogue also for the launches that write GroupNorm partial sums
 #endif
@@ -788,7 +791,14 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
 #endif
             if (!defer_this) {
                 if (O16) { if (d0 + cw < D) epi_plane(y0, d0 + cw); }
-                else {
+                else if (RB && ESTD_W2_RB_BATCH) {
+                    // read-back instance: the loads of BOTH planes back to back, one exposed round trip per tile instead of two
+                    EpiLoads l0, l1;
+                    epi_issue(d0, l0);
+                    if (d0 + 1 < D) epi_issue(d0 + 1, l1);
+                    epi_finish(y0, d0, l0);
+                    if (d0 + 1 < D) epi_finish(y1, d0 + 1, l1);
+                } else {
                     epi_plane(y0, d0);
                     if (d0 + 1 < D) epi_plane(y1, d0 + 1);
                 }
