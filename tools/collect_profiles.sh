@@ -4,7 +4,7 @@
 set -u
 R=$PWD
 OUT=$R/gpurun_out/profiles_r3
-mkdir -p $OUT
+mkdir -p $OUT tools/bin
 cd /tmp && export TMPDIR=/tmp
 for wl in joint estm cfg5; do
   rm -rf /tmp/prof_$wl
@@ -37,6 +37,8 @@ python tools/head_bench.py 2>&1 | grep -v amdgpu >> $OUT/r3_conv_bench.txt
 python tools/kv_bench.py 2>&1 | grep -v amdgpu >> $OUT/r3_conv_bench.txt
 python tools/conv2d_bench.py 2>&1 | grep -v amdgpu > $OUT/r3_conv2d_bench.txt
 python tools/psm_small_bench.py 2>&1 | grep -v amdgpu > $OUT/r3_psm_small_bench.txt
+# (built here, before the gpurun call: /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/src/mfma_valu_overlap.hip -o tools/bin/mfma_valu_overlap)
+[ -x tools/bin/mfma_valu_overlap ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/src/mfma_valu_overlap.hip -o tools/bin/mfma_valu_overlap
 tools/bin/mfma_valu_overlap > $OUT/r3_mfma_valu_overlap.txt 2>&1
 # default bench lines (with cpu_baseline + parity) of every workload; algorithm A/B; the world-size-1 RCCL run
 last() { grep "^{" | tail -1; }
