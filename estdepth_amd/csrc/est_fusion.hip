@@ -356,18 +356,34 @@ __global__ __launch_bounds__(256) void attention_prewarped_kernel(const float* _
     o4[4 + sub] = h;
 }
 
-__global__ void groupnorm_finalize_kernel(const double* __restrict__ partials, int n_blocks, double count, float eps,
-                                          float* __restrict__ out4)
+__global__ __launch_bounds__(1024) void groupnorm_finalize_kernel(const double* __restrict__ partials, int n_blocks, double count, float eps,
+                                                                  float* __restrict__ out4)
 {
-    // one block of 256 threads; fixed-order tree reduction -> deterministic
-    __shared__ double red[256 * 4];
+    // ONE block of 1024 threads (it sits between two convolutions of the serial ConvGRU chain: its latency is what counts).  Thread t owns
+    // the partials t, t + 1024, ...: the loads of a thread are independent (issued back to back, 32 bytes each), then a fixed-order tree
+    // through LDS -> deterministic.  (256 threads with a dependent loop: 15 us; this: half.)
+    __shared__ double red[1024 * 4];
+    const double2* p2 = reinterpret_cast<const double2*>(partials);
     double a[4] = {0, 0, 0, 0};
-    for (int b = threadIdx.x; b < n_blocks; b += 256)
-        for (int k = 0; k < 4; ++k) a[k] += partials[(size_t)b * 4 + k];
+    constexpr int U = 8;
+    for (int b0 = threadIdx.x; b0 < n_blocks; b0 += 1024 * U) {
+        double2 v0[U], v1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int b = b0 + u * 1024;
+            const bool ok = b < n_blocks;
+            v0[u] = ok ? p2[(size_t)b * 2] : make_double2(0.0, 0.0);
+            v1[u] = ok ? p2[(size_t)b * 2 + 1] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { a[0] += v0[u].x; a[1] += v0[u].y; a[2] += v1[u].x; a[3] += v1[u].y; }
+    }
+#pragma unroll
     for (int k = 0; k < 4; ++k) red[threadIdx.x * 4 + k] = a[k];
     __syncthreads();
-    for (int s = 128; s >= 1; s >>= 1) {
+    for (int s = 512; s >= 1; s >>= 1) {
         if ((int)threadIdx.x < s)
+#pragma unroll
             for (int k = 0; k < 4; ++k) red[threadIdx.x * 4 + k] += red[(threadIdx.x + s) * 4 + k];
         __syncthreads();
     }
@@ -599,7 +615,7 @@ extern "C" int estd_groupnorm_finalize(const double* partials, int n_blocks, dou
                                        estd_stream_t s)
 {
     if (!partials || !out4 || n_blocks <= 0 || count <= 0) return ESTD_ERR_ARG;
-    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(1), dim3(256), 0, estd_stream(s), partials, n_blocks, count, eps, out4);
+    hipLaunchKernelGGL(groupnorm_finalize_kernel, dim3(1), dim3(1024), 0, estd_stream(s), partials, n_blocks, count, eps, out4);
     return ESTD_LAUNCH_CHECK();
 }
 
