@@ -147,6 +147,8 @@ class GraphedForward:
                 up = st["upload_stream"] = torch.cuda.Stream()
             if st.get("b_done") is not None:
                 up.wait_event(st["b_done"])
+            else:
+                up.wait_stream(main)                     # first replay: after the capture-time runs that read these buffers
             with torch.cuda.stream(up):
                 cam = camera.finish(pending)
                 for name, t in cam.items():
