@@ -1,0 +1,121 @@
+"""CPU checks of the Winograd weight packers (estdepth_amd/packing.py): the packed buffers are unpacked with the lane / k-step / tap
+indexing the kernels use (csrc/conv3d_wino.hip, conv3d_wino2.hip, conv2d_wino.hip) and the Winograd algebra the kernels implement
+(input transform B^T x, product with the packed U, output transform A^T m) is evaluated in numpy on a small random map -- it must
+reproduce the direct 3x3(x3) cross-correlation (networks/layers_op.py:10-39: Conv2d / Conv3d, padding 1).  No GPU involved: a packing
+regression (tap order, K permutation, channel-half split, G matrix) shows up here before any kernel runs."""
+import numpy as np
+import pytest
+import torch
+
+from estdepth_amd import packing
+
+BT = np.array([[1.0, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]])     # input transform of F(2,3): t = B^T x
+AT = np.array([[1.0, 1, 1, 0], [0, 1, -1, -1]])                                  # output transform: y = A^T m
+
+
+def _unpack_k(packed_lane_major, cin=32):
+    """[..., 2 quads, 64 lanes, 4] -> [..., 16 columns j, cin] using the kernels' K permutation ch(g, t), t = 4 q + e."""
+    lead = packed_lane_major.shape[:-3]
+    out = np.zeros(lead + (16, cin), packed_lane_major.dtype)
+    for lane in range(64):
+        g, j = lane >> 4, lane & 15
+        for t in range(8):
+            out[..., j, packing._ch(32, g, t)] = packed_lane_major[..., t // 4, lane, t % 4]
+    return out
+
+
+def _direct3d(x, w):
+    """x [Cin, D, H, W], w [Cout, Cin, 3, 3, 3] -> [Cout, D, H, W] (zero padding 1), float64"""
+    cin, D, H, W = x.shape
+    xp = np.zeros((cin, D + 2, H + 2, W + 2)); xp[:, 1:-1, 1:-1, 1:-1] = x
+    y = np.zeros((w.shape[0], D, H, W))
+    for kd in range(3):
+        for kh in range(3):
+            for kw in range(3):
+                y += np.einsum("oi,idhw->odhw", w[:, :, kd, kh, kw], xp[:, kd:kd + D, kh:kh + H, kw:kw + W])
+    return y
+
+
+@pytest.mark.parametrize("n_out", [32, 16])
+def test_pack_conv3d_wino2_reproduces_the_direct_convolution(n_out):
+    rng = np.random.default_rng(3)
+    w = rng.standard_normal((n_out, 32, 3, 3, 3)) * 0.1
+    main_idx = list(rng.permutation(32))                      # the packers take index lists: exercise a non-trivial one
+    out_idx = list(rng.permutation(n_out))
+    packed = packing.pack_conv3d_wino2(torch.from_numpy(w).float(), main_idx, out_idx).numpy()     # [48][NH][2][64][4]
+    nh = n_out // 16
+    U = _unpack_k(packed.reshape(4, 3, 4, nh, 2, 64, 4))      # [sd][kw][sh][nh][j][ci]  (tap = (3 sd + kw) * 4 + sh)
+    D, H, W = 4, 6, 5
+    x = rng.standard_normal((32, D, H, W))                    # channel c of x = weight input channel main_idx[c]
+    xp = np.zeros((32, D + 2, H + 2, W + 2)); xp[:, 1:-1, 1:-1, 1:-1] = x
+    y = np.zeros((n_out, D, H, W))
+    for d0 in range(0, D, 2):
+        for h0 in range(0, H, 2):
+            patch = xp[:, d0:d0 + 4, h0:h0 + 4, :]                                       # [ci, 4, 4, W + 2]
+            T = np.einsum("sd,th,cdhw->stcw", BT, BT, patch)                             # [sd][sh][ci][W + 2]
+            m = np.zeros((4, 4, nh, 16, W))
+            for kw in range(3):
+                m += np.einsum("sthjc,stcw->sthjw", U[:, kw].astype(np.float64), T[:, :, :, kw:kw + W])
+            yy = np.einsum("ds,et,sthjw->dehjw", AT, AT, m)                              # [2][2][nh][j][W]
+            y[:, d0:d0 + 2, h0:h0 + 2, :] = yy.reshape(2, 2, n_out, W).transpose(2, 0, 1, 3)  # output row 16 nh + j
+    w_used = w[np.asarray(out_idx)][:, np.asarray(main_idx)]   # output row k = filter out_idx[k]; input slot c = channel main_idx[c]
+    ref = _direct3d(x, w_used)
+    assert np.abs(y - ref).max() < 2e-6 * max(1.0, np.abs(ref).max())
+
+
+def test_pack_conv3d_wino_depth_axis_reproduces_the_direct_convolution():
+    rng = np.random.default_rng(4)
+    w = rng.standard_normal((32, 32, 3, 3, 3)) * 0.1
+    idx = list(range(32))
+    packed = packing.pack_conv3d_wino(torch.from_numpy(w).float(), idx, idx).numpy()               # [37][2][2][64][4]
+    U = _unpack_k(packed[:36].reshape(4, 3, 3, 2, 2, 64, 4))   # [s][kh][kw][nh][j][ci]  (tap = 9 s + 3 kh + kw)
+    assert not packed[36].any()                                # the padding tap
+    D, H, W = 4, 3, 5
+    x = rng.standard_normal((32, D, H, W))
+    xp = np.zeros((32, D + 2, H + 2, W + 2)); xp[:, 1:-1, 1:-1, 1:-1] = x
+    y = np.zeros((32, D, H, W))
+    for d0 in range(0, D, 2):
+        T = np.einsum("sd,cdhw->schw", BT, xp[:, d0:d0 + 4])                                  # [s][ci][H + 2][W + 2]
+        m = np.zeros((4, 2, 16, H, W))
+        for kh in range(3):
+            for kw in range(3):
+                m += np.einsum("snjc,schw->snjhw", U[:, kh, kw].astype(np.float64), T[:, :, kh:kh + H, kw:kw + W])
+        yy = np.einsum("ds,snjhw->dnjhw", AT, m)
+        y[:, d0:d0 + 2] = yy.reshape(2, 32, H, W).transpose(1, 0, 2, 3)
+    assert np.abs(y - _direct3d(x, w)).max() < 2e-6 * max(1.0, np.abs(y).max())
+
+
+@pytest.mark.parametrize("nt", [2, 4])
+def test_pack_conv2d_wino_row_axis_reproduces_the_direct_convolution(nt):
+    rng = np.random.default_rng(5)
+    cin, cout = 64, 64
+    w = rng.standard_normal((cout, cin, 3, 3)) * 0.1
+    packed = packing.pack_conv2d_wino(torch.from_numpy(w).float(), nt).numpy()     # [groups][chunks][13][2 nt][64][4]
+    groups, chunks = cout // (16 * nt), cin // 32
+    assert not packed[:, :, 12].any()                          # the padding tap
+    # quad index of (k-step t, N tile n) = (t nt + n) // 4, element (t nt + n) % 4; output channel = 16 nt grp + nt j + n
+    U = np.zeros((4, 3, cout, cin))                            # [i][kw][co][ci]  (tap = 3 i + kw)
+    for grp in range(groups):
+        for c in range(chunks):
+            for lane in range(64):
+                g, j = lane >> 4, lane & 15
+                for t in range(8):
+                    for n in range(nt):
+                        idx = t * nt + n
+                        U[:, :, grp * 16 * nt + nt * j + n, c * 32 + packing._ch(32, g, t)] = \
+                            packed[grp, c, :12, idx // 4, lane, idx % 4].reshape(4, 3)
+    H, W = 6, 7
+    x = rng.standard_normal((cin, H, W))
+    xp = np.zeros((cin, H + 2, W + 2)); xp[:, 1:-1, 1:-1] = x
+    y = np.zeros((cout, H, W))
+    for h0 in range(0, H, 2):
+        T = np.einsum("ih,chw->icw", BT, xp[:, h0:h0 + 4])     # [i][ci][W + 2]
+        m = np.zeros((4, cout, W))
+        for kw in range(3):
+            m += np.einsum("ioc,icw->iow", U[:, kw], T[:, :, kw:kw + W])
+        y[:, h0:h0 + 2] = np.einsum("ri,iow->orw", AT, m)
+    ref = np.zeros((cout, H, W))
+    for kh in range(3):
+        for kw in range(3):
+            ref += np.einsum("oi,ihw->ohw", w[:, :, kh, kw], xp[:, kh:kh + H, kw:kw + W])
+    assert np.abs(y - ref).max() < 2e-6 * max(1.0, np.abs(ref).max())
