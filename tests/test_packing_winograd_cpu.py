@@ -119,3 +119,53 @@ def test_pack_conv2d_wino_row_axis_reproduces_the_direct_convolution(nt):
         for kw in range(3):
             ref += np.einsum("oi,ihw->ohw", w[:, :, kh, kw], xp[:, kh:kh + H, kw:kw + W])
     assert np.abs(y - ref).max() < 2e-6 * max(1.0, np.abs(ref).max())
+
+
+def test_pack_conv3d_wino2_extra_scalar_channel():
+    """33rd (scalar) input channel of the key|value convolution: [4 sd][2 halves][64 lanes][4 sh], lane group g = column tap kw (g = 3: zeros);
+    evaluated like the kernel's extra stage it must add exactly the direct convolution of that channel."""
+    rng = np.random.default_rng(6)
+    w = rng.standard_normal((32, 33, 3, 3, 3)) * 0.1
+    out_idx = list(range(32))
+    packed = packing.pack_conv3d_wino2_extra(torch.from_numpy(w).float(), 32, out_idx).numpy()     # [4][2][64][4]
+    U = np.zeros((4, 4, 32, 3))                               # [sd][sh][co][kw]
+    for lane in range(64):
+        g, j = lane >> 4, lane & 15
+        if g == 3:
+            assert not packed[:, :, lane, :].any()
+            continue
+        for nh in range(2):
+            U[:, :, 16 * nh + j, g] = packed[:, nh, lane, :]
+    D, H, W = 4, 4, 5
+    e = rng.standard_normal((1, D, H, W))
+    ep = np.zeros((1, D + 2, H + 2, W + 2)); ep[:, 1:-1, 1:-1, 1:-1] = e
+    y = np.zeros((32, D, H, W))
+    for d0 in range(0, D, 2):
+        for h0 in range(0, H, 2):
+            T = np.einsum("sd,th,dhw->stw", BT, BT, ep[0, d0:d0 + 4, h0:h0 + 4, :])
+            m = np.zeros((4, 4, 32, W))
+            for kw in range(3):
+                m += np.einsum("sto,stw->stow", U[..., kw], T[:, :, kw:kw + W])
+            y[:, d0:d0 + 2, h0:h0 + 2, :] = np.einsum("ds,et,stow->odew", AT, AT, m)
+    ref = _direct3d(e, w[:, 32:33])
+    assert np.abs(y - ref).max() < 2e-6 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("k, cin, cout", [(1, 32, 48), (3, 16, 32)])
+def test_pack_conv2d_small_and_to16_layouts(k, cin, cout):
+    rng = np.random.default_rng(7)
+    w = rng.standard_normal((cout, cin, k, k)).astype(np.float32)
+    p = packing.pack_conv2d_small(torch.from_numpy(w)).numpy()                     # [cout/16][k*k][cin/16][64][4]
+    for lane in (0, 17, 38, 63):
+        g, i = lane >> 4, lane & 15
+        for nt in range(cout // 16):
+            for q in range(cin // 16):
+                for ks in range(4):
+                    assert np.array_equal(p[nt, :, q, lane, ks], w[16 * nt + i, 16 * q + 4 * g + ks].reshape(k * k))
+    if k == 3:
+        w16 = w[:16]
+        p16 = packing.pack_conv2d_to16(torch.from_numpy(w16)).numpy()              # [9][cin/16][64][4]
+        for lane in (3, 29, 50):
+            g, i = lane >> 4, lane & 15
+            for ks in range(4):
+                assert np.array_equal(p16[:, 0, lane, ks], w16[i, 4 * g + ks].reshape(9))
