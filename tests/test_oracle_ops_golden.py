@@ -110,3 +110,20 @@ def test_identity_pose_known_answer():
     exp = torch.nn.functional.grid_sample(t, grid, mode="bilinear", padding_mode="zeros", align_corners=False).numpy()
     for d in range(D):
         assert np.abs(out[:, :, d] - exp).max() < 1e-5
+
+
+def test_attention_known_answers():
+    """SURVEY §4, transformer/epipolar_transformer.py:62-73 (softmax over the views, then the MEAN over views of the weighted values):
+    one source => weight 1 => h = V_1; n identical sources => weights 1/n => h = V / n; a source whose key correlates far more
+    strongly than the other takes all the weight => h = V_1 / 2."""
+    rs = np.random.RandomState(1)
+    B, C, D, H, W = 1, 16, 3, 4, 5
+    tk = rs.randn(B, C, D, H, W).astype(np.float32)
+    k1, v1 = rs.randn(B, C, D, H, W).astype(np.float32), rs.randn(B, C, D, H, W).astype(np.float32)
+    h = O.epipolar_attention(tk, [k1], [v1])
+    assert np.abs(h - v1).max() < 1e-6
+    h = O.epipolar_attention(tk, [k1, k1, k1], [v1, v1, v1])
+    assert np.abs(h - v1 / 3.0).max() < 1e-6
+    v2 = rs.randn(B, C, D, H, W).astype(np.float32)
+    h = O.epipolar_attention(tk, [50.0 * tk, -50.0 * tk], [v1, v2])     # correlation +50|k|^2 vs -50|k|^2
+    assert np.abs(h - v1 / 2.0).max() < 1e-5
