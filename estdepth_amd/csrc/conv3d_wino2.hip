@@ -34,7 +34,7 @@
 #include "estd_common.h"
 
 #ifndef ESTD_W2PRIO
-#define ESTD_W2PRIO 0   // 1: per-step alternating s_setprio between the two waves of a SIMD; 2: static priority 1 for waves 4..7
+#define ESTD_W2PRIO 2   // 0: none; 1: per-step alternating s_setprio between the two waves of a SIMD (slower); 2: static priority 1 for waves 4..7 (default: -1.2 % at sustained clocks)
 #endif
 #ifndef ESTD_W2PK
 #define ESTD_W2PK 0     // row transforms: 0 vector arithmetic (the compiler packs some, unpacks others next to MFMAs), 1 inline-assembly
