@@ -152,7 +152,7 @@ def _cpu_model_name():
 _DEFAULT_TORCH_THREADS = [0]        # torch's own default (= the physical cores of the box), recorded before anything changes it
 
 
-def cpu_baseline(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses, gpu_outputs, frames):
+def cpu_baseline(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses, gpu_outputs, frames, gpu_logits=None):
     """The CPU oracle (C/OpenMP restatement of the reference + the product's plain 2D nn.Modules on torch-CPU = a
     "port") timed on ONE full step of the same workload on the box's host cores: the whole DepthNetHybrid.forward of the
     timed step -- PSM, ResNet, plane sweeps, every 3D convolution, the 2N volume warps + attention + ConvGRU per target,
@@ -191,6 +191,18 @@ def cpu_baseline(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses,
     parity = {"max_abs_depth_diff_vs_oracle_m": {"scale%d" % s: float("%.3g" % w) for s, w in sorted(worst.items())},
               "tolerance_m": 1e-4, "within_tolerance": bool(max(worst.values()) <= 1e-4),
               "what": "hipGraph/eager HIP path of THIS benchmark configuration vs the CPU oracle on the same inputs, all depth outputs"}
+    if gpu_logits:
+        # the raw logit volumes of stereo_head0 / stereo_head1 (hybrid_depth_decoder.py:200-204,:256-260): what the depth maps hide
+        # behind a flat softmax -- every 3x3x3 convolution of the step undamped (bar: the G11 bar of the small-size fixtures, 1.5e-4)
+        lg = {}
+        for name, key in (("init", ("init_logits",)), ("fused", ("fused_logits",))):
+            if name in gpu_logits and key in ref:
+                a, b = np_(gpu_logits[name]), np.asarray(ref[key])
+                lg[name] = {"max_abs_diff": float("%.3g" % np.abs(a - b).max()), "oracle_range": float("%.3g" % np.abs(b).max()),
+                            "oracle_std": float("%.3g" % b.std()), "voxels": int(b.size)}
+        parity["logit_volumes_vs_oracle"] = lg
+        parity["logit_tolerance"] = 1.5e-4
+        parity["logits_within_tolerance"] = bool(lg and all(v["max_abs_diff"] <= 1.5e-4 for v in lg.values()))
     return base, parity
 
 
@@ -322,6 +334,7 @@ def main():
             dist.destroy_process_group()
         return
     model = build_model(args.workload, device)
+    model.CostRegNet.keep_logits = True      # keeps references to the two logit volumes of the last forward (no extra work): parity block
     imgs, poses, intr, sample = make_inputs(args.workload, rank, device)
     sl, frames, pre_costs, pre_poses = steady_state(model, args.workload, imgs, poses, intr, sample)
     x_imgs, x_poses = imgs[:, sl].contiguous(), poses[:, sl].contiguous()
@@ -387,6 +400,7 @@ def main():
     elapsed = time.perf_counter() - t0
     gathered = state["allgather"]
     gpu_outputs = {k: v.clone() for k, v in last[0].items()}        # outputs of the timed configuration (for the parity report)
+    gpu_logits = {k: v.clone() for k, v in (getattr(model.CostRegNet, "last_logits", None) or {}).items()}
     # "gathered bank equals each owner's tensors bit for bit" -- every rank checks the shard it owns
     bank_ok = None
     if gathered and state["bank"] is not None:
@@ -552,7 +566,7 @@ def main():
             counts = [args.cpu_threads] if args.cpu_threads > 0 else [8, 0]
             runs = []
             for th in counts:
-                base, parity = cpu_baseline(args.workload, th, x_imgs, x_poses, intr, pre_costs, pre_poses, gpu_outputs, frames)
+                base, parity = cpu_baseline(args.workload, th, x_imgs, x_poses, intr, pre_costs, pre_poses, gpu_outputs, frames, gpu_logits)
                 runs.append(base)
             best = max(runs, key=lambda b: b["value"])
             line["cpu_baseline"] = dict(best)

@@ -13,7 +13,7 @@
  * contribute 0), nearest upsample src=floor(dst/scale), BatchNorm eval affine,
  * GroupNorm(1 group) population variance, max-subtracted softmax.
  *
- * Parity pin: tests/test_oracle_golden.py checks every function against golden
+ * Parity pin: tests/test_oracle_ops_golden.py + tests/test_oracle_model_golden.py checks every function against golden
  * vectors produced by tools/gen_golden.py, which imports the reference itself.
  *
  * All tensors fp32, contiguous, batch-less (the Python wrapper loops over batch).

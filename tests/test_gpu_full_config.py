@@ -22,6 +22,22 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL_DEPTH = 1e-4
+# Logit volumes of stereo_head0 / stereo_head1 (hybrid_depth_decoder.py:200-204,:256-260) at FULL size vs the oracle's: the depth
+# maps above sit behind a softmax over D planes that forgives convolution errors when the logits are flat (head gain 1), the raw
+# logits do not -- every one of the ~10 3x3x3 convolutions in front of them (864-term fp32 sums, Winograd-transformed at full tile
+# counts) shows up here undamped.  Bar = the G11 bar (tests/test_gpu_parity.py::test_estm_stream): 1.5e-4 abs.
+TOL_LOGIT = 1.5e-4
+
+
+def _logit_diffs(dec, ref):
+    """max |logit_HIP - logit_oracle| of the two heads + the oracle's logit range (a bar without the range says nothing)"""
+    lg = dec.last_logits
+    out = {}
+    for name, key in (("init", ("init_logits",)), ("fused", ("fused_logits",))):
+        a, b = _np(lg[name]), np.asarray(ref[key])
+        assert a.shape == b.shape, (name, a.shape, b.shape)
+        out[name] = (float(np.abs(a - b).max()), float(np.abs(b).max()), float(b.std()))
+    return out
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -72,6 +88,7 @@ def cfg2_joint():
         out_plain, _, _ = plain(x_imgs, x_poses, intr, x_sample, pre_costs, list(pre_poses), mode="val")
     out_plain = {k: v.clone() for k, v in out_plain.items()}
     acc = B.build_model("joint", dev)                               # exactly what bench.py times
+    acc.CostRegNet.keep_logits = True
     fwd = GraphedForward(acc)
     with torch.no_grad():
         for _ in range(2):                                          # capture, then a pure replay
@@ -79,23 +96,35 @@ def cfg2_joint():
     out_acc = {k: v.clone() for k, v in out_acc.items()}
     torch.cuda.synchronize()
     ref = _oracle_forward("joint", x_imgs, x_poses, intr, pre_costs, pre_poses)
-    return out_plain, out_acc, ref
+    return out_plain, out_acc, ref, _logit_diffs(acc.CostRegNet, ref)
 
 
 def test_cfg2_accelerated_graph_path_matches_plain_eager_path(cfg2_joint):
-    out_plain, out_acc, _ = cfg2_joint
+    out_plain, out_acc, _, _ = cfg2_joint
     assert set(out_plain) == set(out_acc) and len(out_plain) == 18           # 3 targets x (4 depths + 2 probabilities)
     for k in out_plain:
         assert float((out_plain[k] - out_acc[k]).abs().max()) < 5e-5, k
 
 
 def test_cfg2_plain_and_accelerated_paths_match_the_oracle(cfg2_joint):
-    out_plain, out_acc, ref = cfg2_joint
+    out_plain, out_acc, ref, _ = cfg2_joint
     for tag, out in (("plain", out_plain), ("accelerated+hipGraph", out_acc)):
         for k, v in out.items():
             d = float(np.abs(_np(v) - ref[k]).max())
             bar = TOL_DEPTH if k[0] == "depth" else 5e-5                     # probabilities: max of a softmax over 64 planes
             assert d < bar, (tag, k, d)
+
+
+def _assert_logits(tag, diffs):
+    for name, (d, rng, std) in diffs.items():
+        print("%s %s logits: max |HIP - oracle| = %.3g on a range of +-%.3g (std %.3g)" % (tag, name, d, rng, std))
+        assert rng > 0.05 and std > 0.01, (tag, name, rng, std)         # a constant volume would pin nothing
+        assert np.isfinite(d) and d < TOL_LOGIT, (tag, name, d, rng)
+
+
+def test_cfg2_logit_volumes_match_the_oracle(cfg2_joint):
+    """3 targets x 64 x 120 x 160 logits of both heads, accelerated + hipGraph path vs the oracle (same inputs, same memory)"""
+    _assert_logits("cfg2", cfg2_joint[3])
 
 
 def test_semantic_encoder_resnet50_fused_path_vs_torch_cpu():
@@ -126,6 +155,7 @@ def test_cfg3_estm_window_matches_the_oracle():
     from estdepth_amd.graph import GraphedForward
     dev = torch.device(DEV)
     model = B.build_model("estm", dev)
+    model.CostRegNet.keep_logits = True
     imgs, poses, intr, sample = B.make_inputs("estm", 0, dev)
     sl, frames, pre_costs, pre_poses = B.steady_state(model, "estm", imgs, poses, intr, sample)
     assert frames == 1 and len(pre_costs["keys"]) == 2
@@ -142,6 +172,7 @@ def test_cfg3_estm_window_matches_the_oracle():
     for k, v in out.items():
         d = float(np.abs(_np(v) - ref[k]).max())
         assert np.isfinite(d) and d < (TOL_DEPTH if k[0] == "depth" else 5e-5), (k, d)
+    _assert_logits("cfg3", _logit_diffs(model.CostRegNet, ref))
 
 
 @pytest.fixture(scope="module")
@@ -150,6 +181,7 @@ def cfg5_window():
     from estdepth_amd.graph import GraphedForward
     dev = torch.device(DEV)
     model = B.build_model("cfg5", dev)
+    model.CostRegNet.keep_logits = True
     imgs, poses, intr, sample = B.make_inputs("cfg5", 0, dev)
     sl, frames, pre_costs, pre_poses = B.steady_state(model, "cfg5", imgs, poses, intr, sample)
     x_imgs, x_poses = imgs[:, sl].contiguous(), poses[:, sl].contiguous()
@@ -158,14 +190,19 @@ def cfg5_window():
         out, costs, cposes = GraphedForward(model)(x_imgs, x_poses, intr, x_sample, pre_costs, list(pre_poses), mode="val")
     out = {k: v.clone() for k, v in out.items()}
     torch.cuda.synchronize()
+    logits = {k: v.cpu() for k, v in model.CostRegNet.last_logits.items()}
     del model
     torch.cuda.empty_cache()
     ref = _oracle_forward("cfg5", x_imgs, x_poses, intr, pre_costs, pre_poses)
-    return out, ref, pre_costs
+
+    class _L:
+        last_logits = logits
+    return out, ref, pre_costs, _logit_diffs(_L, ref)
 
 
 def test_cfg5_estm_window_matches_the_oracle(cfg5_window):
-    out, ref, _ = cfg5_window
+    out, ref, _, ldiff = cfg5_window
+    _assert_logits("cfg5", ldiff)                  # 128 x 240 x 320 logits per head
     assert len(out) == 6 and tuple(out[("depth", 0, 0)].shape) == (1, 1, 960, 1280)
     for k, v in out.items():
         d = float(np.abs(_np(v) - ref[k]).max())
@@ -179,7 +216,7 @@ def test_cfg5_fusion_properties_and_groupnorm_statistics(cfg5_window):
     from estdepth_amd import ops, synth
     from estdepth_amd.hybrid_depth_decoder import kv_from_pair
     from estdepth_amd.epipolar_transformer import EpipolarTransformer
-    _, _, pre_costs = cfg5_window
+    _, _, pre_costs, _ = cfg5_window
     D, H, W = 128, 240, 320
     kv = [kv_from_pair(k, v) for k, v in zip(pre_costs["keys"], pre_costs["values"])]
     assert tuple(kv[0].shape) == (D, H, W, 32)

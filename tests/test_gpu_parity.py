@@ -195,7 +195,9 @@ def test_get_costvolume(golden_dir):
     with torch.no_grad():
         out = m.get_costvolume(feats, poses, K[None].to(DEV), dv)
     assert tuple(out.shape) == (1, 32, 16, 16, 20)
-    _vol_close(out.cpu().numpy(), g["out"], flip_frac=1e-3)
+    # no flipped sample behind the two 3x3x3 convolutions either: every element within 5e-5 (|values| <= 9.1, std 1.24; the oracle's
+    # own distance to this fixture is 6.4e-6, tests/test_oracle_ops_golden.py::test_g2_get_costvolume)
+    _vol_close(out.cpu().numpy(), g["out"], flip_frac=0.0)
 
 
 def test_epipolar_transformer(golden_dir):

@@ -20,9 +20,11 @@ def test_g1_homo_warping(golden_dir):
         out = O.homo_warping(src.numpy(), sp.numpy(), rp.numpy(), dv.numpy())
         ref = g[name]
         diff = np.abs(out - ref)
-        # mask discontinuity (|xn|>1 -> 2): a 1-ulp coordinate difference may flip single samples
-        assert (diff > 1e-4).mean() < 2e-4, (name, diff.max())
-        assert np.median(diff) < 5e-6
+        # mask discontinuity (|xn|>1 -> 2): the oracle composes its coordinates with the reference's own rounding sequence, so NO
+        # sample may flip (a flip moves a value by a texel's worth, 0.1 .. 1).  Measured: max 2.3e-5 / 7.1e-6 on |values| <= 3.3
+        # (interpolation-weight rounding), zero elements above 5e-5 -- the same bar the GPU path is held to (_vol_close).
+        assert diff.max() < 5e-5, (name, float(diff.max()), int((diff > 5e-5).sum()))
+        assert np.median(diff) < 1e-6
         assert (ref != 0).mean() > 0.3
 
 
@@ -31,8 +33,8 @@ def test_g3_warp_volume(golden_dir):
     vol, depth, rel, K, dmin, dint = S.g3_case()
     out = O.warp_volume(vol.numpy(), depth.numpy(), rel.numpy(), K.numpy(), None, dmin, dint)
     diff = np.abs(out - g["out"])
-    assert (diff > 1e-4).mean() < 2e-4, diff.max()
-    assert np.median(diff) < 5e-6
+    # measured: bit-identical to the reference's output (max 0.0); one ulp of the volume's range is the bar, no flipped sample
+    assert diff.max() < 1e-6, (float(diff.max()), int((diff > 1e-6).sum()))
     assert abs((out == 0).mean() - float(g["zero_frac"])) < 1e-3
 
 
@@ -93,7 +95,8 @@ def test_g2_get_costvolume(golden_dir):
     dv = m.depth_cands.view(1, 16, 1, 1).numpy()
     out = M.get_costvolume(P, feats, poses, K[None], dv, 16)
     diff = np.abs(out - g["out"])
-    assert (diff > 1e-4).mean() < 5e-4, diff.max()
+    # two 3x3x3 convolutions behind the sweep: measured max 6.4e-6 on |values| <= 9.1 (std 1.24), zero flipped samples
+    assert diff.max() < 2e-5, (float(diff.max()), int((diff > 2e-5).sum()))
     assert np.median(diff) < 2e-6
 
 
