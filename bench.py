@@ -193,7 +193,7 @@ def cpu_baseline(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses,
               "what": "hipGraph/eager HIP path of THIS benchmark configuration vs the CPU oracle on the same inputs, all depth outputs"}
     if gpu_logits:
         # the raw logit volumes of stereo_head0 / stereo_head1 (hybrid_depth_decoder.py:200-204,:256-260): what the depth maps hide
-        # behind a flat softmax -- every 3x3x3 convolution of the step undamped (bar: the G11 bar of the small-size fixtures, 1.5e-4)
+        # behind a flat softmax -- every 3x3x3 convolution of the step undamped (bar: 6e-5, tests/test_gpu_full_config.py)
         lg = {}
         for name, key in (("init", ("init_logits",)), ("fused", ("fused_logits",))):
             if name in gpu_logits and key in ref:
@@ -201,8 +201,8 @@ def cpu_baseline(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses,
                 lg[name] = {"max_abs_diff": float("%.3g" % np.abs(a - b).max()), "oracle_range": float("%.3g" % np.abs(b).max()),
                             "oracle_std": float("%.3g" % b.std()), "voxels": int(b.size)}
         parity["logit_volumes_vs_oracle"] = lg
-        parity["logit_tolerance"] = 1.5e-4
-        parity["logits_within_tolerance"] = bool(lg and all(v["max_abs_diff"] <= 1.5e-4 for v in lg.values()))
+        parity["logit_tolerance"] = 6e-5
+        parity["logits_within_tolerance"] = bool(lg and all(v["max_abs_diff"] <= 6e-5 for v in lg.values()))
     return base, parity
 
 

@@ -340,7 +340,7 @@ class PSMFeatures(nn.Module):
     def _branch(self, i, skip, pooled=None):
         """SPP branch: AvgPool -> 1x1 conv -> BN -> ReLU (psm_submodule.py:100-110)."""
         br = getattr(self, "branch%d" % i)
-        if getattr(self, "_hip", False) and skip.is_cuda:
+        if getattr(self, "_hip", False) and skip.is_cuda and not self.training:      # folded running statistics: eval only
             p = br[0](skip) if pooled is None else pooled[i]
             z = small_conv_nhwc(br[1][0], br[1][1], self._nhwc(p), relu=True)
             if z is not None:

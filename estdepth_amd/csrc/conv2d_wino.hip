@@ -166,8 +166,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(const estd_conv2d_d
 #pragma unroll
             for (int q = 0; q < QN; ++q) bq[t][q] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w0, wlane, (t * QN + q) * 1024, 0));
     }
-    const float floor_b = p.relu_before_residual ? 0.f : -__builtin_inff();
-    const float floor_a = p.relu_after_residual ? 0.f : -__builtin_inff();
+    const float floor_b = p.relu_before_residual ? 0.f : ESTD_NO_FLOOR;
+    const float floor_a = p.relu_after_residual ? 0.f : ESTD_NO_FLOOR;
 
     int k = 0;                                              // global chunk counter -> LDS slot
     int item_no = 0;

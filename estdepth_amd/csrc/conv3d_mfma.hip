@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_kernel(const estd_conv3d_des
     const int act_u = p.act_split <= 0 ? p.act_b : p.act_a;
     const bool head_only = NT == 1 && !XOUT && p.head_w && !p.out_main && !(ESTD_STATS_ON && p.stats_partials) && act_uniform &&
                            act_u != ESTD_ACT_TANH && !(ESTD_ABL & 128);
-    const float head_floor = act_u == ESTD_ACT_RELU ? 0.f : -__builtin_inff();
+    const float head_floor = act_u == ESTD_ACT_RELU ? 0.f : ESTD_NO_FLOOR;
 
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w_main, (size_t)28 * QN * 256);
     // 16 -> 16 (stereo heads): one weight quad per lane and tap, 27 quads = 108 registers -- the whole filter stays in registers, no

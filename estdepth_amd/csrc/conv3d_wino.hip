@@ -159,7 +159,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino_kernel(const estd_con
     // plain launches (no read-back stream, no tanh): the activation is a per-lane floor and the epilogue has no branch per element
     const bool plain_epi = !p.residual && !p.residual2 && !p.accumulate && p.out_scale == 1.0f &&
                            p.act_a != ESTD_ACT_TANH && p.act_b != ESTD_ACT_TANH && !(ESTD_WABL & 64);
-    const float act_floor = act0 == ESTD_ACT_RELU ? 0.f : -__builtin_inff();
+    const float act_floor = act0 == ESTD_ACT_RELU ? 0.f : ESTD_NO_FLOOR;
     // packed weights: [37 taps (36 + 1 the prefetch may read)][2 halves][2 quads][64 lanes][4]
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w_wino, (size_t)37 * 2 * 2 * 256);
     const int wlane = lane * 16 + nh * 2048;

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
     }
     // activation as a per-channel floor: ReLU = max(v, 0), none = max(v, -inf) -- two VALU operations per value in the epilogue
     // (fp32 MFMAs hide no VALU work: every epilogue instruction is paid in matrix-pipe time); tanh takes the generic path
-    if (tid >= 64 && tid < 96) lds_ss[tid] = ((tid - 64) < p.act_split ? p.act_a : p.act_b) == ESTD_ACT_RELU ? 0.0f : -__builtin_inff();
+    if (tid >= 64 && tid < 96) lds_ss[tid] = ((tid - 64) < p.act_split ? p.act_a : p.act_b) == ESTD_ACT_RELU ? 0.0f : ESTD_NO_FLOOR;
     // (O16: scale / shift hold 16 entries; lanes read channels 0..15 only)
     const bool any_tanh = p.act_a == ESTD_ACT_TANH || p.act_b == ESTD_ACT_TANH;                     // uniform
     const bool tanh_quads = any_tanh && (p.act_split & 3) == 0 && !ESTD_W2_LIBM_TANH;                // uniform

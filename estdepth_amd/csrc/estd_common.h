@@ -10,22 +10,34 @@
 
 static inline hipStream_t estd_stream(estd_stream_t s) { return static_cast<hipStream_t>(s); }
 
+// Activation as a per-channel floor in the straight-line epilogues: out = fmaxf(v, floor) (one v_max_f32).  ReLU: floor 0.
+// Activation "none": the floor is a quiet NaN -- v_max_f32 is IEEE maxNum, max(v, NaN) = v for every v and max(NaN, NaN) = NaN, so
+// a NaN produced by the convolution still reaches the output as the reference's conv3d + BatchNorm would deliver it (with -inf as
+// the floor a NaN came out as -inf).  Same instruction count.
+#define ESTD_NO_FLOOR __builtin_nanf("")
+
 // persistent-grid size of a kernel with `per_cu` resident workgroups per CU: the compute units of the CURRENT device (256 on an
 // MI355X; queried once per device ordinal -- partitioned / other gfx950 parts report their own count) minus the reserve of
 // estd_set_reserved_cus
 extern "C" int estd_get_reserved_cus(void);
+#include <atomic>
+#include <stdio.h>
 static inline int estd_device_cus(void)
 {
-    static int cus[64] = {0};                   // 0 = not queried yet (a benign race: every thread writes the same value)
+    static std::atomic<int> cus[64];            // zero-initialised; 0 = not queried yet (relaxed: every thread would store the same value)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    dev &= 63;
-    if (cus[dev] == 0) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus[dev] = n;
+    int n = 0;
+    const bool cached = (unsigned)dev < 64u;    // ordinals beyond the table are queried every time instead of aliasing a slot
+    if (cached && (n = cus[dev].load(std::memory_order_relaxed)) > 0) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+        static std::atomic<bool> warned{false};
+        if (!warned.exchange(true))
+            fprintf(stderr, "libestd_hip: hipDeviceGetAttribute(MultiprocessorCount) failed for device %d: persistent grids sized for 256 CUs\n", dev);
+        return 256;                             // not cached: a later call may succeed
     }
-    return cus[dev];
+    if (cached) cus[dev].store(n, std::memory_order_relaxed);
+    return n;
 }
 static inline int estd_persistent_wgs(int per_cu)
 {
@@ -38,7 +50,6 @@ static inline int estd_ceil_div(long long a, long long b) { return (int)((a + b 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of (function, device): raise it once per device ordinal and
 // kernel instantiation.  One atomic bit mask per instantiation -- thread-safe, and correct when a process drives
 // several devices (launches under graph capture find the bit already set by the warm-up launch).
-#include <atomic>
 template <auto Kernel>
 static inline void estd_allow_dynamic_lds(int bytes)
 {

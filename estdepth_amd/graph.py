@@ -35,10 +35,11 @@ class GraphedForward:
         self.model = model
         self.warmup = warmup
         self.clone_outputs = clone_outputs
+        self.memory_logits = None                # after a call: fresh copy of DepthHybridDecoder.memory_logits of that call
         self._graphs = {}
 
     def __getattr__(self, name):                 # normalise_images, matchingFeature, ndepths, ... of the wrapped model
-        if name in ("model", "warmup", "_graphs", "clone_outputs"):
+        if name in ("model", "warmup", "_graphs", "clone_outputs", "memory_logits"):
             raise AttributeError(name)
         return getattr(self.model, name)
 
@@ -50,6 +51,7 @@ class GraphedForward:
         n_mem = 0 if pre_costs is None else len(pre_costs["keys"])
         from . import ops
         return (tuple(imgs.shape), n_mem, matching_features is not None, mode, ops.CONV3D_ARITH, ops.CONV2D_ARITH,
+                ops.CONV3D_ALGO, getattr(ops, "CONV2D_ALGO", None), getattr(ops, "CONV2D_NT", None),      # a graph bakes the kernel choice in
                 self.model.camera_algebra,
                 getattr(self.model, "_estd_weights_epoch", 0))     # (last) a captured graph bakes kernel choice and weight buffers in
 
@@ -91,6 +93,7 @@ class GraphedForward:
         with torch.no_grad(), torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
             out = run_b(feats)
         st["graph_a"], st["graph_b"], st["feats2d"], st["out"] = ga, gb, feats, out
+        st["memory_logits"] = getattr(m.CostRegNet, "memory_logits", None)     # static buffer of graph B (rewritten by every replay)
         # the replay reads the packed-weight buffers that existed at capture time: keep them alive even if a PlanCache
         # is rebuilt later (stale-but-valid until the epoch check re-captures), never a use-after-free
         st["keepalive"] = [c._plans for c in (getattr(mod, "_cache", None) for mod in m.modules()) if isinstance(c, PlanCache)]
@@ -160,6 +163,9 @@ class GraphedForward:
             st["b_done"] = torch.cuda.Event()
         st["b_done"].record()
         outputs, costs, cposes = st["out"]
+        # the logit volume that travels with the memory bank (parallel.allgather_memory_bank*): a fresh 4.9 MB tensor, like the memory
+        ml = st.get("memory_logits")
+        self.memory_logits = ml.clone() if ml is not None else None
         if self.clone_outputs:
             outputs = {k: v.clone() for k, v in outputs.items()}
         # memory handed back to the caller: fresh tensors (they outlive the next replay)

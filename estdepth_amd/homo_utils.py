@@ -19,11 +19,18 @@ def set_id_grid(h, w):
 
 
 def _per_plane(depth, batch, num_depth):
-    """[B,D,...] -> ([B,D] per-plane constants, None) when every plane holds one value, else (None, [B,D,H*W] per pixel)."""
+    """[B,D,...] -> ([B,D] per-plane constants, None) when every plane holds one value, else (None, [B,D,H*W] per pixel).
+    No device synchronisation where the layout says it all: a trailing size of 1, or an EXPANDED view (stride 0 over the pixels --
+    what ``depth_values.expand(...)`` hands over).  A materialised [B,D,H,W] tensor (``depth_values.repeat(1,1,H,W)``, the hybrid
+    callers: model_hybrid.py:95, hybrid_depth_decoder.py:238) has to be looked at: one blocking ``.all()`` -- the level-1 operators
+    are the drop-in surface, the fast path (DepthNetHybrid.forward) never comes through here."""
+    if depth.dim() >= 3 and depth.shape[0] == batch and depth.shape[1] == num_depth and all(
+            sz == 1 or st == 0 for sz, st in zip(depth.shape[2:], depth.stride()[2:])):
+        return depth[(slice(None), slice(None)) + (0,) * (depth.dim() - 2)].float().contiguous(), None
     dv = depth.reshape(batch, num_depth, -1).float()
     if dv.shape[2] == 1:
         return dv[:, :, 0].contiguous(), None
-    if bool((dv == dv[:, :, :1]).all()):           # what every caller on the hybrid path passes (depth_values.repeat(H, W))
+    if bool((dv == dv[:, :, :1]).all()):
         return dv[:, :, 0].contiguous(), None
     return None, dv.contiguous()
 

@@ -340,6 +340,9 @@ class DepthHybridDecoder(nn.Module):
         for i in range(num):
             outputs[("depth", i, 1)] = s1[i:i + 1]
             outputs[("depth", i, 0)] = s0[i:i + 1]
+        # the initial logit volume of the frame whose memory is handed on (the per-frame probability volume before its softmax,
+        # :200-204): a view, kept for the multi-GPU memory bank (estdepth_amd/parallel.py); not part of the returned dicts
+        self.memory_logits = init_logits[num - 1]
         key, value = kv_views(kvs[num - 1])                               # unfused key, fused value of the last target
         return outputs, {"keys": [key], "values": [value]}, cam_poses[-1:]    # :292 (stale pose, Q7)
 
@@ -369,6 +372,7 @@ class DepthHybridDecoder(nn.Module):
             outputs[("fused_prob", i)] = p2[i:i + 1]
             outputs[("depth", i, 1)] = s1[i:i + 1]
             outputs[("depth", i, 0)] = s0[i:i + 1]
+        self.memory_logits = init_logits[num - 1]                          # (see forward_transformer)
         key, value = kv_views(kv[num - 1])
         return outputs, {"keys": [key], "values": [value]}, cam_poses[-1:]                   # :417
 

@@ -441,13 +441,17 @@ def warp_volume_ex_cdhw(vol, mats30, depth, depth_per_voxel, depth_min, depth_in
                         border=False, padding_value=0.0):
     """every branch of the reference's warp_volume() signature (include/estd_hip.h::estd_warp_volume_ex)."""
     use_disp = disp_min is not None
+    # values are passed through as given: a zero interval reaches the native check (ESTD_ERR_ARG / RuntimeError) instead of being
+    # replaced silently -- the reference divides by it (homo_utils.py:187-190).  Placeholders only when disparity planes are off.
+    dmin_ = float(disp_min) if use_disp else 0.0
+    dint_ = float(disp_interval) if (use_disp and disp_interval is not None) else (0.0 if use_disp else 1.0)
     if _use_torch():
         return T().warp_volume_ex(vol, mats30, depth, bool(depth_per_voxel), float(depth_min), float(depth_interval), use_disp,
-                                  float(disp_min or 0.0), float(disp_interval or 1.0), bool(border), float(padding_value))
+                                  dmin_, dint_, bool(border), float(padding_value))
     C, D, H, W = vol.shape
     out = torch.empty_like(vol)
     o = N.WarpVolumeOpts(int(bool(depth_per_voxel)), int(use_disp), int(bool(border)), float(depth_min), float(depth_interval),
-                         float(disp_min or 0.0), float(disp_interval or 1.0), float(padding_value))
+                         dmin_, dint_, float(padding_value))
     N.check(N.lib().estd_warp_volume_ex(_p(_chk(vol, "feat_volume")), _p(mats30), _p(_chk(depth, "depth")), ctypes.byref(o),
                                         _p(out), C, D, H, W, _stream()), "estd_warp_volume_ex")
     return out

@@ -3,11 +3,52 @@
 The hot path itself shards at sequence granularity with NO data-path collective (the reference
 cannot even batch sequences, Q15).  The one exchange step with a reference-side meaning is the
 temporal-fusion memory bank: after a window, every rank all-gathers {key, fused value, pose} of
-its stream so that any rank can continue any stream (and so the collective's bandwidth over xGMI
-is exercised and reported).  Backend "nccl" is RCCL on ROCm; CPU tests use gloo.
+its stream -- and, when the caller hands them over, the frame's initial logit volume (the per-frame
+probability volume of `north_star` before its softmax, hybrid_depth_decoder.py:200-204; 4.9 MB beside the
+157 MB of K||V at cfg2/3 size) -- so that any rank can continue any stream (and so the collective's
+bandwidth over xGMI is exercised and reported).  Backend "nccl" is RCCL on ROCm; CPU tests use gloo.
+
+Algorithm of the exchange (``ESTD_AG_ALGO`` / ``algo=``):
+  * ``collective`` (default): ONE ``all_gather_into_tensor`` per stream of the record (RCCL picks ring / direct itself);
+  * ``direct``: every rank posts a send to and a receive from every peer under ONE group
+    (``batch_isend_irecv`` = ncclGroupStart{ncclSend/ncclRecv to all peers}ncclGroupEnd on RCCL) and copies its own shard
+    locally: on the fully connected xGMI mesh of an MI355X node every one of the 7 links of a GPU carries exactly one
+    157 MB message (~1 ms at 153 GB/s per link) where a ring all-gather pushes (N-1) x 157 MB through ONE link per GPU
+    (~7.2 ms at N = 8).  Same receive layout, bit-identical result.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+AG_ALGO = os.environ.get("ESTD_AG_ALGO", "collective")
+
+
+def _gather_flat(recv, send, group, algo, async_op=True):
+    """recv [world * n] <- every rank's send [n].  Returns a list of work handles (possibly empty)."""
+    algo = AG_ALGO if algo is None else algo
+    if algo not in ("collective", "direct"):
+        raise RuntimeError("ESTD_AG_ALGO must be collective or direct, got %r" % (algo,))
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if algo == "collective" or world == 1:
+        w = dist.all_gather_into_tensor(recv, send, group=group, async_op=async_op)
+        return [w] if async_op else []
+    n = send.numel()
+    rv = recv.view(world, n)
+    ops_ = []
+    for d in range(1, world):                          # peer order rotated by rank: at every position of the list the
+        dst, src = (rank + d) % world, (rank - d) % world      # world posts a perfect matching (no link carries two messages at once)
+        gdst = dist.get_global_rank(group, dst) if group is not None else dst
+        gsrc = dist.get_global_rank(group, src) if group is not None else src
+        ops_.append(dist.P2POp(dist.isend, send, gdst, group))
+        ops_.append(dist.P2POp(dist.irecv, rv[src], gsrc, group))
+    works = dist.batch_isend_irecv(ops_)
+    rv[rank].copy_(send)                               # own shard: a device-local copy on the compute stream
+    if not async_op:
+        for w in works:
+            w.wait()
+        return []
+    return list(works)
 
 
 def shard_sequences(n_sequences, rank=None, world=None):
@@ -25,53 +66,63 @@ class _PendingBank:
 
     def wait(self):
         if self.work is not None:
-            self.work.wait()            # the current stream waits for the collective; the host does not block
+            for w in self.work:         # the current stream waits for the exchange; the host does not block
+                w.wait()
             self.work = None
         return _unpack_bank(self.recv, self.n, *self.meta)
 
 
-def _unpack_bank(recv, n, world, kv_shape, key_shape, value_shape, pose_shape, channels_last):
+def _unpack_bank(recv, n, world, kv_shape, key_shape, value_shape, pose_shape, channels_last, logits_shape=None):
     out = []
+    npose = 1
+    for d in pose_shape:
+        npose *= d
     for r in range(world):
-        p = recv[r, n:].reshape(pose_shape)
+        p = recv[r, n:n + npose].reshape(pose_shape)
         if channels_last:
             from .hybrid_depth_decoder import kv_views
             k, v = kv_views(recv[r, :n].reshape(kv_shape))
         else:
             v = recv[r, :n // 2].reshape(value_shape)
             k = recv[r, n // 2:n].reshape(key_shape)
-        out.append(({"keys": [k], "values": [v]}, [p]))
+        costs = {"keys": [k], "values": [v]}
+        if logits_shape is not None:
+            costs["logits"] = [recv[r, n + npose:].reshape(logits_shape)]
+        out.append((costs, [p]))
     return out
 
 
-def allgather_memory_bank_async(costs, cam_poses, group=None, stage=True):
-    """Non-blocking variant: stages {K, V_fused, pose} into one send buffer (so the source may be overwritten by the
-    next forward / graph replay) and starts ONE all-gather on the communication stream.  ``.wait()`` returns the bank.
+def allgather_memory_bank_async(costs, cam_poses, group=None, stage=True, logits=None, algo=None):
+    """Non-blocking variant: stages {K, V_fused, pose[, init logits]} into one send buffer (so the source may be overwritten by
+    the next forward / graph replay) and starts ONE exchange on the communication stream.  ``.wait()`` returns the bank.
     ``stage=False``: the caller guarantees that the memory it hands in is not written again before ``.wait()`` (the fresh
-    tensors GraphedForward returns): the 157 MB record stream is sent from where it lies, the pose in a second, tiny
-    all-gather -- no staging copy on the compute stream."""
+    tensors GraphedForward returns): the 157 MB record stream is sent from where it lies, the pose (and the 4.9 MB logit volume)
+    in a second, small exchange -- no staging copy of the records on the compute stream.
+    ``logits``: the frame's initial logit volume [D,H,W] (``DepthHybridDecoder.memory_logits`` / ``GraphedForward.memory_logits``):
+    every bank entry then carries ``costs["logits"] = [volume]`` as well.  ``algo``: see the module docstring."""
     world = dist.get_world_size(group)
     key, value, pose = costs["keys"][0], costs["values"][0], cam_poses[0]
     kv = getattr(value, "_estd_kv", None)
     channels_last = kv is not None and getattr(key, "_estd_kv", None) is kv
-    meta = (world, tuple(kv.shape) if channels_last else None, tuple(key.shape), tuple(value.shape), tuple(pose.shape), channels_last)
+    lshape = tuple(logits.shape) if logits is not None else None
+    meta = (world, tuple(kv.shape) if channels_last else None, tuple(key.shape), tuple(value.shape), tuple(pose.shape), channels_last, lshape)
     if not stage and channels_last and kv.is_contiguous():
         flat = kv.reshape(-1)
-        psend = pose.reshape(-1).to(flat.dtype).contiguous()
+        small = [pose.reshape(-1).to(flat.dtype)] + ([logits.reshape(-1).to(flat.dtype)] if logits is not None else [])
+        psend = torch.cat(small).contiguous() if len(small) > 1 else small[0].contiguous()
         n, m = flat.numel(), psend.numel()
         recv_kv = torch.empty(world * n, device=flat.device, dtype=flat.dtype)
         recv_p = torch.empty(world * m, device=flat.device, dtype=flat.dtype)
-        work_p = dist.all_gather_into_tensor(recv_p, psend, group=group, async_op=True)
-        work = dist.all_gather_into_tensor(recv_kv, flat, group=group, async_op=True)
-        pend = _PendingBank2((work_p, work), recv_kv.view(world, n), recv_p.view(world, m), meta)
-        pend._send = (flat, psend, kv)  # keep the source alive until the collective has run
+        works = _gather_flat(recv_p, psend, group, algo) + _gather_flat(recv_kv, flat, group, algo)
+        pend = _PendingBank2(works, recv_kv.view(world, n), recv_p.view(world, m), meta)
+        pend._send = (flat, psend, kv)  # keep the source alive until the exchange has run
         return pend
     flat = kv.reshape(-1) if channels_last else torch.cat([value.reshape(-1), key.reshape(-1)])
-    send = torch.cat([flat, pose.reshape(-1).to(flat.dtype)])
+    send = torch.cat([flat, pose.reshape(-1).to(flat.dtype)] + ([logits.reshape(-1).to(flat.dtype)] if logits is not None else []))
     recv = torch.empty(world * send.numel(), device=send.device, dtype=send.dtype)
-    work = dist.all_gather_into_tensor(recv, send, group=group, async_op=True)
-    pend = _PendingBank(work, recv.view(world, send.numel()), flat.numel(), meta)
-    pend._send = send                   # keep the staging buffer alive until the collective has run
+    works = _gather_flat(recv, send, group, algo)
+    pend = _PendingBank(works, recv.view(world, send.numel()), flat.numel(), meta)
+    pend._send = send                   # keep the staging buffer alive until the exchange has run
     return pend
 
 
@@ -89,42 +140,24 @@ class _PendingBank2:
             for w in self.work:
                 w.wait()
             self.work = None
-        world, kv_shape, key_shape, value_shape, pose_shape, _ = self.meta
+        world, kv_shape, key_shape, value_shape, pose_shape, _, logits_shape = self.meta
         from .hybrid_depth_decoder import kv_views
+        npose = 1
+        for d in pose_shape:
+            npose *= d
         out = []
         for r in range(world):
             k, v = kv_views(self.recv_kv[r].reshape(kv_shape))
-            out.append(({"keys": [k], "values": [v]}, [self.recv_p[r].reshape(pose_shape)]))
+            costs = {"keys": [k], "values": [v]}
+            if logits_shape is not None:
+                costs["logits"] = [self.recv_p[r, npose:].reshape(logits_shape)]
+            out.append((costs, [self.recv_p[r, :npose].reshape(pose_shape)]))
         return out
 
 
-def allgather_memory_bank(costs, cam_poses, group=None):
-    """costs = {"keys": [K], "values": [V]} with K, V [1,16,D,H,W]; cam_poses = [pose [1,4,4]].
-    Returns a list (one entry per rank) of (costs, cam_poses) in the same structure; entry[rank] aliases
-    nothing of the input.  One fused buffer per rank -> a single all-gather (per-link bound on xGMI:
-    prefer one large message over three small ones)."""
-    world = dist.get_world_size(group)
-    key, value, pose = costs["keys"][0], costs["values"][0], cam_poses[0]
-    kv = getattr(value, "_estd_kv", None)
-    if kv is not None and getattr(key, "_estd_kv", None) is kv:
-        flat = kv.reshape(-1)                      # already one contiguous [D,H,W,32] record stream
-        channels_last = True
-    else:
-        flat = torch.cat([value.reshape(-1), key.reshape(-1)])
-        channels_last = False
-    send = torch.cat([flat, pose.reshape(-1).to(flat.dtype)])
-    recv = torch.empty(world * send.numel(), device=send.device, dtype=send.dtype)
-    dist.all_gather_into_tensor(recv, send, group=group)
-    recv = recv.view(world, send.numel())
-    n = flat.numel()
-    out = []
-    for r in range(world):
-        p = recv[r, n:].reshape(pose.shape)
-        if channels_last:
-            from .hybrid_depth_decoder import kv_views
-            k, v = kv_views(recv[r, :n].reshape(kv.shape))
-        else:
-            v = recv[r, :n // 2].reshape(value.shape)
-            k = recv[r, n // 2:n].reshape(key.shape)
-        out.append(({"keys": [k], "values": [v]}, [p]))
-    return out
+def allgather_memory_bank(costs, cam_poses, group=None, logits=None, algo=None):
+    """costs = {"keys": [K], "values": [V]} with K, V [1,16,D,H,W]; cam_poses = [pose [1,4,4]]; optional ``logits`` [D,H,W].
+    Returns a list (one entry per rank) of (costs, cam_poses) in the same structure (+ ``costs["logits"]`` when logits were
+    handed in); entry[rank] aliases nothing of the input.  One fused buffer per rank -> a single exchange (per-link bound on
+    xGMI: prefer one large message over three small ones)."""
+    return allgather_memory_bank_async(costs, cam_poses, group=group, stage=True, logits=logits, algo=algo).wait()

@@ -25,8 +25,10 @@ TOL_DEPTH = 1e-4
 # Logit volumes of stereo_head0 / stereo_head1 (hybrid_depth_decoder.py:200-204,:256-260) at FULL size vs the oracle's: the depth
 # maps above sit behind a softmax over D planes that forgives convolution errors when the logits are flat (head gain 1), the raw
 # logits do not -- every one of the ~10 3x3x3 convolutions in front of them (864-term fp32 sums, Winograd-transformed at full tile
-# counts) shows up here undamped.  Bar = the G11 bar (tests/test_gpu_parity.py::test_estm_stream): 1.5e-4 abs.
-TOL_LOGIT = 1.5e-4
+# counts) shows up here undamped.  Measured (round 4): init 1.8e-5 / 1.8e-5 / 1.9e-5, fused 2.4e-5 / 8.9e-6 / 1.1e-5 at cfg2 / cfg3 / cfg5
+# size on ranges of +-3.5 (init) and +-1.0 (fused).  Bar: 6e-5 abs -- 2.5x below the G11 bar of the small fixtures (1.5e-4,
+# tests/test_gpu_parity.py::test_estm_stream), ~1.5x the reference's own 1-vs-8-thread noise on such volumes (3.6e-5).
+TOL_LOGIT = 6e-5
 
 
 def _logit_diffs(dec, ref):

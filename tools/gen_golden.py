@@ -97,6 +97,27 @@ def gen_g12(hu):
     print("G12 done", {k: float(np.abs(v).mean()) for k, v in out.items()})
 
 
+def gen_g13(mh):
+    """G13: key list + shapes (+ dtypes) of the REFERENCE model's state dict (hybrid_models/model_hybrid.py:15-60), R18 and R50, EST on
+    and off.  The ``semanticFeature.encoder.*`` entries come from the torchvision stand-in registered above (torchvision is absent
+    in this image) -- the fixture marks them, and tests/test_state_dict_keys.py checks those against torchvision's published ResNet
+    layout enumerated independently; every other key is the reference's own module tree."""
+    import json
+    out = {}
+    for resnet in (18, 50):
+        for est in (True, False):
+            m = mh.DepthNetHybrid(ndepths=64, depth_min=0.1, depth_max=10.0, resnet=resnet, IF_EST_transformer=est)
+            sd = m.state_dict()
+            tag = "r%d_est%d" % (resnet, int(est))
+            out[tag] = {"entries": [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()],
+                        "nparams": sum(p.numel() for p in m.parameters()),
+                        "from_stub_prefix": "semanticFeature.encoder."}
+            print("G13", tag, len(sd), "entries,", sum(k.startswith("semanticFeature.encoder.") for k in sd), "from the torchvision stand-in,",
+                  out[tag]["nparams"], "parameters")
+    with open(os.path.join(OUT, "g13_state_dict_keys.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+
+
 def main():
     if "--metrics-only" in sys.argv:
         os.makedirs(OUT, exist_ok=True)
@@ -107,7 +128,10 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if "--g12-only" in sys.argv:
         return gen_g12(hu)
+    if "--g13-only" in sys.argv:
+        return gen_g13(mh)
     gen_g12(hu)
+    gen_g13(mh)
 
     # G1 homo_warping
     out = {}
