@@ -30,7 +30,7 @@ def _gather_flat(recv, send, group, algo, async_op=True):
     if algo not in ("collective", "direct"):
         raise RuntimeError("ESTD_AG_ALGO must be collective or direct, got %r" % (algo,))
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    if algo == "collective" or world == 1:
+    if algo == "collective":
         w = dist.all_gather_into_tensor(recv, send, group=group, async_op=async_op)
         return [w] if async_op else []
     n = send.numel()
@@ -42,7 +42,7 @@ def _gather_flat(recv, send, group, algo, async_op=True):
         gsrc = dist.get_global_rank(group, src) if group is not None else src
         ops_.append(dist.P2POp(dist.isend, send, gdst, group))
         ops_.append(dist.P2POp(dist.irecv, rv[src], gsrc, group))
-    works = dist.batch_isend_irecv(ops_)
+    works = dist.batch_isend_irecv(ops_) if ops_ else []        # (world size 1: the own-shard copy is the whole exchange)
     rv[rank].copy_(send)                               # own shard: a device-local copy on the compute stream
     if not async_op:
         for w in works:

@@ -55,9 +55,14 @@ def _worker(rank, world, port, ret):
             with torch.no_grad():
                 _, costs, cposes = m(imgs[:, sl], poses[:, sl], intr, smp(sample, sl), pre_costs, pre_poses, mode="val")
             own.append((costs, cposes))
-            bank = parallel.allgather_memory_bank_async(costs, cposes, stage=(w == 0)).wait()        # both flavours of the collective
+            # both flavours of the staging, both exchange algorithms (one all-gather | one send + receive per peer), and the frame's
+            # initial logit volume in the record (north_star: "all-gather of per-frame probability volumes")
+            lg = m.CostRegNet.memory_logits
+            bank = parallel.allgather_memory_bank_async(costs, cposes, stage=(w == 0), logits=lg,
+                                                        algo=("collective" if w == 0 else "direct")).wait()
             torch.cuda.synchronize()
             ok = ok and len(bank) == world
+            ok = ok and tuple(lg.shape) == (64, S.E2E_HI // 4, S.E2E_WI // 4) and torch.equal(bank[rank][0]["logits"][0], lg)
             ok = ok and torch.equal(bank[rank][0]["keys"][0], costs["keys"][0]) and torch.equal(bank[rank][0]["values"][0], costs["values"][0])
             ok = ok and torch.equal(bank[rank][1][0], cposes[0])
             banks.append(bank)
@@ -80,6 +85,13 @@ def _worker(rank, world, port, ret):
                     res["compared"] = res.get("compared", 0) + 1
             res["worst_vs_g8_window2"] = worst
             res["pose_equal"] = bool(np.array_equal(cposes[0].cpu().numpy(), g["w2|pose"]))
+            # the gathered logit volume of rank 0's window 1 IS that frame's probability volume before its softmax: its soft-argmin
+            # reproduces the reference's ("depth", 0, 3) of window 1 (G8), computed here by the rank that never ran that window
+            from estdepth_amd import ops
+            dv = m.depth_cands.view(-1).to(dev)
+            d3, p3 = ops.softargmin_up(banks[1][0][0]["logits"][0][None].contiguous(), dv, 4)
+            res["gathered_logits_depth_vs_g8_window1"] = float(np.abs(d3.cpu().numpy().reshape(g["w1|depth|0|3"].shape) - g["w1|depth|0|3"]).max())
+            res["gathered_logits_prob_vs_g8_window1"] = float(np.abs(p3.cpu().numpy().reshape(g["w1|init_prob|0"].shape) - g["w1|init_prob|0"]).max())
         ret[rank] = res
     finally:
         dist.barrier()
@@ -97,3 +109,4 @@ def test_rank1_continues_rank0_stream_from_the_gathered_bank():
     r1 = ret[1]
     assert r1["compared"] >= 4 and r1["pose_equal"], r1
     assert r1["worst_vs_g8_window2"] < 1e-4, r1                 # the tolerance of test_estm_stream (depth within 1e-4 of the reference)
+    assert r1["gathered_logits_depth_vs_g8_window1"] < 1e-4 and r1["gathered_logits_prob_vs_g8_window1"] < 5e-5, r1

@@ -29,10 +29,11 @@ def _last_json(out):
 
 
 def test_bench_single_gpu_line():
-    out = subprocess.run([sys.executable, "bench.py", "--workload", "cfg1", "--steps", "3", "--warmup", "1"], cwd=ROOT,
+    out = subprocess.run([sys.executable, "bench.py", "--workload", "cfg1", "--steps", "3", "--warmup", "1", "--no-replay-profile"], cwd=ROOT,
                          capture_output=True, text=True, timeout=900)
     d = _last_json(out.stdout)
     assert REQUIRED <= set(d) and "cpu_baseline" in d
+    assert d["parity"]["logits_within_tolerance"] and set(d["parity"]["logit_volumes_vs_oracle"]) == {"init", "fused"}
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["workload"].startswith("cfg1")
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] <= 1
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
@@ -46,13 +47,32 @@ def test_bench_single_gpu_line():
 
 
 def test_bench_headline_workload_roofline_fields_are_hardware_fractions():
-    """BASELINE configs[1] (the workload `value` is quoted on), 3 steps: `frac` is the EXECUTED fraction of the fp32 MFMA peak
+    """BASELINE configs[1] (the workload `value` is quoted on): `frac` is the EXECUTED fraction of the fp32 MFMA peak
     (<= 1 -- the algorithmic rate of a Winograd kernel is above the peak and lives in its own field), the dominant kernel's
-    launches fit inside the step, the stand-alone HBM-kernel figures are present."""
-    out = subprocess.run([sys.executable, "bench.py", "--workload", "joint", "--steps", "3", "--warmup", "1", "--no-alt", "--no-cpu-baseline"],
-                         cwd=ROOT, capture_output=True, text=True, timeout=900)
+    launches fit inside the step, the stand-alone HBM-kernel figures are present.  The per-kernel in-step figures describe the
+    hipGraph REPLAY that produced `value` (rocprofv3 kernel trace of a child run), the dominant kernel's live HIP-event brackets
+    agree with it within 15 %, and every family whose eager bracket is further off is named.  The other single-GPU workloads
+    (ESTM window, cfg5, stream) are timed in the same run."""
+    out = subprocess.run([sys.executable, "bench.py", "--workload", "joint", "--steps", "5", "--warmup", "2", "--no-alt", "--no-cpu-baseline"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=1500)
     d = _last_json(out.stdout)
     r = d["roofline"]
+    assert r["replay_trace"] and "error" not in r["replay_trace"], r["replay_trace"]
+    assert abs(r["replay_trace"]["ms_per_step"] / d["ms_per_step"] - 1.0) < 0.10           # the traced child ran the same step
+    fams = dict(r["mfma_kernels"], **r["hbm_kernels"])
+    assert {"conv3d:32->32", "conv3d:33->32", "conv3d:33->33", "conv3d:16->16", "conv3d:32->16", "warp_attention", "homo_warp_costvol",
+            "softargmin", "gru_elementwise"} <= set(fams)
+    for name, k in fams.items():
+        assert k["source"] == "replay", (name, k)                                           # no family falls back to the eager brackets
+        assert abs(k["launches_per_step"] - k["launches"] / d["steps"]) < 1e-6, (name, k)   # same launches in both passes
+        off = abs(k["eager_over_replay"] - 1.0) > 0.15
+        assert off == (name in r["families_perturbed_by_eager_brackets"]), (name, k)
+    assert "conv3d:32->32" not in r["families_perturbed_by_eager_brackets"], r["replay"]   # the contract's live HIP-event figure holds
+    assert abs(r["replay"]["eager_over_replay"] - 1.0) <= 0.15
+    assert sum(k["launches_per_step"] * k["avg_launch_ms"] for k in r["mfma_kernels"].values()) <= d["ms_per_step"]
+    ow = d["other_workloads"]
+    assert set(ow) == {"estm", "cfg5", "stream"} and all(v.get("value", 0) > 0 for v in ow.values()), ow
+    assert ow["estm"]["workload"].startswith("cfg3") and ow["cfg5"]["workload"].startswith("cfg5")
     assert REQUIRED <= set(d) and d["config"]["workload"].startswith("cfg2")
     assert 0 < r["frac"] <= 1 and r["achieved"] <= r["peak"] and abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3
     assert r["algorithmic_tflops"] >= r["achieved"] and abs(r["achieved"] - r["algorithmic_tflops"] * r["executed_factor"]) < 0.05
@@ -76,6 +96,18 @@ def test_bench_world_size_one_rccl_communicator():
     ag = d["config"]["allgather"]
     assert d["n_gpus"] == 1 and ag["backend"].startswith("RCCL") and ag["own_shard_bit_equal"] is True
     assert ag["ms_alone"] > 0 and ag["ms_per_step_without_collective"] > 0 and "CUs left free" in d["config"]["parallelism"]
+    assert "logit volume" in ag["record"] and ag["algo"] == "collective"
+    assert ag["rccl"].get("debug_lines", 0) > 0, ag["rccl"]           # RCCL's own account of its set-up was captured and summarised
+
+
+def test_bench_direct_exchange_world_size_one_rccl():
+    """ESTD_AG_ALGO=direct on the world-size-1 RCCL communicator (the all-to-all send/recv list is empty there: own-shard copy only)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ESTD_FORCE_DIST="1", ESTD_AG_ALGO="direct")
+    out = subprocess.run([sys.executable, "bench.py", "--workload", "cfg1", "--steps", "3", "--warmup", "1", "--no-alt", "--no-cpu-baseline"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    d = _last_json(out.stdout)
+    assert d["config"]["allgather"]["algo"] == "direct" and d["config"]["allgather"]["own_shard_bit_equal"] is True
 
 
 def _check_two_ranks(d):
@@ -83,7 +115,8 @@ def _check_two_ranks(d):
     assert "all-gather" in d["config"]["parallelism"]
     assert len(d["config"]["per_rank_ms_per_step"]) == 2
     ag = d["config"]["allgather"]
-    assert ag["bytes_sent_per_rank"] == 4 * (2 * 16 * 16 * 32 * 40 + 16) and ag["bus_gbs_per_rank"] > 0
+    assert ag["bytes_sent_per_rank"] == 4 * (2 * 16 * 16 * 32 * 40 + 16 + 16 * 32 * 40) and ag["bus_gbs_per_rank"] > 0      # K||V + pose + logits
+    assert ag["other_algo"]["algo"] == "direct" and ag["other_algo"]["ms_alone"] > 0            # both exchange algorithms ran (gloo here)
     assert ag["own_shard_bit_equal"] is True             # the gathered bank equals the owner's tensors bit for bit
 
 
