@@ -105,7 +105,7 @@ def rccl_debug_summary(path):
     import re
     files = sorted(glob.glob(path.replace("%p", "*").replace("%h", "*")))
     if not files:
-        return {"note": "no RCCL debug file (%s)" % path}
+        return {"note": "no RCCL debug file (%s); NCCL_DEBUG=%s NCCL_DEBUG_SUBSYS=%s" % (path, os.environ.get("NCCL_DEBUG"), os.environ.get("NCCL_DEBUG_SUBSYS"))}
     lines = []
     for f in files[:1]:
         try:
@@ -411,6 +411,16 @@ def summarize(prof, peak_tf, algo="direct", arith="f32", replay=None):
 def main():
     args = parse()
     self_launch_if_needed(args)
+    if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("ESTD_FORCE_DIST", "0") == "1") \
+            and os.environ.get("ESTD_DIST_BACKEND", "nccl") == "nccl" and os.environ.get("ESTD_RCCL_DEBUG", "1") == "1":
+        # RCCL's own account of its topology / channels / algorithm choice goes to a file per process (stdout keeps the one JSON
+        # line); rank 0's file is summarised into config.allgather.rccl.  Set BEFORE torch (and with it librccl) is loaded: the
+        # library latches its debug level at its first log call.
+        import tempfile
+        if os.environ.get("NCCL_DEBUG", "").upper() not in ("INFO", "TRACE"):
+            os.environ["NCCL_DEBUG"] = "INFO"
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,TUNING,COLL")
+        os.environ.setdefault("NCCL_DEBUG_FILE", os.path.join(tempfile.gettempdir(), "estd_rccl_%d_r%s.log" % (os.getpid(), os.environ.get("RANK", "0"))))
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -445,13 +455,6 @@ def main():
         # convolution grids leave free (estd_set_reserved_cus(8) below: one per XCD).
         os.environ.setdefault("NCCL_MAX_NCHANNELS", "8")
         backend = os.environ.get("ESTD_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
-        if backend == "nccl" and os.environ.get("ESTD_RCCL_DEBUG", "1") == "1":
-            # RCCL's own account of its topology / channels / algorithm choice goes to a file per process (stdout keeps the one JSON
-            # line); rank 0's file is summarised into config.allgather.rccl
-            import tempfile
-            os.environ.setdefault("NCCL_DEBUG", "INFO")
-            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,TUNING,COLL")
-            os.environ.setdefault("NCCL_DEBUG_FILE", os.path.join(tempfile.gettempdir(), "estd_rccl_%d_r%d_%%p.log" % (os.getppid(), rank)))
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=device)
         else:
