@@ -348,15 +348,15 @@ def replay_profile(args):
 
 def conv3d_algo_of(group, algo, arith):
     """which kernel a profiled conv3d group ran on: the 32->32 and 33->32 instances follow --conv3d-algo, the 33->33 instance (dres2)
-    takes the depth-only Winograd kernel under wino / wino2, 32->16 has a wino2 instance, the 16->16 heads are always direct."""
+    takes the depth-only Winograd kernel under wino / wino2, 32->16 and the 16->16 heads have wino2 instances."""
     if arith != "f32":
         return "direct"
     if group in ("conv3d:32->32", "conv3d:33->32"):      # the key || value convolution (33 -> 32) has a wino2 instance as well
         return algo
     if group == "conv3d:33->33":
         return "wino" if algo in ("wino", "wino2") else "direct"
-    if group == "conv3d:32->16":                     # the GRU output convolution: 16-output-channel instance of the wino2 kernel
-        return "wino2" if algo == "wino2" else "direct"
+    if group in ("conv3d:32->16", "conv3d:16->16"):  # the GRU output convolution (16-output-channel instance of the wino2 kernel) and the
+        return "wino2" if algo == "wino2" else "direct"      # stereo heads (csrc/conv3d_wino2_c16.hip)
     return "direct"
 
 

@@ -824,7 +824,16 @@ extern "C" int estd_conv3d_k3_wino2(const estd_conv3d_desc* dp, estd_stream_t s)
     if (!dp) return ESTD_ERR_ARG;
     const estd_conv3d_desc& d = *dp;
     if (d.N <= 0 || d.D <= 0 || d.H <= 0 || d.W <= 0) return ESTD_ERR_ARG;
-    if (!d.in_main || !d.w_wino2 || !d.scale || !d.shift || !d.out_main) return ESTD_ERR_ARG;
+    if (!d.in_main || !d.w_wino2 || !d.scale || !d.shift) return ESTD_ERR_ARG;
+    if (d.cin_main == 16) {
+        // 16 -> 16 + fused 1x1x1 head, only the logit volume leaves the kernel (the stereo heads): csrc/conv3d_wino2_c16.hip
+        if (d.n_tiles != 1 || !d.head_w || !d.head_b || !d.out_head) return ESTD_ERR_ARG;
+        if (d.out_main || d.in_extra || d.w_extra || d.out_extra || d.residual || d.residual2 || d.accumulate || d.stats_partials ||
+            d.out_scale != 1.0f || d.act_a == ESTD_ACT_TANH || d.act_b == ESTD_ACT_TANH) return ESTD_ERR_UNSUPPORTED;
+        if (d.in_stride < 16 || (d.in_stride & 3)) return ESTD_ERR_ARG;
+        return estd_wino2_c16_launch(d, estd_stream(s));
+    }
+    if (!d.out_main) return ESTD_ERR_ARG;
     // 32 input channels on the MFMA (+ an optional scalar 33rd input channel), 32 or 16 output channels; no 33rd output channel, no fused head
     if (d.cin_main != 32 || (d.n_tiles != 2 && d.n_tiles != 1) || d.out_head || d.out_extra) return ESTD_ERR_UNSUPPORTED;
     const bool o16 = d.n_tiles == 1;                 // 32 -> 16 (the GRU output convolution)

@@ -48,7 +48,7 @@ constexpr int VTAB_BYTES = SIT * NTHREADS * 4;      // per-thread global offsets
 constexpr int W_OFF = 4 * SLICE_BYTES + SS_BYTES + VTAB_BYTES;
 constexpr int LDS_BYTES = W_OFF + NTAPS * TAP_BYTES;            // 138 496
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
-static_assert(3 * SLICE_BYTES + IN_W * 64 * IN_H < 65536 && (NTAPS - 1) * TAP_BYTES < 65536, "ds_read immediate offsets");
+static_assert(3 * SLICE_BYTES < 65536 && (NTAPS - 1) * TAP_BYTES < 65536, "ds_read immediate offsets");
 constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;
 constexpr int NSTEPS = 12;                          // (sd, kw)
 constexpr int RB_STEP = 7;                          // slices 0..2 are rewritten in front of this step (rows of step 8 = (sd 2, kw 2) are fetched at the end of step 6)

@@ -45,6 +45,9 @@ static inline int estd_persistent_wgs(int per_cu)
     return (cus > 8 ? cus : 8) * per_cu;
 }
 
+// csrc/conv3d_wino2_c16.hip: the 16 -> 16 + head instance behind estd_conv3d_k3_wino2 (arguments validated by the caller)
+int estd_wino2_c16_launch(const estd_conv3d_desc& d, hipStream_t stream);
+
 static inline int estd_ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of (function, device): raise it once per device ordinal and

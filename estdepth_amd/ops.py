@@ -222,6 +222,9 @@ class Conv3dPlan:
         # 32 -> 16 (the GRU output convolution): the wino2 kernel's 16-output-channel instance
         self.w_wino2_o16 = packing.pack_conv3d_wino2(weight, main_idx, out_idx[:16]).to(device) \
             if (len(main_idx) == 32 and n_tiles == 1 and len(out_idx) == 16 and extra_idx is None and head_w is None) else None
+        # 16 -> 16 + 1x1x1 head (the stereo heads): csrc/conv3d_wino2_c16.hip
+        self.w_wino2_c16 = packing.pack_conv3d_wino2_c16(weight, main_idx, out_idx[:16]).to(device) \
+            if (len(main_idx) == 16 and n_tiles == 1 and len(out_idx) == 16 and extra_idx is None and head_w is not None) else None
         self.w_main = wm.to(device)
         self.w_extra = wx.to(device) if wx is not None else None
         self.scale = scale.float().contiguous().to(device)
@@ -272,7 +275,12 @@ class Conv3dPlan:
         wino2 = wino and CONV3D_ALGO == "wino2" and self.w_wino2 is not None and (in_extra is None or stats_partials is None)
         o16 = (not split) and CONV3D_ALGO == "wino2" and self.w_wino2_o16 is not None and out is not None and out_head is None \
             and in_extra is None and out_channels == 16 and out_extra is None
-        variant, w_alt = (1, self.w_split) if split else (3, self.w_wino2_o16) if o16 else (3, self.w_wino2) if wino2 else (2, self.w_wino) if wino else (0, None)
+        # the stereo heads: only the head's logit volume leaves the kernel, no tanh
+        c16 = (not split) and CONV3D_ALGO == "wino2" and self.w_wino2_c16 is not None and out is None and out_head is not None \
+            and in_extra is None and out_extra is None and residual is None and residual2 is None and not accumulate \
+            and stats_partials is None and float(out_scale) == 1.0 and not tanh
+        variant, w_alt = (1, self.w_split) if split else (3, self.w_wino2_c16) if c16 else (3, self.w_wino2_o16) if o16 else (3, self.w_wino2) if wino2 \
+            else (2, self.w_wino) if wino else (0, None)
         cin = self.cin_main + (1 if self.w_extra is not None else 0)
         with _Prof("conv3d:%d->%d" % (cin, self.n_out), 2.0 * 27 * cin * self.n_out * Nn * D * H * W):
             if _use_torch():
@@ -306,6 +314,9 @@ class Conv3dPlan:
             if split:
                 d.w_split = self.w_split.data_ptr()
                 N.check(N.lib().estd_conv3d_k3_split(ctypes.byref(d), _stream()), "estd_conv3d_k3_split")
+            elif c16:
+                d.w_wino2 = self.w_wino2_c16.data_ptr()
+                N.check(N.lib().estd_conv3d_k3_wino2(ctypes.byref(d), _stream()), "estd_conv3d_k3_wino2")
             elif o16:
                 d.w_wino2 = self.w_wino2_o16.data_ptr()
                 N.check(N.lib().estd_conv3d_k3_wino2(ctypes.byref(d), _stream()), "estd_conv3d_k3_wino2")

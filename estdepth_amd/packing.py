@@ -294,6 +294,23 @@ def pack_conv3d_wino2(weight, main_idx, out_idx):
     return torch.from_numpy(out.reshape(48, nhalf, 2, 64, 4))
 
 
+def pack_conv3d_wino2_c16(weight, main_idx, out_idx):
+    """16 -> 16 filters (the stereo heads) for csrc/conv3d_wino2_c16.hip: U = G g G^T over (kd, kh) as in pack_conv3d_wino2, packed as
+    float32 [48 taps = (3 sd + kw) * 4 + sh][64 lanes][4]: element e of lane (g, j) = U[sd][sh][out_idx[j]][main_idx[4 g + e]][kw] -- output
+    channel j as the MFMA's M row, the four consecutive input channels of the lane's 16-byte chunk as its four k-steps."""
+    assert len(main_idx) == 16 and len(out_idx) == 16
+    w = weight.detach().double().cpu().numpy()                       # [Cout, Cin, kd, kh, kw]
+    G = np.array([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
+    U = np.einsum("sd,th,oidhw->stoiw", G, G, w).astype(np.float32)  # [4 sd, 4 sh, Cout, Cin, 3 kw]
+    out = np.zeros((4, 3, 4, 64, 4), np.float32)                     # [sd][kw][sh][lane][e]
+    oi, mi = np.asarray(out_idx), np.asarray(main_idx)
+    for lane in range(64):
+        g, j = lane >> 4, lane & 15
+        for e in range(4):
+            out[:, :, :, lane, e] = U[:, :, oi[j], mi[4 * g + e], :].transpose(0, 2, 1)
+    return torch.from_numpy(out.reshape(48, 64, 4))
+
+
 def pack_conv3d_wino2_extra(weight, extra_idx, out_idx):
     """the scalar 33rd input channel of a 33 -> 32 convolution for csrc/conv3d_wino2.hip<EXTRA>: float32
     [4 sd][2 channel halves][64 lanes][4 sh]; element sh of lane (g, j) of (sd, half nh) = U[sd][sh][out_idx[16 nh + j]][extra_idx]

@@ -151,8 +151,10 @@ int estd_conv3d_k3_wino(const estd_conv3d_desc* desc, estd_stream_t stream);
  * 4 x 4 transformed input patch, 48 tap products per 4 outputs = 0.444 of the direct kernel's MFMA work (csrc/conv3d_wino2.hip).
  * Instances: cin_main = 32 with n_tiles = 2 (32 -> 32; with in_extra + w_extra the 33 -> 32 key|value form; every epilogue feature of
  * estd_conv3d_k3_wino -- GroupNorm partials not together with in_extra) and n_tiles = 1 (32 -> 16, the ConvGRU output convolution;
- * no in_extra).  Reads w_wino2 (packing.py::pack_conv3d_wino2).  No head, no 33rd output channel:
- * ESTD_ERR_UNSUPPORTED for any other shape. */
+ * no in_extra), and cin_main = 16 with n_tiles = 1, head_w / head_b / out_head set and out_main = NULL (16 -> 16 + the fused 1x1x1
+ * head, only the logit volume is written: stereo_head0 / stereo_head1, hybrid_depth_decoder.py:96-112; csrc/conv3d_wino2_c16.hip,
+ * weights float32 [48 taps][64 lanes][4], packing.py::pack_conv3d_wino2_c16; no residuals / statistics / tanh).
+ * Reads w_wino2 (packing.py::pack_conv3d_wino2).  No 33rd output channel: ESTD_ERR_UNSUPPORTED for any other shape. */
 int estd_conv3d_k3_wino2(const estd_conv3d_desc* desc, estd_stream_t stream);
 /* number of thread blocks estd_conv3d_k3 launches for a volume (size of stats_partials / 4 doubles) */
 int estd_conv3d_k3_grid(int N, int D, int H, int W);

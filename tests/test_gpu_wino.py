@@ -261,3 +261,72 @@ def test_wino2_16_output_channels_matches_direct_kernel_and_fp64(dims):
         sa = ops.groupnorm_finalize(parts["direct"], nblk, 16.0 * N * D * H * W).cpu()
         sb = ops.groupnorm_finalize(parts["wino2"], nblk, 16.0 * N * D * H * W).cpu()
         assert float((sa[:2] - sb[:2]).abs().max()) < 1e-5 * max(1.0, float(sa[:2].abs().max())), (sa, sb)
+
+
+def _head_plan(seed, act="relu"):
+    from estdepth_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(16, 16, 3, 3, 3, generator=g) * 0.08
+    sc, sh = torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.3
+    hw, hb = torch.randn(16, generator=g), torch.randn(1, generator=g)
+    plan = ops.Conv3dPlan(w, list(range(16)), None, list(range(16)), 1, sc, sh, act_a=act, head_w=hw, head_b=hb, device=DEV)
+    return plan, (w, sc, sh, hw, hb)
+
+
+@pytest.mark.parametrize("dims,stride,scale", [((1, 6, 19, 45), 32, 1.0), ((2, 3, 16, 16), 16, 100.0), ((1, 1, 5, 7), 32, 1e-3), ((1, 7, 33, 18), 16, 1.0),
+                                              ((3, 5, 17, 31), 32, 1.0), ((1, 64, 30, 40), 32, 1.0)])
+@pytest.mark.parametrize("act", ["relu", "none"])
+def test_stereo_head_c16_wino2_vs_fp64_and_the_direct_kernel(dims, stride, scale, act):
+    """csrc/conv3d_wino2_c16.hip (16 -> 16 + BN + activation + 1x1x1 head, only the logit volume is written; stereo_head0/1,
+    hybrid_depth_decoder.py:96-112) against an fp64 evaluation of the same fp32 data and against the direct kernel: ragged tiles
+    (H, W not multiples of 16), odd D, D = 1, batches, both record strides (16 and the 32 of the key|value records)."""
+    from estdepth_amd import ops
+    plan, (w, sc, sh, hw, hb) = _head_plan(sum(dims) + stride, act)
+    assert plan.w_wino2_c16 is not None
+    N, D, H, W = dims
+    x = torch.randn(N, D, H, W, stride, generator=torch.Generator().manual_seed(7)) * scale
+    y = torch.nn.functional.conv3d(x[..., :16].permute(0, 4, 1, 2, 3).double(), w.double(), padding=1)
+    y = y * sc.double()[None, :, None, None, None] + sh.double()[None, :, None, None, None]
+    if act == "relu":
+        y = y.clamp_min(0)
+    ref = (y * hw.double()[None, :, None, None, None]).sum(1) + hb.double()
+    xd = x.to(DEV)
+    outs = {}
+    old = ops.CONV3D_ALGO
+    try:
+        for algo in ("direct", "wino2"):
+            ops.CONV3D_ALGO = algo
+            lg = torch.full((N, D, H, W), float("nan"), device=DEV)
+            plan.run(xd, dims, in_stride=stride, out_head=lg)
+            torch.cuda.synchronize()
+            outs[algo] = lg.double().cpu()
+    finally:
+        ops.CONV3D_ALGO = old
+    mag = ref.abs().max().item()
+    e_dir, e_win = (outs["direct"] - ref).abs().max().item(), (outs["wino2"] - ref).abs().max().item()
+    print("head fp64 check dims=%s stride=%d scale=%g act=%s: |ref|max %.3g  err direct %.3g  err wino2-c16 %.3g" % (dims, stride, scale, act, mag, e_dir, e_win))
+    assert not torch.isnan(outs["wino2"]).any()                      # every voxel written (ragged tiles, odd D)
+    assert e_win <= 3.0 * e_dir + 2e-7 * mag, (e_win, e_dir)
+    assert e_win < 3e-6 * mag
+
+
+def test_stereo_head_c16_is_the_default_and_refuses_what_it_cannot_do():
+    from estdepth_amd import ops, _native
+    plan, _ = _head_plan(5)
+    d = _native.Conv3dDesc()
+    d.N, d.D, d.H, d.W = 1, 4, 16, 16
+    d.cin_main, d.in_stride, d.n_tiles = 16, 16, 1
+    x = torch.zeros(1, 4, 16, 16, 16, device=DEV)
+    lg = torch.zeros(1, 4, 16, 16, device=DEV)
+    o = torch.zeros(1, 4, 16, 16, 16, device=DEV)
+    d.in_main, d.w_wino2 = x.data_ptr(), plan.w_wino2_c16.data_ptr()
+    d.scale, d.shift = plan.scale.data_ptr(), plan.shift.data_ptr()
+    d.act_a = d.act_b = ops.ACT["relu"]
+    d.out_scale = 1.0
+    lib = _native.lib()
+    assert lib.estd_conv3d_k3_wino2(d, None) == -1                               # no head: ESTD_ERR_ARG
+    d.head_w, d.head_b, d.out_head = plan.head_w.data_ptr(), plan.head_b.data_ptr(), lg.data_ptr()
+    assert lib.estd_conv3d_k3_wino2(d, None) == 0
+    d.out_main, d.out_stride, d.out_channels = o.data_ptr(), 16, 16
+    assert lib.estd_conv3d_k3_wino2(d, None) == -3                               # a 16-channel main output: ESTD_ERR_UNSUPPORTED (direct kernel)
+    torch.cuda.synchronize()

@@ -24,10 +24,13 @@ for N in (1, 3):
     kv = torch.randn(N, D, H, W, 32, device=dev)
     lg = torch.empty(N, D, H, W, device=dev)
     o = torch.empty(N, D, H, W, 16, device=dev)
-    a = t(lambda: head.run(kv, (N, D, H, W), in_stride=32, out_head=lg))
+    ops.CONV3D_ALGO = "wino2"
+    a2 = t(lambda: head.run(kv, (N, D, H, W), in_stride=32, out_head=lg))
     ops.CONV3D_ALGO = "direct"
+    a = t(lambda: head.run(kv, (N, D, H, W), in_stride=32, out_head=lg))
     b = t(lambda: outc.run(kv, (N, D, H, W), out=o, out_stride=16))
     ops.CONV3D_ALGO = "wino2"
     b2 = t(lambda: outc.run(kv, (N, D, H, W), out=o, out_stride=16))
     gfa, gfb = N * 2 * 27 * 16 * 16 * D * H * W / 1e9, N * 2 * 27 * 32 * 16 * D * H * W / 1e9
+    print("N=%d  head 16->16 direct %.4f ms (%.1f TF/s)  wino2-c16 %.4f ms (%.1f algorithmic TF/s)" % (N, a, gfa / a, a2, gfa / a2))
     print("N=%d  head 16->16 %.4f ms (%.1f TF/s)   out 32->16 direct %.4f ms (%.1f TF/s)  wino2 %.4f ms (%.1f TF/s)" % (N, a, gfa / a, b, gfb / b, b2, gfb / b2))
