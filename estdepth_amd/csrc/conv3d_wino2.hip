@@ -83,7 +83,11 @@ constexpr int NTAPS = 48;
 #ifndef ESTD_W2LDS_TAPS
 #define ESTD_W2LDS_TAPS 14
 #endif
-constexpr int WLDS_TAPS = ESTD_W2LDS_TAPS;           // weights of the first taps of every tile come from LDS
+constexpr int WLDS_TAPS = ESTD_W2LDS_TAPS;           // weights of WLDS_TAPS consecutive taps of every tile come from LDS ...
+#ifndef ESTD_W2LDS_T0
+#define ESTD_W2LDS_T0 4     // taps 4..17 = steps 2..8: the plane prefetch (steps 4..9) then sits next to LDS-fed steps -- a weight request behind a plane request waits for HBM (vector-memory loads return in order); T0 = 0: 0.839, 4: 0.823, 6: 0.827, 8: 0.826-0.833, 10: 0.850, 12: 0.845, 16: 0.871 ms (N = 3)
+#endif
+constexpr int WLDS_T0 = ESTD_W2LDS_T0;               // ... starting with this tap (32-channel instances; the 16-output-channel instance: tap 0)
 constexpr int WLDS_BYTES = WLDS_TAPS * 4096;         // [tap][2 halves][2 quads][64 lanes][4]
 constexpr int SS_BYTES = 3 * 32 * 4;                 // folded BN scale | shift | activation floor of the 32 output channels
 constexpr int VTAB_BYTES = 6 * 256 * 4 + 512 * 4;     // per-thread global offsets of the slice chunks (3 x 512 or 6 x 256 threads) + of the scalar channel's voxel
@@ -220,8 +224,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
     float* lds_x = reinterpret_cast<float*>(smem + 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES);          // [4][SL_VOX] (EXTRA)
     char* lds_xch = smem + 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES;               // O16: [8 waves][2 rows][64 lanes] float4
     char* lds_w = smem + 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + (O16 ? O16_XCH_BYTES : XSL_BYTES);     // weights of the first taps
+    constexpr int WT0 = O16 ? 0 : WLDS_T0;                                        // first LDS-resident tap
     for (int e = tid; e < WTAPS * TAP_BYTES / 16; e += NTHREADS)                  // (visible after the first tile's barriers)
-        reinterpret_cast<float4*>(lds_w)[e] = reinterpret_cast<const float4*>(p.w_wino2)[e];
+        reinterpret_cast<float4*>(lds_w)[e] = reinterpret_cast<const float4*>(p.w_wino2)[WT0 * (TAP_BYTES / 16) + e];
 
     // packed weights: [48 taps][2 halves][2 quads][64 lanes][4]
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w_wino2, (size_t)NTAPS * (O16 ? 1 : 2) * 2 * 256);
@@ -544,7 +549,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
             f32x4 acc[4][4][NHW];
 
             auto load_w = [&](int t, int q, int x) {        // t, x are compile-time constants after unrolling (q too, except O16: q = cw)
-                if (t < WTAPS) return *reinterpret_cast<const float4*>(lds_w + t * TAP_BYTES + x * 2048 + q * 1024 + wlane);
+                if (t >= WT0 && t < WT0 + WTAPS) return *reinterpret_cast<const float4*>(lds_w + (t - WT0) * TAP_BYTES + x * 2048 + q * 1024 + wlane);
                 return as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane + (O16 ? q * 1024 : 0), t * TAP_BYTES + x * 2048 + (O16 ? 0 : q * 1024), 0));
             };
             // 16-byte chunk c (channels 4g.. for c = 0, 16+4g.. for c = 1) of halo row 2rp + r at column shift kw of depth slice sd
@@ -590,7 +595,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
             // transforms the raw rows of step s+1 (read during step s-1) two components at a time -- T's registers are recycled as
             // the MFMAs consume them -- and then reads the raw rows of step s+2.  Weights: one step ahead (8 waves), two steps ahead
             // with one wave per SIMD (nobody covers an L2 round trip there, and the registers are free).
-            constexpr int BD = NW == 4 ? 3 : 2;          // weight buffers in flight
+#ifndef ESTD_W2BD
+#define ESTD_W2BD 2
+#endif
+            constexpr int BD = NW == 4 ? 3 : ESTD_W2BD;  // weight buffers in flight
             float4 bq[BD][4][NHW];                       // [buffer][sh][channel half]: one step's quad of the four taps of a group
             f32x2 T[2][4];                               // [component pair][sh]
             float4 R[4];
@@ -618,15 +626,22 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                 if (step == NSTEPS / 2) W2STAMP(3);
                 if (step == 3 * NSTEPS / 4) W2STAMP(4);
                 if (step == 3 * NSTEPS / 4 + 1) W2STAMP(5);
+#ifndef ESTD_W2SPREAD
+#define ESTD_W2SPREAD 0     // A/B: 1 = the rewrite of slices 0..2 one slice per step (steps RB_STEP .. RB_STEP + 2) instead of all nine writes at once
+#endif
                 if (has_next && step == RB_STEP) {
                     // slices 0..2 have been read for the last time by every wave (the rows of step 17 are fetched at the end of step
                     // 15); DEFER: this barrier also publishes slice 3, rewritten at the top of this tile and first read at the end of
                     // step 16
                     lds_barrier();
                     write_slice(0);
-                    write_slice(1);
-                    write_slice(2);
+                    if (!ESTD_W2SPREAD) {
+                        write_slice(1);
+                        write_slice(2);
+                    }
                 }
+                if (ESTD_W2SPREAD && has_next && step == RB_STEP + 1) write_slice(1);
+                if (ESTD_W2SPREAD && has_next && step == RB_STEP + 2) write_slice(2);
                 // weights of step + BD - 1
                 if (step + BD - 1 < NSTEPS && !(ESTD_W2ABL & 8)) load_b(step + BD - 1, bq[(step + BD - 1) % BD]);
                 // chunks of the NEXT tile's two new planes: spread over the first steps (their offsets were read from the LDS table
