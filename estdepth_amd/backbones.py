@@ -66,6 +66,20 @@ def conv1x1_gemm(conv, x):
 
 HIP_STEM = os.environ.get("ESTD_HIP_STEM", "1") == "1"       # A/B switch: PSM first layer on csrc/refine2d.hip
 GEMM_EPILOGUE = os.environ.get("ESTD_GEMM_EPILOGUE", "1") == "1"     # A/B switch, read once at import
+# 1x1 convolutions of the fused-BN path on csrc/conv1x1.hip (conv + BN + residual + ReLU in one launch): "auto" = where that kernel
+# is at least as fast as the library GEMM (+ BN pass) at the semantic branch's sizes -- every convolution with a residual, the
+# stride-2 downsample convolutions up to 512 input channels, 64 -> 64 (tools/conv1x1_bench.py, profiles/r4_conv1x1_bench.txt: it
+# streams its operands from L2 without LDS reuse and is L2-bandwidth bound at ~100 TFLOP/s, so the K-heavy small-map layers of
+# layer3 / layer4 stay on hipBLASLt); "all" = every 1x1 convolution (no library GEMM left in the branch); "0" = library only.
+HIP_1X1 = os.environ.get("ESTD_HIP_1X1", "auto")
+
+
+def _hip_1x1_wanted(conv, residual):
+    if HIP_1X1 == "all" or HIP_1X1 == "1":
+        return True
+    if HIP_1X1 != "auto":
+        return False
+    return residual is not None or (conv.stride == (2, 2) and conv.in_channels <= 512) or (conv.in_channels <= 64 and conv.out_channels <= 64)
 
 
 def conv1x1_bn_gemm(conv, bn, x, relu):
@@ -137,6 +151,18 @@ def conv_bn_act(conv, bn, x, relu, residual=None):
         xn = x.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
         rn = residual.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1) if residual is not None else None
         return plan.run(xn, residual=rn).permute(0, 3, 1, 2)
+    if _is_1x1(conv) and conv.bias is None and conv.stride in ((1, 1), (2, 2)) and conv.in_channels % 16 == 0 \
+            and conv.out_channels % 32 == 0 and _hip_1x1_wanted(conv, residual):
+        # conv + BN [+ residual] [+ ReLU] in ONE launch of csrc/conv1x1.hip (the ResNet bottlenecks' conv1 / conv3 / downsample)
+        key = (conv.weight.device, conv.weight._version, conv.weight.data_ptr())
+        c = conv.__dict__.get("_estd_w1x1")
+        if c is None or c[0] != key:
+            c = (key, conv.weight.detach().reshape(conv.out_channels, conv.in_channels).contiguous())
+            conv.__dict__["_estd_w1x1"] = c
+        sc, sh = _folded(bn)
+        xn = x.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        rn = residual.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1) if residual is not None else None
+        return ops.conv1x1_nhwc(xn, c[1], sc, sh, conv.stride[0], relu, rn).permute(0, 3, 1, 2)
     if GEMM_EPILOGUE and residual is None and _is_1x1(conv) and conv.bias is None:
         return conv1x1_bn_gemm(conv, bn, x, relu)
     y = conv1x1_gemm(conv, x) if _is_1x1(conv) else conv(x)

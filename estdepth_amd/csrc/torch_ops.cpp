@@ -394,6 +394,28 @@ Tensor spp_upsample_cat(const Tensor& raw, const Tensor& skip, at::TensorList br
     return out;
 }
 
+Tensor conv1x1_nhwc(const Tensor& x, const Tensor& w2, const OptTensor& scale, const OptTensor& shift, int64_t stride, bool relu,
+                    const OptTensor& residual)
+{
+    const OpScope scope(x);
+    TORCH_CHECK(x.dim() == 4 && w2.dim() == 2 && w2.size(1) == x.size(3), "conv1x1_nhwc: NHWC x [N,H,W,cin] and w [cout,cin] expected");
+    TORCH_CHECK(stride == 1 || stride == 2, "conv1x1_nhwc: stride 1 or 2");
+    const int64_t n = x.size(0), h = x.size(1), w = x.size(2), cin = x.size(3), cout = w2.size(0);
+    const int64_t ho = (h - 1) / stride + 1, wo = (w - 1) / stride + 1;
+    estd_conv1x1_desc d{};
+    d.N = (int)n; d.H = (int)h; d.W = (int)w; d.cin = (int)cin; d.cout = (int)cout; d.stride = (int)stride; d.relu = relu ? 1 : 0;
+    d.in = fptr(x, "x"); d.w = fptr(w2, "w");
+    d.scale = opt_fptr(scale, "scale"); d.shift = opt_fptr(shift, "shift");
+    if (d.scale) TORCH_CHECK(scale->numel() == cout, "conv1x1_nhwc: scale [cout] expected");
+    if (d.shift) TORCH_CHECK(shift->numel() == cout, "conv1x1_nhwc: shift [cout] expected");
+    d.residual = opt_fptr(residual, "residual");
+    if (d.residual) TORCH_CHECK(residual->numel() == n * ho * wo * cout, "conv1x1_nhwc: residual must be NHWC [N,Ho,Wo,cout]");
+    Tensor out = new_f32({n, ho, wo, cout}, x);
+    d.out = out.data_ptr<float>();
+    check_status(estd_conv1x1_nhwc(&d, cur_stream()), "estd_conv1x1_nhwc");
+    return out;
+}
+
 Tensor conv2d_small_nhwc(const Tensor& x, const Tensor& w_packed, const Tensor& scale, const Tensor& shift, int64_t cout, int64_t ksize,
                          int64_t stride, bool relu)
 {
@@ -610,6 +632,7 @@ TORCH_LIBRARY(estdepth_hip, m)
           "Tensor beta_o, Tensor(a!) out_value, int out_stride) -> ()");
     m.def("bn_act_nhwc_(Tensor(a!) x, Tensor scale, Tensor shift, bool relu, Tensor? residual) -> Tensor(a!)");
     m.def("spp_upsample_cat(Tensor raw, Tensor skip, Tensor[] branches) -> Tensor");
+    m.def("conv1x1_nhwc(Tensor x, Tensor w, Tensor? scale, Tensor? shift, int stride, bool relu, Tensor? residual) -> Tensor");
     m.def("conv2d_small_nhwc(Tensor x, Tensor w_packed, Tensor scale, Tensor shift, int cout, int ksize, int stride, bool relu) -> Tensor");
     m.def("conv2d_k3_to16_nhwc(Tensor x, Tensor w_packed, Tensor scale, Tensor shift, bool upsample) -> Tensor");
     m.def("normalise_nhwc(Tensor imgs) -> Tensor");
@@ -649,6 +672,7 @@ TORCH_LIBRARY_IMPL(estdepth_hip, CUDA, m)
     m.impl("gru_blend", gru_blend);
     m.impl("bn_act_nhwc_", bn_act_nhwc_);
     m.impl("spp_upsample_cat", spp_upsample_cat);
+    m.impl("conv1x1_nhwc", conv1x1_nhwc);
     m.impl("conv2d_small_nhwc", conv2d_small_nhwc);
     m.impl("conv2d_k3_to16_nhwc", conv2d_k3_to16_nhwc);
     m.impl("normalise_nhwc", normalise_nhwc);

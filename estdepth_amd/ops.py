@@ -550,6 +550,30 @@ def conv2d_k3_to16_nhwc(x, w_packed, scale, shift, upsample=False):
     return out
 
 
+def conv1x1_nhwc(x, w2, scale, shift, stride=1, relu=False, residual=None):
+    """1x1 convolution (stride 1|2) + folded BN [+ residual] [+ ReLU] of an NHWC map in one launch (csrc/conv1x1.hip).
+    x [N,H,W,cin]; w2 [cout,cin] (the Conv2d weight as it lies); scale / shift [cout] or None -> NHWC [N,Ho,Wo,cout]."""
+    if _use_torch():
+        return T().conv1x1_nhwc(x, w2, scale, shift, int(stride), bool(relu), residual)
+    _need_f32_cuda("conv1x1_nhwc", x, w2)
+    n, h, w, c = x.shape
+    cout = w2.shape[0]
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    out = torch.empty((n, ho, wo, cout), device=x.device, dtype=torch.float32)
+    d = N.Conv1x1Desc()
+    d.N, d.H, d.W, d.cin, d.cout, d.stride, d.relu = n, h, w, c, cout, int(stride), int(bool(relu))
+    d.in_, d.w = _chk(x, "x").data_ptr(), _chk(w2, "w").data_ptr()
+    d.scale = scale.data_ptr() if scale is not None else None
+    d.shift = shift.data_ptr() if shift is not None else None
+    if residual is not None:
+        if tuple(residual.shape) != (n, ho, wo, cout):
+            raise RuntimeError("conv1x1_nhwc: residual must be NHWC [%d,%d,%d,%d]" % (n, ho, wo, cout))
+        d.residual = _chk(residual, "residual").data_ptr()
+    d.out = out.data_ptr()
+    N.check(N.lib().estd_conv1x1_nhwc(ctypes.byref(d), _stream()), "estd_conv1x1_nhwc")
+    return out
+
+
 SMALL_CONV_SHAPES = {(32, 3, 2), (32, 1, 2), (32, 1, 1), (64, 1, 1), (128, 1, 1)}      # (cin, ksize, stride) instances of estd_conv2d_small_nhwc
 
 

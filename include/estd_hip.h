@@ -298,6 +298,24 @@ int estd_spp_upsample_cat(const float* raw, int c_raw, const float* skip, int c_
  * w_packed: packing.pack_conv2d_small ([cout/16][ksize^2 taps][cin/16][64 lanes][4]).  Other shapes: ESTD_ERR_UNSUPPORTED. */
 int estd_conv2d_small_nhwc(const float* in, const float* w_packed, const float* scale, const float* shift, float* out, int N, int Hin,
                            int Win, int cin, int cout, int ksize, int stride, int relu, estd_stream_t stream);
+/* 1x1 convolution (stride 1 | 2, no padding) of an NHWC map + folded BatchNorm2d(eval) [+ residual] [+ ReLU] in ONE launch: the
+ * bottleneck convolutions of the semantic branch's ResNet (hybrid_models/resnet_encoder.py:40-51 over torchvision's Bottleneck:
+ * conv1 + bn1 + relu, conv3 + bn3 + shortcut + relu, downsample[0] + downsample[1]).  out = max(in . w^T * scale + shift
+ * (+ residual), relu ? 0 : -inf).  cin a multiple of 16, cout a multiple of 32; other shapes: ESTD_ERR_UNSUPPORTED
+ * (csrc/conv1x1.hip). */
+typedef struct estd_conv1x1_desc {
+    int N, H, W;              /* input map */
+    int cin, cout;
+    int stride;               /* 1 or 2: output pixel (y, x) reads input pixel (stride*y, stride*x); Ho = (H-1)/stride+1 */
+    int relu;                 /* 1: ReLU after the (residual) add */
+    const float* in;          /* [N][H][W][cin] */
+    const float* w;           /* [cout][cin]: the Conv2d weight [cout, cin, 1, 1] as it lies in memory */
+    const float* scale;       /* [cout] folded BN scale, or NULL (= 1) */
+    const float* shift;       /* [cout] folded BN shift / bias, or NULL (= 0) */
+    const float* residual;    /* [N][Ho][Wo][cout] added before the ReLU, or NULL */
+    float* out;               /* [N][Ho][Wo][cout] */
+} estd_conv1x1_desc;
+int estd_conv1x1_nhwc(const estd_conv1x1_desc* desc, estd_stream_t stream);
 int estd_conv2d_k3_to16_nhwc(const float* in, const float* w_packed, const float* scale, const float* shift, float* out, int N,
                              int H, int W, int cin, int upsample, estd_stream_t stream);
 /* image normalisation of DepthNetHybrid.forward (hybrid_models/model_hybrid.py:119: imgs = 2 * (imgs / 255.) - 1.):

@@ -71,6 +71,25 @@ def test_desc_struct_layout(libpath, tmp_path):
         assert getattr(_native.Conv3dDesc, f).offset == off, f
 
 
+def test_conv1x1_desc_struct_layout(libpath, tmp_path):
+    """sizeof/offsetof of estd_conv1x1_desc as the C compiler sees it == the ctypes mirror."""
+    from estdepth_amd import _native
+    src = tmp_path / "layout1.c"
+    names = {"in_": "in"}
+    fields = [f[0] for f in _native.Conv1x1Desc._fields_]
+    body = "\n".join('printf("%%zu\\n", offsetof(estd_conv1x1_desc, %s));' % names.get(f, f) for f in fields)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "estd_hip.h"\nint main(){printf("%zu\\n", sizeof(estd_conv1x1_desc));\n'
+                   + body + "\nreturn 0;}\n")
+    exe = tmp_path / "layout1"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert out[0] == ctypes.sizeof(_native.Conv1x1Desc)
+    for f, off in zip(fields, out[1:]):
+        assert getattr(_native.Conv1x1Desc, f).offset == off, f
+    assert _native.lib().estd_conv1x1_nhwc(None, None) == -1
+    assert _native.lib().estd_conv1x1_nhwc(ctypes.byref(_native.Conv1x1Desc()), None) == -1
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from estdepth_amd import _native
     monkeypatch.setattr(_native, "_lib", None)

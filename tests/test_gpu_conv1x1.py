@@ -1,0 +1,103 @@
+"""GPU: estd_conv1x1_nhwc (csrc/conv1x1.hip) -- 1x1 convolution (stride 1|2) + folded BatchNorm [+ residual] [+ ReLU] of an NHWC
+map, the ResNet bottleneck convolutions of the semantic branch (hybrid_models/resnet_encoder.py:40-51) -- against an fp64
+evaluation of the same fp32 data, through both bindings, on both wave-tile sizes, ragged pixel counts and every epilogue."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ref(x, w, sc, sh, stride, relu, res):
+    xs = x[:, ::stride, ::stride].double()
+    y = torch.einsum("nhwc,oc->nhwo", xs, w.double())
+    if sc is not None:
+        y = y * sc.double()
+    if sh is not None:
+        y = y + sh.double()
+    if res is not None:
+        y = y + res.double()
+    return y.clamp_min(0) if relu else y
+
+
+CASES = [  # N, H, W, cin, cout, stride, relu, residual, affine
+    (2, 24, 40, 64, 256, 1, True, True, True),        # layer1 conv3 + shortcut (64 x 64 blocks need >= 2048 wave tiles: this one takes 32 x 32)
+    (3, 120, 160, 64, 256, 1, True, True, True),      # the full-size one: 64 x 64 blocks
+    (3, 120, 160, 256, 64, 1, True, False, True),     # layer1 conv1
+    (2, 24, 40, 256, 512, 2, False, False, True),     # downsample, stride 2
+    (1, 7, 9, 16, 32, 1, False, False, False),        # smallest channels, ragged pixel count, no affine
+    (1, 15, 20, 2048, 512, 1, True, False, True),     # layer4 conv1: long K, few pixels
+    (2, 5, 7, 48, 96, 2, True, True, True),           # odd chunk count (cin = 48), odd map with stride 2, residual
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("binding", ["torch", "ctypes"])
+def test_conv1x1_vs_fp64(case, binding):
+    from estdepth_amd import ops
+    N, H, W, cin, cout, stride, relu, has_res, affine = case
+    g = torch.Generator().manual_seed(sum(case[:6]))
+    x = torch.randn(N, H, W, cin, generator=g)
+    w = torch.randn(cout, cin, generator=g) / np.sqrt(cin)
+    sc = (torch.rand(cout, generator=g) + 0.5) if affine else None
+    sh = torch.randn(cout, generator=g) if affine else None
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = torch.randn(N, Ho, Wo, cout, generator=g) if has_res else None
+    ref = _ref(x, w, sc, sh, stride, relu, res)
+    old = ops.BINDING
+    ops.BINDING = binding
+    try:
+        out = ops.conv1x1_nhwc(x.to(DEV), w.to(DEV), sc.to(DEV) if affine else None, sh.to(DEV) if affine else None, stride, relu,
+                               res.to(DEV) if has_res else None)
+        torch.cuda.synchronize()
+    finally:
+        ops.BINDING = old
+    assert tuple(out.shape) == (N, Ho, Wo, cout)
+    err = (out.double().cpu() - ref).abs().max().item()
+    mag = ref.abs().max().item()
+    # fp32 accumulation over cin products: the error of a length-cin fp32 dot product
+    assert err < 2e-7 * np.sqrt(cin) * max(mag, 1.0) + 1e-6, (err, mag)
+
+
+def test_conv1x1_rejects_what_it_has_no_instance_for():
+    from estdepth_amd import ops
+    x = torch.zeros(1, 4, 4, 24, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.conv1x1_nhwc(x, torch.zeros(32, 24, device=DEV), None, None)             # cin not a multiple of 16
+    with pytest.raises(RuntimeError):
+        ops.conv1x1_nhwc(torch.zeros(1, 4, 4, 32, device=DEV), torch.zeros(32, 32, device=DEV), None, None, stride=3)
+
+
+@pytest.mark.parametrize("policy", ["all", "auto"])
+def test_bottleneck_fused_path(policy):
+    """ResNet-50 layer1 (three stride-1 bottlenecks at 120x160) in the fused-BN path: with ESTD_HIP_1X1=all every convolution, the
+    residual add and the ReLUs run in csrc/conv1x1.hip / the MFMA conv2d kernel -- no hipBLASLt / rocBLAS / MIOpen kernel and no
+    separate BatchNorm pass; with the default policy the convolutions with a residual do.  Both equal the plain module."""
+    from estdepth_amd import backbones, synth
+    from estdepth_amd.backbones import ResNetTrunk, enable_fused_bn, enable_hip_3x3
+    trunk = ResNetTrunk(50).eval()
+    synth.fill_state_dict(trunk, seed=6)
+    stage = trunk.layer1
+    x = torch.randn(2, 64, 120, 160, generator=torch.Generator().manual_seed(3))
+    old = backbones.HIP_1X1
+    backbones.HIP_1X1 = policy
+    try:
+        with torch.no_grad():
+            ref = stage(x)
+            gs = stage.to(DEV).to(memory_format=torch.channels_last)
+            enable_fused_bn(gs, True)
+            enable_hip_3x3(gs, True)
+            xg = x.to(DEV).contiguous(memory_format=torch.channels_last)
+            gs(xg)                                                     # plans
+            with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+                got = gs(xg)
+                torch.cuda.synchronize()
+    finally:
+        backbones.HIP_1X1 = old
+    names = [e.key for e in prof.key_averages()]
+    assert sum("conv1x1_nhwc_kernel" in n for n in names) >= 1, names
+    if policy == "all":
+        assert not any(("Cijk" in n) or ("gemm" in n.lower()) or ("bn_act" in n) or ("miopen" in n.lower()) for n in names), names
+    scale = float(ref.abs().max())
+    assert float((got.cpu() - ref).abs().max()) < 2e-5 * max(scale, 1.0)
