@@ -88,6 +88,7 @@ _SIGNATURES = {
     "estd_conv2d_k3": (ctypes.c_int, [ctypes.POINTER(Conv2dDesc), c_stream]),
     "estd_conv2d_k3_split": (ctypes.c_int, [ctypes.POINTER(Conv2dDesc), c_stream]),
     "estd_conv2d_k3_wino": (ctypes.c_int, [ctypes.POINTER(Conv2dDesc), c_stream]),
+    "estd_conv2d_k3_wino2": (ctypes.c_int, [ctypes.POINTER(Conv2dDesc), c_stream]),
     "estd_conv3d_k3_grid": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "estd_groupnorm_finalize": (ctypes.c_int, [c_float_p, ctypes.c_int, ctypes.c_double, ctypes.c_float,
                                                c_float_p, c_stream]),

@@ -256,6 +256,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino_kernel(const estd_conv2d_d
                 const float av[8] = {a0c.x, a0c.y, a0c.z, a0c.w, a1c.x, a1c.y, a1c.z, a1c.w};
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) {
+                    if ((ESTD_W2ABL & 64) && tap % 3 == 2) continue;      // timing ablation: 2/3 of the MFMAs (what a second Winograd axis would leave)
 #pragma unroll
                     for (int nn = 0; nn < NT; ++nn) {
                         const int idx = ks * NT + nn;

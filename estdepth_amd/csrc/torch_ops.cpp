@@ -230,6 +230,9 @@ Tensor conv2d_k3(const Tensor& x_nhwc, const Tensor& w, const OptTensor& w_alt, 
     } else if (variant == 2) {
         d.w_wino = fptr(*w_alt, "Winograd-packed weights");
         check_status(estd_conv2d_k3_wino(&d, cur_stream()), "estd_conv2d_k3_wino");
+    } else if (variant == 3) {          // both image axes in Winograd form (w_alt = packing.pack_conv2d_wino2)
+        d.w_wino = fptr(*w_alt, "2-axis Winograd-packed weights");
+        check_status(estd_conv2d_k3_wino2(&d, cur_stream()), "estd_conv2d_k3_wino2");
     } else {
         TORCH_CHECK(variant == 0, "conv2d_k3: unknown variant ", variant);
         check_status(estd_conv2d_k3(&d, cur_stream()), "estd_conv2d_k3");

@@ -79,7 +79,7 @@ CONV2D_ARITH = os.environ.get("ESTD_CONV2D_ARITH", "f32")     # same choice for 
 # (csrc/conv3d_wino.hip); "direct" = 27 taps (csrc/conv3d_mfma.hip)
 CONV3D_ALGO = os.environ.get("ESTD_CONV3D_ALGO", "wino2")
 # same choice for the 3x3 / dilation-1 NHWC convolutions: row axis in Winograd F(2,3) form (csrc/conv2d_wino.hip) or direct
-CONV2D_ALGO = os.environ.get("ESTD_CONV2D_ALGO", "wino")
+CONV2D_ALGO = os.environ.get("ESTD_CONV2D_ALGO", "wino2")
 CONV2D_NT = os.environ.get("ESTD_CONV2D_NT", "auto")
 
 
@@ -353,6 +353,7 @@ class Conv2dPlan:
             self.w_nt[4] = packing.pack_conv2d(conv.weight, 4).to(dev)
         self.w_split = packing.pack_conv2d_split(conv.weight).to(dev)
         self.w_wino = {nt: packing.pack_conv2d_wino(conv.weight, nt).to(dev) for nt in self.w_nt}
+        self.w_wino2 = packing.pack_conv2d_wino2(conv.weight).to(dev) if self.dil == 1 else None      # F(2x2, 3x3): csrc/conv2d_wino2.hip
         sc, sh = packing.fold_bn_fp32(bn, list(range(self.cout)))
         self.scale, self.shift = sc.to(dev), sh.to(dev)
         self.relu_before, self.relu_after = int(relu_before), int(relu_after)
@@ -378,12 +379,13 @@ class Conv2dPlan:
             raise RuntimeError("Conv2dPlan.run: residual must be contiguous NHWC of the output shape")
         nt = self._pick_nt(Nn, H, W)
         split = CONV2D_ARITH == "bf16x3" and self.w_split is not None
-        if self.dil == 2 and not split and CONV2D_ALGO == "wino":
+        if self.dil == 2 and not split and CONV2D_ALGO in ("wino", "wino2"):
             nt = 2        # the 64-channel work item of the dilated Winograd kernel spills registers into its MFMA loop (5x slower)
-        if CONV2D_ALGO not in ("wino", "direct"):
-            raise RuntimeError("ESTD_CONV2D_ALGO must be wino or direct, got %r" % (CONV2D_ALGO,))
-        wino = (not split) and CONV2D_ALGO == "wino" and nt in self.w_wino
-        variant, w_alt = (1, self.w_split) if split else (2, self.w_wino[nt]) if wino else (0, None)
+        if CONV2D_ALGO not in ("wino2", "wino", "direct"):
+            raise RuntimeError("ESTD_CONV2D_ALGO must be wino2, wino or direct, got %r" % (CONV2D_ALGO,))
+        wino2 = (not split) and CONV2D_ALGO == "wino2" and self.w_wino2 is not None         # dilation 1; dilation 2 takes the row-only kernel
+        wino = (not split) and not wino2 and CONV2D_ALGO in ("wino", "wino2") and nt in self.w_wino
+        variant, w_alt = (1, self.w_split) if split else (3, self.w_wino2) if wino2 else (2, self.w_wino[nt]) if wino else (0, None)
         if _use_torch():
             return T().conv2d_k3(x_nhwc, self.w_nt[nt], w_alt, self.scale, self.shift, self.cout, self.dil, nt,
                                  bool(self.relu_before), bool(self.relu_after), residual, variant)
@@ -398,6 +400,9 @@ class Conv2dPlan:
         if split:
             d.w_split = self.w_split.data_ptr()
             N.check(N.lib().estd_conv2d_k3_split(ctypes.byref(d), _stream()), "estd_conv2d_k3_split")
+        elif wino2:
+            d.w_wino = self.w_wino2.data_ptr()
+            N.check(N.lib().estd_conv2d_k3_wino2(ctypes.byref(d), _stream()), "estd_conv2d_k3_wino2")
         elif wino:
             d.w_wino = self.w_wino[nt].data_ptr()
             N.check(N.lib().estd_conv2d_k3_wino(ctypes.byref(d), _stream()), "estd_conv2d_k3_wino")

@@ -188,6 +188,33 @@ def pack_conv3d_split(weight, main_idx, out_idx, extra_idx=None, n_tiles=2):
     return torch.from_numpy(rec.view(np.int16).copy())
 
 
+def pack_conv2d_wino2(weight):
+    """3x3 Conv2d weight [Cout, Cin, 3, 3] for csrc/conv2d_wino2.hip: both axes in Winograd F(2,3) form, U = G g G^T with
+    G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]] on kh and on kw (float64, rounded once to float32), packed as float32
+    [Cout/32][Cin/32][8 steps = 2 sh + channel half][4 sw][2 output tiles][64 lanes][4]: element e of lane (g, j) of (group, chunk, step,
+    sw, tile nt) = U[sh][sw][32 group + 16 nt + j][32 chunk + 16 half + 4 g + e] -- output channel j as the MFMA's M row, the four
+    consecutive input channels of the lane's 16-byte chunk as its four k-steps."""
+    w = weight.detach().double().cpu().numpy()
+    cout, cin = w.shape[:2]
+    assert cin % 32 == 0 and cout % 32 == 0 and w.shape[2:] == (3, 3)
+    G = np.array([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
+    U = np.einsum("sh,tw,oihw->stoi", G, G, w).astype(np.float32)           # [4 sh, 4 sw, Cout, Cin]
+    groups, chunks = cout // 32, cin // 32
+    out = np.zeros((groups, chunks, 8, 4, 2, 64, 4), np.float32)
+    lane = np.arange(64)
+    g, j = lane >> 4, lane & 15
+    for grp in range(groups):
+        for c in range(chunks):
+            for st in range(8):
+                sh, half = st >> 1, st & 1
+                for nt in range(2):
+                    co = grp * 32 + nt * 16 + j                              # [64]
+                    for e in range(4):
+                        ci = c * 32 + 16 * half + 4 * g + e                  # [64]
+                        out[grp, c, st, :, nt, :, e] = U[sh][:, co, ci]
+    return torch.from_numpy(out)
+
+
 def pack_conv2d_split(weight):
     """3x3 Conv2d weight [Cout, Cin, 3, 3] (multiples of 32) for csrc/conv2d_split_bf16.hip: int16
     [Cout/32 groups][Cin/32 chunks][9 taps][4096]: per record bytes 0..6143 = [3 pieces][2 n-tiles][64 lanes][8] bf16

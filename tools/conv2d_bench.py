@@ -13,9 +13,9 @@ for (h, w, cin, cout, dil) in [(240, 320, 32, 32, 1), (120, 160, 64, 64, 1), (12
     x = torch.randn(5, h, w, cin, device=dev)
     gf = 2.0 * 9 * 5 * h * w * cin * cout / 1e9
     line = "%3dx%-3d %3d->%-3d dil %d" % (h, w, cin, cout, dil)
-    for arith in ("f32/wino", "f32/direct", "bf16x3"):
+    for arith in ("f32/wino2", "f32/wino", "f32/direct", "bf16x3"):
         ops.CONV2D_ARITH = arith.split("/")[0]
-        ops.CONV2D_ALGO = "direct" if arith.endswith("direct") else "wino"
+        ops.CONV2D_ALGO = arith.split("/")[1] if "/" in arith else "wino"
         warm(lambda: plan.run(x), 0.1)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -27,7 +27,7 @@ for (h, w, cin, cout, dil) in [(240, 320, 32, 32, 1), (120, 160, 64, 64, 1), (12
     if cin == cout:                                         # BasicBlock tail: conv + BN + residual add
         res = torch.randn(5, h, w, cout, device=dev)
         line = "%3dx%-3d %3d->%-3d dil %d + residual" % (h, w, cin, cout, dil)
-        for algo in ("wino", "direct"):
+        for algo in ("wino2", "wino", "direct"):
             ops.CONV2D_ARITH, ops.CONV2D_ALGO = "f32", algo
             warm(lambda: plan.run(x, residual=res), 0.1)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
