@@ -172,9 +172,14 @@ __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float
 // the two waves of a SIMD split the INPUT channels instead -- wave (rp, cw) multiplies chunk cw (16 of the 32 channels) in 12 steps of
 // 16 MFMAs -- and sum their outputs through a 16 KB LDS exchange after the output transform: wave cw keeps plane d0 + cw, sends the
 // other one to its partner, and runs the epilogue of its plane only.
-template <int NW, bool RB, bool EXTRA, bool O16>
+template <int NW, int RBK, bool EXTRA, bool O16>
 __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int dpairs, int total_tiles)
 {
+    // RBK: read-back streams of the epilogue.  0 none; 1 = running sum only (out += result: the second source view of pre1), deferred
+    // epilogue like the plain instance; 2 = two residuals + scale (pre2 over both source views), deferred; 3 = any combination, epilogue
+    // between the tiles.  (profiles/r4_wino2_rb.txt)
+    constexpr bool RB = RBK != 0;
+    constexpr bool RB_ACC = RBK == 1 || RBK == 3, RB_RES = RBK == 2 || RBK == 3;
     constexpr int NTHREADS = 64 * NW;
     constexpr int NHW = 8 / NW;                          // channel halves per wave
     constexpr int SIT = (SL_CHUNKS + NTHREADS - 1) / NTHREADS;     // chunks per thread per slice: 3 | 6
@@ -340,19 +345,19 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
         struct EpiLoads { float4 r1[2][NHW], r2[2][NHW], ro[2][NHW]; };
         auto epi_issue = [&](int dd, EpiLoads& L) {       // the read-back streams of one plane, all loads back to back
             const int so = dd * out_plane_bytes;
-            if (RB && p.residual) {
+            if (RB_RES && p.residual) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int x = 0; x < NHW; ++x) L.r1[m][x] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_res, eoff_of(m), so + 64 * x, 0));
             }
-            if (RB && p.residual2) {
+            if (RB_RES && p.residual2) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int x = 0; x < NHW; ++x) L.r2[m][x] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_res2, eoff_of(m), so + 64 * x, 0));
             }
-            if (RB && p.accumulate) {
+            if (RB_ACC && p.accumulate) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -367,10 +372,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                 for (int x = 0; x < NHW; ++x) {
                     float4 v;
                     bn_act(a[m][x], 16 * (nh0 + x) + 4 * g, v);
-                    if (RB && p.residual) v = f4_add(v, L.r1[m][x]);
-                    if (RB && p.residual2) v = f4_add(v, L.r2[m][x]);
-                    if (RB) v = make_float4(v.x * p.out_scale, v.y * p.out_scale, v.z * p.out_scale, v.w * p.out_scale);
-                    if (RB && p.accumulate) v = f4_add(v, L.ro[m][x]);
+                    if (RB_RES && p.residual) v = f4_add(v, L.r1[m][x]);
+                    if (RB_RES && p.residual2) v = f4_add(v, L.r2[m][x]);
+                    if (RB_RES) v = make_float4(v.x * p.out_scale, v.y * p.out_scale, v.z * p.out_scale, v.w * p.out_scale);
+                    if (RB_ACC && p.accumulate) v = f4_add(v, L.ro[m][x]);
                     u32x4 bits;
                     __builtin_memcpy(&bits, &v, 16);
                     if (!(ESTD_W2ABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(bits, rs_out, eoff_of(m), so + 64 * x, 0);
@@ -515,7 +520,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
         // the last MFMA of a tile and the first of the next there is then ONE barrier and the prologue (measured before: ~6 000 of
         // 35 500 cycles per tile without a single MFMA: two barriers, the slice-3 rewrite and the epilogue of all eight waves at once,
         // profiles/r3_wino2_tile_timeline.txt).  Their registers are the ones the next-plane prefetch occupies later in the loop.
-        constexpr bool DEFER = ESTD_W2DEFER != 0 && !RB;        // (with read-back streams the deferred form spills inside the tap loop)
+#ifndef ESTD_W2_RB_DEFER
+#define ESTD_W2_RB_DEFER 1      // bit 0: deferred epilogue for RBK = 1 (0.969 -> 0.946 ms, 34 spilled VGPRs), bit 1: for RBK = 2 (1.04 -> 1.09 ms: 43 spilled, off)
+#endif
+        constexpr bool DEFER = ESTD_W2DEFER != 0 && (RBK == 0 || (RBK == 1 && (ESTD_W2_RB_DEFER & 1)) || (RBK == 2 && (ESTD_W2_RB_DEFER & 2)));   // (the generic read-back instance spills in the deferred form)
         // step in front of which slices 0..2 are rewritten (every read of them has been issued: rows are fetched two steps ahead)
         constexpr int RB_STEP = O16 ? (DEFER ? 7 : 9) : (DEFER ? 16 : 18);
         constexpr int PF_STEP = (DEFER && !O16) ? 4 : 0; // first step of the next-plane prefetch
@@ -869,7 +877,10 @@ extern "C" int estd_conv3d_k3_wino2(const estd_conv3d_desc* dp, estd_stream_t s)
     int grid = total < slots ? (int)total : slots;
     if (grid >= 8) grid &= ~7;
     static const int nw = [] { const char* e = getenv("ESTD_WINO2_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
-    const bool rb = d.residual || d.residual2 || d.accumulate || d.out_scale != 1.0f;      // (the scale multiply lives in that instance)
+    // read-back kind of the launch (the scale multiply lives in the residual instances)
+    const bool res_any = d.residual || d.residual2 || d.out_scale != 1.0f;
+    const int rbk = (!res_any && !d.accumulate) ? 0 : (!res_any ? 1 : (!d.accumulate ? 2 : 3));
+    const bool rb = rbk != 0;
 #define ESTD_W2_LAUNCH(NWV, RBV, EXV, OV)                                                                                            \
     do {                                                                                                                             \
         const int lds_bytes = OV ? O16_LDS_BYTES : LDS_BYTES;                                                                        \
@@ -878,11 +889,17 @@ extern "C" int estd_conv3d_k3_wino2(const estd_conv3d_desc* dp, estd_stream_t s)
                            tiles_w, tiles_h, dpairs, (int)total);                                                                    \
     } while (0)
     if (o16) {                                       // 8-wave form only
-        if (rb) ESTD_W2_LAUNCH(8, true, false, true); else ESTD_W2_LAUNCH(8, false, false, true);
+        if (rb) ESTD_W2_LAUNCH(8, 3, false, true); else ESTD_W2_LAUNCH(8, 0, false, true);
     } else if (extra) {                              // 8-wave form only (the key || value convolution)
-        if (rb) ESTD_W2_LAUNCH(8, true, true, false); else ESTD_W2_LAUNCH(8, false, true, false);
-    } else if (nw == 8) { if (rb) ESTD_W2_LAUNCH(8, true, false, false); else ESTD_W2_LAUNCH(8, false, false, false); }
-    else { if (rb) ESTD_W2_LAUNCH(4, true, false, false); else ESTD_W2_LAUNCH(4, false, false, false); }
+        if (rb) ESTD_W2_LAUNCH(8, 3, true, false); else ESTD_W2_LAUNCH(8, 0, true, false);
+    } else if (nw == 8) {
+        switch (rbk) {
+        case 0: ESTD_W2_LAUNCH(8, 0, false, false); break;
+        case 1: ESTD_W2_LAUNCH(8, 1, false, false); break;
+        case 2: ESTD_W2_LAUNCH(8, 2, false, false); break;
+        default: ESTD_W2_LAUNCH(8, 3, false, false); break;
+        }
+    } else { if (rb) ESTD_W2_LAUNCH(4, 3, false, false); else ESTD_W2_LAUNCH(4, 0, false, false); }
 #undef ESTD_W2_LAUNCH
     return ESTD_LAUNCH_CHECK();
 }
