@@ -11,8 +11,8 @@ import re
 from collections import defaultdict
 
 # family names are ops._Prof's group names (estdepth_amd/ops.py), so that amounts (FLOPs / bytes per launch) recorded there apply
-_W2 = re.compile(r"conv3d_wino2_kernel<\s*(\d+),\s*(true|false),\s*(true|false),\s*(true|false)(?:,\s*(true|false))?\s*>")
-_W2H = re.compile(r"conv3d_wino2_c16_kernel<")
+_W2 = re.compile(r"conv3d_wino2_kernel<\s*(\d+),\s*(\d+|true|false),\s*(true|false),\s*(true|false)(?:,\s*(true|false))?\s*>")
+_W2H = re.compile(r"conv3d_wino2_c16_kernel")
 _W1 = re.compile(r"conv3d_wino_kernel<\s*(true|false),\s*(true|false)\s*>")
 _K3 = re.compile(r"conv3d_k3_kernel<\s*(\d+),\s*(\d+),\s*(true|false),\s*(true|false)\s*>")
 
