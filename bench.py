@@ -117,7 +117,7 @@ def rccl_debug_summary(path):
     if chan:
         m = re.search(r"Channel \d+/(\d+) *:", chan[0])
         out["ring_channels"] = int(m.group(1))
-        out["ring_order_channel0"] = chan[0].split(":", 1)[-1].strip()[:120]
+        out["ring_order_channel0"] = re.search(r"Channel \d+/\d+ *: *(.*)", chan[0]).group(1).strip()[:120]
     for l in lines:
         if "coll channels" in l:
             out["channels_line"] = l.split("NCCL INFO", 1)[-1].strip()[:200]
