@@ -66,12 +66,14 @@ def conv1x1_gemm(conv, x):
 
 HIP_STEM = os.environ.get("ESTD_HIP_STEM", "1") == "1"       # A/B switch: PSM first layer on csrc/refine2d.hip
 GEMM_EPILOGUE = os.environ.get("ESTD_GEMM_EPILOGUE", "1") == "1"     # A/B switch, read once at import
-# 1x1 convolutions of the fused-BN path on csrc/conv1x1.hip (conv + BN + residual + ReLU in one launch): "auto" = where that kernel
-# is at least as fast as the library GEMM (+ BN pass) at the semantic branch's sizes -- every convolution with a residual, the
-# stride-2 downsample convolutions up to 512 input channels, 64 -> 64 (tools/conv1x1_bench.py, profiles/r4_conv1x1_bench.txt: it
-# streams its operands from L2 without LDS reuse and is L2-bandwidth bound at ~100 TFLOP/s, so the K-heavy small-map layers of
-# layer3 / layer4 stay on hipBLASLt); "all" = every 1x1 convolution (no library GEMM left in the branch); "0" = library only.
-HIP_1X1 = os.environ.get("ESTD_HIP_1X1", "auto")
+# 1x1 convolutions of the fused-BN path on csrc/conv1x1.hip (conv + BN + residual + ReLU in one launch): "all" (default) = every 1x1
+# convolution with cin % 16 == 0 and cout % 32 == 0 -- no library GEMM and no separate BatchNorm pass left in the ResNet branch's 1x1 layers;
+# "auto" = only where that kernel beats the library GEMM (+ BN pass) stand-alone: every convolution with a residual, the stride-2
+# downsample convolutions up to 512 input channels, 64 -> 64; "0" = library only.  tools/conv1x1_bench.py, profiles/r4_conv1x1_bench.txt:
+# the kernel streams its operands from L2 without LDS reuse (L2-bandwidth bound at ~90 TFLOP/s); with the K ranges of the long-K /
+# small-map layers split over the four waves of a workgroup the sixteen ResNet-50 shapes sum to 539 us against the library's 551, and
+# "all" and "auto" time the same in the step (18.56 / 18.61 vs 18.55 / 18.59 ms; "0": 18.62).
+HIP_1X1 = os.environ.get("ESTD_HIP_1X1", "all")
 
 
 def _hip_1x1_wanted(conv, residual):
@@ -106,7 +108,7 @@ def _is_1x1(conv):
     return conv.kernel_size == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and conv.dilation == (1, 1)
 
 
-HIP_3X3_MIN_ITEMS = int(os.environ.get("ESTD_HIP3X3_MIN_ITEMS", "256"))     # work items (8x16-pixel tiles x 32-channel groups) below which the persistent MFMA kernel cannot fill 256 CUs
+HIP_3X3_MIN_ITEMS = int(os.environ.get("ESTD_HIP3X3_MIN_ITEMS", "128"))     # work items (8x16-pixel tiles x 32-channel groups) below which the persistent MFMA kernel cannot fill 256 CUs
 
 
 def _hip_3x3_plan(conv, bn, x, relu, has_residual):

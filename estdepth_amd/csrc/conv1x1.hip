@@ -35,14 +35,19 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, s
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
 }
 
-template <int TM, int TN, int PF>
+// SK = 1: the four waves of a workgroup own four neighbouring blocks.  SK = 4 (K-heavy layers on small maps: few blocks, long K): the
+// four waves of a workgroup share ONE block and split its input channels into four contiguous ranges; waves 1..3 hand their partial
+// sums to wave 0 through LDS, which adds them in a fixed order (deterministic) and runs the epilogue.  Larger blocks per wave = fewer
+// operand bytes per MFMA from L2, which is what bounds this kernel.
+template <int TM, int TN, int PF, int SK>
 __global__ __launch_bounds__(256) void conv1x1_nhwc_kernel(const estd_conv1x1_desc p, int Ho, int Wo, int tiles_m, int tiles_n)
 {
+    __shared__ float4 red[SK > 1 ? (SK - 1) * TN * TM * 64 : 1];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, i = lane & 15;
-    const int wt = blockIdx.x * 4 + wave;                       // wave tile: channel block fastest
-    if (wt >= tiles_m * tiles_n) return;
+    const int wt = SK > 1 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;      // wave tile: channel block fastest
+    if (wt >= tiles_m * tiles_n) return;                        // (workgroup-uniform when SK > 1)
     const int tn = wt % tiles_n, tm = wt / tiles_n;
     const int m0 = tm * 16 * TM, n0 = tn * 16 * TN;
     const int Mtot = p.N * Ho * Wo;
@@ -89,17 +94,38 @@ __global__ __launch_bounds__(256) void conv1x1_nhwc_kernel(const estd_conv1x1_de
                 }
             }
     };
-    const int nchunks = cin >> 4;
+    const int nchunks = (cin >> 4) / SK;                        // this wave's share of the input channels: chunks kbase .. kbase + nchunks
+    const int kbase = SK > 1 ? wave * nchunks : 0;
 #pragma unroll
     for (int j = 0; j < PF - 1; ++j)
-        if (j < nchunks) load_chunk(j * 16, xq[j], wq[j]);
+        if (j < nchunks) load_chunk((kbase + j) * 16, xq[j], wq[j]);
     for (int c = 0; c < nchunks; c += PF) {                     // PF chunks per trip: the ring slots are compile-time constants
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
             const int cc = c + j;                                // (wave-uniform conditions)
-            if (cc + PF - 1 < nchunks) load_chunk((cc + PF - 1) * 16, xq[(j + PF - 1) % PF], wq[(j + PF - 1) % PF]);
+            if (cc + PF - 1 < nchunks) load_chunk((kbase + cc + PF - 1) * 16, xq[(j + PF - 1) % PF], wq[(j + PF - 1) % PF]);
             if (cc < nchunks) mfma_chunk(xq[j], wq[j]);
         }
+    }
+    if (SK > 1) {
+        if (wave > 0) {
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b)
+                    red[(((wave - 1) * TN + a) * TM + b) * 64 + lane] = make_float4(acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]);
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < SK - 1; ++w)
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+                    const float4 r = red[((w * TN + a) * TM + b) * 64 + lane];
+                    acc[a][b] += (f32x4){r.x, r.y, r.z, r.w};
+                }
     }
 
     // ---- epilogue: folded BatchNorm, + residual, ReLU; 16-byte stores ----
@@ -137,13 +163,14 @@ __global__ __launch_bounds__(256) void conv1x1_nhwc_kernel(const estd_conv1x1_de
     }
 }
 
-template <int TM, int TN, int PF>
+template <int TM, int TN, int PF, int SK>
 int launch1x1(const estd_conv1x1_desc& d, int Ho, int Wo, hipStream_t stream)
 {
     const long long Mtot = (long long)d.N * Ho * Wo;
     const int tiles_m = (int)((Mtot + 16 * TM - 1) / (16 * TM)), tiles_n = d.cout / (16 * TN);
     const long long wts = (long long)tiles_m * tiles_n;
-    hipLaunchKernelGGL((conv1x1_nhwc_kernel<TM, TN, PF>), dim3((unsigned)((wts + 3) / 4)), dim3(256), 0, stream, d, Ho, Wo, tiles_m, tiles_n);
+    const unsigned grid = SK > 1 ? (unsigned)wts : (unsigned)((wts + 3) / 4);
+    hipLaunchKernelGGL((conv1x1_nhwc_kernel<TM, TN, PF, SK>), dim3(grid), dim3(256), 0, stream, d, Ho, Wo, tiles_m, tiles_n);
     return ESTD_LAUNCH_CHECK();
 }
 
@@ -162,26 +189,36 @@ extern "C" int estd_conv1x1_nhwc(const estd_conv1x1_desc* dp, estd_stream_t s)
     if ((long long)d.N * d.H * d.W * d.cin * 4 >= 0x7fffff00LL || Mtot * d.cout * 4 >= 0x7fffff00LL || (long long)d.cin * d.cout * 4 >= 0x7fffff00LL)
         return ESTD_ERR_UNSUPPORTED;
     hipStream_t stream = estd_stream(s);
-    // Block per wave: the largest one that still gives the device ~one wave per SIMD (tools/conv1x1_bench.py: 64 x 64 wins from
-    // ~900 wave tiles on, below that the next smaller block with a deeper operand ring).  ESTD_C1X1_CFG forces one (A/B).
+    // Block per wave: the largest one that still gives the device ~one wave per SIMD (tools/conv1x1_bench.py).  ESTD_C1X1_CFG = 100 TM + 10 TN + SK
+    // forces one (A/B).
     static const int cfg_env = [] { const char* e = getenv("ESTD_C1X1_CFG"); return e ? atoi(e) : 0; }();
     const long long want = (long long)estd_device_cus() * 7 / 2;                        // 896 on 256 CUs
     auto tiles = [&](int tm, int tn) { return ((Mtot + 16 * tm - 1) / (16 * tm)) * (d.cout / (16 * tn)); };
+    const bool sk4 = (d.cin & 63) == 0 && d.cin >= 256;                                 // four K ranges of whole chunks, long enough to be worth the exchange
     int cfg = cfg_env;
     if (cfg == 0) {
-        if ((d.cout & 63) == 0 && tiles(4, 4) >= want) cfg = 44;
-        else if (tiles(4, 2) >= want) cfg = 42;
-        else if (tiles(2, 2) >= want) cfg = 22;
-        else cfg = 12;
+        const bool c64 = (d.cout & 63) == 0;
+        if (c64 && tiles(4, 4) >= want) cfg = 441;
+        else if (sk4 && d.cin >= 1024 && c64 && tiles(4, 4) >= want / 4) cfg = 444;     // few blocks, long K: split K over the four waves
+        else if (tiles(4, 2) >= want) cfg = 421;
+        else if (sk4 && c64 && tiles(4, 4) >= want / 4) cfg = 444;
+        else if (sk4 && c64 && tiles(2, 4) >= want / 4) cfg = 244;
+        else if (tiles(2, 2) >= want) cfg = 221;
+        else if (sk4 && tiles(2, 2) >= want / 4) cfg = 224;
+        else cfg = 121;
     }
-    if (cfg == 44 && (d.cout & 63)) cfg = 42;
-    if (cfg == 24 && (d.cout & 63)) cfg = 22;
+    if ((cfg % 10) == 4 && !((d.cin & 63) == 0)) cfg = cfg - 3;                         // SK needs cin % 64 == 0
+    if ((cfg / 10) % 10 == 4 && (d.cout & 63)) cfg -= 20;                               // TN = 4 needs cout % 64 == 0
     switch (cfg) {
-    case 44: return launch1x1<4, 4, 2>(d, Ho, Wo, stream);
-    case 42: return launch1x1<4, 2, 3>(d, Ho, Wo, stream);
-    case 24: return launch1x1<2, 4, 3>(d, Ho, Wo, stream);
-    case 22: return launch1x1<2, 2, 4>(d, Ho, Wo, stream);
-    case 21: return launch1x1<2, 1, 6>(d, Ho, Wo, stream);
-    default: return launch1x1<1, 2, 8>(d, Ho, Wo, stream);
+    case 441: return launch1x1<4, 4, 2, 1>(d, Ho, Wo, stream);
+    case 421: return launch1x1<4, 2, 3, 1>(d, Ho, Wo, stream);
+    case 241: return launch1x1<2, 4, 3, 1>(d, Ho, Wo, stream);
+    case 221: return launch1x1<2, 2, 4, 1>(d, Ho, Wo, stream);
+    case 444: return launch1x1<4, 4, 2, 4>(d, Ho, Wo, stream);
+    case 424: return launch1x1<4, 2, 3, 4>(d, Ho, Wo, stream);
+    case 244: return launch1x1<2, 4, 3, 4>(d, Ho, Wo, stream);
+    case 224: return launch1x1<2, 2, 4, 4>(d, Ho, Wo, stream);
+    case 124: return launch1x1<1, 2, 4, 4>(d, Ho, Wo, stream);
+    default: return launch1x1<1, 2, 8, 1>(d, Ho, Wo, stream);
     }
 }

@@ -25,6 +25,7 @@ Align_Corners_Range = False
 FAST_PATH = os.environ.get("ESTD_FAST_PATH", "1") == "1"
 FUSED_NORM = os.environ.get("ESTD_FUSED_NORM", "1") == "1"     # image normalisation + NHWC layout in one kernel
 MIX_GEMM = os.environ.get("ESTD_MIX_GEMM", "1") == "1"         # pre0 halves as two library GEMMs on NHWC features
+MIX_HIP = os.environ.get("ESTD_MIX_HIP", "1") == "1"           # ... as two 1x1 convolutions on csrc/conv1x1.hip instead (A/B switch)
 R50_HIP = os.environ.get("ESTD_R50_HIP", "1") == "1"           # ResNet stride-1 3x3 convolutions on the MFMA conv2d kernel
 HIP_REFINE = os.environ.get("ESTD_HIP_REFINE", "1") == "1"     # decoder 2D tail glue kernels (csrc/refine2d.hip)
 
@@ -310,8 +311,13 @@ class DepthNetHybrid(nn.Module):
             # records as they lie -- two launches for all views instead of a CHW copy + one mix kernel per view and role
             V, _, Hf, Wf = matching.shape
             rec = matching.permute(0, 2, 3, 1).reshape(V * Hf * Wf, 32)
-            src_all = torch.mm(rec, P["w_src"].t()).view(V, Hf, Wf, 32)
-            ref_all = torch.addmm(P["b_ref"], rec[Hf * Wf:(target_num + 1) * Hf * Wf], P["w_ref"].t()).view(target_num, Hf, Wf, 32)
+            if MIX_HIP:      # pre0's two halves as 1x1 convolutions of the NHWC records on csrc/conv1x1.hip (no library GEMM in the hot path)
+                nhwc = matching.permute(0, 2, 3, 1)
+                src_all = ops.conv1x1_nhwc(nhwc, P["w_src"], None, None)
+                ref_all = ops.conv1x1_nhwc(nhwc[1:target_num + 1], P["w_ref"], None, P["b_ref"])
+            else:
+                src_all = torch.mm(rec, P["w_src"].t()).view(V, Hf, Wf, 32)
+                ref_all = torch.addmm(P["b_ref"], rec[Hf * Wf:(target_num + 1) * Hf * Wf], P["w_ref"].t()).view(target_num, Hf, Wf, 32)
             src_mix = [src_all[v] for v in range(views_num)]
             ref_mix = [ref_all[t] for t in range(target_num)]
         else:

@@ -101,3 +101,27 @@ def test_bottleneck_fused_path(policy):
         assert not any(("Cijk" in n) or ("gemm" in n.lower()) or ("bn_act" in n) or ("miopen" in n.lower()) for n in names), names
     scale = float(ref.abs().max())
     assert float((got.cpu() - ref).abs().max()) < 2e-5 * max(scale, 1.0)
+
+
+def test_semantic_encoder_launches_no_library_gemm():
+    """the whole ResNet-50 semantic branch in the default fused path at the benchmark's size (3 images of 480x640): every 1x1
+    convolution (csrc/conv1x1.hip) and every stride-1 3x3 convolution (csrc/conv2d_wino2.hip) is in-house -- no hipBLASLt / rocBLAS
+    GEMM; what is left to MIOpen are the 7x7 stem and the three stride-2 3x3 convolutions (4 launches)."""
+    from estdepth_amd import synth
+    from estdepth_amd.backbones import SemanticEncoder, enable_fused_bn, enable_hip_3x3
+    enc = SemanticEncoder(50, "pretrained").eval()
+    synth.fill_state_dict(enc, seed=4)
+    g = enc.to(DEV).to(memory_format=torch.channels_last)
+    enable_fused_bn(g, True)
+    enable_hip_3x3(g, True)
+    x = torch.randn(3, 3, 480, 640, device=DEV).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        g(x)
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+            g(x)
+            torch.cuda.synchronize()
+    ev = {e.key: e.count for e in prof.key_averages()}
+    assert not any("Cijk" in k for k in ev), [k for k in ev if "Cijk" in k]
+    assert sum(c for k, c in ev.items() if "conv1x1_nhwc_kernel" in k) == 36           # 16 bottlenecks x (conv1, conv3) + 4 downsample convolutions
+    assert sum(c for k, c in ev.items() if "conv2d_wino2_kernel" in k) == 13           # the stride-1 3x3 convolutions
+    assert sum(c for k, c in ev.items() if "igemm" in k or "gemm" in k.lower() and "Cijk" not in k) <= 6, ev
