@@ -48,12 +48,7 @@ typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
 constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;
 
 constexpr int TH = 8, TW = 16;
-constexpr int IN_H = TH + 2, IN_W = TW + 2;          // haloed brick: 10 x 18
-constexpr int PITCH = IN_W + 1;                      // 19 voxels per transformed row (odd)
 constexpr int TROWS = 16;                            // 4 transforms x 4 row pairs
-constexpr int SLOT_BYTES = TROWS * PITCH * 128;      // 38 912
-constexpr int SH_BYTES = 4 * PITCH * 128;            // 9 728: one row transform index further
-constexpr int LOADERS = IN_W * 8;                    // 144 threads hold the brick: (column, 16-byte chunk)
 constexpr int NSTEP = 8;                             // steps per 32-channel chunk: (sh, channel half)
 constexpr int WD = 2, WR = 4;                        // weight stream: WD steps ahead, ring slot = step % WR (8 % WR == 0)
 
@@ -66,10 +61,21 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, s
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(elems * 4), 0x00020000);
 }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__device__ __forceinline__ int lds_off(int row, int col, int chunk) { return (row * PITCH + col) * 128 + ((chunk ^ ((col >> 1) & 7)) << 4); }
 
+// DIL = 2 (PSM layer4, networks/psm_submodule.py:58): pixels of equal parity form the F(2,3) sequences on both axes -- a block is the
+// outputs (a, a+2) x (b, b+2) with a in {0,1,4,5}, b in {0,1,4,5,8,9,12,13} of the tile, fed by brick rows a, a+2, a+4, a+6 and columns b,
+// b+2, b+4, b+6 of a 12 x 20 brick.  The pitch stays 20 (two slots of 16 x 20 x 128 B, two workgroups per CU = the whole LDS): the eight
+// column blocks of a row pair already alternate between the halves of a bank row (b is even / odd), and the two row pairs of a
+// ds_read_b128 lane group differ in bit 0 of the lane group index, i.e. of the chunk position.
+template <int DIL>
 __global__ __launch_bounds__(256, 2) void conv2d_wino2_kernel(const estd_conv2d_desc p, int tiles_w, int tiles_h, int total_items)
 {
+    constexpr int IN_H = TH + 2 * DIL, IN_W = TW + 2 * DIL;      // haloed brick: 10 x 18 | 12 x 20
+    constexpr int PITCH = DIL == 1 ? IN_W + 1 : IN_W;            // voxels per transformed row: 19 (odd, see the header) | 20
+    constexpr int SLOT_BYTES = TROWS * PITCH * 128;              // 38 912 | 40 960
+    constexpr int SH_BYTES = 4 * PITCH * 128;                    // one row transform index further
+    constexpr int LOADERS = IN_W * 8;                            // 144 | 160 threads hold the brick: (column, 16-byte chunk)
+    auto lds_off = [](int row, int col, int chunk) { return (row * PITCH + col) * 128 + ((chunk ^ ((col >> 1) & 7)) << 4); };
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -80,6 +86,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino2_kernel(const estd_conv2d_
     const int blk_rp = (i >= 4 && i < 12) ? 1 : 0;     // MFMA column <-> block (see the header)
     const int cb = i < 4 ? i : i < 12 ? i - 4 : i - 8;
     const int rp = 2 * rpp + blk_rp;
+    const int row_a = DIL == 1 ? 2 * rp : (rp & 1) + 4 * (rp >> 1);      // first tile row of the block's row pair (rows row_a, row_a + DIL)
+    const int col_b = DIL == 1 ? 2 * cb : (cb & 1) + 4 * (cb >> 1);      // first tile column of the block (columns col_b, col_b + DIL)
     const int H = p.H, W = p.W, Cin = p.cin, Cout = p.cout;
     const int nchunks = Cin >> 5;
     const int tiles_per_group = p.N * tiles_h * tiles_w;
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino2_kernel(const estd_conv2d_
     // swizzled chunk order (chunk + 4 = chunk position ^ 4)
     int aoff[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) aoff[q] = lds_off(rp, 2 * cb + q, g);
+    for (int q = 0; q < 4; ++q) aoff[q] = lds_off(rp, col_b + DIL * q, g);
 
     auto decode = [&](int item, int& grp, int& n, int& th0, int& tw0) {
         grp = item / tiles_per_group;
@@ -113,13 +121,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino2_kernel(const estd_conv2d_
         th0 = thi * TH; tw0 = twi * TW;
     };
     auto brick_offsets = [&](int th0, int tw0, unsigned (&voff)[IN_H], bool enable) {
-        const int gx = tw0 - 1 + lzx;
+        const int gx = tw0 - DIL + lzx;
         const bool colok = enable && loader && (unsigned)gx < (unsigned)W;
         const unsigned base = (unsigned)(gx * Cin + lc * 4) * 4u;
         const unsigned rowbytes = (unsigned)(W * Cin) * 4u;
 #pragma unroll
         for (int zy = 0; zy < IN_H; ++zy) {
-            const int gy = th0 - 1 + zy;                                     // uniform
+            const int gy = th0 - DIL + zy;                                   // uniform
             const bool rowok = (unsigned)gy < (unsigned)H;                   // uniform
             voff[zy] = (colok && rowok) ? base + (unsigned)gy * rowbytes : OOB_OFFSET;
         }
@@ -168,7 +176,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino2_kernel(const estd_conv2d_
             if (loader && !(ESTD_C2W2ABL & 2)) {
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
-                    const float4 d0 = pf[2 * w], d1 = pf[2 * w + 1], d2 = pf[2 * w + 2], d3 = pf[2 * w + 3];
+                    const int a = DIL == 1 ? 2 * w : (w & 1) + 4 * (w >> 1);         // compile-time after unrolling
+                    const float4 d0 = pf[a], d1 = pf[a + DIL], d2 = pf[a + 2 * DIL], d3 = pf[a + 3 * DIL];
                     *reinterpret_cast<float4*>(slot + wbase + (0 * 4 + w) * PITCH * 128) = f4_sub(d0, d2);
                     *reinterpret_cast<float4*>(slot + wbase + (1 * 4 + w) * PITCH * 128) = f4_add(d1, d2);
                     *reinterpret_cast<float4*>(slot + wbase + (2 * 4 + w) * PITCH * 128) = f4_sub(d2, d1);
@@ -224,9 +233,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino2_kernel(const estd_conv2d_
                             ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, (wbase_q + tgt * 4 + sw) * 2048, 0))
                             : as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_wx, wlane, (wnext_q + (tgt - NSTEP) * 4 + sw) * 2048, 0));
                 }
-                // the next brick: rows 0,1 | 2 | 3 | 4 | 5 | 6 | 7 | 8,9 over the eight steps
+                // the next brick over the eight steps: rows 0,1 | 2 | 3 | 4 | 5 | 6 | 7 | 8,9 (dilation 2: 0,1 | 2 | 3,4 | 5 | 6,7 | 8 | 9,10 | 11)
                 {
-                    const int r0 = st == 0 ? 0 : st + 1, r1 = (st == 0 || st == NSTEP - 1) ? r0 + 2 : r0 + 1;
+                    const int r0 = DIL == 1 ? (st == 0 ? 0 : st + 1) : (3 * st + 1) / 2;
+                    const int r1 = DIL == 1 ? ((st == 0 || st == NSTEP - 1) ? r0 + 2 : r0 + 1) : (3 * (st + 1) + 1) / 2;
 #pragma unroll
                     for (int r = r0; r < r1; ++r) pf[r] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[r], pf_soff, 0));
                 }
@@ -277,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino2_kernel(const estd_conv2d_
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int y = th0 + 2 * rp + r, x = tw0 + 2 * cb + j;
+                    const int y = th0 + row_a + DIL * r, x = tw0 + col_b + DIL * j;
                     eo[r][j] = (y < H && x < W) ? (unsigned)((y * W + x) * Cout + cbase) * 4u : OOB_OFFSET;
                 }
             float4 res[2][2];
@@ -325,18 +335,24 @@ extern "C" int estd_conv2d_k3_wino2(const estd_conv2d_desc* dp, estd_stream_t s)
     const estd_conv2d_desc& d = *dp;
     if (d.N <= 0 || d.H <= 0 || d.W <= 0 || !d.in || !d.w_wino || !d.scale || !d.shift || !d.out) return ESTD_ERR_ARG;
     if (d.cin < 32 || (d.cin & 31) || d.cout < 32 || (d.cout & 31)) return ESTD_ERR_ARG;
-    if (d.dilation != 1) return ESTD_ERR_UNSUPPORTED;
+    if (d.dilation != 1 && d.dilation != 2) return ESTD_ERR_UNSUPPORTED;
     const long long widest = (long long)d.H * d.W * (d.cin > d.cout ? d.cin : d.cout) * 4;
     if (widest >= 0x7fffff00LL) return ESTD_ERR_UNSUPPORTED;
     const int tiles_w = (d.W + TW - 1) / TW, tiles_h = (d.H + TH - 1) / TH;
     const int groups = d.cout / 32;
     const long long total = (long long)groups * d.N * tiles_h * tiles_w;
     if (total > 0x7fffffffLL) return ESTD_ERR_ARG;
-    const size_t lds = (size_t)2 * SLOT_BYTES;               // 76 KB: two workgroups per CU
     const int slots = estd_persistent_wgs(2);
     int grid = total < slots ? (int)total : slots;
     if (grid >= 8) grid &= ~7;
-    estd_allow_dynamic_lds<conv2d_wino2_kernel>((int)lds);
-    hipLaunchKernelGGL(conv2d_wino2_kernel, dim3(grid), dim3(256), lds, estd_stream(s), d, tiles_w, tiles_h, (int)total);
+    if (d.dilation == 1) {
+        const size_t lds = (size_t)2 * TROWS * (TW + 3) * 128;          // 76 KB: two workgroups per CU
+        estd_allow_dynamic_lds<conv2d_wino2_kernel<1>>((int)lds);
+        hipLaunchKernelGGL(conv2d_wino2_kernel<1>, dim3(grid), dim3(256), lds, estd_stream(s), d, tiles_w, tiles_h, (int)total);
+    } else {
+        const size_t lds = (size_t)2 * TROWS * (TW + 4) * 128;          // 80 KB: two workgroups per CU = all of the LDS
+        estd_allow_dynamic_lds<conv2d_wino2_kernel<2>>((int)lds);
+        hipLaunchKernelGGL(conv2d_wino2_kernel<2>, dim3(grid), dim3(256), lds, estd_stream(s), d, tiles_w, tiles_h, (int)total);
+    }
     return ESTD_LAUNCH_CHECK();
 }

@@ -81,6 +81,7 @@ CONV3D_ALGO = os.environ.get("ESTD_CONV3D_ALGO", "wino2")
 # same choice for the 3x3 / dilation-1 NHWC convolutions: row axis in Winograd F(2,3) form (csrc/conv2d_wino.hip) or direct
 CONV2D_ALGO = os.environ.get("ESTD_CONV2D_ALGO", "wino2")
 CONV2D_NT = os.environ.get("ESTD_CONV2D_NT", "auto")
+C2W2_DIL2 = os.environ.get("ESTD_C2W2_DIL2", "1") == "1"      # A/B switch: dilation-2 convolutions on the F(2x2,3x3) kernel too (0: row-only kernel)
 
 
 def _stream():
@@ -353,7 +354,7 @@ class Conv2dPlan:
             self.w_nt[4] = packing.pack_conv2d(conv.weight, 4).to(dev)
         self.w_split = packing.pack_conv2d_split(conv.weight).to(dev)
         self.w_wino = {nt: packing.pack_conv2d_wino(conv.weight, nt).to(dev) for nt in self.w_nt}
-        self.w_wino2 = packing.pack_conv2d_wino2(conv.weight).to(dev) if self.dil == 1 else None      # F(2x2, 3x3): csrc/conv2d_wino2.hip
+        self.w_wino2 = packing.pack_conv2d_wino2(conv.weight).to(dev)      # F(2x2, 3x3): csrc/conv2d_wino2.hip (dilation 1 and 2)
         sc, sh = packing.fold_bn_fp32(bn, list(range(self.cout)))
         self.scale, self.shift = sc.to(dev), sh.to(dev)
         self.relu_before, self.relu_after = int(relu_before), int(relu_after)
@@ -383,7 +384,7 @@ class Conv2dPlan:
             nt = 2        # the 64-channel work item of the dilated Winograd kernel spills registers into its MFMA loop (5x slower)
         if CONV2D_ALGO not in ("wino2", "wino", "direct"):
             raise RuntimeError("ESTD_CONV2D_ALGO must be wino2, wino or direct, got %r" % (CONV2D_ALGO,))
-        wino2 = (not split) and CONV2D_ALGO == "wino2" and self.w_wino2 is not None         # dilation 1; dilation 2 takes the row-only kernel
+        wino2 = (not split) and CONV2D_ALGO == "wino2" and self.w_wino2 is not None and (self.dil == 1 or C2W2_DIL2)
         wino = (not split) and not wino2 and CONV2D_ALGO in ("wino", "wino2") and nt in self.w_wino
         variant, w_alt = (1, self.w_split) if split else (3, self.w_wino2) if wino2 else (2, self.w_wino[nt]) if wino else (0, None)
         if _use_torch():

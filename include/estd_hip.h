@@ -187,10 +187,10 @@ int estd_conv2d_k3(const estd_conv2d_desc* desc, estd_stream_t stream);
 /* Same operator with the row axis in Winograd F(2,3) form: two output rows from four transformed input rows, 12 instead of
  * 18 tap products, every product an fp32 MFMA with fp32 accumulation (csrc/conv2d_wino.hip).  Reads w_wino instead of w. */
 int estd_conv2d_k3_wino(const estd_conv2d_desc* desc, estd_stream_t stream);
-/* Same operator (dilation 1 only; group_tiles ignored: 32 output channels per work item) with BOTH image axes in Winograd form,
+/* Same operator (dilation 1 | 2; group_tiles ignored: 32 output channels per work item) with BOTH image axes in Winograd form,
  * F(2x2, 3x3): 2 x 2 output pixels from a 4 x 4 transformed input patch, 16 instead of 36 tap products = 0.444 of the direct kernel's
  * MFMA work (csrc/conv2d_wino2.hip).  Reads desc->w_wino, which must then hold the F(2x2, 3x3) packing: float32
- * [cout/32][cin/32][8 steps][4][2][64][4] (packing.py::pack_conv2d_wino2).  Dilation 2: ESTD_ERR_UNSUPPORTED. */
+ * [cout/32][cin/32][8 steps][4][2][64][4] (packing.py::pack_conv2d_wino2). */
 int estd_conv2d_k3_wino2(const estd_conv2d_desc* desc, estd_stream_t stream);
 /* Same operator (group_tiles ignored: 32 output channels per work item) with every fp32 product as six
  * bf16 MFMA products of exactly 3-way split operands, fp32 accumulation (see estd_conv3d_k3_split). */
