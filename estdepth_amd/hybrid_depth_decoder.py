@@ -60,6 +60,9 @@ def kv_from_pair(key, value):
 HIP_TO16 = os.environ.get("ESTD_HIP_TO16", "1") == "1"      # A/B switch, read once at import: full-resolution ConvBlocks on csrc/refine2d.hip
 
 
+OVERLAP_HEADS = os.environ.get("ESTD_OVERLAP_HEADS", "0") == "1"      # 1 = stereo heads + soft-argmin on a side stream beside the EST chain.  Default off (round 4): every convolution kernel holds whole CUs, so nothing co-resides and the overlap only made warp+attention wait (Joint 18.25 / 18.20 ms with, 18.20 / 18.13 without; ESTM 8.07 / 8.05 vs 8.04 / 8.05; cfg5 43.9 / 43.7 vs 43.3 / 43.5)
+
+
 class DepthHybridDecoder(nn.Module):
     def __init__(self, num_ch_enc, num_output_channels=1, use_skips=True,
                  ndepths=64, depth_max=10.0, IF_EST_transformer=True):
@@ -226,7 +229,7 @@ class DepthHybridDecoder(nn.Module):
     def _heads_stream(self):
         """side stream for the (MFMA-light) stereo-head convs + soft-argmin when stream overlap is enabled: they fill the
         matrix pipe while the main chain runs its HBM-bound kernels (warp+attention, GRU elementwise)."""
-        if not getattr(self, "_overlap_heads", False):
+        if not getattr(self, "_overlap_heads", False) or not OVERLAP_HEADS:
             return None
         if getattr(self, "_side_stream", None) is None:
             self._side_stream = torch.cuda.Stream()
