@@ -91,6 +91,10 @@ def self_launch_if_needed(args):
     if ndev < args.gpus:
         env["ESTD_OVERSUBSCRIBED"] = str(max(ndev, 1))
         env.setdefault("ESTD_DIST_BACKEND", "gloo")
+        # several processes on ONE GPU oversubscribe its hardware queues (4 per process by default + gloo's streams): the queue
+        # scheduler then time-slices them with millisecond quanta (measured: 5 ms per cfg1 step with 2 queues per process, 25-500 ms
+        # with 4-8).  Only this code-path mode; one process per GPU is not affected.
+        env.setdefault("GPU_MAX_HW_QUEUES", "2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     sys.stdout.flush()
