@@ -63,6 +63,9 @@ HIP_TO16 = os.environ.get("ESTD_HIP_TO16", "1") == "1"      # A/B switch, read o
 OVERLAP_HEADS = os.environ.get("ESTD_OVERLAP_HEADS", "0") == "1"      # 1 = stereo heads + soft-argmin on a side stream beside the EST chain.  Default off (round 4): every convolution kernel holds whole CUs, so nothing co-resides and the overlap only made warp+attention wait (Joint 18.25 / 18.20 ms with, 18.20 / 18.13 without; ESTM 8.07 / 8.05 vs 8.04 / 8.05; cfg5 43.9 / 43.7 vs 43.3 / 43.5)
 
 
+BATCH_HEAD1 = os.environ.get("ESTD_BATCH_HEAD1", "1") == "1"          # A/B switch (see forward_transformer)
+
+
 class DepthHybridDecoder(nn.Module):
     def __init__(self, num_ch_enc, num_output_channels=1, use_skips=True,
                  ndepths=64, depth_max=10.0, IF_EST_transformer=True):
@@ -325,13 +328,18 @@ class DepthHybridDecoder(nn.Module):
             self.epipolar_transformer.fuse_kv(kvs[i], [kvs[j] for j in others], mats, dv, depth_min, depth_interval,
                                               before_write=join)
             if side is None:
-                P["head1"].run(kvs[i], (1, D, H, W), in_stride=32, out_head=fused_logits[i])   # :256
+                # stereo_head1 (:256) of every target in ONE launch behind the loop: a fused value is final once written (later
+                # targets only read it), and one launch of `num` volumes is cheaper than `num` launches of one
+                if not (BATCH_HEAD1 and kv.is_contiguous()):
+                    P["head1"].run(kvs[i], (1, D, H, W), in_stride=32, out_head=fused_logits[i])
             else:                                   # head of target i overlaps the (HBM-bound) start of target i+1
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     P["head1"].run(kvs[i], (1, D, H, W), in_stride=32, out_head=fused_logits[i])
         if side is not None:
             main.wait_stream(side)
+        elif BATCH_HEAD1 and kv.is_contiguous():
+            P["head1"].run(kv, (num, D, H, W), in_stride=32, out_head=fused_logits)           # :256, all targets
         d2, p2 = ops.softargmin_up(fused_logits, dv, 4)                   # :259-260
         if getattr(self, "keep_logits", False):          # test hook: the low-resolution logit volumes of stereo_head0 / stereo_head1
             self.last_logits = {"init": init_logits, "fused": fused_logits}
