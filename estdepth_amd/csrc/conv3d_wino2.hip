@@ -51,6 +51,12 @@
 #ifndef ESTD_W2DEFER
 #define ESTD_W2DEFER 1  // 1: epilogue of tile k inside the first steps of tile k+1, two barriers per tile; 0: epilogue between the tiles
 #endif
+#ifndef ESTD_W2_AUX_IN
+#define ESTD_W2_AUX_IN 0     // cache policy of the plane loads (A/B: 2 = non-temporal)
+#endif
+#ifndef ESTD_W2_AUX_OUT
+#define ESTD_W2_AUX_OUT 0    // cache policy of the output stores (A/B: 2 = non-temporal)
+#endif
 #ifndef ESTD_W2ABL
 #define ESTD_W2ABL 0    // timing ablations only (results are wrong): 1 no output stores, 2 no slice writes, 8 no weight stream,
 #endif                  // 16 no next-plane prefetch, 128 no row transform (raw rows as operands)
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
             const bool pv = (unsigned)pd < (unsigned)D;        // wave-uniform; planes outside the volume are zero padding
 #pragma unroll
             for (int it = 0; it < SIT; ++it)
-                dst[it] = pv ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, chunk_voff(it), pd * in_slice_bytes, 0))
+                dst[it] = pv ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, chunk_voff(it), pd * in_slice_bytes, ESTD_W2_AUX_IN))
                              : make_float4(0.f, 0.f, 0.f, 0.f);
         };
 
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                     if (RB_ACC && p.accumulate) v = f4_add(v, L.ro[m][x]);
                     u32x4 bits;
                     __builtin_memcpy(&bits, &v, 16);
-                    if (!(ESTD_W2ABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(bits, rs_out, eoff_of(m), so + 64 * x, 0);
+                    if (!(ESTD_W2ABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(bits, rs_out, eoff_of(m), so + 64 * x, ESTD_W2_AUX_OUT);
                 }
         };
         // epilogue of one plane: tile rows row0, row0 + 1 (m), channel halves (x).  Every read-back stream (residuals, the running
@@ -623,6 +629,11 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                 for (int k = 0; k < PER; ++k) vo_next[k] = chunk_voff(k % SIT);
             }
             EpiLoads pl;                                 // read-back loads of the deferred epilogue (issued one step before use)
+#ifndef ESTD_W2_RB_EARLY
+#define ESTD_W2_RB_EARLY 0      // A/B: non-deferred read-back instances request the streams of BOTH planes in the last two steps of the tap loop
+#endif                          // (the raw rows / next-step transforms are dead there), the epilogue behind the loop finds them on their way
+            constexpr bool RB_EARLY = ESTD_W2_RB_EARLY != 0 && RB && !DEFER && !O16;
+            EpiLoads el0, el1;
             __builtin_amdgcn_sched_barrier(0);
             W2STAMP(1);
 
@@ -652,6 +663,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                 if (ESTD_W2SPREAD && has_next && step == RB_STEP + 2) write_slice(2);
                 // weights of step + BD - 1
                 if (step + BD - 1 < NSTEPS && !(ESTD_W2ABL & 8)) load_b(step + BD - 1, bq[(step + BD - 1) % BD]);
+                if (RB_EARLY && step == NSTEPS - 2) epi_issue(d0, el0);
+                if (RB_EARLY && step == NSTEPS - 1 && d0 + 1 < D) epi_issue(d0 + 1, el1);
                 // chunks of the NEXT tile's two new planes: spread over the first steps (their offsets were read from the LDS table
                 // at the end of the previous step)
                 if (has_next && !(ESTD_W2ABL & 16)) {
@@ -660,9 +673,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                         for (int k = 0; k < PER; ++k) {
                             const int idx = (step - PF_STEP) * PER + k, it = idx % SIT;
                             const unsigned vo = vo_next[k];
-                            if (idx < SIT) xc[it] = v0 ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, nd * in_slice_bytes, 0))
+                            if (idx < SIT) xc[it] = v0 ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, nd * in_slice_bytes, ESTD_W2_AUX_IN))
                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
-                            else           xd[it] = v1 ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, (nd + 1) * in_slice_bytes, 0))
+                            else           xd[it] = v1 ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, (nd + 1) * in_slice_bytes, ESTD_W2_AUX_IN))
                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
                         }
                     }
@@ -814,7 +827,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
 #endif
             if (!defer_this) {
                 if (O16) { if (d0 + cw < D) epi_plane(y0, d0 + cw); }
-                else if (RB && ESTD_W2_RB_BATCH) {
+                else if (RB_EARLY) {
+                    epi_finish(y0, d0, el0);
+                    if (d0 + 1 < D) epi_finish(y1, d0 + 1, el1);
+                } else if (RB && ESTD_W2_RB_BATCH) {
                     // read-back instance: the loads of BOTH planes back to back, one exposed round trip per tile instead of two
                     EpiLoads l0, l1;
                     epi_issue(d0, l0);
