@@ -57,6 +57,9 @@
 #ifndef ESTD_W2_AUX_OUT
 #define ESTD_W2_AUX_OUT 0    // cache policy of the output stores (A/B: 2 = non-temporal)
 #endif
+#ifndef ESTD_W2FOLD
+#define ESTD_W2FOLD 0   // 1: the products of a depth transform are folded into the output planes as soon as it is complete (32 accumulator registers less)
+#endif
 #ifndef ESTD_W2ABL
 #define ESTD_W2ABL 0    // timing ablations only (results are wrong): 1 no output stores, 2 no slice writes, 8 no weight stream,
 #endif                  // 16 no next-plane prefetch, 128 no row transform (raw rows as operands)
@@ -105,6 +108,14 @@ constexpr int O16_WLDS_TAPS = 20;
 constexpr int O16_XCH_BYTES = 8 * 2 * 64 * 16;
 constexpr int O16_LDS_BYTES = 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + O16_XCH_BYTES + O16_WLDS_TAPS * 2048;
 static_assert(O16_LDS_BYTES <= 160 * 1024, "LDS budget (O16)");
+// XOUT (a 33rd OUTPUT channel, dres2): two LDS-resident taps less; their place takes the 33rd channel's own weights -- [24 steps][4 sh][4 lane
+// groups][4] main input channels + [4 sd][4 lane groups][4 sh] scalar input channel (packing.pack_conv3d_wino2_xout) -- and the exchange
+// buffer of its cross-wave sum, [2 tile parities][4 row pairs][64 lanes]
+constexpr int XOUT_WLDS_TAPS = WLDS_TAPS - 2;
+constexpr int XOUT_W_BYTES = (24 * 4 * 4 + 4 * 4) * 16;
+constexpr int XOUT_XCH_BYTES = 2 * 4 * 64 * 4;
+constexpr int XOUT_LDS_BYTES = 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + XSL_BYTES + XOUT_WLDS_TAPS * 4096 + XOUT_W_BYTES + XOUT_XCH_BYTES;
+static_assert(XOUT_LDS_BYTES <= 160 * 1024, "LDS budget (XOUT)");
 constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;        // beyond num_records of any descriptor: loads return 0, stores are dropped
 
 __device__ __forceinline__ float4 as_float4(u32x4 v)
@@ -145,6 +156,15 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 __device__ __forceinline__ int lds_chunk_off(int v, int c) { return v * 128 + ((c ^ ((v >> 1) & 7)) << 4); }
+// ESTD_W2COLKEY (round 4): the swizzle key is taken from the COLUMN of the haloed slice only -- (col >> 1) & 7; IN_W is even, so the
+// bank half (voxel & 1) is the column's parity and the 8 even / 8 odd columns a fragment read touches still have 8 distinct keys --
+// which makes the byte offset of (row, col, chunk) = row * IN_W * 128 + f(col, chunk): the fragment reads of a tap loop then need one
+// address register per (column tap, channel chunk) and immediates for the halo row and the depth slice, instead of one register per
+// (row, column tap) plus an XOR per second-chunk read.
+#ifndef ESTD_W2COLKEY
+#define ESTD_W2COLKEY 1
+#endif
+__device__ __forceinline__ int lds_colkey_off(int col, int c) { return col * 128 + ((c ^ ((col >> 1) & 7)) << 4); }
 
 // tanh x = 1 - 2 / (exp(2x) + 1) on the transcendental units (v_exp_f32, v_rcp_f32: 1 ulp each; five instructions instead of the device
 // library's ~30).  Absolute error <= 2e-7 over the whole range (cancellation near 0 costs relative, not absolute accuracy); +-inf -> +-1.
@@ -178,7 +198,13 @@ __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float
 // the two waves of a SIMD split the INPUT channels instead -- wave (rp, cw) multiplies chunk cw (16 of the 32 channels) in 12 steps of
 // 16 MFMAs -- and sum their outputs through a 16 KB LDS exchange after the output transform: wave cw keeps plane d0 + cw, sends the
 // other one to its partner, and runs the epilogue of its plane only.
-template <int NW, int RBK, bool EXTRA, bool O16>
+// XOUT: a 33rd OUTPUT channel on top of EXTRA (dres2, hybrid_depth_decoder.py:106 / :195): a GEMV -- 1/16 efficient as an MFMA tile -- so it
+// runs on the VALU from the row-transformed fragments T the MFMAs of a step consume anyway.  The two waves of a SIMD hold the SAME
+// fragments (they differ in the output channel half), so they split the k range: wave (rp, nh) takes the steps of channel chunk c = nh --
+// 4 weight reads and 8 packed FMAs in every other step -- folds its partial products m33[sd][sh] through both output transforms as the
+// depth transforms complete, and after the loop the lane groups (shuffles) and the two waves (1 KB through LDS, published by the tile's
+// post-loop barrier) add up; wave nh = 0 applies BN + activation and stores the 2 planes x 2 rows x 16 voxels to out_extra.
+template <int NW, int RBK, bool EXTRA, bool O16, bool XOUT = false>
 __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int dpairs, int total_tiles)
 {
     // RBK: read-back streams of the epilogue.  0 none; 1 = running sum only (out += result: the second source view of pre1), deferred
@@ -197,11 +223,15 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rp = wave & 3;            // tile rows 2rp, 2rp+1 (halo rows 2rp .. 2rp+3)
     static_assert(!O16 || (NW == 8 && !EXTRA), "O16: 8-wave form without the scalar channel");
+    static_assert(!XOUT || (NW == 8 && EXTRA && RBK == 0), "XOUT: 8-wave form with the scalar channel, no read-back streams");
+    // the products of a depth transform folded into the output planes as soon as it is complete: 32 accumulator registers less on paper;
+    // measured neutral to ~2 % slower, and the allocator spills MORE in the 33 -> 33 instance with it (62 vs 32 registers)
+    constexpr bool FOLD = ESTD_W2FOLD != 0;
     const int cw = wave >> 2;                           // O16: this wave's input-channel chunk and the output plane (d0 + cw) it finishes
     const int nh0 = (NW == 8 && !O16) ? wave >> 2 : 0;  // first channel half of this wave
     constexpr int NSTEPS = O16 ? 12 : 24;
     constexpr int TAP_BYTES = O16 ? 2048 : 4096;
-    constexpr int WTAPS = O16 ? O16_WLDS_TAPS : WLDS_TAPS;
+    constexpr int WTAPS = O16 ? O16_WLDS_TAPS : XOUT ? XOUT_WLDS_TAPS : WLDS_TAPS;
     const int g = lane >> 4;            // k index inside an MFMA
     const int i = lane & 15;            // voxel column of the (transposed) MFMA
     // MFMA column <-> voxel of a tile row (conflict-free ds_read_b128 for every tap; see csrc/conv3d_wino.hip)
@@ -236,6 +266,12 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
     char* lds_xch = smem + 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES;               // O16: [8 waves][2 rows][64 lanes] float4
     char* lds_w = smem + 4 * SLICE_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + (O16 ? O16_XCH_BYTES : XSL_BYTES);     // weights of the first taps
     constexpr int WT0 = O16 ? 0 : WLDS_T0;                                        // first LDS-resident tap
+    char* lds_wxo = lds_w + WTAPS * TAP_BYTES;                                    // XOUT: the 33rd output channel's weights ...
+    float* lds_xo = reinterpret_cast<float*>(lds_wxo + XOUT_W_BYTES);             // ... and the exchange buffer of its cross-wave sum
+    if (XOUT) {
+        for (int e = tid; e < XOUT_W_BYTES / 16; e += NTHREADS)
+            reinterpret_cast<float4*>(lds_wxo)[e] = reinterpret_cast<const float4*>(p.w_xout)[e];
+    }
     for (int e = tid; e < WTAPS * TAP_BYTES / 16; e += NTHREADS)                  // (visible after the first tile's barriers)
         reinterpret_cast<float4*>(lds_w)[e] = reinterpret_cast<const float4*>(p.w_wino2)[WT0 * (TAP_BYTES / 16) + e];
 
@@ -243,6 +279,11 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w_wino2, (size_t)NTAPS * (O16 ? 1 : 2) * 2 * 256);
     const int wlane = lane * 16 + nh0 * 2048;
     const int row0 = 2 * rp;
+    int rbase[3][2];                     // column-keyed swizzle: byte offset of (halo row row0, column kw + pi, chunk g + 4c) of slice 0
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) rbase[kw][c] = row0 * (IN_W * 128) + lds_colkey_off(kw + pi, g + 4 * c);
 
     int tl_tile = 0;        // (timeline builds) tiles done by this workgroup
 #if ESTD_W2PRIO == 2
@@ -299,6 +340,12 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
             return lds_vt[it * NTHREADS + wave * 64 + l];
         };
         const int loff0 = lds_chunk_off(tid >> 3, tid & 7);
+        int loffk[SIT];                                  // column-keyed swizzle: the key changes with the chunk's column
+#pragma unroll
+        for (int it = 0; it < SIT; ++it) {
+            const int vs = (tid >> 3) + it * (NTHREADS / 8);
+            loffk[it] = (vs / IN_W) * (IN_W * 128) + lds_colkey_off(vs % IN_W, tid & 7);
+        }
         const bool last_ok = tid + (SIT - 1) * NTHREADS < SL_CHUNKS;      // the last chunk of a slice exists for this thread
         auto load_plane = [&](int pd, float4 (&dst)[SIT]) {
             const bool pv = (unsigned)pd < (unsigned)D;        // wave-uniform; planes outside the volume are zero padding
@@ -512,7 +559,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                 if ((it < SIT - 1 || last_ok) && !(ESTD_W2ABL & 2)) {
                     const float4 v = sl == 0 ? f4_sub(xa[it], xc[it]) : sl == 1 ? f4_add(xb[it], xc[it])
                                    : sl == 2 ? f4_sub(xc[it], xb[it]) : f4_sub(xb[it], xd[it]);
-                    *reinterpret_cast<float4*>(smem + loff0 + sl * SLICE_BYTES + it * NTHREADS * 16) = v;
+                    if (ESTD_W2COLKEY) *reinterpret_cast<float4*>(smem + loffk[it] + sl * SLICE_BYTES) = v;
+                    else *reinterpret_cast<float4*>(smem + loff0 + sl * SLICE_BYTES + it * NTHREADS * 16) = v;
                 }
             }
         };
@@ -527,9 +575,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
         // 35 500 cycles per tile without a single MFMA: two barriers, the slice-3 rewrite and the epilogue of all eight waves at once,
         // profiles/r3_wino2_tile_timeline.txt).  Their registers are the ones the next-plane prefetch occupies later in the loop.
 #ifndef ESTD_W2_RB_DEFER
-#define ESTD_W2_RB_DEFER 1      // bit 0: deferred epilogue for RBK = 1 (0.969 -> 0.946 ms, 34 spilled VGPRs), bit 1: for RBK = 2 (1.04 -> 1.09 ms: 43 spilled, off)
+#define ESTD_W2_RB_DEFER 3      // bit 0: deferred epilogue for RBK = 1 (0.969 -> 0.946 ms, 34 spilled VGPRs), bit 1: for RBK = 2 (1.04 -> 1.09 ms: 43 spilled, off)
 #endif
-        constexpr bool DEFER = ESTD_W2DEFER != 0 && (RBK == 0 || (RBK == 1 && (ESTD_W2_RB_DEFER & 1)) || (RBK == 2 && (ESTD_W2_RB_DEFER & 2)));   // (the generic read-back instance spills in the deferred form)
+        constexpr bool DEFER = ESTD_W2DEFER != 0 && (RBK == 0 || (RBK == 1 && (ESTD_W2_RB_DEFER & 1)) || (RBK == 2 && (ESTD_W2_RB_DEFER & 2)) || (RBK == 3 && (ESTD_W2_RB_DEFER & 4)));   // (the generic read-back instance spills in the deferred form)
         // step in front of which slices 0..2 are rewritten (every read of them has been issued: rows are fetched two steps ahead)
         constexpr int RB_STEP = O16 ? (DEFER ? 7 : 9) : (DEFER ? 16 : 18);
         constexpr int PF_STEP = (DEFER && !O16) ? 4 : 0; // first step of the next-plane prefetch
@@ -560,7 +608,21 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
 
             // m[sd][sh] per channel half.  No zero fill (64 register moves per tile and wave, paid in matrix time, §3.0 of DESIGN.md): the
             // first product of every accumulator -- column tap 0, channel chunk 0, k-step 0 of its depth transform -- takes C = 0.
-            f32x4 acc[4][4][NHW];
+            // FOLD (round 4): only the four products m[sd][0..3] of the CURRENT depth transform are held (the steps run sd-major);
+            // behind the last step of a depth transform they go through the row half of the output transform and are added into the two
+            // output planes (y0 = z0 + z1 + z2, y1 = z1 - z2 - z3) -- 16 + 16 accumulator registers per channel half instead of 64.
+            f32x4 acc[FOLD ? 1 : 4][4][NHW];
+            f32x4 y0[2][NHW], y1[2][NHW];
+            auto fold_sd = [&](int sd_, const f32x4 (&a)[4][NHW]) {
+#pragma unroll
+                for (int x = 0; x < NHW; ++x) {
+                    const f32x4 z0 = a[0][x] + a[1][x] + a[2][x], z1 = a[1][x] - a[2][x] - a[3][x];
+                    if (sd_ == 0) { y0[0][x] = z0; y0[1][x] = z1; }
+                    else if (sd_ == 1) { y0[0][x] += z0; y0[1][x] += z1; y1[0][x] = z0; y1[1][x] = z1; }
+                    else if (sd_ == 2) { y0[0][x] += z0; y0[1][x] += z1; y1[0][x] -= z0; y1[1][x] -= z1; }
+                    else { y1[0][x] -= z0; y1[1][x] -= z1; }
+                }
+            };
 
             auto load_w = [&](int t, int q, int x) {        // t, x are compile-time constants after unrolling (q too, except O16: q = cw)
                 if (t >= WT0 && t < WT0 + WTAPS) return *reinterpret_cast<const float4*>(lds_w + (t - WT0) * TAP_BYTES + x * 2048 + q * 1024 + wlane);
@@ -568,6 +630,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
             };
             // 16-byte chunk c (channels 4g.. for c = 0, 16+4g.. for c = 1) of halo row 2rp + r at column shift kw of depth slice sd
             auto load_row = [&](int sd, int kw, int c, int r) {
+                if (ESTD_W2COLKEY)
+                    return *reinterpret_cast<const float4*>(smem + rbase[kw][c] + sd * SLICE_BYTES + r * (IN_W * 128));
                 const int vs = (row0 + r) * IN_W + kw + pi;
                 int off = sd * SLICE_BYTES + lds_chunk_off(vs, g);
                 if (c) off ^= 64;
@@ -634,6 +698,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
 #endif                          // (the raw rows / next-step transforms are dead there), the epilogue behind the loop finds them on their way
             constexpr bool RB_EARLY = ESTD_W2_RB_EARLY != 0 && RB && !DEFER && !O16;
             EpiLoads el0, el1;
+            // XOUT: partial products of the current depth transform per row-transform index (two running sums each: the products pair up
+            // into v_pk_fma_f32), the [plane][row] sums behind both output transforms, and this step's four weight quads
+            f32x2 xm[4], xP[2][2];
+            float4 xw[4];
             __builtin_amdgcn_sched_barrier(0);
             W2STAMP(1);
 
@@ -661,6 +729,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                 }
                 if (ESTD_W2SPREAD && has_next && step == RB_STEP + 1) write_slice(1);
                 if (ESTD_W2SPREAD && has_next && step == RB_STEP + 2) write_slice(2);
+                if (XOUT && nh0 == (step & 1)) {         // (uniform branch) this wave's channel chunk: the 33rd output channel's weights of the step
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) xw[t] = *reinterpret_cast<const float4*>(lds_wxo + ((step * 4 + t) * 4) * 16 + g * 16);
+                }
                 // weights of step + BD - 1
                 if (step + BD - 1 < NSTEPS && !(ESTD_W2ABL & 8)) load_b(step + BD - 1, bq[(step + BD - 1) % BD]);
                 if (RB_EARLY && step == NSTEPS - 2) epi_issue(d0, el0);
@@ -705,8 +777,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                                 const float4 b4 = bq[cur][t][x];
                                 const float b = h == 0 ? (e == 0 ? b4.x : b4.y) : (e == 0 ? b4.z : b4.w);
                                 const bool first_product = gi % 3 == 0 && (O16 || (step & 1) == 0) && h == 0 && e == 0;
-                                const f32x4 c_in = first_product ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[sd][t][x];
-                                acc[sd][t][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, T[h][t][e], c_in, 0, 0, 0);
+                                const f32x4 c_in = first_product ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[FOLD ? 0 : sd][t][x];
+                                acc[FOLD ? 0 : sd][t][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, T[h][t][e], c_in, 0, 0, 0);
                             }
                     if (ESTD_W2PK == 1) __builtin_amdgcn_sched_barrier(0);   // the MFMAs of two components, then the next step's 4 packed transforms
                     if (step + 1 < NSTEPS) xform2(R, h, Tn[h]);
@@ -736,6 +808,23 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                     }
                     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
                 }
+                // (the FMAs at the START of the step -- T is live there anyway -- with the weights read one step earlier: 59 spilled registers
+                // instead of 32, 1.06 instead of 0.98 ms)
+                if (XOUT && nh0 == (step & 1)) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const f32x2 wlo = {xw[t].x, xw[t].y}, whi = {xw[t].z, xw[t].w};
+                        xm[t] = gi % 3 == 0 ? T[0][t] * wlo : __builtin_elementwise_fma(T[0][t], wlo, xm[t]);
+                        xm[t] = __builtin_elementwise_fma(T[1][t], whi, xm[t]);
+                    }
+                    if (gi % 3 == 2) {                   // depth transform sd complete (for this wave's chunk): row half, then depth half
+                        const f32x2 r0 = xm[0] + xm[1] + xm[2], r1 = xm[1] - xm[2] - xm[3];
+                        if (sd == 0) { xP[0][0] = r0; xP[0][1] = r1; }
+                        else if (sd == 1) { xP[0][0] += r0; xP[0][1] += r1; xP[1][0] = r0; xP[1][1] = r1; }
+                        else if (sd == 2) { xP[0][0] += r0; xP[0][1] += r1; xP[1][0] -= r0; xP[1][1] -= r1; }
+                        else { xP[1][0] -= r0; xP[1][1] -= r1; }
+                    }
+                }
                 if (step + 1 < NSTEPS) {
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
@@ -743,6 +832,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                         for (int t = 0; t < 4; ++t) T[h][t] = Tn[h][t];
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (FOLD && gi % 3 == 2 && (O16 || (step & 1) == 1)) {      // last step of depth transform sd
+                    fold_sd(sd, acc[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
 
             W2STAMP(6);
@@ -760,29 +853,58 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
 #pragma unroll
                     for (int k = 0; k < 4; ++k) r[k] = lds_x[s * SL_VOX + (row0 + k) * IN_W + kwc + pi];
                     const float t[4] = {r[0] - r[2], r[1] + r[2], r[2] - r[1], r[1] - r[3]};
+                    if (FOLD) {
+                        // the scalar channel's products of depth transform s on their own (C = 0) and folded like the others: the output
+                        // transform is linear.  (They cannot join the tap loop: lds_x is published by the in-loop barrier only.)
+                        f32x4 ax[4][NHW];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int x = 0; x < NHW; ++x) {
+                                const float w = q == 0 ? wx[x].x : q == 1 ? wx[x].y : q == 2 ? wx[x].z : wx[x].w;
+                                ax[q][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, t[q], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                            }
 #pragma unroll
                         for (int x = 0; x < NHW; ++x) {
-                            const float w = q == 0 ? wx[x].x : q == 1 ? wx[x].y : q == 2 ? wx[x].z : wx[x].w;
-                            acc[s][q][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, t[q], acc[s][q][x], 0, 0, 0);
+                            const f32x4 z0 = ax[0][x] + ax[1][x] + ax[2][x], z1 = ax[1][x] - ax[2][x] - ax[3][x];
+                            if (s <= 2) { y0[0][x] += z0; y0[1][x] += z1; }
+                            if (s == 1) { y1[0][x] += z0; y1[1][x] += z1; }
+                            if (s >= 2) { y1[0][x] -= z0; y1[1][x] -= z1; }
                         }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int x = 0; x < NHW; ++x) {
+                                const float w = q == 0 ? wx[x].x : q == 1 ? wx[x].y : q == 2 ? wx[x].z : wx[x].w;
+                                acc[s][q][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, t[q], acc[s][q][x], 0, 0, 0);
+                            }
+                    }
+                    if (XOUT && nh0 == 0) {              // (uniform) scalar input channel x 33rd output channel: column tap kw = g, once per row pair
+                        const float4 ux = *reinterpret_cast<const float4*>(lds_wxo + 24 * 4 * 4 * 16 + (s * 4 + g) * 16);
+                        const float m0 = t[0] * ux.x, m1 = t[1] * ux.y, m2 = t[2] * ux.z, m3 = t[3] * ux.w;
+                        const float r0 = m0 + m1 + m2, r1 = m1 - m2 - m3;
+                        if (s <= 2) { xP[0][0].x += r0; xP[0][1].x += r1; }
+                        if (s == 1) { xP[1][0].x += r0; xP[1][1].x += r1; }
+                        if (s >= 2) { xP[1][0].x -= r0; xP[1][1].x -= r1; }
+                    }
                 }
             }
-            // ---- output transform A^T m A ----
-            f32x4 y0[2][NHW], y1[2][NHW];
+            // ---- output transform A^T m A (FOLD: done, one depth transform at a time, inside the loop) ----
+            if (!FOLD) {
 #pragma unroll
-            for (int x = 0; x < NHW; ++x) {
-                f32x4 z[4][2];
+                for (int x = 0; x < NHW; ++x) {
+                    f32x4 z[4][2];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    z[s][0] = acc[s][0][x] + acc[s][1][x] + acc[s][2][x];
-                    z[s][1] = acc[s][1][x] - acc[s][2][x] - acc[s][3][x];
-                }
+                    for (int s = 0; s < 4; ++s) {
+                        z[s][0] = acc[s][0][x] + acc[s][1][x] + acc[s][2][x];
+                        z[s][1] = acc[s][1][x] - acc[s][2][x] - acc[s][3][x];
+                    }
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    y0[m][x] = z[0][m] + z[1][m] + z[2][m];
-                    y1[m][x] = z[1][m] - z[2][m] - z[3][m];
+                    for (int m = 0; m < 2; ++m) {
+                        y0[m][x] = z[0][m] + z[1][m] + z[2][m];
+                        y1[m][x] = z[1][m] - z[2][m] - z[3][m];
+                    }
                 }
             }
             if (O16) {
@@ -795,8 +917,26 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                     xw[m * 64] = make_float4(snd[0], snd[1], snd[2], snd[3]);
                 }
             }
-            if (has_next || O16) {
+            float xo = 0.f;
+            if (XOUT) {
+                // sum over the four lane groups (the k range of an MFMA), transposing on the way: lane group g ends up with value g of
+                // (plane 0 row 0, plane 0 row 1, plane 1 row 0, plane 1 row 1) -- three shuffles instead of eight
+                const float a = xP[0][0].x + xP[0][0].y, b = xP[0][1].x + xP[0][1].y, c = xP[1][0].x + xP[1][0].y, d = xP[1][1].x + xP[1][1].y;
+                const bool g1 = (g & 1) != 0, g2 = (g & 2) != 0;
+                const float k0 = (g1 ? b : a) + __shfl_xor(g1 ? a : b, 16);
+                const float k1 = (g1 ? d : c) + __shfl_xor(g1 ? c : d, 16);
+                xo = (g2 ? k1 : k0) + __shfl_xor(g2 ? k0 : k1, 32);
+                if (nh0 == 1) lds_xo[((tl_tile & 1) * 4 + rp) * 64 + lane] = xo;       // (double-buffered by tile parity: the partner reads it behind the barrier)
+            }
+            if (has_next || O16 || XOUT) {
                 lds_barrier();                            // every wave has read slice 3 for the last time; slices 0..2 (rewritten in the loop) are visible
+            }
+            if (XOUT && nh0 == 0) {
+                xo += lds_xo[((tl_tile & 1) * 4 + rp) * 64 + lane];
+                const int dd = d0 + (g >> 1), y = th0 + row0 + (g & 1), x = tw0 + pi;
+                const int act2 = 32 < p.act_split ? p.act_a : p.act_b;
+                if (dd < D && y < H && x < W)
+                    p.out_extra[((size_t)n * D + dd) * HW + (size_t)y * W + x] = act_apply(xo * p.scale[32] + p.shift[32], act2);
             }
             if (O16) {
                 const float4* xr = reinterpret_cast<const float4*>(lds_xch) + ((wave ^ 4) * 2) * 64 + lane;
@@ -874,9 +1014,13 @@ extern "C" int estd_conv3d_k3_wino2(const estd_conv3d_desc* dp, estd_stream_t s)
     }
     if (!d.out_main) return ESTD_ERR_ARG;
     // 32 input channels on the MFMA (+ an optional scalar 33rd input channel), 32 or 16 output channels; no 33rd output channel, no fused head
-    if (d.cin_main != 32 || (d.n_tiles != 2 && d.n_tiles != 1) || d.out_head || d.out_extra) return ESTD_ERR_UNSUPPORTED;
+    if (d.cin_main != 32 || (d.n_tiles != 2 && d.n_tiles != 1 && d.n_tiles != 3) || d.out_head) return ESTD_ERR_UNSUPPORTED;
     const bool o16 = d.n_tiles == 1;                 // 32 -> 16 (the GRU output convolution)
     const bool extra = d.in_extra != nullptr;
+    const bool xout = d.n_tiles == 3;                // 33 -> 33 (dres2): w_xout in pack_conv3d_wino2_xout form
+    if (xout && (!extra || !d.out_extra || !d.w_xout)) return ESTD_ERR_ARG;
+    if (!xout && d.out_extra) return ESTD_ERR_UNSUPPORTED;
+    if (xout && (d.residual || d.residual2 || d.accumulate || d.out_scale != 1.0f || d.stats_partials)) return ESTD_ERR_UNSUPPORTED;
     if (o16 && (extra || d.out_stride < 16)) return ESTD_ERR_UNSUPPORTED;
     if (extra != (d.w_extra != nullptr)) return ESTD_ERR_ARG;
     if (extra && d.stats_partials) return ESTD_ERR_UNSUPPORTED;
@@ -906,6 +1050,10 @@ extern "C" int estd_conv3d_k3_wino2(const estd_conv3d_desc* dp, estd_stream_t s)
     } while (0)
     if (o16) {                                       // 8-wave form only
         if (rb) ESTD_W2_LAUNCH(8, 3, false, true); else ESTD_W2_LAUNCH(8, 0, false, true);
+    } else if (xout) {
+        estd_allow_dynamic_lds<conv3d_wino2_kernel<8, 0, true, false, true>>(XOUT_LDS_BYTES);
+        hipLaunchKernelGGL((conv3d_wino2_kernel<8, 0, true, false, true>), dim3(grid), dim3(512), XOUT_LDS_BYTES, estd_stream(s), d,
+                           tiles_w, tiles_h, dpairs, (int)total);
     } else if (extra) {                              // 8-wave form only (the key || value convolution)
         if (rb) ESTD_W2_LAUNCH(8, 3, true, false); else ESTD_W2_LAUNCH(8, 0, true, false);
     } else if (nw == 8) {

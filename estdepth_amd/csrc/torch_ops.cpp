@@ -187,7 +187,7 @@ void conv3d_k3(const Tensor& x, const OptTensor& x_extra, const Tensor& w_main, 
         d.stats_partials = stats_partials->data_ptr<double>();
     }
     // variant: 0 = direct fp32 MFMA; 1 = exact 3 x bf16 operand split (w_alt = split weights); 2 = fp32 MFMA with the depth
-    // axis in Winograd F(2,3) form (w_alt = transformed filters); 3 = depth and row axis in Winograd form (plain 32 -> 32 only)
+    // axis in Winograd F(2,3) form (w_alt = transformed filters); 3 = depth and row axis in Winograd form (w_extra / w_xout in that kernel's packing)
     if (variant != 0) TORCH_CHECK(w_alt.has_value() && w_alt->defined() && w_alt->is_cuda(), "conv3d_k3: this variant needs its packed weights");
     if (variant == 1) {
         d.w_split = w_alt->data_ptr();

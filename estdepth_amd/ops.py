@@ -75,9 +75,11 @@ CONV3D_ARITH = os.environ.get("ESTD_CONV3D_ARITH", "f32")
 CONV2D_ARITH = os.environ.get("ESTD_CONV2D_ARITH", "f32")     # same choice for the 3x3 / dilation-1 NHWC convolutions
 # Algorithm of the plain 32->32 3x3x3 convolutions under CONV3D_ARITH == "f32" (every product an fp32 MFMA either way):
 # "wino2" = depth AND row axis in Winograd F(2,3) form for the plain 32 -> 32 instance, 0.444 of the products
-# (csrc/conv3d_wino2.hip; the 33-channel instances take the "wino" kernel); "wino" = depth axis only, 2/3 of the products
+# (csrc/conv3d_wino2.hip, every 3x3x3 instance of the step); "wino" = depth axis only, 2/3 of the products
 # (csrc/conv3d_wino.hip); "direct" = 27 taps (csrc/conv3d_mfma.hip)
 CONV3D_ALGO = os.environ.get("ESTD_CONV3D_ALGO", "wino2")
+# A/B: "0" sends the 33 -> 33 convolution (dres2) to the depth-only Winograd kernel as in round 3
+W2_XOUT = os.environ.get("ESTD_W2_XOUT", "1") != "0"
 # same choice for the 3x3 / dilation-1 NHWC convolutions: row axis in Winograd F(2,3) form (csrc/conv2d_wino.hip) or direct
 CONV2D_ALGO = os.environ.get("ESTD_CONV2D_ALGO", "wino2")
 CONV2D_NT = os.environ.get("ESTD_CONV2D_NT", "auto")
@@ -217,9 +219,11 @@ class Conv3dPlan:
         self.w_wino = packing.pack_conv3d_wino(weight, main_idx, out_idx[:32]).to(device) if wino_ok else None
         self.w_wino_extra = packing.pack_conv3d_wino_extra(weight, extra_idx, out_idx[:32]).to(device) if (wino_ok and extra_idx is not None) else None
         self.w_wino_xout = packing.pack_conv3d_wino_xout(weight, main_idx, extra_idx, out_idx[32]).to(device) if (wino_ok and n_tiles == 3) else None
-        self.w_wino2 = packing.pack_conv3d_wino2(weight, main_idx, out_idx[:32]).to(device) if (wino_ok and n_tiles == 2) else None
+        self.w_wino2 = packing.pack_conv3d_wino2(weight, main_idx, out_idx[:32]).to(device) if wino_ok else None
         self.w_wino2_extra = packing.pack_conv3d_wino2_extra(weight, extra_idx, out_idx[:32]).to(device) \
-            if (wino_ok and n_tiles == 2 and extra_idx is not None) else None
+            if (wino_ok and extra_idx is not None) else None
+        # 33 -> 33 (dres2): the 33rd output channel of the wino2 kernel's XOUT instance
+        self.w_wino2_xout = packing.pack_conv3d_wino2_xout(weight, main_idx, extra_idx, out_idx[32]).to(device) if (wino_ok and n_tiles == 3) else None
         # 32 -> 16 (the GRU output convolution): the wino2 kernel's 16-output-channel instance
         self.w_wino2_o16 = packing.pack_conv3d_wino2(weight, main_idx, out_idx[:16]).to(device) \
             if (len(main_idx) == 32 and n_tiles == 1 and len(out_idx) == 16 and extra_idx is None and head_w is None) else None
@@ -274,6 +278,8 @@ class Conv3dPlan:
             and (out_extra is not None) == (self.n_tiles == 3) and out_head is None and out_channels == 32 \
             and (stats_partials is None or self.w_extra is None)
         wino2 = wino and CONV3D_ALGO == "wino2" and self.w_wino2 is not None and (in_extra is None or stats_partials is None)
+        if self.n_tiles == 3:                             # the XOUT instance has no read-back streams / statistics (dres2 needs none)
+            wino2 = wino2 and W2_XOUT and residual is None and residual2 is None and not accumulate and float(out_scale) == 1.0 and stats_partials is None
         o16 = (not split) and CONV3D_ALGO == "wino2" and self.w_wino2_o16 is not None and out is not None and out_head is None \
             and in_extra is None and out_channels == 16 and out_extra is None
         # the stereo heads: only the head's logit volume leaves the kernel, no tanh
@@ -286,7 +292,7 @@ class Conv3dPlan:
         with _Prof("conv3d:%d->%d" % (cin, self.n_out), 2.0 * 27 * cin * self.n_out * Nn * D * H * W):
             if _use_torch():
                 T().conv3d_k3(x, in_extra, self.w_main, self.w_wino2_extra if wino2 else self.w_wino_extra if wino else self.w_extra,
-                              self.w_wino_xout if wino else self.w_xout, w_alt, self.scale, self.shift,
+                              (self.w_wino2_xout if wino2 else self.w_wino_xout) if wino else self.w_xout, w_alt, self.scale, self.shift,
                               (Nn, D, H, W), self.cin_main, in_stride, self.n_tiles, self.act_a, self.act_b, self.act_split, out,
                               out_stride, out_channels, residual, residual2, float(out_scale), bool(accumulate), out_extra, head_w, head_b,
                               out_head, stats_partials, variant)
@@ -324,6 +330,7 @@ class Conv3dPlan:
             elif wino2:
                 d.w_wino2 = self.w_wino2.data_ptr()
                 d.w_extra = self.w_wino2_extra.data_ptr() if self.w_wino2_extra is not None else None
+                d.w_xout = self.w_wino2_xout.data_ptr() if self.w_wino2_xout is not None else None
                 N.check(N.lib().estd_conv3d_k3_wino2(ctypes.byref(d), _stream()), "estd_conv3d_k3_wino2")
             elif wino:
                 d.w_wino = self.w_wino.data_ptr()

@@ -355,6 +355,29 @@ def pack_conv3d_wino2_extra(weight, extra_idx, out_idx):
     return torch.from_numpy(out)
 
 
+def pack_conv3d_wino2_xout(weight, main_idx, extra_idx, out_ch):
+    """the 33rd OUTPUT channel of a 33 -> 33 convolution for csrc/conv3d_wino2.hip<EXTRA, XOUT>: float32
+    [24 steps = (3 sd + kw) * 2 + c][4 sh][4 lane groups][4] -- element j of (step, sh, g) = U[sd][sh][out_ch][main_idx[16 c + 4 g + j]][kw], the
+    channels a B-fragment lane of group g holds in chunk c -- followed by the scalar input channel's [4 sd][4 lane groups][4 sh]
+    (element sh of (sd, g) = U[sd][sh][out_ch][extra_idx] at column tap kw = g; g = 3: zero).  U = G g G^T over (kd, kh) as in
+    pack_conv3d_wino2."""
+    w = weight.detach().double().cpu().numpy()[out_ch]               # [Cin, kd, kh, kw]
+    G = np.array([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
+    U = np.einsum("sd,th,idhw->stiw", G, G, w).astype(np.float32)    # [4 sd, 4 sh, Cin, 3 kw]
+    mi = np.asarray(main_idx)
+    out = np.zeros((24 * 4 + 4, 4, 4), np.float32)
+    for sd in range(4):
+        for kw in range(3):
+            for c in range(2):
+                step = (3 * sd + kw) * 2 + c
+                for sh in range(4):
+                    for g in range(4):
+                        out[step * 4 + sh, g] = U[sd, sh, mi[16 * c + 4 * g:16 * c + 4 * g + 4], kw]
+        for g in range(3):
+            out[96 + sd, g] = U[sd, :, extra_idx, g]
+    return torch.from_numpy(out)
+
+
 def pack_conv2d_to16(weight):
     """Conv2d weight [16, cin, 3, 3] (cin = 16 | 32) for csrc/refine2d.hip conv2d_k3_to16_kernel: float32 [9 taps][cin/16][64 lanes][4];
     element ks of lane (g, i) of (tap, half q) = weight[i][16 q + 4 g + ks][ky][kx] -- output channel i as the MFMA's M row, the

@@ -105,7 +105,8 @@ typedef struct estd_conv3d_desc {
     const float* in_extra;    /* [N][D][H][W] scalar input channel, or NULL */
     const float* w_main;      /* packed, see packing.py */
     const float* w_extra;     /* packed extra-channel taps, or NULL */
-    const float* w_xout;      /* n_tiles == 3 only: output channel 32 in A-fragment order (packing.py), else NULL */
+    const float* w_xout;      /* n_tiles == 3 only: output channel 32's weights in the packing of the entry point called (packing.py:
+                               * pack_xout / pack_conv3d_wino_xout / pack_conv3d_wino2_xout), else NULL */
     const float* scale;       /* [n_out] folded BN scale per output channel (n_out = 16, 32 or 33) */
     const float* shift;       /* [n_out] folded BN shift / conv bias */
     int act_a, act_b, act_split;  /* channels < act_split use act_a, others act_b */
@@ -154,7 +155,9 @@ int estd_conv3d_k3_wino(const estd_conv3d_desc* desc, estd_stream_t stream);
  * no in_extra), and cin_main = 16 with n_tiles = 1, head_w / head_b / out_head set and out_main = NULL (16 -> 16 + the fused 1x1x1
  * head, only the logit volume is written: stereo_head0 / stereo_head1, hybrid_depth_decoder.py:96-112; csrc/conv3d_wino2_c16.hip,
  * weights float32 [48 taps][64 lanes][4], packing.py::pack_conv3d_wino2_c16; no residuals / statistics / tanh).
- * Reads w_wino2 (packing.py::pack_conv3d_wino2).  No 33rd output channel: ESTD_ERR_UNSUPPORTED for any other shape. */
+ * n_tiles = 3 with in_extra, w_extra, out_extra and w_xout (packing.py::pack_conv3d_wino2_xout): the 33 -> 33 instance (dres2,
+ * hybrid_depth_decoder.py:106) -- output channel 32 on the VALU from the fragments the MFMAs consume; no read-back streams, no statistics.
+ * Reads w_wino2 (packing.py::pack_conv3d_wino2).  ESTD_ERR_UNSUPPORTED for any other shape. */
 int estd_conv3d_k3_wino2(const estd_conv3d_desc* desc, estd_stream_t stream);
 /* number of thread blocks estd_conv3d_k3 launches for a volume (size of stats_partials / 4 doubles) */
 int estd_conv3d_k3_grid(int N, int D, int H, int W);

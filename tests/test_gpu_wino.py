@@ -156,23 +156,26 @@ def test_wino_extra_input_channel_matches_direct_kernel_and_fp64(dims, algo):
     assert float((a - b).abs().max()) < 5e-6 * max(1.0, mag)
 
 
-@pytest.mark.parametrize("dims", [(1, 4, 8, 32), (3, 5, 13, 50), (2, 1, 9, 33), (1, 64, 24, 32)])
-def test_wino_33_to_33_matches_direct_kernel_and_fp64(dims):
-    """dres2's shape: input = [scalar channel 0 | 32 channels-last], output = 32 channels-last + a scalar 33rd volume (ReLU)."""
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("dims", [(1, 4, 8, 32), (3, 5, 13, 50), (2, 1, 9, 33), (1, 64, 24, 32), (1, 3, 120, 160)])
+def test_wino_33_to_33_matches_direct_kernel_and_fp64(dims, algo):
+    """dres2's shape: input = [scalar channel 0 | 32 channels-last], output = 32 channels-last + a scalar 33rd volume (ReLU).  wino2:
+    the XOUT instance of the 2-axis kernel (the 33rd output channel on the VALU from the row-transformed fragments, split over the
+    two waves of a SIMD, cross-wave sum through LDS)."""
     from estdepth_amd import ops
     N, D, H, W = dims
     g = torch.Generator().manual_seed(3 + sum(dims))
     w = torch.randn(33, 33, 3, 3, 3, generator=g) * 0.05
     sc, sh = torch.rand(33, generator=g) + 0.5, torch.randn(33, generator=g) * 0.1
     plan = ops.Conv3dPlan(w, list(range(1, 33)), 0, list(range(33)), 3, sc, sh, act_a="relu", device=DEV)
-    assert plan.w_wino_xout is not None
+    assert plan.w_wino_xout is not None and plan.w_wino2_xout is not None
     x = torch.randn(N, D, H, W, 32, generator=g)
     e = torch.randn(N, D, H, W, generator=g)
     outs = {}
-    for algo in ("direct", "wino"):
+    for a_ in ("direct", algo):
         ex = torch.full((N, D, H, W), float("nan"), device=DEV)
-        o = _run(plan, algo, x.to(DEV), dims, in_extra=e.to(DEV), out_extra=ex)
-        outs[algo] = torch.cat([o, ex[..., None]], -1)
+        o = _run(plan, a_, x.to(DEV), dims, in_extra=e.to(DEV), out_extra=ex)
+        outs["direct" if a_ == "direct" else "wino"] = torch.cat([o, ex[..., None]], -1)
     full = torch.cat([e[:, None], x.permute(0, 4, 1, 2, 3)], 1).double()
     ref = torch.nn.functional.conv3d(full, w.double(), padding=1) * sc.double()[None, :, None, None, None] + sh.double()[None, :, None, None, None]
     ref = torch.relu(ref).permute(0, 2, 3, 4, 1)

@@ -80,7 +80,12 @@ def case_conv3d():
         ea, eb = torch.full((N, D, H, W), float("nan"), device=DEV), torch.full((N, D, H, W), float("nan"), device=DEV)
         a = run3d(plan, "direct", x, dims, in_extra=e, out=torch.empty_like(x), out_extra=ea)
         b = run3d(plan, "wino", x, dims, in_extra=e, out=torch.empty_like(x), out_extra=eb)
-        a, b = torch.cat([a, ea[..., None]], -1), torch.cat([b, eb[..., None]], -1)
+        ec = torch.full((N, D, H, W), float("nan"), device=DEV)
+        b2 = run3d(plan, "wino2", x, dims, in_extra=e, out=torch.empty_like(x), out_extra=ec)
+        a, b, b2 = torch.cat([a, ea[..., None]], -1), torch.cat([b, eb[..., None]], -1), torch.cat([b2, ec[..., None]], -1)
+        d2 = float((a - b2).abs().max())
+        if not ((d2 == d2) and d2 < 4e-5 * max(1.0, float(a.abs().max()))):
+            return False, ("conv3d", "xout/wino2", dims, d2)
     d = float((a - b).abs().max())
     return (d == d) and d < 4e-5 * max(1.0, float(a.abs().max())), ("conv3d", inst, dims, d)
 

@@ -22,7 +22,7 @@ for algo in ("direct", "wino", "wino2", "wino", "wino2"):
 w = torch.randn(33, 33, 3, 3, 3, generator=g) * 0.05
 plan = ops.Conv3dPlan(w, list(range(1, 33)), 0, list(range(33)), 3, torch.ones(33), torch.zeros(33), act_a="relu", device=dev)
 ex = torch.empty(N, D, H, W, device=dev)
-for algo in ("direct", "wino", "direct", "wino"):
+for algo in ("direct", "wino", "wino2", "wino", "wino2"):
     ops.CONV3D_ALGO = algo
     warm(lambda: plan.run(x, (N, D, H, W), in_extra=e, out=y, out_extra=ex), 0.15)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
