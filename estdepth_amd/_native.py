@@ -62,6 +62,16 @@ class Conv1x1Desc(ctypes.Structure):
     ]
 
 
+class Conv2dTapsDesc(ctypes.Structure):
+    """Mirror of struct estd_conv2d_taps_desc (include/estd_hip.h)."""
+    _fields_ = [
+        ("N", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("cin", ctypes.c_int), ("cout", ctypes.c_int),
+        ("ksize", ctypes.c_int), ("stride", ctypes.c_int), ("pad", ctypes.c_int), ("relu", ctypes.c_int),
+        ("in_", ctypes.c_void_p), ("w", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
+        ("residual", ctypes.c_void_p), ("out", ctypes.c_void_p),
+    ]
+
+
 _SIGNATURES = {
     "estd_version": (ctypes.c_int, []),
     "estd_status_string": (ctypes.c_char_p, [ctypes.c_int]),
@@ -106,6 +116,10 @@ _SIGNATURES = {
     "estd_gru_blend": (ctypes.c_int, [c_float_p] * 10 + [ctypes.c_int, ctypes.c_int64, c_stream]),
     "estd_bn_act_nhwc": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, c_stream]),
     "estd_conv1x1_nhwc": (ctypes.c_int, [ctypes.POINTER(Conv1x1Desc), c_stream]),
+    "estd_conv2d_taps_nhwc": (ctypes.c_int, [ctypes.POINTER(Conv2dTapsDesc), c_stream]),
+    "estd_stem7x7s2_nhwc": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
+    "estd_maxpool3x3s2_nhwc": (ctypes.c_int, [c_float_p, c_float_p] + [ctypes.c_int] * 4 + [c_stream]),
+    "estd_avgpool_nhwc": (ctypes.c_int, [c_float_p, c_float_p] + [ctypes.c_int] * 5 + [c_stream]),
     "estd_conv2d_small_nhwc": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p] + [ctypes.c_int] * 8 + [c_stream]),
     "estd_conv2d_k3_to16_nhwc": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.c_int, c_stream]),

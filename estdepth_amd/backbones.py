@@ -65,6 +65,8 @@ def conv1x1_gemm(conv, x):
 
 
 HIP_STEM = os.environ.get("ESTD_HIP_STEM", "1") == "1"       # A/B switch: PSM first layer on csrc/refine2d.hip
+HIP_STEM7 = os.environ.get("ESTD_HIP_STEM7", "1") == "1"     # A/B switch: the semantic ResNet's 7x7 stem on csrc/conv2d_taps.hip
+HIP_POOL = os.environ.get("ESTD_HIP_POOL", "1") == "1"       # A/B switch: max / average pooling of the 2D branches on csrc/conv2d_taps.hip
 GEMM_EPILOGUE = os.environ.get("ESTD_GEMM_EPILOGUE", "1") == "1"     # A/B switch, read once at import
 # 1x1 convolutions of the fused-BN path on csrc/conv1x1.hip (conv + BN + residual + ReLU in one launch): "all" (default) = every 1x1
 # convolution with cin % 16 == 0 and cout % 32 == 0 -- no library GEMM and no separate BatchNorm pass left in the ResNet branch's 1x1 layers;
@@ -102,6 +104,17 @@ def conv1x1_bn_gemm(conv, bn, x, relu):
     x2 = x.permute(0, 2, 3, 1).reshape(n * h * w, cin)
     y = torch._addmm_activation(c[2], x2, c[1], use_gelu=False) if relu else torch.addmm(c[2], x2, c[1])
     return y.view(n, h, w, conv.out_channels).permute(0, 3, 1, 2)
+
+
+# k x k convolutions outside the tiled kernels (stride 2, or maps with too few tiles) on csrc/conv2d_taps.hip: "1" (default) | "0" = library (A/B)
+HIP_TAPS = os.environ.get("ESTD_HIP_TAPS", "1") == "1"
+
+
+def _hip_taps_ok(conv):
+    k = conv.kernel_size[0]
+    return HIP_TAPS and conv.kernel_size == (k, k) and k in (3, 5) and conv.stride in ((1, 1), (2, 2)) and conv.dilation == (1, 1) \
+        and conv.groups == 1 and conv.bias is None and conv.padding[0] == conv.padding[1] and conv.in_channels % 16 == 0 \
+        and conv.out_channels % 32 == 0 and conv.weight.is_cuda
 
 
 def _is_1x1(conv):
@@ -165,6 +178,19 @@ def conv_bn_act(conv, bn, x, relu, residual=None):
         xn = x.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
         rn = residual.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1) if residual is not None else None
         return ops.conv1x1_nhwc(xn, c[1], sc, sh, conv.stride[0], relu, rn).permute(0, 3, 1, 2)
+    if _hip_taps_ok(conv):
+        # k x k, stride 1 | 2 (the stride-2 3x3 convolutions of layer2..4, 3x3 convolutions on maps too small for the tiled kernels):
+        # conv + BN [+ residual] [+ ReLU] in ONE launch of csrc/conv2d_taps.hip
+        from . import packing
+        key = (conv.weight.device, conv.weight._version, conv.weight.data_ptr())
+        c = conv.__dict__.get("_estd_wtaps")
+        if c is None or c[0] != key:
+            c = (key, packing.pack_conv2d_taps(conv.weight).to(conv.weight.device))
+            conv.__dict__["_estd_wtaps"] = c
+        sc, sh = _folded(bn)
+        xn = x.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        rn = residual.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1) if residual is not None else None
+        return ops.conv2d_taps_nhwc(xn, c[1], sc, sh, conv.kernel_size[0], conv.stride[0], conv.padding[0], relu, rn).permute(0, 3, 1, 2)
     if GEMM_EPILOGUE and residual is None and _is_1x1(conv) and conv.bias is None:
         return conv1x1_bn_gemm(conv, bn, x, relu)
     y = conv1x1_gemm(conv, x) if _is_1x1(conv) else conv(x)
@@ -349,8 +375,14 @@ class PSMFeatures(nn.Module):
             # SPP pyramid (windows 4, 8, 16, 32; psm_submodule.py:100-110) from ONE pass over the map: the coarser windows are
             # aligned unions of 4x4 cells, so their means are means of cell means (ATen's NHWC avg_pool2d walks the 49 MB map
             # once per branch and takes up to 290 us for the 32x32 windows)
-            p4 = F.avg_pool2d(skip_nchw, 4, 4)
-            pooled = {4: p4, 3: F.avg_pool2d(p4, 2, 2), 2: F.avg_pool2d(p4, 4, 4), 1: F.avg_pool2d(p4, 8, 8)}
+            if HIP_POOL and skip.shape[3] % 4 == 0:
+                from . import ops
+                p4 = ops.avgpool_nhwc(skip.contiguous(), 4)
+                pooled = {4: self._nchw(p4), 3: self._nchw(ops.avgpool_nhwc(p4, 2)), 2: self._nchw(ops.avgpool_nhwc(p4, 4)),
+                          1: self._nchw(ops.avgpool_nhwc(p4, 8))}
+            else:
+                p4 = F.avg_pool2d(skip_nchw, 4, 4)
+                pooled = {4: p4, 3: F.avg_pool2d(p4, 2, 2), 2: F.avg_pool2d(p4, 4, 4), 1: F.avg_pool2d(p4, 8, 8)}
         if pooled is not None and SPP_FUSED:
             from . import ops
             brs = [self._nhwc(self._branch(i, skip_nchw, pooled)) for i in (4, 3, 2, 1)]
@@ -485,10 +517,39 @@ class SemanticEncoder(nn.Module):
         if num_layers > 34:
             self.num_ch_enc[1:] *= 4
 
+    def _stem_hip(self, x):
+        """conv1 (3 -> 64, 7x7, stride 2, padding 3) + bn1 + relu on csrc/conv2d_taps.hip::stem7x7s2_nhwc_kernel; None when the layer
+        is not that shape (e.g. num_input_images > 1) or the switch is off."""
+        c0 = self.encoder.conv1
+        if not HIP_STEM7 or (c0.in_channels, c0.out_channels, c0.kernel_size, c0.stride, c0.padding, c0.dilation) != \
+                (3, 64, (7, 7), (2, 2), (3, 3), (1, 1)) or c0.bias is not None:
+            return None
+        from . import ops, packing
+        key = (c0.weight.data_ptr(), c0.weight._version, c0.weight.device)
+        cw = c0.__dict__.get("_estd_w7")
+        if cw is None or cw[0] != key:
+            cw = (key, packing.pack_stem7x7(c0.weight).to(c0.weight.device))
+            c0.__dict__["_estd_w7"] = cw
+        sc, sh = _folded(self.encoder.bn1)
+        xn = x.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+        return ops.stem7x7s2_nhwc(xn, cw[1], sc, sh).permute(0, 3, 1, 2)
+
     def forward(self, x):
         e = self.encoder
-        f0 = conv_bn_act(e.conv1, e.bn1, x, relu=True) if fused_on(self, x) else e.relu(e.bn1(e.conv1(x)))
-        f1 = e.layer1(e.maxpool(f0))
+        if fused_on(self, x):
+            f0 = self._stem_hip(x)
+            if f0 is None:
+                f0 = conv_bn_act(e.conv1, e.bn1, x, relu=True)
+            mp = e.maxpool
+            if HIP_POOL and (mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode) == (3, 2, 1, 1, False) and f0.shape[1] % 4 == 0:
+                from . import ops
+                p0 = ops.maxpool3x3s2_nhwc(f0.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+            else:
+                p0 = mp(f0)
+        else:
+            f0 = e.relu(e.bn1(e.conv1(x)))
+            p0 = e.maxpool(f0)
+        f1 = e.layer1(p0)
         f2 = e.layer2(f1)
         f3 = e.layer3(f2)
         f4 = e.layer4(f3)

@@ -419,6 +419,64 @@ Tensor conv1x1_nhwc(const Tensor& x, const Tensor& w2, const OptTensor& scale, c
     return out;
 }
 
+Tensor conv2d_taps_nhwc(const Tensor& x, const Tensor& w_taps, const OptTensor& scale, const OptTensor& shift, int64_t ksize, int64_t stride,
+                        int64_t pad, bool relu, const OptTensor& residual)
+{
+    const OpScope scope(x);
+    TORCH_CHECK(x.dim() == 4 && w_taps.dim() == 3 && w_taps.size(0) == ksize * ksize && w_taps.size(2) == x.size(3),
+                "conv2d_taps_nhwc: NHWC x [N,H,W,cin] and w [k*k,cout,cin] expected");
+    TORCH_CHECK((stride == 1 || stride == 2) && pad >= 0, "conv2d_taps_nhwc: stride 1 or 2, pad >= 0");
+    const int64_t n = x.size(0), h = x.size(1), w = x.size(2), cin = x.size(3), cout = w_taps.size(1);
+    TORCH_CHECK(h + 2 * pad >= ksize && w + 2 * pad >= ksize, "conv2d_taps_nhwc: map smaller than the kernel");
+    const int64_t ho = (h + 2 * pad - ksize) / stride + 1, wo = (w + 2 * pad - ksize) / stride + 1;
+    estd_conv2d_taps_desc d{};
+    d.N = (int)n; d.H = (int)h; d.W = (int)w; d.cin = (int)cin; d.cout = (int)cout;
+    d.ksize = (int)ksize; d.stride = (int)stride; d.pad = (int)pad; d.relu = relu ? 1 : 0;
+    d.in = fptr(x, "x"); d.w = fptr(w_taps, "w");
+    d.scale = opt_fptr(scale, "scale"); d.shift = opt_fptr(shift, "shift");
+    if (d.scale) TORCH_CHECK(scale->numel() == cout, "conv2d_taps_nhwc: scale [cout] expected");
+    if (d.shift) TORCH_CHECK(shift->numel() == cout, "conv2d_taps_nhwc: shift [cout] expected");
+    d.residual = opt_fptr(residual, "residual");
+    if (d.residual) TORCH_CHECK(residual->numel() == n * ho * wo * cout, "conv2d_taps_nhwc: residual must be NHWC [N,Ho,Wo,cout]");
+    Tensor out = new_f32({n, ho, wo, cout}, x);
+    d.out = out.data_ptr<float>();
+    check_status(estd_conv2d_taps_nhwc(&d, cur_stream()), "estd_conv2d_taps_nhwc");
+    return out;
+}
+
+Tensor stem7x7s2_nhwc(const Tensor& x, const Tensor& w_packed, const Tensor& scale, const Tensor& shift)
+{
+    const OpScope scope(x);
+    TORCH_CHECK(x.dim() == 4 && x.size(3) == 3 && w_packed.numel() == 7 * 6 * 4 * 64 && scale.numel() == 64 && shift.numel() == 64,
+                "stem7x7s2_nhwc: NHWC x [N,H,W,3], packed weights [7,6,4,64], scale/shift [64] expected");
+    const int64_t n = x.size(0), h = x.size(1), w = x.size(2);
+    Tensor out = new_f32({n, (h - 1) / 2 + 1, (w - 1) / 2 + 1, 64}, x);
+    check_status(estd_stem7x7s2_nhwc(fptr(x, "x"), fptr(w_packed, "packed weights"), fptr(scale, "scale"), fptr(shift, "shift"), out.data_ptr<float>(),
+                                     (int)n, (int)h, (int)w, cur_stream()), "estd_stem7x7s2_nhwc");
+    return out;
+}
+
+Tensor maxpool3x3s2_nhwc(const Tensor& x)
+{
+    const OpScope scope(x);
+    TORCH_CHECK(x.dim() == 4 && x.size(3) % 4 == 0, "maxpool3x3s2_nhwc: NHWC x [N,H,W,C], C a multiple of 4, expected");
+    const int64_t n = x.size(0), h = x.size(1), w = x.size(2), c = x.size(3);
+    Tensor out = new_f32({n, (h - 1) / 2 + 1, (w - 1) / 2 + 1, c}, x);
+    check_status(estd_maxpool3x3s2_nhwc(fptr(x, "x"), out.data_ptr<float>(), (int)n, (int)h, (int)w, (int)c, cur_stream()), "estd_maxpool3x3s2_nhwc");
+    return out;
+}
+
+Tensor avgpool_nhwc(const Tensor& x, int64_t k)
+{
+    const OpScope scope(x);
+    TORCH_CHECK(x.dim() == 4 && x.size(3) % 4 == 0 && k >= 1 && k <= x.size(1) && k <= x.size(2),
+                "avgpool_nhwc: NHWC x [N,H,W,C], C a multiple of 4, 1 <= k <= min(H, W) expected");
+    const int64_t n = x.size(0), h = x.size(1), w = x.size(2), c = x.size(3);
+    Tensor out = new_f32({n, h / k, w / k, c}, x);
+    check_status(estd_avgpool_nhwc(fptr(x, "x"), out.data_ptr<float>(), (int)n, (int)h, (int)w, (int)c, (int)k, cur_stream()), "estd_avgpool_nhwc");
+    return out;
+}
+
 Tensor conv2d_small_nhwc(const Tensor& x, const Tensor& w_packed, const Tensor& scale, const Tensor& shift, int64_t cout, int64_t ksize,
                          int64_t stride, bool relu)
 {
@@ -636,6 +694,10 @@ TORCH_LIBRARY(estdepth_hip, m)
     m.def("bn_act_nhwc_(Tensor(a!) x, Tensor scale, Tensor shift, bool relu, Tensor? residual) -> Tensor(a!)");
     m.def("spp_upsample_cat(Tensor raw, Tensor skip, Tensor[] branches) -> Tensor");
     m.def("conv1x1_nhwc(Tensor x, Tensor w, Tensor? scale, Tensor? shift, int stride, bool relu, Tensor? residual) -> Tensor");
+    m.def("conv2d_taps_nhwc(Tensor x, Tensor w, Tensor? scale, Tensor? shift, int ksize, int stride, int pad, bool relu, Tensor? residual) -> Tensor");
+    m.def("stem7x7s2_nhwc(Tensor x, Tensor w_packed, Tensor scale, Tensor shift) -> Tensor");
+    m.def("maxpool3x3s2_nhwc(Tensor x) -> Tensor");
+    m.def("avgpool_nhwc(Tensor x, int k) -> Tensor");
     m.def("conv2d_small_nhwc(Tensor x, Tensor w_packed, Tensor scale, Tensor shift, int cout, int ksize, int stride, bool relu) -> Tensor");
     m.def("conv2d_k3_to16_nhwc(Tensor x, Tensor w_packed, Tensor scale, Tensor shift, bool upsample) -> Tensor");
     m.def("normalise_nhwc(Tensor imgs) -> Tensor");
@@ -676,6 +738,10 @@ TORCH_LIBRARY_IMPL(estdepth_hip, CUDA, m)
     m.impl("bn_act_nhwc_", bn_act_nhwc_);
     m.impl("spp_upsample_cat", spp_upsample_cat);
     m.impl("conv1x1_nhwc", conv1x1_nhwc);
+    m.impl("conv2d_taps_nhwc", conv2d_taps_nhwc);
+    m.impl("stem7x7s2_nhwc", stem7x7s2_nhwc);
+    m.impl("maxpool3x3s2_nhwc", maxpool3x3s2_nhwc);
+    m.impl("avgpool_nhwc", avgpool_nhwc);
     m.impl("conv2d_small_nhwc", conv2d_small_nhwc);
     m.impl("conv2d_k3_to16_nhwc", conv2d_k3_to16_nhwc);
     m.impl("normalise_nhwc", normalise_nhwc);

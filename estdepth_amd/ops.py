@@ -587,6 +587,70 @@ def conv1x1_nhwc(x, w2, scale, shift, stride=1, relu=False, residual=None):
     return out
 
 
+def conv2d_taps_nhwc(x, w_taps, scale, shift, ksize, stride=1, pad=None, relu=False, residual=None):
+    """k x k convolution (k = 1|3|5, stride 1|2, zero padding) + folded BN [+ residual] [+ ReLU] of an NHWC map in one launch
+    (csrc/conv2d_taps.hip).  x [N,H,W,cin]; w_taps [k*k,cout,cin] (packing.pack_conv2d_taps) -> NHWC [N,Ho,Wo,cout]."""
+    pad = ksize // 2 if pad is None else pad
+    if _use_torch():
+        return T().conv2d_taps_nhwc(x, w_taps, scale, shift, int(ksize), int(stride), int(pad), bool(relu), residual)
+    _need_f32_cuda("conv2d_taps_nhwc", x, w_taps)
+    n, h, w, c = x.shape
+    if w_taps.dim() != 3 or w_taps.shape[0] != ksize * ksize or w_taps.shape[2] != c:
+        raise RuntimeError("conv2d_taps_nhwc: NHWC x [N,H,W,cin] and w [k*k,cout,cin] expected")
+    cout = w_taps.shape[1]
+    ho, wo = (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
+    out = torch.empty((n, ho, wo, cout), device=x.device, dtype=torch.float32)
+    d = N.Conv2dTapsDesc()
+    d.N, d.H, d.W, d.cin, d.cout = n, h, w, c, cout
+    d.ksize, d.stride, d.pad, d.relu = int(ksize), int(stride), int(pad), int(bool(relu))
+    d.in_, d.w = _chk(x, "x").data_ptr(), _chk(w_taps, "w").data_ptr()
+    d.scale = scale.data_ptr() if scale is not None else None
+    d.shift = shift.data_ptr() if shift is not None else None
+    if residual is not None:
+        if tuple(residual.shape) != (n, ho, wo, cout):
+            raise RuntimeError("conv2d_taps_nhwc: residual must be NHWC [%d,%d,%d,%d]" % (n, ho, wo, cout))
+        d.residual = _chk(residual, "residual").data_ptr()
+    d.out = out.data_ptr()
+    N.check(N.lib().estd_conv2d_taps_nhwc(ctypes.byref(d), _stream()), "estd_conv2d_taps_nhwc")
+    return out
+
+
+def stem7x7s2_nhwc(x, w_packed, scale, shift):
+    """Conv2d(3, 64, 7, stride 2, padding 3) + folded BatchNorm2d + ReLU on an NHWC image batch [N,H,W,3] -> [N,Ho,Wo,64]
+    (torchvision ResNet conv1 / bn1 / relu, hybrid_models/resnet_encoder.py:42-44); w_packed: packing.pack_stem7x7."""
+    if _use_torch():
+        return T().stem7x7s2_nhwc(x, w_packed, scale, shift)
+    _need_f32_cuda("stem7x7s2_nhwc", x, w_packed, scale, shift)
+    n, h, w, c = x.shape
+    if c != 3 or w_packed.numel() != 7 * 6 * 4 * 64 or scale.numel() != 64 or shift.numel() != 64:
+        raise RuntimeError("stem7x7s2_nhwc: NHWC x [N,H,W,3], packed weights [7,6,4,64], scale/shift [64] expected")
+    out = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, 64), device=x.device, dtype=torch.float32)
+    N.check(N.lib().estd_stem7x7s2_nhwc(_p(x), _p(w_packed), _p(scale), _p(shift), _p(out), n, h, w, _stream()), "estd_stem7x7s2_nhwc")
+    return out
+
+
+def maxpool3x3s2_nhwc(x):
+    """MaxPool2d(3, 2, 1) of an NHWC map [N,H,W,C] (C % 4 == 0) -> [N,(H-1)//2+1,(W-1)//2+1,C]."""
+    if _use_torch():
+        return T().maxpool3x3s2_nhwc(x)
+    _need_f32_cuda("maxpool3x3s2_nhwc", x)
+    n, h, w, c = x.shape
+    out = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), device=x.device, dtype=torch.float32)
+    N.check(N.lib().estd_maxpool3x3s2_nhwc(_p(x), _p(out), n, h, w, c, _stream()), "estd_maxpool3x3s2_nhwc")
+    return out
+
+
+def avgpool_nhwc(x, k):
+    """AvgPool2d(k, k) of an NHWC map [N,H,W,C] (C % 4 == 0) -> [N,H//k,W//k,C]."""
+    if _use_torch():
+        return T().avgpool_nhwc(x, int(k))
+    _need_f32_cuda("avgpool_nhwc", x)
+    n, h, w, c = x.shape
+    out = torch.empty((n, h // k, w // k, c), device=x.device, dtype=torch.float32)
+    N.check(N.lib().estd_avgpool_nhwc(_p(x), _p(out), n, h, w, c, int(k), _stream()), "estd_avgpool_nhwc")
+    return out
+
+
 SMALL_CONV_SHAPES = {(32, 3, 2), (32, 1, 2), (32, 1, 1), (64, 1, 1), (128, 1, 1)}      # (cin, ksize, stride) instances of estd_conv2d_small_nhwc
 
 

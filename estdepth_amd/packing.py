@@ -412,6 +412,33 @@ def pack_conv2d_small(weight):
     return torch.from_numpy(out)
 
 
+def pack_conv2d_taps(weight):
+    """Conv2d weight [cout, cin, k, k] for csrc/conv2d_taps.hip: float32 [k*k taps (ky, kx)][cout][cin] -- per tap the [cout][cin]
+    matrix the 1x1 kernel reads as it lies."""
+    w = weight.detach().float()
+    cout, cin, k = w.shape[0], w.shape[1], w.shape[2]
+    assert w.shape[3] == k
+    return w.permute(2, 3, 0, 1).reshape(k * k, cout, cin).contiguous().cpu()
+
+
+def pack_stem7x7(weight):
+    """Conv2d(3, 64, 7) weight [64, 3, 7, 7] for csrc/conv2d_taps.hip stem7x7s2_nhwc_kernel: float32 [7 rows][6 k-steps][4 channel
+    tiles][64 lanes]; lane (g, i) at k-step s of row ky multiplies slot k = 6 g + s of the window row = channel k % 3 of window
+    pixel kx = k // 3 (kx = 7, the second pixel of lane group 3, is a zero tap) into output channel 16 u + i."""
+    w = weight.detach().float().cpu().numpy()
+    assert w.shape == (64, 3, 7, 7)
+    out = np.zeros((7, 6, 4, 64), np.float32)
+    for lane in range(64):
+        g, i = lane >> 4, lane & 15
+        for s in range(6):
+            k = 6 * g + s
+            kx, ch = k // 3, k % 3
+            if kx < 7:
+                for u in range(4):
+                    out[:, s, u, lane] = w[16 * u + i, ch, :, kx]
+    return torch.from_numpy(out)
+
+
 def pack_conv2d_wino(weight, group_tiles):
     """3x3 Conv2d weight [Cout, Cin, 3, 3] for csrc/conv2d_wino.hip: the row taps g0, g1, g2 of every kw column in Winograd
     F(2,3) form U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2 (float64, rounded once to float32), packed as

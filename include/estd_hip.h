@@ -324,6 +324,36 @@ typedef struct estd_conv1x1_desc {
     float* out;               /* [N][Ho][Wo][cout] */
 } estd_conv1x1_desc;
 int estd_conv1x1_nhwc(const estd_conv1x1_desc* desc, estd_stream_t stream);
+/* k x k convolution (k = 1 | 3 | 5, stride 1 | 2, zero padding pad) of an NHWC map + folded BatchNorm2d(eval) [+ residual]
+ * [+ ReLU] in ONE launch: the stride-2 3x3 convolutions of the semantic ResNet's layer2..4 (hybrid_models/resnet_encoder.py:40-51
+ * over torchvision's Bottleneck.conv2 / BasicBlock.conv1 + bn + relu) and the 3x3 convolutions on maps too small for the tiled
+ * Winograd kernels (hybrid_models/hybrid_depth_decoder.py:17-30 ConvBlock on the 1/32 map).  cin a multiple of 16, cout a multiple
+ * of 32; Ho = (H + 2 pad - ksize) / stride + 1.  w: packing.pack_conv2d_taps = [ksize*ksize taps][cout][cin].  Other shapes:
+ * ESTD_ERR_UNSUPPORTED (csrc/conv2d_taps.hip). */
+typedef struct estd_conv2d_taps_desc {
+    int N, H, W;              /* input map */
+    int cin, cout;
+    int ksize, stride, pad;
+    int relu;                 /* 1: ReLU after the (residual) add */
+    const float* in;          /* [N][H][W][cin] */
+    const float* w;           /* [ksize*ksize][cout][cin] */
+    const float* scale;       /* [cout] folded BN scale, or NULL (= 1) */
+    const float* shift;       /* [cout] folded BN shift / bias, or NULL (= 0) */
+    const float* residual;    /* [N][Ho][Wo][cout] added before the ReLU, or NULL */
+    float* out;               /* [N][Ho][Wo][cout] */
+} estd_conv2d_taps_desc;
+int estd_conv2d_taps_nhwc(const estd_conv2d_taps_desc* desc, estd_stream_t stream);
+/* first layer of the semantic ResNet (torchvision conv1 = Conv2d(3, 64, 7, stride 2, padding 3) + bn1 + relu,
+ * hybrid_models/resnet_encoder.py:42-44): in [N][H][W][3] NHWC -> out [N][Ho][Wo][64] NHWC, Ho = (H-1)/2 + 1, Wo = (W-1)/2 + 1.
+ * w_packed: packing.pack_stem7x7 ([7 rows][6 k-steps][4 channel tiles][64 lanes]); scale / shift [64] = folded BatchNorm2d. */
+int estd_stem7x7s2_nhwc(const float* in, const float* w_packed, const float* scale, const float* shift, float* out, int N, int H,
+                        int W, estd_stream_t stream);
+/* MaxPool2d(3, stride 2, padding 1) of an NHWC map (torchvision ResNet.maxpool, resnet_encoder.py:45): in [N][H][W][C] ->
+ * out [N][(H-1)/2+1][(W-1)/2+1][C]; C a multiple of 4; a NaN in a window is the window's result (ATen). */
+int estd_maxpool3x3s2_nhwc(const float* in, float* out, int N, int H, int W, int C, estd_stream_t stream);
+/* AvgPool2d(k, k) of an NHWC map (networks/psm_submodule.py:56-70, the SPP branches): in [N][H][W][C] -> out [N][H/k][W/k][C];
+ * C a multiple of 4; window sum in row-major order, then one division by k*k (ATen's order). */
+int estd_avgpool_nhwc(const float* in, float* out, int N, int H, int W, int C, int k, estd_stream_t stream);
 int estd_conv2d_k3_to16_nhwc(const float* in, const float* w_packed, const float* scale, const float* shift, float* out, int N,
                              int H, int W, int cin, int upsample, estd_stream_t stream);
 /* image normalisation of DepthNetHybrid.forward (hybrid_models/model_hybrid.py:119: imgs = 2 * (imgs / 255.) - 1.):

@@ -90,6 +90,28 @@ def test_conv1x1_desc_struct_layout(libpath, tmp_path):
     assert _native.lib().estd_conv1x1_nhwc(ctypes.byref(_native.Conv1x1Desc()), None) == -1
 
 
+def test_conv2d_taps_desc_struct_layout(libpath, tmp_path):
+    """sizeof/offsetof of estd_conv2d_taps_desc as the C compiler sees it == the ctypes mirror; NULL / empty descriptors are argument errors."""
+    from estdepth_amd import _native
+    src = tmp_path / "layout2.c"
+    names = {"in_": "in"}
+    fields = [f[0] for f in _native.Conv2dTapsDesc._fields_]
+    body = "\n".join('printf("%%zu\\n", offsetof(estd_conv2d_taps_desc, %s));' % names.get(f, f) for f in fields)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "estd_hip.h"\nint main(){printf("%zu\\n", sizeof(estd_conv2d_taps_desc));\n'
+                   + body + "\nreturn 0;}\n")
+    exe = tmp_path / "layout2"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert out[0] == ctypes.sizeof(_native.Conv2dTapsDesc)
+    for f, off in zip(fields, out[1:]):
+        assert getattr(_native.Conv2dTapsDesc, f).offset == off, f
+    assert _native.lib().estd_conv2d_taps_nhwc(None, None) == -1
+    assert _native.lib().estd_conv2d_taps_nhwc(ctypes.byref(_native.Conv2dTapsDesc()), None) == -1
+    assert _native.lib().estd_stem7x7s2_nhwc(None, None, None, None, None, 1, 8, 8, None) == -1
+    assert _native.lib().estd_maxpool3x3s2_nhwc(None, None, 1, 8, 8, 4, None) == -1
+    assert _native.lib().estd_avgpool_nhwc(None, None, 1, 8, 8, 4, 2, None) == -1
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from estdepth_amd import _native
     monkeypatch.setattr(_native, "_lib", None)

@@ -169,3 +169,33 @@ def test_pack_conv2d_small_and_to16_layouts(k, cin, cout):
             g, i = lane >> 4, lane & 15
             for ks in range(4):
                 assert np.array_equal(p16[:, 0, lane, ks], w16[i, 4 * g + ks].reshape(9))
+
+
+def test_stem7x7_and_taps_packers_reproduce_the_convolution():
+    """packing.pack_stem7x7 / pack_conv2d_taps read back with the indexing of csrc/conv2d_taps.hip (lane (g, i) at k-step s of window row ky
+    multiplies slot 6 g + s = channel k % 3 of window pixel k // 3, pixel 7 a zero tap; taps (ky, kx) of [cout][cin] matrices) == conv2d."""
+    import torch.nn.functional as F
+    from estdepth_amd import packing
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(64, 3, 7, 7, generator=g)
+    x = torch.randn(1, 3, 9, 9, generator=g)
+    wp = packing.pack_stem7x7(w).numpy()                                  # [7][6][4][64]
+    ref = F.conv2d(x.double(), w.double(), None, 2, 3)[0, :, 2, 2].numpy()        # output pixel (2, 2): window rows / columns 1..7
+    win = np.zeros((7, 8, 3))
+    win[:, :7] = x[0, :, 1:8, 1:8].permute(1, 2, 0).numpy()
+    win[:, 7] = 1e6                                                       # whatever lies behind the window: must meet a zero weight
+    out = np.zeros(64)
+    for lane in range(64):
+        gg, i = lane >> 4, lane & 15
+        for ky in range(7):
+            for s in range(6):
+                k = 6 * gg + s
+                for u in range(4):
+                    out[16 * u + i] += float(wp[ky, s, u, lane]) * win[ky, k // 3, k % 3]
+    assert np.abs(out - ref).max() < 1e-4
+    w3 = torch.randn(32, 16, 3, 3, generator=g)
+    wt = packing.pack_conv2d_taps(w3)
+    assert tuple(wt.shape) == (9, 32, 16)
+    for ky in range(3):
+        for kx in range(3):
+            assert torch.equal(wt[ky * 3 + kx], w3[:, :, ky, kx])
