@@ -125,6 +125,7 @@ _SIGNATURES = {
                                                 ctypes.c_int, ctypes.c_int, c_stream]),
     "estd_normalise_nhwc": (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_int64, c_stream]),
     "estd_stem3x3s2_nhwc": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
+    "estd_nhwc_to_planes": (ctypes.c_int, [c_float_p, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int64, c_stream]),
     "estd_planes_cat_nhwc": (ctypes.c_int, [c_float_p, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int64, c_stream]),
     "estd_upsample2_cat_nhwc": (ctypes.c_int, [c_float_p, ctypes.c_int, c_float_p, ctypes.c_int, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_stream]),
     "estd_disp_head_nhwc": (ctypes.c_int, [c_float_p, c_float_p, c_float_p, ctypes.c_float, c_float_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

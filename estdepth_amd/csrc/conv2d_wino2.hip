@@ -50,7 +50,13 @@ constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;
 constexpr int TH = 8, TW = 16;
 constexpr int TROWS = 16;                            // 4 transforms x 4 row pairs
 constexpr int NSTEP = 8;                             // steps per 32-channel chunk: (sh, channel half)
-constexpr int WD = 2, WR = 4;                        // weight stream: WD steps ahead, ring slot = step % WR (8 % WR == 0)
+#ifndef ESTD_C2W2_PFS
+#define ESTD_C2W2_PFS 8
+#endif
+#ifndef ESTD_C2W2_WD
+#define ESTD_C2W2_WD 2
+#endif
+constexpr int WD = ESTD_C2W2_WD, WR = 4;             // weight stream: WD steps ahead, ring slot = step % WR (8 % WR == 0, WD < WR)
 
 __device__ __forceinline__ float4 as_float4(u32x4 v) { float4 f; __builtin_memcpy(&f, &v, 16); return f; }
 __device__ __forceinline__ u32x4 as_u32x4(float4 f) { u32x4 v; __builtin_memcpy(&v, &f, 16); return v; }
@@ -235,8 +241,10 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino2_kernel(const estd_conv2d_
                 }
                 // the next brick over the eight steps: rows 0,1 | 2 | 3 | 4 | 5 | 6 | 7 | 8,9 (dilation 2: 0,1 | 2 | 3,4 | 5 | 6,7 | 8 | 9,10 | 11)
                 {
-                    const int r0 = DIL == 1 ? (st == 0 ? 0 : st + 1) : (3 * st + 1) / 2;
-                    const int r1 = DIL == 1 ? ((st == 0 || st == NSTEP - 1) ? r0 + 2 : r0 + 1) : (3 * (st + 1) + 1) / 2;
+                    constexpr int PFS = ESTD_C2W2_PFS;      // the brick's rows go out over the first PFS steps (8: the spread above)
+                    const int r0 = PFS != 8 ? (st < PFS ? st * IN_H / PFS : IN_H) : DIL == 1 ? (st == 0 ? 0 : st + 1) : (3 * st + 1) / 2;
+                    const int r1 = PFS != 8 ? (st < PFS ? (st + 1) * IN_H / PFS : IN_H)
+                                            : DIL == 1 ? ((st == 0 || st == NSTEP - 1) ? r0 + 2 : r0 + 1) : (3 * (st + 1) + 1) / 2;
 #pragma unroll
                     for (int r = r0; r < r1; ++r) pf[r] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[r], pf_soff, 0));
                 }

@@ -53,6 +53,25 @@ __global__ __launch_bounds__(256) void planes_cat_nhwc_kernel(const float* __res
     }
 }
 
+// ---- [N][HW][C] records -> [N][C][HW] planes (the inverse direction), through the same LDS tile ----
+template <int PIX>
+__global__ __launch_bounds__(256) void nhwc_to_planes_kernel(const float* __restrict__ in, int C, float* __restrict__ out, long long HW)
+{
+    extern __shared__ float tile[];                 // [C][PIX + 1]
+    const long long blocks_per_img = (HW + PIX - 1) / PIX;
+    const long long n = blockIdx.x / blocks_per_img;
+    const long long p0 = (blockIdx.x % blocks_per_img) * PIX;
+    for (int e = threadIdx.x; e < C * PIX; e += 256) {
+        const int k = e / C, c = e % C;
+        tile[c * (PIX + 1) + k] = p0 + k < HW ? in[(n * HW + p0 + k) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < C * PIX; e += 256) {
+        const int c = e / PIX, k = e % PIX;
+        if (p0 + k < HW) out[(n * C + c) * HW + p0 + k] = tile[c * (PIX + 1) + k];
+    }
+}
+
 // ---- out[n][y][x] = cat(x[n][y/2][x/2][0..Cx), skip[n][y][x][0..Cs)); one thread per 16-byte chunk ----
 __global__ __launch_bounds__(256) void upsample2_cat_nhwc_kernel(const float4* __restrict__ x, int Cx4, const float4* __restrict__ skip, int Cs4,
                                                                  float4* __restrict__ out, int N, int H, int W)
@@ -454,6 +473,19 @@ extern "C" int estd_planes_cat_nhwc(const float* a, int Ca, const float* b, int 
         hipLaunchKernelGGL(planes_cat_nhwc_kernel<64>, dim3((unsigned)blocks), dim3(256), lds, estd_stream(s), a, Ca, b, Cb, relu_b, out, (long long)HW);
     else
         hipLaunchKernelGGL(planes_cat_nhwc_kernel<32>, dim3((unsigned)blocks), dim3(256), lds, estd_stream(s), a, Ca, b, Cb, relu_b, out, (long long)HW);
+    return ESTD_LAUNCH_CHECK();
+}
+
+extern "C" int estd_nhwc_to_planes(const float* in, int C, float* out, int N, int64_t HW, estd_stream_t s)
+{
+    if (!in || !out || C <= 0 || N <= 0 || HW <= 0) return ESTD_ERR_ARG;
+    const int pix = (size_t)C * 65 * sizeof(float) <= 64 * 1024 ? 64 : 32;
+    const size_t lds = (size_t)C * (pix + 1) * sizeof(float);
+    if (lds > 64 * 1024) return ESTD_ERR_UNSUPPORTED;                                        // <= 496 channels
+    const long long blocks = (long long)N * ((HW + pix - 1) / pix);
+    if (blocks > 0x7fffffffLL) return ESTD_ERR_ARG;
+    if (pix == 64) hipLaunchKernelGGL(nhwc_to_planes_kernel<64>, dim3((unsigned)blocks), dim3(256), lds, estd_stream(s), in, C, out, (long long)HW);
+    else hipLaunchKernelGGL(nhwc_to_planes_kernel<32>, dim3((unsigned)blocks), dim3(256), lds, estd_stream(s), in, C, out, (long long)HW);
     return ESTD_LAUNCH_CHECK();
 }
 

@@ -532,6 +532,16 @@ Tensor stem3x3s2_nhwc(const Tensor& x, const Tensor& weight, const Tensor& scale
     return out;
 }
 
+Tensor nhwc_to_planes(const Tensor& x)
+{
+    const OpScope scope(x);
+    TORCH_CHECK(x.dim() == 4, "nhwc_to_planes: NHWC x [N,H,W,C] expected");
+    const int64_t n = x.size(0), h = x.size(1), w = x.size(2), c = x.size(3);
+    Tensor out = new_f32({n, c, h, w}, x);
+    check_status(estd_nhwc_to_planes(fptr(x, "x"), (int)c, out.data_ptr<float>(), (int)n, h * w, cur_stream()), "estd_nhwc_to_planes");
+    return out;
+}
+
 Tensor planes_cat_nhwc(const Tensor& a, const Tensor& b, bool relu_b)
 {
     const OpScope scope(a);
@@ -702,6 +712,7 @@ TORCH_LIBRARY(estdepth_hip, m)
     m.def("conv2d_k3_to16_nhwc(Tensor x, Tensor w_packed, Tensor scale, Tensor shift, bool upsample) -> Tensor");
     m.def("normalise_nhwc(Tensor imgs) -> Tensor");
     m.def("stem3x3s2_nhwc(Tensor x, Tensor weight, Tensor scale, Tensor shift) -> Tensor");
+    m.def("nhwc_to_planes(Tensor x) -> Tensor");
     m.def("planes_cat_nhwc(Tensor a, Tensor b, bool relu_b) -> Tensor");
     m.def("upsample2_cat_nhwc(Tensor x, Tensor skip) -> Tensor");
     m.def("disp_head_nhwc(Tensor x, Tensor weight, Tensor bias, float depth_max, int upscale) -> Tensor");
@@ -746,6 +757,7 @@ TORCH_LIBRARY_IMPL(estdepth_hip, CUDA, m)
     m.impl("conv2d_k3_to16_nhwc", conv2d_k3_to16_nhwc);
     m.impl("normalise_nhwc", normalise_nhwc);
     m.impl("stem3x3s2_nhwc", stem3x3s2_nhwc);
+    m.impl("nhwc_to_planes", nhwc_to_planes);
     m.impl("planes_cat_nhwc", planes_cat_nhwc);
     m.impl("upsample2_cat_nhwc", upsample2_cat_nhwc);
     m.impl("disp_head_nhwc", disp_head_nhwc);

@@ -150,6 +150,8 @@ class DepthHybridDecoder(nn.Module):
                 x = conv1(ops.upsample2_cat_nhwc(nhwc(x), nhwc(skip)).permute(0, 3, 1, 2))     # cat([upsample(x), skip], 1) in one pass
                 if conv0 is not None:
                     x = conv0(x)
+            if x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous():
+                return ops.nhwc_to_planes(nhwc(x))        # the D-channel NHWC map as the scalar volumes [T,D,H,W] the 3D path reads
             return x
         x = self.upconv_4_0(semantic_features[4])
         x = [upsample(x)]

@@ -695,6 +695,17 @@ def stem3x3s2_nhwc(x, weight, scale, shift):
     return out
 
 
+def nhwc_to_planes(x):
+    """NHWC map [N,H,W,C] -> contiguous NCHW planes [N,C,H,W] (hybrid_depth_decoder.py:162-184: the plane scores as scalar volumes)."""
+    if _use_torch():
+        return T().nhwc_to_planes(x)
+    _need_f32_cuda("nhwc_to_planes", x)
+    n, h, w, c = x.shape
+    out = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
+    N.check(N.lib().estd_nhwc_to_planes(_p(x), c, _p(out), n, h * w, _stream()), "estd_nhwc_to_planes")
+    return out
+
+
 def planes_cat_nhwc(a, b, relu_b=False):
     """torch.cat([a, relu?(b)], 1) of NCHW stacks -> NHWC map [N,H,W,Ca+Cb] (hybrid_depth_decoder.py:268)."""
     if _use_torch():

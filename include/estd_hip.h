@@ -366,6 +366,9 @@ int estd_stem3x3s2_nhwc(const float* in, const float* w, const float* scale, con
                         estd_stream_t stream);
 int estd_planes_cat_nhwc(const float* a, int Ca, const float* b, int Cb, int relu_b, float* out, int N, int64_t HW,
                          estd_stream_t stream);
+/* [N][HW][C] NHWC records -> [N][C][HW] planes: the 2D decoder's plane scores (hybrid_depth_decoder.py:162-184, the last ConvBlock's
+ * D-channel NHWC map) as the scalar volumes [T][D][H][W] the 3D path reads (dres2's 33rd input channel, :268's concatenation). */
+int estd_nhwc_to_planes(const float* in, int C, float* out, int N, int64_t HW, estd_stream_t stream);
 int estd_upsample2_cat_nhwc(const float* x, int Cx, const float* skip, int Cs, float* out, int N, int H, int W,
                             estd_stream_t stream);
 int estd_disp_head_nhwc(const float* in, const float* w, const float* bias, float depth_max, float* out, int N, int H, int W,

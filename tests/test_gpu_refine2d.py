@@ -162,3 +162,21 @@ def test_conv2d_k3_to16_vs_torch_fp64(cin, up, shape):
         ref = torch.relu(bn.double()(conv.double()(xin))).permute(0, 2, 3, 1)
     assert tuple(got.shape) == tuple(ref.shape)
     assert float((got.cpu().double() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(3, 120, 160, 64), (2, 7, 9, 5), (1, 1, 1, 1), (1, 4, 6, 300)])
+def test_nhwc_to_planes_is_a_permuted_copy(shape):
+    """estd_nhwc_to_planes: [N,H,W,C] records -> [N,C,H,W] planes, bit-identical to permute + contiguous, through both bindings."""
+    from estdepth_amd import ops
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(shape[1])).to("cuda")
+    ref = x.permute(0, 3, 1, 2).contiguous()
+    old = ops.BINDING
+    try:
+        for b in ("torch", "ctypes"):
+            ops.BINDING = b
+            out = ops.nhwc_to_planes(x)
+            assert out.is_contiguous() and torch.equal(out, ref)
+    finally:
+        ops.BINDING = old
+    with pytest.raises(RuntimeError):
+        ops.nhwc_to_planes(torch.zeros(1, 2, 2, 600, device="cuda"))       # more channels than the LDS tile holds

@@ -24,7 +24,7 @@ done
 python $R/tools/pmc_json.py $OUT $P          # ${P}_conv3d_pmc.json: what bench.py reads for roofline.traffic (from profiles/)
 bash $R/tools/pmc_collect.sh "FETCH_SIZE WRITE_SIZE" $OUT/${P}_hbm_kernels_pmc.csv -- python $R/tools/hbm_bench.py > /dev/null 2>&1
 # the hardware's own matrix-pipe utilisation counter of every convolution kernel, stand-alone benches
-for b in "conv_bench.py 3 10" "conv_bench.py 1 10" "kv_bench.py" "head_bench.py" "conv2d_bench.py" "conv1x1_bench.py"; do
+for b in "conv_bench.py 3 10" "conv_bench.py 1 10" "kv_bench.py" "head_bench.py" "conv2d_bench.py" "conv1x1_bench.py" "taps_bench.py"; do
   bash $R/tools/pmc_collect.sh "MfmaUtil SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY" /tmp/mfma_one.csv -- python $R/tools/$b > /dev/null 2>&1
   echo "# python tools/$b" >> $OUT/${P}_mfma_util_pmc.csv; grep -v "at::native\|rocclr" /tmp/mfma_one.csv >> $OUT/${P}_mfma_util_pmc.csv
 done
@@ -40,6 +40,7 @@ python tools/kv_bench.py 2>&1 | grep -v amdgpu >> $OUT/${P}_conv_bench.txt
 python tools/conv2d_bench.py 2>&1 | grep -v amdgpu > $OUT/${P}_conv2d_bench.txt
 python tools/psm_small_bench.py 2>&1 | grep -v amdgpu > $OUT/${P}_psm_small_bench.txt
 python tools/conv1x1_bench.py 2>&1 | grep -v amdgpu > $OUT/${P}_conv1x1_bench.txt
+python tools/taps_bench.py 2>&1 | grep -v amdgpu > $OUT/${P}_taps_bench.txt
 # (built here, before the gpurun call: /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/src/mfma_valu_overlap.hip -o tools/bin/mfma_valu_overlap)
 [ -x tools/bin/mfma_valu_overlap ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/src/mfma_valu_overlap.hip -o tools/bin/mfma_valu_overlap
 tools/bin/mfma_valu_overlap > $OUT/${P}_mfma_valu_overlap.txt 2>&1
@@ -58,4 +59,6 @@ ESTD_FORCE_DIST=1 python bench.py --workload estm --no-cpu-baseline --no-alt --n
 python bench.py --gpus 2 --workload cfg1 --steps 5 --warmup 2 2>/dev/null | last > $OUT/${P}_bench_gpus2_codepath.json
 ESTD_CONV2D_ALGO=wino python bench.py --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_conv2d_rowonly.json
 ESTD_HIP_1X1=0 python bench.py --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_lib1x1.json
+ESTD_HIP_TAPS=0 ESTD_HIP_POOL=0 ESTD_HIP_STEM7=0 python bench.py --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_lib2d.json
+ESTD_W2_XOUT=0 python bench.py --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_dres2_wino1.json
 ls -la $OUT

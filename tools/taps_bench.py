@@ -52,3 +52,20 @@ sk = torch.randn(5, 128, 120, 160, device=dev).contiguous(memory_format=torch.ch
 sn = sk.permute(0, 2, 3, 1)
 a = t(lambda: F.avg_pool2d(sk, 4, 4)); b = t(lambda: ops.avgpool_nhwc(sn, 4))
 print("avgpool 4x4 128ch @120x160 x5: ATen %.4f   in-house %.4f ms" % (a, b))
+print("PSM small convolutions (5 images): conv2d_small_kernel vs conv2d_taps / conv1x1")
+from estdepth_amd import packing as _pk
+for (h, w, cin, cout, k, s) in [(240, 320, 32, 64, 3, 2), (240, 320, 32, 64, 1, 2), (120, 160, 128, 32, 1, 1), (120, 160, 64, 128, 1, 1), (30, 40, 128, 32, 1, 1)]:
+    conv = torch.nn.Conv2d(cin, cout, k, s, k // 2, bias=False).to(dev)
+    x = torch.randn(5, h, w, cin, device=dev)
+    sc, sh = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev)
+    a = None
+    if (cin, k, s) in ops.SMALL_CONV_SHAPES:
+        wp = _pk.pack_conv2d_small(conv.weight).to(dev)
+        a = t(lambda: ops.conv2d_small_nhwc(x, wp, sc, sh, cout, k, s, True))
+    if k == 1:
+        w2 = conv.weight.detach().reshape(cout, cin).contiguous()
+        b = t(lambda: ops.conv1x1_nhwc(x, w2, sc, sh, s, True, None))
+    else:
+        wt = _pk.pack_conv2d_taps(conv.weight).to(dev)
+        b = t(lambda: ops.conv2d_taps_nhwc(x, wt, sc, sh, k, s, k // 2, True, None))
+    print("%4dx%-4d %4d->%-4d k%d s%d  small %s   taps/1x1 %.4f" % (h, w, cin, cout, k, s, "%.4f" % a if a else "  -   ", b))
