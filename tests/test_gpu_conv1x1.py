@@ -106,7 +106,8 @@ def test_bottleneck_fused_path(policy):
 def test_semantic_encoder_launches_no_library_gemm():
     """the whole ResNet-50 semantic branch in the default fused path at the benchmark's size (3 images of 480x640): every 1x1
     convolution (csrc/conv1x1.hip) and every stride-1 3x3 convolution (csrc/conv2d_wino2.hip) is in-house -- no hipBLASLt / rocBLAS
-    GEMM; what is left to MIOpen are the 7x7 stem and the three stride-2 3x3 convolutions (4 launches)."""
+    GEMM; the 7x7 stem and the three stride-2 3x3 convolutions are csrc/conv2d_taps.hip's (tests/test_gpu_conv2d_taps.py asserts that NO library
+    kernel is left)."""
     from estdepth_amd import synth
     from estdepth_amd.backbones import SemanticEncoder, enable_fused_bn, enable_hip_3x3
     enc = SemanticEncoder(50, "pretrained").eval()
