@@ -94,7 +94,7 @@ constexpr int NTAPS = 48;
 #endif
 constexpr int WLDS_TAPS = ESTD_W2LDS_TAPS;           // weights of WLDS_TAPS consecutive taps of every tile come from LDS ...
 #ifndef ESTD_W2LDS_T0
-#define ESTD_W2LDS_T0 4     // taps 4..17 = steps 2..8: the plane prefetch (steps 4..9) then sits next to LDS-fed steps -- a weight request behind a plane request waits for HBM (vector-memory loads return in order); T0 = 0: 0.839, 4: 0.823, 6: 0.827, 8: 0.826-0.833, 10: 0.850, 12: 0.845, 16: 0.871 ms (N = 3)
+#define ESTD_W2LDS_T0 0     // with the weights two steps ahead (ESTD_W2BD = 3) the window's place no longer matters for the plain instance and tap 0 is best for the read-back instances (0: 0.806-0.808 / 0.821 / 0.826 / 0.882, 4: 0.808 / 0.832 / 0.840 / 0.890, 2: 0.805-0.808 / 0.841-0.845 / 0.840-0.843 / 0.891 ms plain / + sum / + residual / + 2 residuals).  WITH ONE STEP OF COVER (BD = 2) it was 4: taps 4..17 = steps 2..8: the plane prefetch (steps 4..9) then sits next to LDS-fed steps -- a weight request behind a plane request waits for HBM (vector-memory loads return in order); T0 = 0: 0.839, 4: 0.823, 6: 0.827, 8: 0.826-0.833, 10: 0.850, 12: 0.845, 16: 0.871 ms (N = 3)
 #endif
 constexpr int WLDS_T0 = ESTD_W2LDS_T0;               // ... starting with this tap (32-channel instances; the 16-output-channel instance: tap 0)
 constexpr int WLDS_BYTES = WLDS_TAPS * 4096;         // [tap][2 halves][2 quads][64 lanes][4]
@@ -580,7 +580,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
         constexpr bool DEFER = ESTD_W2DEFER != 0 && (RBK == 0 || (RBK == 1 && (ESTD_W2_RB_DEFER & 1)) || (RBK == 2 && (ESTD_W2_RB_DEFER & 2)) || (RBK == 3 && (ESTD_W2_RB_DEFER & 4)));   // (the generic read-back instance spills in the deferred form)
         // step in front of which slices 0..2 are rewritten (every read of them has been issued: rows are fetched two steps ahead)
         constexpr int RB_STEP = O16 ? (DEFER ? 7 : 9) : (DEFER ? 16 : 18);
-        constexpr int PF_STEP = (DEFER && !O16) ? 4 : 0; // first step of the next-plane prefetch
+#ifndef ESTD_W2PF_STEP
+#define ESTD_W2PF_STEP 4    // (A/B) >= 4: the deferred outputs live in the prefetch registers through steps 0..3; <= 10: six steps of requests in front of the step-16 rewrite
+#endif
+        constexpr int PF_STEP = (DEFER && !O16) ? ESTD_W2PF_STEP : 0; // first step of the next-plane prefetch
         f32x4 py0[2][NHW], py1[2][NHW];
         int pd0 = 0;
         bool have_prev = false;
