@@ -53,6 +53,10 @@ def parse():
                          "the OpenMP oracle and the oneDNN convolutions of the 2D networks down)")
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--graph-memory", default=os.environ.get("ESTD_GRAPH_MEMORY", "zero-copy"), choices=["zero-copy", "copy"],
+                    help="hipGraph replay: zero-copy = memory records are read where they lie and returned in a ring of output buffers "
+                         "(GraphedForward(zero_copy_memory=True), default); copy = static input buffers + a fresh clone per call "
+                         "(two 157 MB device copies per Joint step)")
     ap.add_argument("--conv3d-arith", default=os.environ.get("ESTD_CONV3D_ARITH", "f32"), choices=["f32", "bf16x3"],
                     help="products of the plain 32->32 3D convolutions: native fp32 MFMA (default) or the exact 3-way bf16 "
                          "operand split with six bf16 MFMAs per product block (fp32-level error, opt-in)")
@@ -279,7 +283,10 @@ def stream_bench(args, device, rank, world):
                                    % ("eager launches" if args.no_graph else "hipGraph replay (PSM per frame + window forward)")}}
 
 
-def quick_measure(workload, steps, warmup, device, no_graph=False):
+GRAPH_PRIME = 2      # untimed calls in front of the warm-up steps of a hipGraph run: zero-copy memory alternates between two captures
+
+
+def quick_measure(workload, steps, warmup, device, no_graph=False, zero_copy=True):
     """One of the OTHER single-GPU workloads, timed the same way as the headline (warm-up, K steps between synchronisations, hipGraph
     replay of the whole forward) but without roofline / parity / CPU legs: the numbers beside the headline line."""
     import torch
@@ -289,9 +296,9 @@ def quick_measure(workload, steps, warmup, device, no_graph=False):
     sl, frames, pre_costs, pre_poses = steady_state(model, workload, imgs, poses, intr, sample)
     x_imgs, x_poses = imgs[:, sl].contiguous(), poses[:, sl].contiguous()
     x_sample = {k: v[:, sl] for k, v in sample.items()}
-    fwd = model if no_graph else GraphedForward(model)
+    fwd = model if no_graph else GraphedForward(model, zero_copy_memory=zero_copy)
     with torch.no_grad():
-        for _ in range(warmup):
+        for _ in range(warmup + (0 if no_graph else GRAPH_PRIME)):
             fwd(x_imgs, x_poses, intr, x_sample, pre_costs, list(pre_poses) if pre_poses else None, mode="val")
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -323,7 +330,8 @@ def replay_profile(args):
         env.pop(k, None)
     cmd = [rp, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
            "--workload", args.workload, "--steps", str(steps), "--warmup", "2", "--no-cpu-baseline", "--no-alt",
-           "--conv3d-arith", args.conv3d_arith, "--conv2d-arith", args.conv2d_arith, "--conv3d-algo", args.conv3d_algo] + (["--no-graph"] if args.no_graph else [])
+           "--conv3d-arith", args.conv3d_arith, "--conv2d-arith", args.conv2d_arith, "--conv3d-algo", args.conv3d_algo,
+           "--graph-memory", args.graph_memory] + (["--no-graph"] if args.no_graph else [])
     t0 = time.time()
     try:
         r = subprocess.run(cmd, cwd=tempfile.gettempdir(), env=env, capture_output=True, text=True, timeout=600)
@@ -487,7 +495,8 @@ def main():
     x_sample = {k: v[:, sl] for k, v in sample.items()}
 
     from estdepth_amd.graph import GraphedForward
-    fwd = model if args.no_graph else GraphedForward(model)     # hipGraph replay of the same forward (same kernels)
+    zero_copy = args.graph_memory == "zero-copy"
+    fwd = model if args.no_graph else GraphedForward(model, zero_copy_memory=zero_copy)     # hipGraph replay of the same forward (same kernels)
 
     state = {"pending": None, "fwd": fwd, "allgather": dist_on and not args.no_allgather, "notes": [], "bank": None}
     if force_dist:
@@ -535,6 +544,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if not args.no_graph:
+        for _ in range(GRAPH_PRIME):       # the captures (zero-copy memory alternates between two ring buffers = two captures): untimed set-up
+            step()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -628,8 +640,8 @@ def main():
     if world == 1 and not args.no_alt and (args.conv3d_arith, args.conv2d_arith) == ("f32", "f32"):
         try:
             ops.CONV3D_ARITH = ops.CONV2D_ARITH = "bf16x3"
-            state["fwd"] = model if args.no_graph else GraphedForward(model)
-            for _ in range(args.warmup):
+            state["fwd"] = model if args.no_graph else GraphedForward(model, zero_copy_memory=zero_copy)
+            for _ in range(args.warmup + (0 if args.no_graph else GRAPH_PRIME)):
                 step()
             barrier()
             ta = time.perf_counter()
@@ -704,6 +716,7 @@ def main():
                        "depth_frames_per_step": frames, "input_frames_per_step": x_imgs.shape[1],
                        "input_frames_per_s": round(x_imgs.shape[1] * world * args.steps / elapsed, 3),
                        "launch": "eager" if (args.no_graph or state["fwd"] is model) else "hipGraph replay",
+                       "graph_memory": None if (args.no_graph or state["fwd"] is model) else args.graph_memory,
                        "conv3d_arith": args.conv3d_arith, "conv2d_arith": args.conv2d_arith,
                        "conv3d_algo_32to32": args.conv3d_algo if args.conv3d_arith == "f32" else "direct",
                        "notes": state["notes"],
@@ -752,7 +765,7 @@ def main():
             others = {}
             for name, (k_, w_) in (("estm", (10, 3)), ("cfg5", (5, 2))):
                 try:
-                    others[name] = quick_measure(name, k_, w_, device, args.no_graph)
+                    others[name] = quick_measure(name, k_, w_, device, args.no_graph, zero_copy)
                 except Exception as e:
                     others[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:120])}
             try:

@@ -17,6 +17,17 @@ Contract differences from the eager call (documented, not hidden):
   * memory volumes handed in as ``pre_costs`` are copied into static input buffers (one device copy per volume);
   * ``mode='test'`` (metrics on boolean-masked ground truth) synchronises with the host and cannot be captured:
     it raises.  Run ``mode='val'`` through the graph and evaluate the metrics on the outputs.
+``zero_copy_memory=True`` (opt-in; what bench.py times) removes the two 157 MB device copies per call that the memory contract above
+costs (0.14 ms of a 17.7 ms Joint step):
+  * the memory record a call returns is a VIEW of one of a small ring of output buffers the graph writes directly (no clone).  A
+    buffer is reused only when it is neither an input of the current call nor the buffer the previous call returned, oldest first,
+    and the ring grows on demand -- so a caller that keeps the records it passes back as ``pre_costs`` (the reference's protocols:
+    eval_hybrid_seq.py:160-193 keeps the last ``memory_size`` windows) never sees one change; a record that is NOT passed back is
+    overwritten two calls later at the earliest: clone it to keep it longer;
+  * memory records handed in are read where they lie: a capture is additionally keyed by their addresses and holds a reference to
+    them (ring buffers: a bounded set; at most ``MAX_FOREIGN`` other address sets per call shape, then the static-copy path);
+  * the tensors of ``outputs`` are overwritten by the next call of ANY signature (the captures of a call shape share nothing, but
+    replays alternate between them).
 A capture is keyed by (input shape, number of memory volumes, matching-features given?, mode, convolution arithmetic,
 weights epoch of the model): ``load_state_dict`` / ``.to()`` bump the epoch and force a re-capture; call
 ``invalidate()`` after editing parameters in place.
@@ -29,17 +40,22 @@ from .layers_op import PlanCache
 
 
 class GraphedForward:
-    def __init__(self, model, warmup=2, clone_outputs=False):
+    MAX_FOREIGN = 2          # zero-copy mode: address sets of memory records that do not lie in the ring, per call shape
+
+    def __init__(self, model, warmup=2, clone_outputs=False, zero_copy_memory=False):
         """``clone_outputs=True``: the returned ``outputs`` dict holds fresh tensors (18 device copies of [1,1,Hi,Wi] maps per
-        Joint call) instead of the graph's static output buffers -- a true drop-in for callers that keep outputs across calls."""
+        Joint call) instead of the graph's static output buffers -- a true drop-in for callers that keep outputs across calls.
+        ``zero_copy_memory=True``: see the module docstring."""
         self.model = model
         self.warmup = warmup
         self.clone_outputs = clone_outputs
+        self.zero_copy_memory = zero_copy_memory
         self.memory_logits = None                # after a call: fresh copy of DepthHybridDecoder.memory_logits of that call
         self._graphs = {}
+        self._ring = {}                          # zero-copy mode: kv shape -> {"bufs": [...], "stamp": [...], "last": slot, "clock": n}
 
     def __getattr__(self, name):                 # normalise_images, matchingFeature, ndepths, ... of the wrapped model
-        if name in ("model", "warmup", "_graphs", "clone_outputs", "memory_logits"):
+        if name in ("model", "warmup", "_graphs", "clone_outputs", "memory_logits", "zero_copy_memory", "_ring"):
             raise AttributeError(name)
         return getattr(self.model, name)
 
@@ -47,21 +63,59 @@ class GraphedForward:
         """drop every captured graph (after in-place edits of parameters, which no epoch counter can see)."""
         self._graphs.clear()
 
-    def _signature(self, imgs, pre_costs, mode, matching_features):
+    def _signature(self, imgs, pre_costs, mode, matching_features, placement=(None, None)):
         n_mem = 0 if pre_costs is None else len(pre_costs["keys"])
         from . import ops
         return (tuple(imgs.shape), n_mem, matching_features is not None, mode, ops.CONV3D_ARITH, ops.CONV2D_ARITH,
                 ops.CONV3D_ALGO, getattr(ops, "CONV2D_ALGO", None), getattr(ops, "CONV2D_NT", None),      # a graph bakes the kernel choice in
                 self.model.camera_algebra,
+                placement,                                         # zero-copy mode: (addresses of the memory records, output ring slot)
                 getattr(self.model, "_estd_weights_epoch", 0))     # (last) a captured graph bakes kernel choice and weight buffers in
 
-    def _capture(self, key, imgs, cam_poses, cam_intr, sample, pre_costs, pre_cam_poses, mode, matching_features):
+    def _place_memory(self, imgs, pre_costs, mode, matching_features):
+        """zero-copy mode: where this call reads its memory records and which ring buffer it writes -> (addresses or None, slot)."""
         m = self.model
+        V, Hi, Wi = imgs.shape[1], imgs.shape[3], imgs.shape[4]
+        shape = (V - 2, m.ndepths, Hi // 4, Wi // 4, 32)
+        ring = self._ring.setdefault(shape, {"bufs": [], "stamp": [], "last": None, "clock": 0})
+        resident = {b[-1].data_ptr(): i for i, b in enumerate(ring["bufs"])}      # a call returns the record of its LAST target
+        ptrs, busy = None, set()
+        if pre_costs is not None:
+            kvs = [getattr(v, "_estd_kv", None) if getattr(k, "_estd_kv", None) is getattr(v, "_estd_kv", None) else None
+                   for k, v in zip(pre_costs["keys"], pre_costs["values"])]
+            if all(kv is not None for kv in kvs):
+                ptrs = tuple(kv.data_ptr() for kv in kvs)
+                busy = {resident[q] for q in ptrs if q in resident}
+                if any(q not in resident for q in ptrs):           # records from elsewhere: a bounded number of captures, then the copy path
+                    base = self._signature(imgs, pre_costs, mode, matching_features)
+                    seen = {k[-2][0] for k in self._graphs if k[:-2] == base[:-2] and k[-2][0] is not None
+                            and any(q not in resident for q in k[-2][0])}
+                    if ptrs not in seen and len(seen) >= self.MAX_FOREIGN:
+                        ptrs = None
+        free = [i for i in range(len(ring["bufs"])) if i not in busy and i != ring["last"]]
+        if free:
+            slot = min(free, key=lambda i: ring["stamp"][i])
+        else:
+            ring["bufs"].append(torch.empty(shape, device=imgs.device, dtype=torch.float32))
+            ring["stamp"].append(-1)
+            slot = len(ring["bufs"]) - 1
+        return shape, ptrs, slot
+
+    @staticmethod
+    def _mark_written(ring, slot):
+        ring["clock"] += 1
+        ring["stamp"][slot] = ring["clock"]
+        ring["last"] = slot
+
+    def _capture(self, key, imgs, cam_poses, cam_intr, sample, pre_costs, pre_cam_poses, mode, matching_features, kv_out=None):
+        m = self.model
+        in_place = key[-2][0] is not None            # zero-copy mode: the memory records are read where they lie (a reference is held)
         st = {"imgs": imgs.clone(), "poses": cam_poses.clone(), "intr": cam_intr.clone(),
               "sample": {k: v.clone() for k, v in sample.items()},
               "feats": matching_features.clone() if matching_features is not None else None}
         if pre_costs is not None:
-            st["kv"] = [kv_from_pair(k, v).clone() for k, v in zip(pre_costs["keys"], pre_costs["values"])]
+            st["kv"] = [kv_from_pair(k, v) if in_place else kv_from_pair(k, v).clone()
+                        for k, v in zip(pre_costs["keys"], pre_costs["values"])]
             st["mem_poses"] = [p.clone() for p in pre_cam_poses]
         # Host camera algebra (estdepth_amd/camera.py): the matrices enter stage B as static inputs.  In "device" mode they
         # are formed by kernels inside stage B from the static pose buffers.
@@ -77,7 +131,11 @@ class GraphedForward:
                 pairs = [kv_views(kv) for kv in st["kv"]]
                 pc = {"keys": [k for k, _ in pairs], "values": [v for _, v in pairs]}
                 pp = list(st["mem_poses"])
-            return m.forward_3d(feats, st["poses"], st["intr"], st["sample"], pc, pp, mode, cam_mats=st["cam"])
+            m.CostRegNet.kv_out = kv_out             # zero-copy mode: the kv records of the targets are written into this ring buffer
+            try:
+                return m.forward_3d(feats, st["poses"], st["intr"], st["sample"], pc, pp, mode, cam_mats=st["cam"])
+            finally:
+                m.CostRegNet.kv_out = None
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -97,7 +155,7 @@ class GraphedForward:
         # the replay reads the packed-weight buffers that existed at capture time: keep them alive even if a PlanCache
         # is rebuilt later (stale-but-valid until the epoch check re-captures), never a use-after-free
         st["keepalive"] = [c._plans for c in (getattr(mod, "_cache", None) for mod in m.modules()) if isinstance(c, PlanCache)]
-        for k in [k for k in self._graphs if k[:-1] == key[:-1]]:      # same call shape, older weights epoch
+        for k in [k for k in self._graphs if k[:-2] == key[:-2] and k[-1] != key[-1]]:      # same call shape, older weights epoch
             del self._graphs[k]
         self._graphs[key] = st
         return st
@@ -107,44 +165,49 @@ class GraphedForward:
         if mode != "val":
             raise RuntimeError("GraphedForward replays mode='val' only: mode=%r needs host-side masking/metrics "
                                "(call the model eagerly, or evaluate the metrics on the returned outputs)" % (mode,))
-        key = self._signature(imgs, pre_costs, mode, matching_features)
+        placement, kv_out, ring = (None, None), None, None
+        if self.zero_copy_memory:
+            shape, ptrs, slot = self._place_memory(imgs, pre_costs, mode, matching_features)
+            ring = self._ring[shape]
+            placement, kv_out = (ptrs, slot), ring["bufs"][slot]
+        key = self._signature(imgs, pre_costs, mode, matching_features, placement)
         st = self._graphs.get(key)
         if st is None:
-            st = self._capture(key, imgs, cam_poses, cam_intr, sample, pre_costs, pre_cam_poses, mode, matching_features)
-        # 1. the asynchronous device-to-host copy of the poses goes FIRST into the stream ...
-        pending = self.model.camera_begin(cam_poses, cam_intr, pre_cam_poses)
-        st["imgs"].copy_(imgs)
-        st["poses"].copy_(cam_poses)
-        st["intr"].copy_(cam_intr)
-        for k, v in sample.items():           # unused by mode='val' arithmetic, refreshed anyway so the buffers never go stale
-            st["sample"][k].copy_(v)
-        if matching_features is not None:
-            st["feats"].copy_(matching_features)
-        if pre_costs is not None:
-            # the memory volumes (157 MB each at cfg2 size) are inputs of stage B only: their copies run on a side stream
-            # beside stage A instead of in front of it.  The side stream starts after everything queued so far (the previous
-            # replay of stage B, which reads these buffers; the kernels that produced pre_costs) and stage B waits for it.
-            main = torch.cuda.current_stream()
-            side = st.get("copy_stream")
-            if side is None:
-                side = st["copy_stream"] = torch.cuda.Stream()
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
+            st = self._capture(key, imgs, cam_poses, cam_intr, sample, pre_costs, pre_cam_poses, mode, matching_features, kv_out)
+        # Stage A needs the images only.  Everything else a call hands over -- the poses (their asynchronous device-to-host copy for
+        # the host camera algebra first), intrinsics, ground-truth maps, memory volumes and memory poses -- is an input of the host or of
+        # stage B: those copies go to a side stream that starts after everything queued so far (the previous replay of stage B, which
+        # reads these buffers; the kernels that produced the arguments) and runs BESIDE stage A instead of in front of it (a dozen
+        # 5-10 us copy nodes in series were 0.1 ms of every step with nothing else on the GPU); stage B waits for it.
+        main = torch.cuda.current_stream()
+        side = st.get("copy_stream")
+        if side is None:
+            side = st["copy_stream"] = torch.cuda.Stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            pending = self.model.camera_begin(cam_poses, cam_intr, pre_cam_poses)
+            st["poses"].copy_(cam_poses)
+            st["intr"].copy_(cam_intr)
+            for k, v in sample.items():       # unused by mode='val' arithmetic, refreshed anyway so the buffers never go stale
+                st["sample"][k].copy_(v)
+            if pre_costs is not None:
+                # (157 MB each at cfg2 size; zero-copy mode: the capture reads the records where they lie -- same address, no copy)
                 for dst, k, v in zip(st["kv"], pre_costs["keys"], pre_costs["values"]):
                     src = kv_from_pair(k, v)
                     if src.data_ptr() != dst.data_ptr():
                         dst.copy_(src)
                 for dst, p in zip(st["mem_poses"], pre_cam_poses):
                     dst.copy_(p)
-        # 2. ... then stage A (the 2D networks, ~25 % of a step) is launched; 3. while it runs the host waits for the copy,
-        # composes the camera matrices with the reference's own torch-CPU calls and queues their upload; 4. stage B.
+        st["imgs"].copy_(imgs)
+        if matching_features is not None:
+            st["feats"].copy_(matching_features)
+        # stage A (the 2D networks, ~30 % of a step) is launched; while it runs the host waits for the pose copy, composes the
+        # camera matrices with the reference's own torch-CPU calls and queues their upload; then stage B.
         st["graph_a"].replay()
-        if pre_costs is not None:
-            main.wait_stream(side)
+        main.wait_stream(side)
         if pending is not None:
             # the upload of the composed matrices runs on its own stream BESIDE stage A (the host is ready long before stage A ends):
             # ordered after the previous replay of stage B, which read these buffers; stage B waits for it
-            main = torch.cuda.current_stream()
             up = st.get("upload_stream")
             if up is None:
                 up = st["upload_stream"] = torch.cuda.Stream()
@@ -168,8 +231,12 @@ class GraphedForward:
         self.memory_logits = ml.clone() if ml is not None else None
         if self.clone_outputs:
             outputs = {k: v.clone() for k, v in outputs.items()}
-        # memory handed back to the caller: fresh tensors (they outlive the next replay)
         key_t, value_t = costs["keys"][0], costs["values"][0]
+        if ring is not None:
+            # zero-copy mode: the record lies in the ring buffer this capture writes; it is handed out as it is
+            self._mark_written(ring, placement[1])
+            return outputs, {"keys": [key_t], "values": [value_t]}, [p.clone() for p in cposes]
+        # memory handed back to the caller: fresh tensors (they outlive the next replay)
         kv = getattr(value_t, "_estd_kv", None)
         if kv is not None and getattr(key_t, "_estd_kv", None) is kv:
             k2, v2 = kv_views(kv.clone())

@@ -265,7 +265,11 @@ class DepthHybridDecoder(nn.Module):
         sem = semantic_vs.contiguous()                       # [T,D,H,W]: already a scalar volume
         extra = torch.empty((T, D, H, W), device=dev, dtype=torch.float32)
         P["dres2"].run(b, dims, in_extra=sem, out=a, out_stride=32, out_extra=extra)
-        kv = torch.empty((T, D, H, W, 32), device=dev, dtype=torch.float32)
+        # the kv records of the targets; GraphedForward(zero_copy_memory=True) names the buffer (one of its ring of output buffers:
+        # the record handed on as memory then needs no copy out of the graph's static buffers)
+        kv, self.kv_out = getattr(self, "kv_out", None), None
+        if kv is None or tuple(kv.shape) != (T, D, H, W, 32) or kv.device != dev or kv.dtype != torch.float32 or not kv.is_contiguous():
+            kv = torch.empty((T, D, H, W, 32), device=dev, dtype=torch.float32)
         P["kv"].run(a, dims, in_extra=extra, out=kv, out_stride=32)
         init_logits = torch.empty((T, D, H, W), device=dev, dtype=torch.float32)
         dv = depth_values.reshape(-1)[:D].contiguous().float()

@@ -16,14 +16,17 @@ class ESTMStream:
     def __init__(self, model, lwindow=3, memory_size=2, cache_features=True, graph=False):
         """``graph=True``: replay captured hipGraphs instead of ~330 eager launches per window -- one graph per number of
         memory volumes (0, 1, ..memory_size) for the window forward and one for the per-frame PSM extraction
-        (estdepth_amd.graph); same kernels, same results, returned ``outputs`` live until the next push."""
+        (estdepth_amd.graph); same kernels, same results, returned ``outputs`` live until the next push.  The harness owns the
+        memory protocol, so the replay runs with ``zero_copy_memory=True``: the (costs, poses) a push returns lie in a ring of
+        ``memory_size + 1`` buffers and are read back in place -- they stay valid for ``memory_size`` further pushes (as long as the
+        harness itself uses them); clone them to keep them longer."""
         if lwindow < 3:
             raise RuntimeError("a window needs at least 3 frames (model_hybrid.py:123)")
         self._psm = None                     # None = model.matchingFeature, looked up at call time
         if graph:
             from .graph import GraphedForward, GraphedModule
             if not isinstance(model, GraphedForward):
-                model = GraphedForward(model)
+                model = GraphedForward(model, zero_copy_memory=True)
             self._psm = GraphedModule(model.matchingFeature, owner=model.model)     # keyed on the model's weights epoch
         self.model = model
         self.lwindow = lwindow
