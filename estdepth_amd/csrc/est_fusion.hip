@@ -399,7 +399,16 @@ __global__ __launch_bounds__(1024) void groupnorm_finalize_kernel(const double* 
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
+// A/B switch ESTD_GRU_FAST=1: sigmoid and tanh on the transcendental units (v_exp_f32 / v_rcp_f32, 1 ulp each; 4 and 5 instructions per value
+// where expf + an IEEE division and the device library's tanhf take ~20 and ~30; absolute error <= 2e-7).  Measured NEUTRAL on MI355X
+// (gru_blend 92.9 vs 94.8 us, gru_reset 79.0 vs 80.0 us stand-alone; Joint step 17.40-17.42 vs 17.40 ms, profiles/r4_graph_memory_ab.txt):
+// both kernels are bound by their memory access pattern (64-byte halves of 128-byte records), not by the VALU -- so the default keeps
+// the library functions the oracle uses.
+__device__ __forceinline__ float sigmoid_fast(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
+__device__ __forceinline__ float tanh_fast_(float v) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v * 2.8853900817779268f) + 1.0f); }
+
 // xrh = [x, sigmoid(GN(r_raw)) * h]; one lane per float4 of the 16-channel halves
+template <bool FAST>
 __global__ __launch_bounds__(256) void gru_reset_kernel(const float* __restrict__ xh, const float* __restrict__ ru,
                                                         const float* __restrict__ stats, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ xrh, long long n_vox)
@@ -415,19 +424,14 @@ __global__ __launch_bounds__(256) void gru_reset_kernel(const float* __restrict_
     const float4 g = reinterpret_cast<const float4*>(gamma)[c];
     const float4 b = reinterpret_cast<const float4*>(beta)[c];
     float4 o;
-    o.x = sigmoidf_((r.x - mean) * rstd * g.x + b.x) * h.x;
-    o.y = sigmoidf_((r.y - mean) * rstd * g.y + b.y) * h.y;
-    o.z = sigmoidf_((r.z - mean) * rstd * g.z + b.z) * h.z;
-    o.w = sigmoidf_((r.w - mean) * rstd * g.w + b.w) * h.w;
+    auto sg = [](float v) { return FAST ? sigmoid_fast(v) : sigmoidf_(v); };
+    o.x = sg((r.x - mean) * rstd * g.x + b.x) * h.x;
+    o.y = sg((r.y - mean) * rstd * g.y + b.y) * h.y;
+    o.z = sg((r.z - mean) * rstd * g.z + b.z) * h.z;
+    o.w = sg((r.w - mean) * rstd * g.w + b.w) * h.w;
     reinterpret_cast<float4*>(xrh)[vox * 8 + c] = x;
     reinterpret_cast<float4*>(xrh)[vox * 8 + 4 + c] = o;
 }
-
-// sigmoid and tanh on the transcendental units (v_exp_f32 / v_rcp_f32, 1 ulp each): 4 and 5 instructions per value where expf + an
-// IEEE division and the device library's tanhf take ~20 and ~30 -- the blend kernel evaluates both for every value of a volume and
-// was not at its HBM time with them (85 us for 315 MB).  Absolute error <= 2e-7 on outputs in (0, 1) / (-1, 1); +-inf -> the limits.
-__device__ __forceinline__ float sigmoid_fast(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
-__device__ __forceinline__ float tanh_fast_(float v) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v * 2.8853900817779268f) + 1.0f); }
 
 // out = u * h + (1 - u) * tanh(GN(o)),  u = sigmoid(GN(u_raw))   (transformer/epipolar_transformer.py:47,:82-83)
 template <bool FAST>
@@ -617,12 +621,21 @@ extern "C" int estd_groupnorm_finalize(const double* partials, int n_blocks, dou
     return ESTD_LAUNCH_CHECK();
 }
 
+static bool gru_fast_math()       // A/B switch, read once (default off: measured neutral, see sigmoid_fast)
+{
+    static const bool fast = [] { const char* e = getenv("ESTD_GRU_FAST"); return e && atoi(e) == 1; }();
+    return fast;
+}
+
 extern "C" int estd_gru_reset_apply(const float* xh, const float* ru, const float* stats4, const float* gamma_r,
                                     const float* beta_r, float* xrh, int64_t n_vox, estd_stream_t s)
 {
     if (!xh || !ru || !stats4 || !gamma_r || !beta_r || !xrh || n_vox <= 0) return ESTD_ERR_ARG;
-    hipLaunchKernelGGL(gru_reset_kernel, dim3((unsigned)((n_vox * 4 + 255) / 256)), dim3(256), 0, estd_stream(s),
-                       xh, ru, stats4, gamma_r, beta_r, xrh, (long long)n_vox);
+    const dim3 grid((unsigned)((n_vox * 4 + 255) / 256));
+    if (gru_fast_math())
+        hipLaunchKernelGGL(gru_reset_kernel<true>, grid, dim3(256), 0, estd_stream(s), xh, ru, stats4, gamma_r, beta_r, xrh, (long long)n_vox);
+    else
+        hipLaunchKernelGGL(gru_reset_kernel<false>, grid, dim3(256), 0, estd_stream(s), xh, ru, stats4, gamma_r, beta_r, xrh, (long long)n_vox);
     return ESTD_LAUNCH_CHECK();
 }
 
@@ -633,9 +646,8 @@ extern "C" int estd_gru_blend(const float* xh, const float* ru, const float* o_r
     if (!xh || !ru || !o_raw || !stats_ru4 || !stats_o4 || !gamma_u || !beta_u || !gamma_o || !beta_o || !out_value)
         return ESTD_ERR_ARG;
     if (n_vox <= 0 || out_stride < 16 || (out_stride & 3)) return ESTD_ERR_ARG;
-    static const bool fast = [] { const char* e = getenv("ESTD_GRU_FAST"); return !(e && atoi(e) == 0); }();      // A/B switch, read once
     const dim3 grid((unsigned)((n_vox * 4 + 255) / 256));
-    if (fast)
+    if (gru_fast_math())
         hipLaunchKernelGGL(gru_blend_kernel<true>, grid, dim3(256), 0, estd_stream(s), xh, ru, o_raw, stats_ru4, stats_o4, gamma_u, beta_u,
                            gamma_o, beta_o, out_value, out_stride, (long long)n_vox);
     else
