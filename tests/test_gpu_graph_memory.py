@@ -130,3 +130,35 @@ def test_zero_copy_memory_falls_back_to_the_copy_path_for_ever_new_records():
         keyed = {k[-2][0] for k in gf._graphs if k[-2][0] is not None}
         assert len(keyed) == gf.MAX_FOREIGN
         assert any(k[-2][0] is None for k in gf._graphs)
+
+
+def test_streaming_harness_with_graph_replay_reproduces_estm_golden(golden_dir):
+    """ESTMStream(graph=True) -- hipGraph replay with zero-copy memory (a ring of memory_size + 1 record buffers) and the per-frame PSM
+    graph, what bench.py's `stream` workload times -- fed frame by frame must reproduce the reference's streaming run (G8), and the
+    memory the harness holds must stay what the windows returned."""
+    import os
+    import numpy as np
+    from estdepth_amd.streaming import ESTMStream
+    g = np.load(os.path.join(golden_dir, "g8_estm_stream.npz"))
+    m = _model()
+    imgs, poses, intr, _ = _inputs(6)
+    st = ESTMStream(m, lwindow=3, memory_size=2, cache_features=True, graph=True)
+    assert st.model.zero_copy_memory
+    w, snaps = 0, []
+    for f in range(6):
+        r = st.push(imgs[0, f], poses[0, f], intr[0])
+        if f < 2:
+            assert r is None
+            continue
+        outputs, costs, cposes = r
+        for k, v in outputs.items():
+            name = "w%d|" % w + "|".join(map(str, k))
+            if name in g.files:
+                assert float(np.abs(v.cpu().numpy() - g[name]).max()) < 1e-4, name
+        assert np.array_equal(cposes[0].cpu().numpy(), g["w%d|pose" % w])
+        for rec, snap in snaps:                                  # the records still in the harness's memory are untouched
+            assert torch.equal(rec["values"][0], snap)
+        snaps = (snaps + [(costs, costs["values"][0].clone())])[-2:]
+        w += 1
+    assert w == 4
+    assert len(next(iter(st.model._ring.values()))["bufs"]) == 3

@@ -61,4 +61,7 @@ ESTD_CONV2D_ALGO=wino python bench.py --no-cpu-baseline --no-alt --no-replay-pro
 ESTD_HIP_1X1=0 python bench.py --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_lib1x1.json
 ESTD_HIP_TAPS=0 ESTD_HIP_POOL=0 ESTD_HIP_STEM7=0 python bench.py --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_lib2d.json
 ESTD_W2_XOUT=0 python bench.py --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_dres2_wino1.json
+python bench.py --graph-memory copy --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_graph_copy.json
+python bench.py --workload estm --graph-memory copy --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_estm_graph_copy.json
+timeout 1500 python -m pytest tests/ -q -m gpu > $OUT/${P}_gputests.log 2>&1
 ls -la $OUT
