@@ -32,11 +32,16 @@ A capture is keyed by (input shape, number of memory volumes, matching-features 
 weights epoch of the model): ``load_state_dict`` / ``.to()`` bump the epoch and force a re-capture; call
 ``invalidate()`` after editing parameters in place.
 """
+import os
+
 import torch
 
 from . import camera
 from .hybrid_depth_decoder import kv_from_pair, kv_views
 from .layers_op import PlanCache
+
+
+UPLOAD_STREAM = os.environ.get("ESTD_GRAPH_UPLOAD_STREAM", "side")      # A/B switch, read once at import (see __call__)
 
 
 class GraphedForward:
@@ -204,27 +209,26 @@ class GraphedForward:
         # stage A (the 2D networks, ~30 % of a step) is launched; while it runs the host waits for the pose copy, composes the
         # camera matrices with the reference's own torch-CPU calls and queues their upload; then stage B.
         st["graph_a"].replay()
-        main.wait_stream(side)
         if pending is not None:
-            # the upload of the composed matrices runs on its own stream BESIDE stage A (the host is ready long before stage A ends):
-            # ordered after the previous replay of stage B, which read these buffers; stage B waits for it
-            up = st.get("upload_stream")
-            if up is None:
-                up = st["upload_stream"] = torch.cuda.Stream()
-            if st.get("b_done") is not None:
-                up.wait_event(st["b_done"])
-            else:
-                up.wait_stream(main)                     # first replay: after the capture-time runs that read these buffers
+            # the upload of the composed matrices goes to the same side stream (the host is ready long before stage A ends): it is ordered
+            # after the previous replay of stage B, which read these buffers (the side stream waited for it above), runs BESIDE stage A
+            # on a hardware queue of its own, and stage B waits for it.  (A third stream for the uploads shared the main stream's
+            # hardware queue: its three 5 us copies ran behind stage A, in series with stage B's first kernels.)
+            up = side
+            if UPLOAD_STREAM == "own":                   # A/B: the third stream of before
+                up = st.get("upload_stream")
+                if up is None:
+                    up = st["upload_stream"] = torch.cuda.Stream()
+                up.wait_stream(side)
             with torch.cuda.stream(up):
                 cam = camera.finish(pending)
                 for name, t in cam.items():
                     if t is not None:
                         st["cam"][name].copy_(t)
-            main.wait_stream(up)
+            if up is not side:
+                main.wait_stream(up)
+        main.wait_stream(side)
         st["graph_b"].replay()
-        if st.get("b_done") is None:
-            st["b_done"] = torch.cuda.Event()
-        st["b_done"].record()
         outputs, costs, cposes = st["out"]
         # the logit volume that travels with the memory bank (parallel.allgather_memory_bank*): a fresh 4.9 MB tensor, like the memory
         ml = st.get("memory_logits")
