@@ -586,11 +586,11 @@ def main():
                 return (time.perf_counter() - ta) / reps
             t_ag = exchange_alone(None)                     # the algorithm the timed steps used (ESTD_AG_ALGO, default: one all-gather)
             other = "direct" if parallel.AG_ALGO == "collective" else "collective"
-            try:                                            # the other one beside it: ring-vs-direct on the xGMI mesh is the open question
-                t_other = exchange_alone(other) if world > 1 else None
-            except Exception as e:
-                t_other = None
-                state["notes"].append("exchange algo %s failed alone (%s: %s)" % (other, type(e).__name__, str(e)[:80]))
+            # the other one beside it (ring-vs-direct on the xGMI mesh is the open question) is timed LAST, under a watchdog, when the
+            # line is complete (other_algo_diagnostic below): it is the one call of a multi-GPU run that no timed step has exercised
+            t_other = None
+            if world > 1:
+                state["other_algo"] = (other, exchange_alone)
         nbytes = 4 * (last[1]["keys"][0].numel() + last[1]["values"][0].numel() + 16 + state["logits"].numel())
         ag = {"record": "K||V_fused (%d B) + pose (64 B) + initial logit volume (%d B)" % (4 * 2 * last[1]["keys"][0].numel(), 4 * state["logits"].numel()),
               "bytes_sent_per_rank": nbytes, "algo": parallel.AG_ALGO, "ms_alone": round(1e3 * t_ag, 3),
@@ -788,15 +788,61 @@ def main():
             line["cpu_baseline"] = dict(best)
             line["cpu_baseline"]["all_runs"] = [{"cores": b["cores"], "value": b["value"], "wall_s": b["wall_s"]} for b in runs]
             line["parity"] = parity
+    else:
+        line = None
+
+    def emit():
         try:                               # RCCL's banner sits in the C stdio buffer of a redirected stdout: flush it so that the JSON
             import ctypes                  # line is the LAST line of the output
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
         print(json.dumps(line), flush=True)
+
+    def watchdog(seconds, on_timeout):
+        """runs ``on_timeout`` and ends the process (exit code 0) unless the returned event is set within ``seconds``"""
+        import threading
+        done = threading.Event()
+
+        def dog():
+            if not done.wait(seconds):
+                try:
+                    on_timeout()
+                finally:
+                    os._exit(0)
+        threading.Thread(target=dog, daemon=True).start()
+        return done
+
+    if dist_on and state.get("other_algo") and os.environ.get("ESTD_AG_DIAG", "1") != "0":
+        # every rank: the OTHER exchange algorithm alone.  A hang here (an untested RCCL call pattern at a world size nobody has run)
+        # must not cost the line: after ESTD_AG_DIAG_TIMEOUT seconds rank 0 prints it without the figure and every rank leaves.
+        other, exchange_alone = state["other_algo"]
+        limit = float(os.environ.get("ESTD_AG_DIAG_TIMEOUT", "60"))
+
+        def gave_up():
+            if rank == 0:
+                line["config"]["allgather"]["other_algo"] = {"algo": other, "error": "no result within %.0f s (watchdog)" % limit}
+                emit()
+        done = watchdog(limit, gave_up)
+        try:
+            if os.environ.get("ESTD_AG_DIAG_TEST_HANG") == "1":      # (test hook of the watchdog)
+                time.sleep(1e6)
+            with torch.no_grad():
+                t_other = exchange_alone(other)
+            nb = ag["bytes_sent_per_rank"]
+            res = {"algo": other, "ms_alone": round(1e3 * t_other, 3), "bus_gbs_per_rank": round((world - 1) * nb / t_other / 1e9, 2)}
+        except Exception as e:
+            res = {"algo": other, "error": "%s: %s" % (type(e).__name__, str(e)[:80])}
+        done.set()
+        if rank == 0:
+            line["config"]["allgather"]["other_algo"] = res
+    if rank == 0:
+        emit()
     if dist_on:
+        done = watchdog(30.0, lambda: None)       # the line is out: a rank that never arrives must not keep the others (and the launcher) waiting
         dist.barrier()
         dist.destroy_process_group()
+        done.set()
 
 
 if __name__ == "__main__":

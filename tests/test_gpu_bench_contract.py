@@ -137,3 +137,18 @@ def test_bench_two_ranks_under_an_external_launcher():
            "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--workload", "cfg1", "--steps", "3", "--warmup", "1"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     _check_two_ranks(_last_json(out.stdout))
+
+
+def test_bench_line_survives_a_hanging_exchange_diagnostic():
+    """the other exchange algorithm is timed last, under a watchdog: if it never returns (ESTD_AG_DIAG_TEST_HANG=1 = a sleep in its
+    place on every rank) rank 0 still prints the complete line, says so in `other_algo`, and every rank exits with status 0"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ESTD_AG_DIAG_TEST_HANG="1", ESTD_AG_DIAG_TIMEOUT="5")
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--workload", "cfg1", "--steps", "3", "--warmup", "1"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and len(d["config"]["per_rank_ms_per_step"]) == 2
+    ag = d["config"]["allgather"]
+    assert ag["own_shard_bit_equal"] is True and ag["bus_gbs_per_rank"] > 0
+    assert ag["other_algo"]["algo"] == "direct" and "watchdog" in ag["other_algo"]["error"]
