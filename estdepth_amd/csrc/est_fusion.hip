@@ -196,7 +196,13 @@ struct WarpAttnArgs {
     const float* kv_src[ESTD_MAX_ATTENTION_SOURCES];
 };
 
-template <int NS>
+// BUF: the corner records through buffer loads -- a source volume is one buffer descriptor (4 SGPRs) and a corner is ONE 32-bit byte offset for
+// its value chunk and its key chunk (immediate +64) -- instead of two 64-bit flat addresses per corner: half the address data into the
+// texture-address unit per gather and a third of the address arithmetic.  Volumes of 2 GiB and more take the pointer form.
+typedef unsigned int wa_u32x4 __attribute__((__vector_size__(16)));
+__device__ __forceinline__ float4 wa_as_float4(wa_u32x4 v) { float4 f; __builtin_memcpy(&f, &v, 16); return f; }
+
+template <int NS, bool BUF>
 __global__ __launch_bounds__(256) void warp_attention_kernel(const float* __restrict__ kv_t, WarpAttnArgs srcs,
                                                              const float* __restrict__ mats, int n_src,
                                                              const float* __restrict__ dvals, float depth_min, float depth_interval,
@@ -237,6 +243,16 @@ __global__ __launch_bounds__(256) void warp_attention_kernel(const float* __rest
             const Tri t = volume_coords(mats + j * 30, dep, x, y, depth_min, depth_interval, D, H, W);
             const float4* s4 = reinterpret_cast<const float4*>(srcs.kv_src[j]) + sub;
             float4 cv[8], ck[8];
+            if (BUF) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(srcs.kv_src[j]), 0,
+                                                                                    (int)((long long)D * HW * 128), 0x00020000);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {          // all 16 gathers of this source before any is used
+                    const int vo = t.off[k] * 128 + sub * 16;
+                    cv[k] = wa_as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0));
+                    ck[k] = wa_as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs, vo + 64, 0, 0));
+                }
+            } else {
 #if WA_SHARE
             // Corner sharing across x-neighbours: the texture-address path, not HBM, bounds this kernel (TA busy 90 % of the CU-busy
             // cycles, 31 TA cycles per 64-lane 16-byte gather, profiles/r2_warp_attention_ta_pmc.csv).  The voxel one step further
@@ -278,6 +294,7 @@ __global__ __launch_bounds__(256) void warp_attention_kernel(const float* __rest
                 ck[k] = s4[(long long)t.off[k] * 8 + 4];
             }
 #endif
+            }
             float4 av = make_float4(0.f, 0.f, 0.f, 0.f), ak = av;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -586,8 +603,26 @@ extern "C" int estd_warp_attention(const float* kv_target, const float* const* k
     for (int j = 0; j < n_src; ++j) if (!kv_src[j]) return ESTD_ERR_ARG;
     for (int j = 0; j < ESTD_MAX_ATTENTION_SOURCES; ++j) a.kv_src[j] = kv_src[j < n_src ? j : 0];
     const dim3 grid((unsigned)(((D + WA_TD - 1) / WA_TD) * ((H + WA_TY - 1) / WA_TY) * ((W + WA_TX - 1) / WA_TX)));   // one workgroup per brick
-#define ESTD_WA_LAUNCH(NS) hipLaunchKernelGGL(warp_attention_kernel<NS>, grid, dim3(256), 0, estd_stream(s), kv_target, a, \
-                                              mats_dev, n_src, dvals, depth_min, depth_interval, xh_out, D, H, W)
+    // Buffer-load gathers (BUF) where they measured faster: 3 sources 236-243 -> 220-226 us (same 144 registers, same occupancy: the gain is the
+    // address traffic); 2 sources are SLOWER with them (84 instead of 104 registers -> 6 waves per SIMD: 205 us; capped to the pointer form's 4
+    // by an unused LDS allocation: 190 us; pointer form 182-187 us), 1 source equal, 4 sources need 224 instead of 184 registers (not measured).
+    // ESTD_WA_BUF = 0 | 1 forces the form for every source count, ESTD_WA_OCC = n caps the resident workgroups per CU (sweep: profiles/r4_warp_attention_buf.txt).
+    static const int buf_env = [] { const char* e = getenv("ESTD_WA_BUF"); return e ? atoi(e) : -1; }();             // A/B switches, read once
+    static const int occ_env = [] { const char* e = getenv("ESTD_WA_OCC"); return e ? atoi(e) : 0; }();
+    const bool buf = (buf_env >= 0 ? buf_env != 0 : n_src == 3) && (long long)D * H * W * 128 < 0x7fffffffLL;
+    const int lds = occ_env > 0 ? ((160 * 1024 / occ_env) & ~255) : 0;
+#define ESTD_WA_LAUNCH(NS)                                                                                                              \
+    do {                                                                                                                                \
+        if (buf) {                                                                                                                      \
+            if (lds > 48 * 1024) estd_allow_dynamic_lds<warp_attention_kernel<NS, true>>(160 * 1024);                                   \
+            hipLaunchKernelGGL((warp_attention_kernel<NS, true>), grid, dim3(256), lds, estd_stream(s), kv_target, a, mats_dev,         \
+                               n_src, dvals, depth_min, depth_interval, xh_out, D, H, W);                                               \
+        } else {                                                                                                                        \
+            if (lds > 48 * 1024) estd_allow_dynamic_lds<warp_attention_kernel<NS, false>>(160 * 1024);                                  \
+            hipLaunchKernelGGL((warp_attention_kernel<NS, false>), grid, dim3(256), lds, estd_stream(s), kv_target, a, mats_dev,        \
+                               n_src, dvals, depth_min, depth_interval, xh_out, D, H, W);                                               \
+        }                                                                                                                               \
+    } while (0)
     switch (n_src) {
         case 2: ESTD_WA_LAUNCH(2); break;
         case 3: ESTD_WA_LAUNCH(3); break;
