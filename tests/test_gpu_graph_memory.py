@@ -162,3 +162,38 @@ def test_streaming_harness_with_graph_replay_reproduces_estm_golden(golden_dir):
         w += 1
     assert w == 4
     assert len(next(iter(st.model._ring.values()))["bufs"]) == 3
+
+
+@pytest.mark.parametrize("zero_copy", [False, True])
+def test_new_weights_force_a_recapture(zero_copy):
+    """load_state_dict bumps the model's weights epoch: the next call re-captures (packed weights are baked into a graph) and the
+    captures of the old weights are dropped -- in both memory modes, with every ring position"""
+    from estdepth_amd import synth, DepthNetHybrid
+    from estdepth_amd.graph import GraphedForward
+    m = _model()
+    other = DepthNetHybrid(ndepths=64, depth_min=0.1, depth_max=10.0, resnet=18, IF_EST_transformer=True).eval()
+    synth.fill_state_dict(other, seed=7, head_gain=1.0)
+    sd_b = {k: v.clone() for k, v in other.state_dict().items()}
+    imgs, poses, intr, smp = _inputs(5)
+    sl = slice(1, 4)
+    gf = GraphedForward(m, zero_copy_memory=zero_copy)
+    with torch.no_grad():
+        _, c0, p0 = m(imgs[:, 0:3], poses[:, 0:3], intr, smp(slice(0, 3)), None, None, mode="val")
+        pc = {"keys": [c0["keys"][0].clone()], "values": [c0["values"][0].clone()]}      # plain tensors: the memory does not change with the weights
+        ea, _, _ = m(imgs[:, sl], poses[:, sl], intr, smp(sl), pc, [p0[0]], mode="val")
+        ea = {k: v.clone() for k, v in ea.items()}
+        for _ in range(3):
+            ga, _, _ = gf(imgs[:, sl], poses[:, sl], intr, smp(sl), pc, [p0[0]], mode="val")
+        for k in ea:
+            assert (ea[k] - ga[k]).abs().max().item() < 2e-5, k
+        old_epoch = m._estd_weights_epoch
+        m.load_state_dict(sd_b)
+        assert m._estd_weights_epoch != old_epoch
+        eb, _, _ = m(imgs[:, sl], poses[:, sl], intr, smp(sl), pc, [p0[0]], mode="val")
+        eb = {k: v.clone() for k, v in eb.items()}
+        assert max((ea[k] - eb[k]).abs().max().item() for k in ea) > 1e-3          # the two weight sets give different depths
+        for _ in range(3):
+            gb, _, _ = gf(imgs[:, sl], poses[:, sl], intr, smp(sl), pc, [p0[0]], mode="val")
+            for k in eb:
+                assert (eb[k] - gb[k]).abs().max().item() < 2e-5, k
+    assert all(k[-1] == m._estd_weights_epoch for k in gf._graphs)                  # nothing of the old weights is kept
