@@ -56,6 +56,19 @@ constexpr int NSTEP = 8;                             // steps per 32-channel chu
 #ifndef ESTD_C2W2_WD
 #define ESTD_C2W2_WD 2
 #endif
+// ESTD_C2W2_INLOOP = 1: the row transform + LDS write of the NEXT chunk inside the step loop of the current one (steps INLOOP_W0 .. NSTEP - 1, the
+// brick's rows requested in the first INLOOP_PFS steps), as csrc/conv3d_wino2.hip rewrites its slices inside the tap loop: the other slot of
+// the ring was last read in the previous chunk, which every wave has left once it passed this chunk's barrier -- so the write is legal there,
+// and the top of a chunk is the barrier alone instead of "wait for the brick, transform, write, barrier" with three quarters of the threads idle.
+#ifndef ESTD_C2W2_INLOOP
+#define ESTD_C2W2_INLOOP 1
+#endif
+#ifndef ESTD_C2W2_INLOOP_PFS
+#define ESTD_C2W2_INLOOP_PFS 4
+#endif
+#ifndef ESTD_C2W2_INLOOP_W0
+#define ESTD_C2W2_INLOOP_W0 4
+#endif
 constexpr int WD = ESTD_C2W2_WD, WR = 4;             // weight stream: WD steps ahead, ring slot = step % WR (8 % WR == 0, WD < WR)
 
 __device__ __forceinline__ float4 as_float4(u32x4 v) { float4 f; __builtin_memcpy(&f, &v, 16); return f; }
@@ -77,6 +90,7 @@ template <int DIL>
 __global__ __launch_bounds__(256, 2) void conv2d_wino2_kernel(const estd_conv2d_desc p, int tiles_w, int tiles_h, int total_items)
 {
     constexpr int IN_H = TH + 2 * DIL, IN_W = TW + 2 * DIL;      // haloed brick: 10 x 18 | 12 x 20
+    constexpr bool INLOOP = ESTD_C2W2_INLOOP != 0 && (DIL == 1 || ESTD_C2W2_INLOOP == 2);     // (the dilation-2 instance spills with it: 256 VGPRs, 9 spilled, +4 %)
     constexpr int PITCH = DIL == 1 ? IN_W + 1 : IN_W;            // voxels per transformed row: 19 (odd, see the header) | 20
     constexpr int SLOT_BYTES = TROWS * PITCH * 128;              // 38 912 | 40 960
     constexpr int SH_BYTES = 4 * PITCH * 128;                    // one row transform index further
@@ -162,6 +176,19 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino2_kernel(const estd_conv2d_
     const float floor_a = p.relu_after_residual ? 0.f : ESTD_NO_FLOOR;
 
     int k = 0;                                              // global chunk counter -> LDS slot
+    if (INLOOP) {                                           // the first brick of this workgroup: transformed into slot 0 here, every later one in a step loop
+        if (loader && !(ESTD_C2W2ABL & 2)) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int a = DIL == 1 ? 2 * w : (w & 1) + 4 * (w >> 1);
+                const float4 d0 = pf[a], d1 = pf[a + DIL], d2 = pf[a + 2 * DIL], d3 = pf[a + 3 * DIL];
+                *reinterpret_cast<float4*>(smem + wbase + (0 * 4 + w) * PITCH * 128) = f4_sub(d0, d2);
+                *reinterpret_cast<float4*>(smem + wbase + (1 * 4 + w) * PITCH * 128) = f4_add(d1, d2);
+                *reinterpret_cast<float4*>(smem + wbase + (2 * 4 + w) * PITCH * 128) = f4_sub(d2, d1);
+                *reinterpret_cast<float4*>(smem + wbase + (3 * 4 + w) * PITCH * 128) = f4_sub(d1, d3);
+            }
+        }
+    }
     while (true) {
         const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w_wino + (size_t)grp * wgrp_elems, wgrp_elems);
         // folded BatchNorm of this lane's four channels, requested an item ahead of the epilogue that uses it
@@ -174,14 +201,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino2_kernel(const estd_conv2d_
         if (has_next_item) decode(u + 1, ngrp, nn_, nth0, ntw0);
         const __amdgpu_buffer_rsrc_t rs_wni = make_rsrc(p.w_wino + (size_t)ngrp * wgrp_elems, wgrp_elems);
 
-        auto chunk_body = [&](auto first_c, const int c) {
-            constexpr bool FIRST = decltype(first_c)::value;
-            const int sb = (k & 1) * SLOT_BYTES;
-            char* slot = smem + sb;
-            // ---- row transform B^T d of the brick columns, straight into the slot: row = 4 sh + row pair ----
+        // row transform of row pairs w0 .. w1 - 1 of the brick in pf, written to ``slot`` (row = 4 sh + row pair)
+        auto write_rows = [&](char* slot, int w0, int w1) {
             if (loader && !(ESTD_C2W2ABL & 2)) {
 #pragma unroll
                 for (int w = 0; w < 4; ++w) {
+                    if (w < w0 || w >= w1) continue;
                     const int a = DIL == 1 ? 2 * w : (w & 1) + 4 * (w >> 1);         // compile-time after unrolling
                     const float4 d0 = pf[a], d1 = pf[a + DIL], d2 = pf[a + 2 * DIL], d3 = pf[a + 3 * DIL];
                     *reinterpret_cast<float4*>(slot + wbase + (0 * 4 + w) * PITCH * 128) = f4_sub(d0, d2);
@@ -190,6 +215,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino2_kernel(const estd_conv2d_
                     *reinterpret_cast<float4*>(slot + wbase + (3 * 4 + w) * PITCH * 128) = f4_sub(d1, d3);
                 }
             }
+        };
+        auto chunk_body = [&](auto first_c, const int c) {
+            constexpr bool FIRST = decltype(first_c)::value;
+            const int sb = (k & 1) * SLOT_BYTES;
+            char* slot = smem + sb;
+            // ---- row transform B^T d of the brick columns, straight into the slot: row = 4 sh + row pair ----
+            if (!INLOOP) write_rows(slot, 0, 4);
             lds_barrier();
 
             // what to prefetch while this chunk computes: the next 32-channel chunk of the same pixels, or chunk 0 of the next item
@@ -241,12 +273,18 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino2_kernel(const estd_conv2d_
                 }
                 // the next brick over the eight steps: rows 0,1 | 2 | 3 | 4 | 5 | 6 | 7 | 8,9 (dilation 2: 0,1 | 2 | 3,4 | 5 | 6,7 | 8 | 9,10 | 11)
                 {
-                    constexpr int PFS = ESTD_C2W2_PFS;      // the brick's rows go out over the first PFS steps (8: the spread above)
+                    constexpr int PFS = INLOOP ? ESTD_C2W2_INLOOP_PFS : ESTD_C2W2_PFS;      // the brick's rows go out over the first PFS steps (8: the spread above)
                     const int r0 = PFS != 8 ? (st < PFS ? st * IN_H / PFS : IN_H) : DIL == 1 ? (st == 0 ? 0 : st + 1) : (3 * st + 1) / 2;
                     const int r1 = PFS != 8 ? (st < PFS ? (st + 1) * IN_H / PFS : IN_H)
                                             : DIL == 1 ? ((st == 0 || st == NSTEP - 1) ? r0 + 2 : r0 + 1) : (3 * (st + 1) + 1) / 2;
 #pragma unroll
                     for (int r = r0; r < r1; ++r) pf[r] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[r], pf_soff, 0));
+                }
+                if (INLOOP && st >= ESTD_C2W2_INLOOP_W0 && (!last_chunk || has_next_item)) {
+                    // the next chunk's (or the next item's first) brick -> the other slot; its row pairs spread over the last steps
+                    constexpr int WN = NSTEP - ESTD_C2W2_INLOOP_W0;
+                    const int i0 = (st - ESTD_C2W2_INLOOP_W0) * 4 / WN, i1 = (st - ESTD_C2W2_INLOOP_W0 + 1) * 4 / WN;
+                    write_rows(smem + (((k + 1) & 1) * SLOT_BYTES), i0, i1);
                 }
                 __builtin_amdgcn_sched_barrier(0);      // memory requests in front of the step's MFMAs
                 f32x2 Tn[2][4];
