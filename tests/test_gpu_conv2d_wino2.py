@@ -23,7 +23,10 @@ def _run(plan, algo, x, res=None):
 
 CASES = [(32, 32, (2, 13, 21), 1), (64, 64, (1, 24, 32), 1), (96, 64, (1, 8, 16), 1), (320, 128, (1, 9, 20), 1), (32, 32, (5, 30, 40), 1),
          (128, 128, (3, 7, 50), 1), (32, 64, (1, 1, 1), 1), (64, 32, (1, 120, 160), 1),
-         (128, 128, (1, 17, 35), 2), (32, 64, (2, 8, 16), 2), (64, 64, (1, 3, 5), 2), (128, 128, (2, 60, 80), 2), (32, 32, (1, 1, 1), 2)]
+         (128, 128, (1, 17, 35), 2), (32, 64, (2, 8, 16), 2), (64, 64, (1, 3, 5), 2), (128, 128, (2, 60, 80), 2), (32, 32, (1, 1, 1), 2),
+         # more work items than the 512 persistent workgroups: every workgroup walks SEVERAL items (the next item's first chunk is requested,
+         # transformed and written inside the step loop of the current item's last chunk; 1 / 2 / 4 chunks per item, 1 / 2 / 4 channel groups)
+         (32, 32, (3, 240, 320), 1), (64, 64, (4, 120, 160), 1), (128, 64, (2, 120, 160), 1), (128, 128, (2, 120, 160), 2)]
 
 
 @pytest.mark.parametrize("cin,cout,dims,dil", CASES)
