@@ -1,5 +1,6 @@
 """Randomised A/B of the Winograd kernels against the direct kernels (same operator, same descriptor): random ragged shapes,
-batch sizes, epilogue flags, instances.  python tools/fuzz_convs.py [seconds] [seed]     (GPU; prints the first mismatch and exits 1)"""
+batch sizes, epilogue flags, instances; the 2D case runs the row-only AND the two-axis kernel (the default) and, one time in four, a map with
+more work items than persistent workgroups (the multi-item path of the in-loop transform).  python tools/fuzz_convs.py [seconds] [seed]     (GPU; prints the first mismatch and exits 1)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -94,6 +95,8 @@ def case_conv2d():
     cin, cout = int(rng.choice([32, 64, 96, 128, 320])), int(rng.choice([32, 64, 128]))
     dil = int(rng.choice([1, 2]))
     N, H, W = int(rng.integers(1, 6)), int(rng.integers(1, 60)), int(rng.integers(1, 90))
+    if rng.integers(4) == 0:            # a map with more work items than persistent workgroups: every workgroup walks several items
+        H, W = int(rng.integers(100, 250)), int(rng.integers(120, 330))
     conv = torch.nn.Conv2d(cin, cout, 3, 1, dil, dil, bias=False)
     with torch.no_grad():
         conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * 0.05)
@@ -108,12 +111,12 @@ def case_conv2d():
     x = rnd(N, H, W, cin)
     res = rnd(N, H, W, cout) if rng.integers(2) else None
     outs = {}
-    for algo in ("direct", "wino"):
+    for algo in ("direct", "wino", "wino2"):            # row-only and two-axis Winograd (the default) against the direct kernel
         ops.CONV2D_ALGO = algo
         outs[algo] = plan.run(x, residual=res)
         torch.cuda.synchronize()
-    a, b = outs["direct"], outs["wino"]
-    d = float((a - b).abs().max())
+    a = outs["direct"]
+    d = max(float((a - outs["wino"]).abs().max()), float((a - outs["wino2"]).abs().max()))
     return (d == d) and d < 4e-5 * max(1.0, float(a.abs().max())), ("conv2d", (N, H, W), cin, cout, dil, rb, ra, res is not None, d)
 
 
