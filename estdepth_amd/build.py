@@ -20,7 +20,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(OUT_DIR, "obj" + os.environ.get("ESTD_LIB_SUFFIX", ""))
 LIB = os.path.join(OUT_DIR, "libestd_hip%s.so" % os.environ.get("ESTD_LIB_SUFFIX", ""))
-SOURCES = ["conv3d_mfma.hip", "conv3d_wino.hip", "conv3d_wino2.hip", "conv3d_wino2_c16.hip", "conv3d_split_bf16.hip", "conv2d_mfma.hip", "conv2d_wino.hip", "conv2d_wino2.hip", "conv2d_split_bf16.hip", "plane_sweep.hip", "est_fusion.hip", "refine2d.hip", "conv1x1.hip", "conv2d_taps.hip"]
+SOURCES = ["conv3d_mfma.hip", "conv3d_wino.hip", "conv3d_wino2.hip", "conv3d_wino2x.hip", "conv3d_wino2_c16.hip", "conv3d_split_bf16.hip", "conv2d_mfma.hip", "conv2d_wino.hip", "conv2d_wino2.hip", "conv2d_split_bf16.hip", "plane_sweep.hip", "est_fusion.hip", "refine2d.hip", "conv1x1.hip", "conv2d_taps.hip"]
 HEADERS = [os.path.join(ROOT, "include", "estd_hip.h"), os.path.join(CSRC, "estd_common.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]

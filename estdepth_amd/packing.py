@@ -321,6 +321,26 @@ def pack_conv3d_wino2(weight, main_idx, out_idx):
     return torch.from_numpy(out.reshape(48, nhalf, 2, 64, 4))
 
 
+def pack_conv3d_wino2x(weight, main_idx, out_idx):
+    """32 -> 32 filters for csrc/conv3d_wino2x.hip (v_mfma_f32_32x32x2_f32, weights as the A operand): U = G g G^T over (kd, kh) as in
+    pack_conv3d_wino2, packed as float32 [4 sd][3 kw][2 chunks c][2 q][4 sh][64 lanes][4]: element e of lane (k2 = lane >> 5, o = lane & 31)
+    = U[sd][sh][out_idx[o]][main_idx[16 c + 8 q + 4 k2 + e]][kw] -- MFMA row o = output channel o, the lane's four consecutive input
+    channels = the four k-steps that consume one 16-byte piece of a voxel record."""
+    assert len(main_idx) == 32 and len(out_idx) == 32
+    w = weight.detach().double().cpu().numpy()                       # [Cout, Cin, kd, kh, kw]
+    G = np.array([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
+    U = np.einsum("sd,th,oidhw->stoiw", G, G, w).astype(np.float32)  # [4 sd, 4 sh, Cout, Cin, 3 kw]
+    oi, mi = np.asarray(out_idx), np.asarray(main_idx)
+    out = np.zeros((4, 3, 2, 2, 4, 64, 4), np.float32)               # [sd][kw][c][q][sh][lane][e]
+    for lane in range(64):
+        k2, o = lane >> 5, lane & 31
+        for c in range(2):
+            for q in range(2):
+                for e in range(4):
+                    out[:, :, c, q, :, lane, e] = U[:, :, oi[o], mi[16 * c + 8 * q + 4 * k2 + e], :].transpose(0, 2, 1)
+    return torch.from_numpy(out.reshape(4 * 3 * 2 * 2, 4, 64, 4))
+
+
 def pack_conv3d_wino2_c16(weight, main_idx, out_idx):
     """16 -> 16 filters (the stereo heads) for csrc/conv3d_wino2_c16.hip: U = G g G^T over (kd, kh) as in pack_conv3d_wino2, packed as
     float32 [48 taps = (3 sd + kw) * 4 + sh][64 lanes][4]: element e of lane (g, j) = U[sd][sh][out_idx[j]][main_idx[4 g + e]][kw] -- output

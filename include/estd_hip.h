@@ -159,6 +159,12 @@ int estd_conv3d_k3_wino(const estd_conv3d_desc* desc, estd_stream_t stream);
  * hybrid_depth_decoder.py:106) -- output channel 32 on the VALU from the fragments the MFMAs consume; no read-back streams, no statistics.
  * Reads w_wino2 (packing.py::pack_conv3d_wino2).  ESTD_ERR_UNSUPPORTED for any other shape. */
 int estd_conv3d_k3_wino2(const estd_conv3d_desc* desc, estd_stream_t stream);
+/* The 32 -> 32 instance of estd_conv3d_k3_wino2 (cin_main = 32, n_tiles = 2, no in_extra / out_extra / head; BN, ReLU, residuals, scale,
+ * running sum, GroupNorm partials -- the latter without read-back streams; no tanh) on the operand-reuse kernel csrc/conv3d_wino2x.hip:
+ * same F(2x2, 3x3) arithmetic, one 512-register wave per SIMD on v_mfma_f32_32x32x2_f32, both transforms in front of the LDS, wave-private
+ * operand blocks.  Reads desc->w_wino2, which must then hold the packing of packing.py::pack_conv3d_wino2x: float32
+ * [4 sd][3 kw][2 chunks][2 q][4 sh][64 lanes][4].  ESTD_ERR_UNSUPPORTED for any other shape (callers fall back to estd_conv3d_k3_wino2). */
+int estd_conv3d_k3_wino2x(const estd_conv3d_desc* desc, estd_stream_t stream);
 /* number of thread blocks estd_conv3d_k3 launches for a volume (size of stats_partials / 4 doubles) */
 int estd_conv3d_k3_grid(int N, int D, int H, int W);
 

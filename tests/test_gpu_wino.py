@@ -28,8 +28,9 @@ def _plan(seed, act="relu"):
 
 def _run(plan, algo, x, dims, **kw):
     from estdepth_amd import ops
-    old = ops.CONV3D_ALGO
-    ops.CONV3D_ALGO = algo
+    old, old_x = ops.CONV3D_ALGO, ops.W2X
+    # "wino2x" = the two-axis form on the operand-reuse kernel (csrc/conv3d_wino2x.hip, opt-in: ESTD_W2X=1) for the plain 32 -> 32 instance
+    ops.CONV3D_ALGO, ops.W2X = ("wino2", True) if algo == "wino2x" else (algo, False)
     try:
         out = kw.pop("out", None)
         if out is None:
@@ -38,13 +39,14 @@ def _run(plan, algo, x, dims, **kw):
         torch.cuda.synchronize()
         return out
     finally:
-        ops.CONV3D_ALGO = old
+        ops.CONV3D_ALGO, ops.W2X = old, old_x
 
 
 ALGOS = ("wino", "wino2")      # depth axis / depth and row axis in Winograd form
+ALGOS_PLAIN = ALGOS + ("wino2x",)      # instances without a scalar channel: + the operand-reuse kernel
 
 
-@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("algo", ALGOS_PLAIN)
 @pytest.mark.parametrize("dims,scale", [((1, 6, 19, 45), 1.0), ((2, 3, 8, 32), 100.0), ((1, 1, 5, 7), 1e-3), ((1, 64, 24, 32), 1.0)])
 def test_wino_error_vs_fp64_is_at_the_direct_kernels_level(dims, scale, algo):
     mod, plan = _plan(11, act=None)
@@ -65,7 +67,7 @@ def test_wino_error_vs_fp64_is_at_the_direct_kernels_level(dims, scale, algo):
     assert e_win < 3e-6 * mag
 
 
-@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("algo", ALGOS_PLAIN)
 @pytest.mark.parametrize("dims", [(1, 4, 8, 32), (3, 5, 13, 50), (1, 2, 120, 160), (2, 1, 9, 33), (1, 7, 8, 16), (1, 70, 8, 32)])
 def test_wino_matches_direct_kernel_all_epilogues(dims, algo):
     """ReLU / none, residual, two residuals + scale, running accumulation, strided output, GroupNorm partial sums."""
@@ -103,7 +105,7 @@ def test_wino_matches_direct_kernel_all_epilogues(dims, algo):
     assert int((pb.view(-1, 4)[:, 1] == 0).sum()) == 0
 
 
-@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("algo", ALGOS_PLAIN)
 def test_wino_vs_oracle_ragged(algo):
     from oracle import ref_ops as O
     mod, plan = _plan(21, act="relu")
@@ -117,7 +119,7 @@ def test_wino_vs_oracle_ragged(algo):
     assert np.abs(np.moveaxis(out, -1, 1) - ref).max() < 2e-5
 
 
-@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("algo", ALGOS_PLAIN)
 def test_wino_full_size_linearity_and_match(algo):
     """BASELINE configs[1] size (3 volumes of 64x120x160): against the direct kernel and a linearity property."""
     _, plan = _plan(5, act=None)

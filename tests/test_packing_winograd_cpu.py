@@ -36,6 +36,35 @@ def _direct3d(x, w):
     return y
 
 
+def test_pack_conv3d_wino2x_reproduces_the_direct_convolution():
+    """csrc/conv3d_wino2x.hip: v_mfma_f32_32x32x2_f32 with the weights as the A operand -- lane (k2, o) of half step (sd, kw, c, q), row-transform
+    index sh, element e multiplies input channel 16 c + 8 q + 4 k2 + e of the voxel record into output channel o."""
+    rng = np.random.default_rng(4)
+    w = rng.standard_normal((32, 32, 3, 3, 3)) * 0.1
+    main_idx, out_idx = list(rng.permutation(32)), list(rng.permutation(32))
+    packed = packing.pack_conv3d_wino2x(torch.from_numpy(w).float(), main_idx, out_idx).numpy().reshape(4, 3, 2, 2, 4, 64, 4)   # [sd][kw][c][q][sh][lane][e]
+    U = np.zeros((4, 3, 4, 32, 32), np.float32)               # [sd][kw][sh][o][record position]
+    for lane in range(64):
+        k2, o = lane >> 5, lane & 31
+        for c in range(2):
+            for q in range(2):
+                for e in range(4):
+                    U[:, :, :, o, 16 * c + 8 * q + 4 * k2 + e] = packed[:, :, c, q, :, lane, e]
+    D, H, W = 4, 6, 5
+    x = rng.standard_normal((32, D, H, W))                    # record position p of x = weight input channel main_idx[p]
+    xp = np.zeros((32, D + 2, H + 2, W + 2)); xp[:, 1:-1, 1:-1, 1:-1] = x
+    y = np.zeros((32, D, H, W))
+    for d0 in range(0, D, 2):
+        for h0 in range(0, H, 2):
+            T = np.einsum("sd,th,cdhw->stcw", BT, BT, xp[:, d0:d0 + 4, h0:h0 + 4, :])
+            m = np.zeros((4, 4, 32, W))
+            for kw in range(3):
+                m += np.einsum("stoc,stcw->stow", U[:, kw].astype(np.float64), T[:, :, :, kw:kw + W])
+            y[:, d0:d0 + 2, h0:h0 + 2, :] = np.einsum("ds,et,stow->odew", AT, AT, m)     # MFMA row o = output position o
+    ref = _direct3d(x, w[:, main_idx][out_idx])
+    assert np.abs(y - ref).max() < 1e-5 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("n_out", [32, 16])
 def test_pack_conv3d_wino2_reproduces_the_direct_convolution(n_out):
     rng = np.random.default_rng(3)
