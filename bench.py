@@ -62,7 +62,7 @@ def parse():
                          "operand split with six bf16 MFMAs per product block (fp32-level error, opt-in)")
     ap.add_argument("--conv3d-algo", default=os.environ.get("ESTD_CONV3D_ALGO", "wino2"), choices=["wino2", "wino", "direct"],
                     help="3D convolutions under f32 arithmetic: wino2 = depth and row axis of the plain 32->32 instance in Winograd F(2,3) "
-                         "form (0.444 of the fp32 MFMA products, csrc/conv3d_wino2.hip; the 33-channel instances take wino; default), "
+                         "form (0.444 of the fp32 MFMA products, csrc/conv3d_wino2.hip: every 32/33-channel instance, 32->16 and the 16->16 heads; default), "
                          "wino = depth axis only (2/3 of the products, csrc/conv3d_wino.hip), direct = 27-tap implicit GEMM (csrc/conv3d_mfma.hip)")
     ap.add_argument("--no-alt", action="store_true", help="skip the second timed loop with the other convolution arithmetic")
     ap.add_argument("--no-replay-profile", action="store_true",
@@ -202,15 +202,18 @@ def _cpu_model_name():
 _DEFAULT_TORCH_THREADS = [0]        # torch's own default (= the physical cores of the box), recorded before anything changes it
 
 
-def cpu_baseline(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses, gpu_outputs, frames, gpu_logits=None):
-    """The CPU oracle (C/OpenMP restatement of the reference + the product's plain 2D nn.Modules on torch-CPU = a
-    "port") timed on ONE full step of the same workload on the box's host cores: the whole DepthNetHybrid.forward of the
-    timed step -- PSM, ResNet, plane sweeps, every 3D convolution, the 2N volume warps + attention + ConvGRU per target,
-    soft-argmin, 2D refinement -- on the very inputs (and carried memory) of the GPU step.  Nothing is extrapolated.
-    The same call doubles as the full-size parity check of the benchmarked configuration (max |depth_gpu - depth_oracle|)."""
+def cpu_baseline(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses, gpu_outputs, frames, gpu_logits=None, kind="port"):
+    """A CPU restatement of the reference timed on ONE full step of the same workload on the box's host cores: the whole
+    DepthNetHybrid.forward of the timed step -- PSM, ResNet, plane sweeps, every 3D convolution, the 2N volume warps + attention +
+    ConvGRU per target, soft-argmin, 2D refinement -- on the very inputs (and carried memory) of the GPU step.  Nothing is extrapolated.
+      kind "port"      = the C/OpenMP oracle (oracle/estd_oracle.c) under the numpy composition of oracle/ref_model.py: the parity checker;
+      kind "torch-ops" = the same composition on torch's own CPU operators (oracle/torch_ops.py: oneDNN convolutions, ATen grid_sample /
+                         group_norm / softmax -- the operators the reference itself runs on a CPU).
+    The 2D networks are the product's plain nn.Modules on torch-CPU in both.  Either call doubles as the full-size parity check of the
+    benchmarked configuration (max |depth_gpu - depth_cpu|, abs_rel(depth_gpu, depth_cpu))."""
     import numpy as np
     import torch
-    from oracle import ref_model as M, ref_ops as O
+    from oracle import ref_model as M, ref_ops as O, torch_ops as TO
     from oracle.nets2d import Nets2D, sd_numpy
     ncores = os.cpu_count() or 1
     threads = _DEFAULT_TORCH_THREADS[0] if threads <= 0 else min(threads, ncores)
@@ -226,19 +229,29 @@ def cpu_baseline(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses,
         pc = {"keys": [np_(k) for k in pre_costs["keys"]], "values": [np_(v) for v in pre_costs["values"]]}
         pp = [np_(p) for p in pre_poses]
     a_imgs, a_poses, a_intr = np_(x_imgs), np_(x_poses), np_(intr)
+    import contextlib
     t0 = time.time()
-    ref, _, _ = M.model_forward(P, a_imgs, a_poses, a_intr, pc, pp, nets, ndepths=D, depth_min=0.1, depth_max=10.0,
-                                IF_EST_transformer=WORKLOADS[workload][5])
+    with (M.use_ops(TO) if kind == "torch-ops" else contextlib.nullcontext()):
+        ref, _, _ = M.model_forward(P, a_imgs, a_poses, a_intr, pc, pp, nets, ndepths=D, depth_min=0.1, depth_max=10.0,
+                                    IF_EST_transformer=WORKLOADS[workload][5])
     dt = time.time() - t0
-    worst = {}
+    worst, arel = {}, {}
     for k, v in gpu_outputs.items():
         if k[0] == "depth":
-            worst[k[2]] = max(worst.get(k[2], 0.0), float(np.abs(np_(v) - ref[k]).max()))
-    base = {"value": round(frames / dt, 4), "unit": "depth frames/s", "cores": threads, "kind": "port", "wall_s": round(dt, 2),
+            g = np_(v)
+            worst[k[2]] = max(worst.get(k[2], 0.0), float(np.abs(g - ref[k]).max()))
+            # abs_rel(pred, ref) = mean(|ref - pred| / ref) (metric.py:131-150, model_hybrid.py:306) of the GPU depth against the CPU depth
+            arel.setdefault(k[2], []).append(float(np.mean(np.abs(ref[k] - g) / ref[k])))
+    how = "C/OpenMP oracle" if kind == "port" else "torch-CPU operators (oneDNN conv3d, ATen grid_sample / group_norm)"
+    base = {"value": round(frames / dt, 4), "unit": "depth frames/s", "cores": threads, "kind": kind, "wall_s": round(dt, 2),
             "cpu": "%s (%d hardware threads on the box)" % (_cpu_model_name(), ncores),
-            "sample": "ONE full step of this workload (%d depth frames: 2D networks on torch-CPU + C/OpenMP oracle for the whole 3D "
-                      "hot path incl. volume warps, attention, ConvGRU), %.1f s wall, %d threads" % (frames, dt, threads)}
+            "sample": "ONE full step of this workload (%d depth frames: 2D networks on torch-CPU + %s for the whole 3D "
+                      "hot path incl. volume warps, attention, ConvGRU), %.1f s wall, %d threads" % (frames, how, dt, threads)}
     parity = {"max_abs_depth_diff_vs_oracle_m": {"scale%d" % s: float("%.3g" % w) for s, w in sorted(worst.items())},
+              "abs_rel_vs_oracle": {"scale%d" % s: float("%.3g" % (sum(a) / len(a))) for s, a in sorted(arel.items())},
+              "abs_rel_def": "mean(|depth_oracle - depth_gpu| / depth_oracle) per output scale, averaged over the depth frames of the step "
+                             "(metric.py:131-150, model_hybrid.py:306)",
+              "oracle_kind": kind,
               "tolerance_m": 1e-4, "within_tolerance": bool(max(worst.values()) <= 1e-4),
               "what": "hipGraph/eager HIP path of THIS benchmark configuration vs the CPU oracle on the same inputs, all depth outputs"}
     if gpu_logits:
@@ -359,14 +372,18 @@ def replay_profile(args):
 
 
 def conv3d_algo_of(group, algo, arith):
-    """which kernel a profiled conv3d group ran on: the 32->32 and 33->32 instances follow --conv3d-algo, the 33->33 instance (dres2)
-    takes the depth-only Winograd kernel under wino / wino2, 32->16 and the 16->16 heads have wino2 instances."""
+    """which kernel a profiled conv3d group ran on: every instance follows --conv3d-algo; under wino2 the 33->33 instance (dres2) runs on
+    the two-axis kernel's XOUT instance (ops.W2_XOUT, the default: 12/27 of the products) and on the depth-only kernel (18/27) only with
+    ESTD_W2_XOUT=0; 32->16 and the 16->16 heads have wino2 instances and fall back to the direct kernel under wino."""
+    from estdepth_amd import ops
     if arith != "f32":
         return "direct"
     if group in ("conv3d:32->32", "conv3d:33->32"):      # the key || value convolution (33 -> 32) has a wino2 instance as well
         return algo
     if group == "conv3d:33->33":
-        return "wino" if algo in ("wino", "wino2") else "direct"
+        if algo == "wino2":
+            return "wino2" if ops.W2_XOUT else "wino"
+        return algo
     if group in ("conv3d:32->16", "conv3d:16->16"):  # the GRU output convolution (16-output-channel instance of the wino2 kernel) and the
         return "wino2" if algo == "wino2" else "direct"      # stereo heads (csrc/conv3d_wino2_c16.hip)
     return "direct"
@@ -778,15 +795,25 @@ def main():
                 others["stream"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:120])}
             line["other_workloads"] = others
         if world == 1 and not args.no_cpu_baseline:
-            # the port timed with 8 threads AND with all physical cores; the headline entry is the faster of the two
-            counts = [args.cpu_threads] if args.cpu_threads > 0 else [8, 0]
-            runs = []
-            for th in counts:
-                base, parity = cpu_baseline(args.workload, th, x_imgs, x_poses, intr, pre_costs, pre_poses, gpu_outputs, frames, gpu_logits)
+            # two CPU restatements on the box's host cores -- the C/OpenMP port (the parity checker, 8 threads: it
+            # does not scale further) and the torch-operator leg (oneDNN / ATen, what the reference itself would run: 8 threads for
+            # comparability with BASELINE.md section 2 AND torch's default = all physical cores); headline entry = the fastest
+            legs = [("port", args.cpu_threads)] if args.cpu_threads > 0 else [("port", 8), ("torch-ops", 8), ("torch-ops", 0)]
+            if args.cpu_threads > 0:
+                legs.append(("torch-ops", args.cpu_threads))
+            runs, parity, parity_t = [], None, None
+            for kind, th in legs:
+                base, par = cpu_baseline(args.workload, th, x_imgs, x_poses, intr, pre_costs, pre_poses, gpu_outputs, frames, gpu_logits, kind=kind)
                 runs.append(base)
+                if kind == "port":
+                    parity = par
+                else:
+                    parity_t = par
             best = max(runs, key=lambda b: b["value"])
             line["cpu_baseline"] = dict(best)
-            line["cpu_baseline"]["all_runs"] = [{"cores": b["cores"], "value": b["value"], "wall_s": b["wall_s"]} for b in runs]
+            line["cpu_baseline"]["all_runs"] = [{"kind": b["kind"], "cores": b["cores"], "value": b["value"], "wall_s": b["wall_s"]} for b in runs]
+            if parity_t is not None:      # the torch-operator leg's own view of the GPU depth (a second, independent CPU arithmetic)
+                parity["vs_torch_ops"] = {"max_abs_depth_diff_m": parity_t["max_abs_depth_diff_vs_oracle_m"], "abs_rel": parity_t["abs_rel_vs_oracle"]}
             line["parity"] = parity
     else:
         line = None

@@ -14,7 +14,21 @@ as callables (``nets``) working on numpy arrays so this package stays independen
 """
 import numpy as np
 
+import contextlib
+
 from . import ref_ops as O
+
+
+@contextlib.contextmanager
+def use_ops(module):
+    """Evaluate the composition below with another operator module of the same surface (oracle/torch_ops.py: torch's own CPU
+    operators instead of the C restatement -- the "torch-ops" cpu_baseline leg of bench.py)."""
+    global O
+    old, O = O, module
+    try:
+        yield
+    finally:
+        O = old
 
 
 def _bn(P, key):
