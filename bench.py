@@ -654,7 +654,8 @@ def main():
     # Second opinion, reported beside (never instead of) the headline: the same K steps with the 3x3x3 / 3x3 convolutions
     # on the exact 3-way bf16 operand split (fp32-level error, tests/test_gpu_split_conv.py), N = 1 only.
     alt = None
-    if world == 1 and not args.no_alt and (args.conv3d_arith, args.conv2d_arith) == ("f32", "f32"):
+    from estdepth_amd import _native
+    if world == 1 and not args.no_alt and (args.conv3d_arith, args.conv2d_arith) == ("f32", "f32") and _native.has_ab():     # (A/B build only: ESTD_BUILD_AB=1)
         try:
             ops.CONV3D_ARITH = ops.CONV2D_ARITH = "bf16x3"
             state["fwd"] = model if args.no_graph else GraphedForward(model, zero_copy_memory=zero_copy)

@@ -138,7 +138,9 @@ _SIGNATURES = {
     "estd_vol_to_cdhw": (ctypes.c_int, [c_float_p, c_float_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, c_stream]),
 }
 
-EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
+# the superseded A/B kernels: exported only by a library built with ESTD_BUILD_AB=1 (estdepth_amd/build.py)
+AB_SYMBOLS = ("estd_conv3d_k3_split", "estd_conv3d_k3_wino", "estd_conv2d_k3_split", "estd_conv2d_k3_wino")
+EXPORTED_SYMBOLS = tuple(k for k in _SIGNATURES if k not in AB_SYMBOLS)
 
 _lib = None
 
@@ -152,11 +154,23 @@ def lib():
                                "(there is no CPU/eager fallback)" % LIB_PATH)
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
+            if name in AB_SYMBOLS and not hasattr(handle, name):
+                continue
             fn = getattr(handle, name)      # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
         _lib = handle
     return _lib
+
+
+def has_ab():
+    """True when the loaded library carries the superseded A/B kernels (built with ESTD_BUILD_AB=1)."""
+    return all(hasattr(lib(), n) for n in AB_SYMBOLS)
+
+
+def require_ab(what):
+    if not has_ab():
+        raise RuntimeError("%s needs the A/B kernels: rebuild the library with ESTD_BUILD_AB=1 (python -m estdepth_amd.build)" % what)
 
 
 def check(status, what):

@@ -20,10 +20,19 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(OUT_DIR, "obj" + os.environ.get("ESTD_LIB_SUFFIX", ""))
 LIB = os.path.join(OUT_DIR, "libestd_hip%s.so" % os.environ.get("ESTD_LIB_SUFFIX", ""))
-SOURCES = ["conv3d_mfma.hip", "conv3d_wino.hip", "conv3d_wino2.hip", "conv3d_wino2x.hip", "conv3d_wino2_c16.hip", "conv3d_split_bf16.hip", "conv2d_mfma.hip", "conv2d_wino.hip", "conv2d_wino2.hip", "conv2d_split_bf16.hip", "plane_sweep.hip", "est_fusion.hip", "refine2d.hip", "conv1x1.hip", "conv2d_taps.hip"]
+# Kernels with a default caller.  The superseded A/B kernels -- depth-only Winograd conv3d, row-only Winograd conv2d, the two 3 x bf16
+# operand-split kernels (none has a default caller since round 4; the two-axis Winograd kernels cover every instance and are faster) --
+# are built, exported (include/estd_hip.h: #ifdef ESTD_BUILD_AB), bound and tested only with ESTD_BUILD_AB=1 in the environment.
+SOURCES = ["conv3d_mfma.hip", "conv3d_wino2.hip", "conv3d_wino2x.hip", "conv3d_wino2_c16.hip", "conv2d_mfma.hip", "conv2d_wino2.hip",
+           "plane_sweep.hip", "est_fusion.hip", "refine2d.hip", "conv1x1.hip", "conv2d_taps.hip"]
+AB_SOURCES = ["conv3d_wino.hip", "conv3d_split_bf16.hip", "conv2d_wino.hip", "conv2d_split_bf16.hip"]
+BUILD_AB = os.environ.get("ESTD_BUILD_AB", "0") == "1"
+if BUILD_AB:
+    SOURCES = SOURCES + AB_SOURCES
 HEADERS = [os.path.join(ROOT, "include", "estd_hip.h"), os.path.join(CSRC, "estd_common.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
-         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + (["-DESTD_BUILD_AB=1"] if BUILD_AB else [])
+MODE_STAMP = os.path.join(OUT_DIR, ".build_mode" + os.environ.get("ESTD_LIB_SUFFIX", ""))
 
 
 def _hipcc():
@@ -43,6 +52,8 @@ def _stale(target, deps):
 def build(force=False, verbose=False):
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = _hipcc()
+    mode = "ab" if BUILD_AB else "default"
+    relink = (open(MODE_STAMP).read().strip() if os.path.exists(MODE_STAMP) else "default" if os.path.exists(LIB) else "") != mode
     jobs = []
     objs = []
     for src in SOURCES:
@@ -64,9 +75,10 @@ def build(force=False, verbose=False):
             for log in ex.map(run, jobs):
                 if verbose and log:
                     sys.stderr.write(log)
-    if force or jobs or _stale(LIB, objs):
+    if force or jobs or relink or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
-    build_torch_ops(force=force)
+    open(MODE_STAMP, "w").write(mode)
+    build_torch_ops(force=force or relink)
     return LIB
 
 
@@ -82,7 +94,8 @@ def build_torch_ops(force=False):
     from torch.utils import cpp_extension
     tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
     cmd = [_hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DHIPBLAS_V2",
-           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI), "-I" + os.path.join(ROOT, "include")]
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI), "-I" + os.path.join(ROOT, "include")] \
+        + (["-DESTD_BUILD_AB=1"] if BUILD_AB else [])
     cmd += ["-I" + p for p in cpp_extension.include_paths("cuda")]
     cmd += [TORCH_OPS_SRC, "-o", TORCH_OPS_LIB, "-L" + OUT_DIR, "-l:" + os.path.basename(LIB), "-L" + tlib,
             "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib]

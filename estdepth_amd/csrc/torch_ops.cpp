@@ -189,12 +189,18 @@ void conv3d_k3(const Tensor& x, const OptTensor& x_extra, const Tensor& w_main, 
     // variant: 0 = direct fp32 MFMA; 1 = exact 3 x bf16 operand split (w_alt = split weights); 2 = fp32 MFMA with the depth
     // axis in Winograd F(2,3) form (w_alt = transformed filters); 3 = depth and row axis in Winograd form (w_extra / w_xout in that kernel's packing)
     if (variant != 0) TORCH_CHECK(w_alt.has_value() && w_alt->defined() && w_alt->is_cuda(), "conv3d_k3: this variant needs its packed weights");
-    if (variant == 1) {
-        d.w_split = w_alt->data_ptr();
-        check_status(estd_conv3d_k3_split(&d, cur_stream()), "estd_conv3d_k3_split");
-    } else if (variant == 2) {
-        d.w_wino = fptr(*w_alt, "Winograd-packed weights");
-        check_status(estd_conv3d_k3_wino(&d, cur_stream()), "estd_conv3d_k3_wino");
+    if (variant == 1 || variant == 2) {
+#ifdef ESTD_BUILD_AB
+        if (variant == 1) {
+            d.w_split = w_alt->data_ptr();
+            check_status(estd_conv3d_k3_split(&d, cur_stream()), "estd_conv3d_k3_split");
+        } else {
+            d.w_wino = fptr(*w_alt, "Winograd-packed weights");
+            check_status(estd_conv3d_k3_wino(&d, cur_stream()), "estd_conv3d_k3_wino");
+        }
+#else
+        TORCH_CHECK(false, "conv3d_k3: variant ", variant, " (bf16 operand split / depth-only Winograd) needs a library built with ESTD_BUILD_AB=1");
+#endif
     } else if (variant == 3) {
         d.w_wino2 = fptr(*w_alt, "2-axis Winograd-packed weights");
         check_status(estd_conv3d_k3_wino2(&d, cur_stream()), "estd_conv3d_k3_wino2");
@@ -227,12 +233,18 @@ Tensor conv2d_k3(const Tensor& x_nhwc, const Tensor& w, const OptTensor& w_alt, 
     d.out = out.data_ptr<float>();
     // variant: 0 = direct fp32 MFMA; 1 = exact 3 x bf16 operand split; 2 = fp32 MFMA with the row axis in Winograd F(2,3) form
     if (variant != 0) TORCH_CHECK(w_alt.has_value() && w_alt->defined() && w_alt->is_cuda(), "conv2d_k3: this variant needs its packed weights");
-    if (variant == 1) {
-        d.w_split = w_alt->data_ptr();
-        check_status(estd_conv2d_k3_split(&d, cur_stream()), "estd_conv2d_k3_split");
-    } else if (variant == 2) {
-        d.w_wino = fptr(*w_alt, "Winograd-packed weights");
-        check_status(estd_conv2d_k3_wino(&d, cur_stream()), "estd_conv2d_k3_wino");
+    if (variant == 1 || variant == 2) {
+#ifdef ESTD_BUILD_AB
+        if (variant == 1) {
+            d.w_split = w_alt->data_ptr();
+            check_status(estd_conv2d_k3_split(&d, cur_stream()), "estd_conv2d_k3_split");
+        } else {
+            d.w_wino = fptr(*w_alt, "Winograd-packed weights");
+            check_status(estd_conv2d_k3_wino(&d, cur_stream()), "estd_conv2d_k3_wino");
+        }
+#else
+        TORCH_CHECK(false, "conv2d_k3: variant ", variant, " (bf16 operand split / row-only Winograd) needs a library built with ESTD_BUILD_AB=1");
+#endif
     } else if (variant == 3) {          // both image axes in Winograd form (w_alt = packing.pack_conv2d_wino2)
         d.w_wino = fptr(*w_alt, "2-axis Winograd-packed weights");
         check_status(estd_conv2d_k3_wino2(&d, cur_stream()), "estd_conv2d_k3_wino2");

@@ -216,12 +216,14 @@ class Conv3dPlan:
         self.n_out = len(out_idx)
         splittable = len(main_idx) == 32 and head_w is None and \
             (n_tiles == 2 or (n_tiles == 3 and extra_idx is not None) or (n_tiles == 1 and extra_idx is None))
-        self.w_split = packing.pack_conv3d_split(weight, main_idx, out_idx, extra_idx, n_tiles).to(device) if splittable else None
+        ab = N.has_ab()      # the superseded A/B kernels (bf16 operand split, depth-only Winograd): only in a library built with ESTD_BUILD_AB=1
+        self.w_split = packing.pack_conv3d_split(weight, main_idx, out_idx, extra_idx, n_tiles).to(device) if (splittable and ab) else None
         wino_ok = len(main_idx) == 32 and head_w is None and \
             ((n_tiles == 2 and len(out_idx) == 32) or (n_tiles == 3 and len(out_idx) == 33 and extra_idx is not None))
-        self.w_wino = packing.pack_conv3d_wino(weight, main_idx, out_idx[:32]).to(device) if wino_ok else None
-        self.w_wino_extra = packing.pack_conv3d_wino_extra(weight, extra_idx, out_idx[:32]).to(device) if (wino_ok and extra_idx is not None) else None
-        self.w_wino_xout = packing.pack_conv3d_wino_xout(weight, main_idx, extra_idx, out_idx[32]).to(device) if (wino_ok and n_tiles == 3) else None
+        self.wino_ok = wino_ok
+        self.w_wino = packing.pack_conv3d_wino(weight, main_idx, out_idx[:32]).to(device) if (wino_ok and ab) else None
+        self.w_wino_extra = packing.pack_conv3d_wino_extra(weight, extra_idx, out_idx[:32]).to(device) if (wino_ok and ab and extra_idx is not None) else None
+        self.w_wino_xout = packing.pack_conv3d_wino_xout(weight, main_idx, extra_idx, out_idx[32]).to(device) if (wino_ok and ab and n_tiles == 3) else None
         self.w_wino2 = packing.pack_conv3d_wino2(weight, main_idx, out_idx[:32]).to(device) if wino_ok else None
         self.w_wino2x = packing.pack_conv3d_wino2x(weight, main_idx, out_idx[:32]).to(device) \
             if (wino_ok and n_tiles == 2 and extra_idx is None) else None
@@ -276,15 +278,21 @@ class Conv3dPlan:
             inst = stats_partials is None
         else:
             inst = not tanh
+        if CONV3D_ARITH == "bf16x3":
+            N.require_ab("ESTD_CONV3D_ARITH=bf16x3 (csrc/conv3d_split_bf16.hip)")
         split = CONV3D_ARITH == "bf16x3" and self.w_split is not None and out is not None and inst
         if CONV3D_ALGO not in ("wino2", "wino", "direct"):
             raise RuntimeError("ESTD_CONV3D_ALGO must be wino2, wino or direct, got %r" % (CONV3D_ALGO,))
-        wino = (not split) and CONV3D_ALGO in ("wino", "wino2") and self.w_wino is not None and out is not None \
+        if CONV3D_ALGO == "wino":
+            N.require_ab("ESTD_CONV3D_ALGO=wino (csrc/conv3d_wino.hip)")
+        wino_shape = (not split) and CONV3D_ALGO in ("wino", "wino2") and self.wino_ok and out is not None \
             and (out_extra is not None) == (self.n_tiles == 3) and out_head is None and out_channels == 32 \
             and (stats_partials is None or self.w_extra is None)
-        wino2 = wino and CONV3D_ALGO == "wino2" and self.w_wino2 is not None and (in_extra is None or stats_partials is None)
+        wino2 = wino_shape and CONV3D_ALGO == "wino2" and self.w_wino2 is not None and (in_extra is None or stats_partials is None)
         if self.n_tiles == 3:                             # the XOUT instance has no read-back streams / statistics (dres2 needs none)
             wino2 = wino2 and W2_XOUT and residual is None and residual2 is None and not accumulate and float(out_scale) == 1.0 and stats_partials is None
+        # the depth-only kernel: ESTD_CONV3D_ALGO=wino, or dres2 with ESTD_W2_XOUT=0 -- where the library carries it (else the direct kernel)
+        wino = wino_shape and not wino2 and self.w_wino is not None
         o16 = (not split) and CONV3D_ALGO == "wino2" and self.w_wino2_o16 is not None and out is not None and out_head is None \
             and in_extra is None and out_channels == 16 and out_extra is None
         # the stereo heads: only the head's logit volume leaves the kernel, no tanh
@@ -300,7 +308,7 @@ class Conv3dPlan:
         with _Prof("conv3d:%d->%d" % (cin, self.n_out), 2.0 * 27 * cin * self.n_out * Nn * D * H * W):
             if _use_torch():
                 T().conv3d_k3(x, in_extra, self.w_main, self.w_wino2_extra if wino2 else self.w_wino_extra if wino else self.w_extra,
-                              (self.w_wino2_xout if wino2 else self.w_wino_xout) if wino else self.w_xout, w_alt, self.scale, self.shift,
+                              self.w_wino2_xout if wino2 else self.w_wino_xout if wino else self.w_xout, w_alt, self.scale, self.shift,
                               (Nn, D, H, W), self.cin_main, in_stride, self.n_tiles, self.act_a, self.act_b, self.act_split, out,
                               out_stride, out_channels, residual, residual2, float(out_scale), bool(accumulate), out_extra, head_w, head_b,
                               out_head, stats_partials, variant)
@@ -370,8 +378,9 @@ class Conv2dPlan:
         self.w_nt = {2: packing.pack_conv2d(conv.weight, 2).to(dev)}
         if self.cout % 64 == 0:
             self.w_nt[4] = packing.pack_conv2d(conv.weight, 4).to(dev)
-        self.w_split = packing.pack_conv2d_split(conv.weight).to(dev)
-        self.w_wino = {nt: packing.pack_conv2d_wino(conv.weight, nt).to(dev) for nt in self.w_nt}
+        ab = N.has_ab()      # row-only Winograd / bf16 operand split: only in a library built with ESTD_BUILD_AB=1
+        self.w_split = packing.pack_conv2d_split(conv.weight).to(dev) if ab else None
+        self.w_wino = {nt: packing.pack_conv2d_wino(conv.weight, nt).to(dev) for nt in self.w_nt} if ab else {}
         self.w_wino2 = packing.pack_conv2d_wino2(conv.weight).to(dev)      # F(2x2, 3x3): csrc/conv2d_wino2.hip (dilation 1 and 2)
         sc, sh = packing.fold_bn_fp32(bn, list(range(self.cout)))
         self.scale, self.shift = sc.to(dev), sh.to(dev)
@@ -397,6 +406,10 @@ class Conv2dPlan:
         if residual is not None and (tuple(residual.shape) != (Nn, H, W, self.cout) or not residual.is_contiguous()):
             raise RuntimeError("Conv2dPlan.run: residual must be contiguous NHWC of the output shape")
         nt = self._pick_nt(Nn, H, W)
+        if CONV2D_ARITH == "bf16x3":
+            N.require_ab("ESTD_CONV2D_ARITH=bf16x3 (csrc/conv2d_split_bf16.hip)")
+        if CONV2D_ALGO == "wino":
+            N.require_ab("ESTD_CONV2D_ALGO=wino (csrc/conv2d_wino.hip)")
         split = CONV2D_ARITH == "bf16x3" and self.w_split is not None
         if self.dil == 2 and not split and CONV2D_ALGO in ("wino", "wino2"):
             nt = 2        # the 64-channel work item of the dilated Winograd kernel spills registers into its MFMA loop (5x slower)

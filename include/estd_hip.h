@@ -138,16 +138,20 @@ typedef struct estd_conv3d_desc {
 } estd_conv3d_desc;
 
 int estd_conv3d_k3(const estd_conv3d_desc* desc, estd_stream_t stream);
+#ifdef ESTD_BUILD_AB   /* superseded A/B kernel: built and exported only with ESTD_BUILD_AB=1 (estdepth_amd/build.py) */
 /* Same operator for the plain 32->32 case (cin_main = 32, n_tiles = 2, no extra channel / head / 33rd output), with
  * every fp32 product evaluated as six bf16 MFMA products of exactly split operands (a = a1+a2+a3, b = b1+b2+b3,
  * fp32 accumulation; dropped terms <= 2^-26 |ab|): fp32-level error at 96 instead of 256 matrix-pipe cycles per
  * 16x16x32 block.  Reads w_split instead of w_main.  ESTD_ERR_UNSUPPORTED for any other shape. */
 int estd_conv3d_k3_split(const estd_conv3d_desc* desc, estd_stream_t stream);
+#endif
+#ifdef ESTD_BUILD_AB   /* superseded A/B kernel: built and exported only with ESTD_BUILD_AB=1 (estdepth_amd/build.py) */
 /* Same operator for the plain 32->32 instance (cin_main = 32, n_tiles = 2, no extra channel / head / 33rd output; BN, ReLU,
  * residuals, scale, accumulation and GroupNorm partials as estd_conv3d_k3) with the depth axis in Winograd F(2,3) form:
  * two output planes from four transformed input planes, 36 instead of 54 tap products, every product an fp32 MFMA with
  * fp32 accumulation (csrc/conv3d_wino.hip).  Reads w_wino instead of w_main.  ESTD_ERR_UNSUPPORTED for any other shape. */
 int estd_conv3d_k3_wino(const estd_conv3d_desc* desc, estd_stream_t stream);
+#endif
 /* Same operator with the depth AND the image-row axis in Winograd form, F(2x2, 3x3): 2 x 2 outputs (two planes, two rows) from a
  * 4 x 4 transformed input patch, 48 tap products per 4 outputs = 0.444 of the direct kernel's MFMA work (csrc/conv3d_wino2.hip).
  * Instances: cin_main = 32 with n_tiles = 2 (32 -> 32; with in_extra + w_extra the 33 -> 32 key|value form; every epilogue feature of
@@ -193,17 +197,21 @@ typedef struct estd_conv2d_desc {
 } estd_conv2d_desc;
 
 int estd_conv2d_k3(const estd_conv2d_desc* desc, estd_stream_t stream);
+#ifdef ESTD_BUILD_AB   /* superseded A/B kernel: built and exported only with ESTD_BUILD_AB=1 (estdepth_amd/build.py) */
 /* Same operator with the row axis in Winograd F(2,3) form: two output rows from four transformed input rows, 12 instead of
  * 18 tap products, every product an fp32 MFMA with fp32 accumulation (csrc/conv2d_wino.hip).  Reads w_wino instead of w. */
 int estd_conv2d_k3_wino(const estd_conv2d_desc* desc, estd_stream_t stream);
+#endif
 /* Same operator (dilation 1 | 2; group_tiles ignored: 32 output channels per work item) with BOTH image axes in Winograd form,
  * F(2x2, 3x3): 2 x 2 output pixels from a 4 x 4 transformed input patch, 16 instead of 36 tap products = 0.444 of the direct kernel's
  * MFMA work (csrc/conv2d_wino2.hip).  Reads desc->w_wino, which must then hold the F(2x2, 3x3) packing: float32
  * [cout/32][cin/32][8 steps][4][2][64][4] (packing.py::pack_conv2d_wino2). */
 int estd_conv2d_k3_wino2(const estd_conv2d_desc* desc, estd_stream_t stream);
+#ifdef ESTD_BUILD_AB   /* superseded A/B kernel: built and exported only with ESTD_BUILD_AB=1 (estdepth_amd/build.py) */
 /* Same operator (group_tiles ignored: 32 output channels per work item) with every fp32 product as six
  * bf16 MFMA products of exactly 3-way split operands, fp32 accumulation (see estd_conv3d_k3_split). */
 int estd_conv2d_k3_split(const estd_conv2d_desc* desc, estd_stream_t stream);
+#endif
 
 /* mean/rstd from the partials: stats_out = {mean_g0, rstd_g0, mean_g1, rstd_g1}; count = 16*D*H*W per group
  * (transformer/epipolar_transformer.py:22-23,:27 GroupNorm(1, 16, eps=1e-5)). */

@@ -13,6 +13,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "ab: exercises the superseded A/B kernels (depth-only / row-only Winograd, bf16 operand split): "
+                                       "runs only against a library built with ESTD_BUILD_AB=1")
 
 
 def pytest_collection_modifyitems(config, items):
@@ -30,6 +32,11 @@ def pytest_collection_modifyitems(config, items):
         for item in items:
             if "gpu" in item.keywords:
                 item.add_marker(skip)
+    elif not _native.has_ab():
+        skip_ab = pytest.mark.skip(reason="library built without the A/B kernels (ESTD_BUILD_AB=1)")
+        for item in items:
+            if "ab" in item.keywords:
+                item.add_marker(skip_ab)
 
 
 @pytest.fixture(scope="session")

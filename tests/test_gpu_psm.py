@@ -183,6 +183,7 @@ def test_e2e_golden_with_fused_bn(golden_dir):
                                                         (96, 64, (1, 8, 16), False, False, 1), (320, 128, (1, 9, 40), True, False, 1),
                                                         (64, 64, (5, 120, 160), False, True, 1), (128, 128, (1, 17, 35), True, False, 2),
                                                         (32, 64, (2, 8, 16), False, True, 2), (128, 128, (5, 120, 160), True, False, 2)])
+@pytest.mark.ab
 def test_conv2d_split_vs_fp64_and_fp32_kernel(cin, cout, dims, relu, res, dil):
     """3xbf16 split conv2d: fp32-level error against an fp64 convolution, agreement with the fp32 MFMA kernel."""
     from estdepth_amd import synth, ops
@@ -223,6 +224,7 @@ def test_conv2d_split_vs_fp64_and_fp32_kernel(cin, cout, dims, relu, res, dil):
         assert esp <= 2.0 * e32 + 1e-7 * mag, (esp, e32)
 
 
+@pytest.mark.ab
 def test_e2e_golden_with_all_split_arithmetic(golden_dir):
     """Joint carry golden with conv3d AND the PSM conv2d kernels on the split arithmetic: depth within 1e-4."""
     import os

@@ -10,7 +10,7 @@ import torch
 import fixtures_spec as S
 from helpers import checksum, checksum_close
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.ab]
 DEV = torch.device("cuda:0")
 
 

@@ -42,7 +42,16 @@ def _run(plan, algo, x, dims, **kw):
         ops.CONV3D_ALGO, ops.W2X = old, old_x
 
 
-ALGOS = ("wino", "wino2")      # depth axis / depth and row axis in Winograd form
+def _has_ab():
+    from estdepth_amd import _native
+    try:
+        return _native.has_ab()
+    except RuntimeError:
+        return False
+
+
+# depth and row axis in Winograd form (default); "wino" = depth axis only (csrc/conv3d_wino.hip: part of the ESTD_BUILD_AB=1 build)
+ALGOS = ("wino2",) + (("wino",) if _has_ab() else ())
 ALGOS_PLAIN = ALGOS + ("wino2x",)      # instances without a scalar channel: + the operand-reuse kernel
 
 
@@ -144,7 +153,7 @@ def test_wino_extra_input_channel_matches_direct_kernel_and_fp64(dims, algo):
     w = torch.randn(32, 33, 3, 3, 3, generator=g) * 0.05
     sc, sh = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.1
     plan = ops.Conv3dPlan(w, list(range(32)), 32, list(range(32)), 2, sc, sh, act_a="relu", device=DEV)
-    assert plan.w_wino_extra is not None and plan.w_wino2_extra is not None
+    assert plan.w_wino2_extra is not None and (plan.w_wino_extra is not None or not _has_ab())
     x = torch.randn(N, D, H, W, 32, generator=g)
     e = torch.randn(N, D, H, W, generator=g)
     a = _run(plan, "direct", x.to(DEV), dims, in_extra=e.to(DEV))
@@ -170,7 +179,7 @@ def test_wino_33_to_33_matches_direct_kernel_and_fp64(dims, algo):
     w = torch.randn(33, 33, 3, 3, 3, generator=g) * 0.05
     sc, sh = torch.rand(33, generator=g) + 0.5, torch.randn(33, generator=g) * 0.1
     plan = ops.Conv3dPlan(w, list(range(1, 33)), 0, list(range(33)), 3, sc, sh, act_a="relu", device=DEV)
-    assert plan.w_wino_xout is not None and plan.w_wino2_xout is not None
+    assert plan.w_wino2_xout is not None and (plan.w_wino_xout is not None or not _has_ab())
     x = torch.randn(N, D, H, W, 32, generator=g)
     e = torch.randn(N, D, H, W, generator=g)
     outs = {}
@@ -205,7 +214,7 @@ def test_reserved_cus_changes_the_partition_not_the_result():
             eff = ops.set_reserved_cus(r)
             assert eff == {0: 0, 8: 8, 5: 8, 128: 128, 1000: 128}[r]
             part = torch.zeros(nblk * 4, device=DEV, dtype=torch.float64)
-            res[r] = (_run(plan, "wino", x, dims, stats_partials=part), part, _run(plan, "direct", x, dims), p2.run(x2))
+            res[r] = (_run(plan, "wino2", x, dims, stats_partials=part), part, _run(plan, "direct", x, dims), p2.run(x2))
     finally:
         ops.set_reserved_cus(0)
     for r in (8, 128):
@@ -222,6 +231,7 @@ def test_fuzz_winograd_kernels_against_direct_kernels():
     assert r.returncode == 0 and "random cases agree" in r.stdout, (r.stdout[-500:], r.stderr[-500:])
 
 
+@pytest.mark.ab
 def test_wino_rejects_other_shapes():
     from estdepth_amd import _native
     d = _native.Conv3dDesc()

@@ -8,7 +8,10 @@ import numpy as np
 import torch
 from estdepth_amd import ops
 
+from estdepth_amd import _native
 DEV = torch.device("cuda:0")
+AB = _native.has_ab()                                         # depth-only / row-only Winograd kernels: ESTD_BUILD_AB=1 builds only
+WINO3D = ("wino", "wino2") if AB else ("wino2",)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
@@ -46,7 +49,7 @@ def case_conv3d():
             kw_common = dict(accumulate=True, out_scale=float(rng.uniform(0.3, 1.0)))
         outs = {}
         base = rnd(N, D, H, W, 32)
-        for algo in ("direct", "wino", "wino2"):
+        for algo in ("direct",) + WINO3D:
             kw = dict(kw_common)
             if mode == "stats":
                 kw["stats_partials"] = torch.zeros(ops.conv3d_grid(*dims) * 4, device=DEV, dtype=torch.float64)
@@ -54,7 +57,7 @@ def case_conv3d():
         a = outs["direct"][0]
         tol = 4e-5 * max(1.0, float(a.abs().max()))
         ok, worst = True, 0.0
-        for alg in ("wino", "wino2"):
+        for alg in WINO3D:
             b = outs[alg][0]
             worst = max(worst, float((a - b).abs().max()))
             ok = ok and float((a - b).abs().max()) < tol
@@ -69,8 +72,8 @@ def case_conv3d():
         plan = ops.Conv3dPlan(w, list(range(32)), 32, list(range(32)), 2, torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.1,
                               act_a="tanh", act_b="relu", act_split=16, device=DEV)
         a = run3d(plan, "direct", x, dims, in_extra=e, out=torch.empty_like(x))
-        b = run3d(plan, "wino", x, dims, in_extra=e, out=torch.empty_like(x))
         b2 = run3d(plan, "wino2", x, dims, in_extra=e, out=torch.empty_like(x))
+        b = run3d(plan, "wino", x, dims, in_extra=e, out=torch.empty_like(x)) if AB else b2
         d2 = float((a - b2).abs().max())
         if not ((d2 == d2) and d2 < 4e-5 * max(1.0, float(a.abs().max()))):
             return False, ("conv3d", "extra/wino2", dims, d2)
@@ -80,9 +83,12 @@ def case_conv3d():
                               act_a="relu", device=DEV)
         ea, eb = torch.full((N, D, H, W), float("nan"), device=DEV), torch.full((N, D, H, W), float("nan"), device=DEV)
         a = run3d(plan, "direct", x, dims, in_extra=e, out=torch.empty_like(x), out_extra=ea)
-        b = run3d(plan, "wino", x, dims, in_extra=e, out=torch.empty_like(x), out_extra=eb)
         ec = torch.full((N, D, H, W), float("nan"), device=DEV)
         b2 = run3d(plan, "wino2", x, dims, in_extra=e, out=torch.empty_like(x), out_extra=ec)
+        if AB:
+            b = run3d(plan, "wino", x, dims, in_extra=e, out=torch.empty_like(x), out_extra=eb)
+        else:
+            b, eb = b2, ec
         a, b, b2 = torch.cat([a, ea[..., None]], -1), torch.cat([b, eb[..., None]], -1), torch.cat([b2, ec[..., None]], -1)
         d2 = float((a - b2).abs().max())
         if not ((d2 == d2) and d2 < 4e-5 * max(1.0, float(a.abs().max()))):
@@ -111,12 +117,12 @@ def case_conv2d():
     x = rnd(N, H, W, cin)
     res = rnd(N, H, W, cout) if rng.integers(2) else None
     outs = {}
-    for algo in ("direct", "wino", "wino2"):            # row-only and two-axis Winograd (the default) against the direct kernel
+    for algo in ("direct",) + WINO3D:            # two-axis Winograd (the default; + row-only in an ESTD_BUILD_AB=1 build) against the direct kernel
         ops.CONV2D_ALGO = algo
         outs[algo] = plan.run(x, residual=res)
         torch.cuda.synchronize()
     a = outs["direct"]
-    d = max(float((a - outs["wino"]).abs().max()), float((a - outs["wino2"]).abs().max()))
+    d = max(float((a - outs[alg]).abs().max()) for alg in WINO3D)
     return (d == d) and d < 4e-5 * max(1.0, float(a.abs().max())), ("conv2d", (N, H, W), cin, cout, dil, rb, ra, res is not None, d)
 
 
