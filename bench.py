@@ -269,6 +269,20 @@ def cpu_baseline(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses,
     return base, parity
 
 
+def _prime_until_captured(push, model, at_least, limit):
+    """untimed calls until the set of captured hipGraphs has stopped growing for three calls in a row (a streaming harness in zero-copy mode
+    walks through start-up signatures -- 0, 1, 2 memory records, no cached features -- and then through the slots of its memory ring: the
+    steady-state captures are complete only after that), at least ``at_least`` and at most ``limit`` calls.  Returns the number of calls made."""
+    n, stable, last = 0, 0, -1
+    while n < limit and (n < at_least or stable < 3):
+        push(n)
+        n += 1
+        now = len(getattr(model, "_graphs", ()))
+        stable = stable + 1 if now == last else 0
+        last = now
+    return n
+
+
 def stream_bench(args, device, rank, world):
     """Extra (not the headline): frame-by-frame ESTM streaming at cfg3 size through estdepth_amd.streaming.ESTMStream
     with the per-frame PSM feature cache; one step = one pushed frame = one depth frame."""
@@ -276,15 +290,16 @@ def stream_bench(args, device, rank, world):
     from estdepth_amd import synth
     from estdepth_amd.streaming import ESTMStream
     model = build_model("estm", device)
-    n = args.warmup + args.steps + 4
+    prime_max = args.warmup + 12
+    n = prime_max + args.steps
     imgs, poses, intr, _ = synth.make_sequence(n, 480, 640, seed=1003 + rank)
     imgs, poses, intr = imgs.to(device), poses.to(device), intr.to(device)
     st = ESTMStream(model, cache_features=True, graph=not args.no_graph)
-    for f in range(args.warmup + 4):          # fills the window, the memory (graphs for 0, 1, 2 memories are captured here)
-        st.push(imgs[0, f], poses[0, f], intr[0])
+    # fills the window and the memory; every capture of the steady state is made here, not inside the timed loop
+    f0 = _prime_until_captured(lambda f: st.push(imgs[0, f], poses[0, f], intr[0]), st.model, args.warmup + 4, prime_max)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for f in range(args.warmup + 4, n):
+    for f in range(f0, f0 + args.steps):
         st.push(imgs[0, f], poses[0, f], intr[0])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -293,7 +308,37 @@ def stream_bench(args, device, rank, world):
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "ESTM stream: 1 new frame per step, window 3, memory 2, %s"
-                                   % ("eager launches" if args.no_graph else "hipGraph replay (PSM per frame + window forward)")}}
+                                   % ("eager launches" if args.no_graph else "hipGraph replay (the new frame's PSM features inside stage A of the window forward)"),
+                       "untimed_priming_calls": f0, "captures": len(getattr(st.model, "_graphs", ()))}}
+
+
+def joint_stream_bench(steps, warmup, device, no_graph=False):
+    """Extra (not the headline, which stays the whole forward): the Joint protocol as a stream -- consecutive 5-frame clips at stride 3
+    (data/general_eval.py:52) with carried memory (eval_hybrid.py:229-243) through estdepth_amd.streaming.JointStream, which keeps the
+    matching features of the two frames a clip shares with its predecessor: 3 of 5 frames go through the PSM extractor per step."""
+    import torch
+    from estdepth_amd import synth
+    from estdepth_amd.streaming import JointStream
+    model = build_model("joint", device)
+    prime_max = warmup + 8
+    nclips = prime_max + steps
+    imgs, poses, intr, _ = synth.make_sequence(5 + 3 * (nclips - 1), 480, 640, seed=1002)
+    imgs, poses, intr = imgs.to(device), poses.to(device), intr.to(device)
+    st = JointStream(model, seq_len=5, cache_features=True, graph=not no_graph)
+    clip = lambda c: st.push_clip(imgs[0, 3 * c:3 * c + 5], poses[0, 3 * c:3 * c + 5], intr[0])
+    c0 = _prime_until_captured(clip, st.model, warmup + 3, prime_max)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for c in range(c0, c0 + steps):
+        clip(c)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    del st, model
+    torch.cuda.empty_cache()
+    return {"workload": "Joint stream: 5-frame clips at stride 3 with carried memory, matching features of the 2 shared frames cached "
+                        "(3 of 5 frames extracted per step), 480x640, D=64, ResNet-50, %s" % ("eager launches" if no_graph else "hipGraph replay"),
+            "value": round(3 * steps / dt, 3), "unit": "depth frames/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warmup,
+            "depth_frames_per_step": 3, "untimed_priming_calls": c0}
 
 
 GRAPH_PRIME = 2      # untimed calls in front of the warm-up steps of a hipGraph run: zero-copy memory alternates between two captures
@@ -790,10 +835,14 @@ def main():
                 sa = argparse.Namespace(steps=20, warmup=3, no_graph=args.no_graph)
                 sl_ = stream_bench(sa, device, 0, 1)
                 others["stream"] = {"workload": sl_["config"]["workload"], "value": sl_["value"], "unit": sl_["unit"], "ms_per_step": sl_["ms_per_step"],
-                                    "steps": 20, "warmup": 3, "depth_frames_per_step": 1}
+                                    "steps": 20, "warmup": 3, "depth_frames_per_step": 1, "untimed_priming_calls": sl_["config"]["untimed_priming_calls"]}
                 torch.cuda.empty_cache()
             except Exception as e:
                 others["stream"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:120])}
+            try:
+                others["joint_stream"] = joint_stream_bench(10, 3, device, args.no_graph)
+            except Exception as e:
+                others["joint_stream"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:120])}
             line["other_workloads"] = others
         if world == 1 and not args.no_cpu_baseline:
             # two CPU restatements on the box's host cores -- the C/OpenMP port (the parity checker, 8 threads: it

@@ -28,7 +28,7 @@ costs (0.14 ms of a 17.7 ms Joint step):
     them (ring buffers: a bounded set; at most ``MAX_FOREIGN`` other address sets per call shape, then the static-copy path);
   * the tensors of ``outputs`` are overwritten by the next call of ANY signature (the captures of a call shape share nothing, but
     replays alternate between them).
-A capture is keyed by (input shape, number of memory volumes, matching-features given?, mode, convolution arithmetic,
+A capture is keyed by (input shape, number of memory volumes, number of frames whose matching features are handed in, mode, convolution arithmetic,
 weights epoch of the model): ``load_state_dict`` / ``.to()`` bump the epoch and force a re-capture; call
 ``invalidate()`` after editing parameters in place.
 """
@@ -56,11 +56,13 @@ class GraphedForward:
         self.clone_outputs = clone_outputs
         self.zero_copy_memory = zero_copy_memory
         self.memory_logits = None                # after a call: fresh copy of DepthHybridDecoder.memory_logits of that call
+        self.last_matching = None                # after a call: the PSM features [V,32,H/4,W/4] of its frames (stage A's static buffer: valid until
+                                                 # the next call; estdepth_amd.streaming copies the frames it shares with the next call out of it)
         self._graphs = {}
         self._ring = {}                          # zero-copy mode: kv shape -> {"bufs": [...], "stamp": [...], "last": slot, "clock": n}
 
     def __getattr__(self, name):                 # normalise_images, matchingFeature, ndepths, ... of the wrapped model
-        if name in ("model", "warmup", "_graphs", "clone_outputs", "memory_logits", "zero_copy_memory", "_ring"):
+        if name in ("model", "warmup", "_graphs", "clone_outputs", "memory_logits", "zero_copy_memory", "_ring", "last_matching"):
             raise AttributeError(name)
         return getattr(self.model, name)
 
@@ -71,7 +73,7 @@ class GraphedForward:
     def _signature(self, imgs, pre_costs, mode, matching_features, placement=(None, None)):
         n_mem = 0 if pre_costs is None else len(pre_costs["keys"])
         from . import ops
-        return (tuple(imgs.shape), n_mem, matching_features is not None, mode, ops.CONV3D_ARITH, ops.CONV2D_ARITH,
+        return (tuple(imgs.shape), n_mem, None if matching_features is None else int(matching_features.shape[0]), mode, ops.CONV3D_ARITH, ops.CONV2D_ARITH,
                 ops.CONV3D_ALGO, getattr(ops, "CONV2D_ALGO", None), getattr(ops, "CONV2D_NT", None),      # a graph bakes the kernel choice in
                 self.model.camera_algebra,
                 placement,                                         # zero-copy mode: (addresses of the memory records, output ring slot)
@@ -230,6 +232,7 @@ class GraphedForward:
         main.wait_stream(side)
         st["graph_b"].replay()
         outputs, costs, cposes = st["out"]
+        self.last_matching = st["feats2d"]["matching"]
         # the logit volume that travels with the memory bank (parallel.allgather_memory_bank*): a fresh 4.9 MB tensor, like the memory
         ml = st.get("memory_logits")
         self.memory_logits = ml.clone() if ml is not None else None

@@ -246,10 +246,27 @@ class DepthNetHybrid(nn.Module):
     #   forward_3d  -- plane sweeps, cost volumes, 3D regularisation, EST fusion, soft-argmin, 2D refinement.
     # forward() starts the (asynchronous) device-to-host copy of the poses, launches stage 1, and only then waits for the
     # copy and composes the matrices (estdepth_amd/camera.py): the synchronisation the exact host algebra needs costs no GPU time.
+    def _matching(self, flat, matching_features):
+        """PSM matching features of the V frames of a call (model_hybrid.py:128).  ``matching_features`` [Vc,32,H/4,W/4], Vc <= V: features
+        of the LEADING Vc frames a caller already holds (overlapping windows / clips: estdepth_amd.streaming) -- only the trailing V - Vc
+        frames go through the extractor, on the stream this is called on (beside the semantic branch), and the result is the full stack."""
+        if matching_features is None:
+            return self.matchingFeature(flat)
+        vc = matching_features.shape[0]
+        if vc == flat.shape[0]:
+            return matching_features
+        if vc > flat.shape[0]:
+            raise RuntimeError("matching_features holds %d frames, the call has %d" % (vc, flat.shape[0]))
+        new = self.matchingFeature(flat[vc:])
+        if matching_features.is_contiguous(memory_format=torch.channels_last) != new.is_contiguous(memory_format=torch.channels_last):
+            matching_features = matching_features.contiguous(memory_format=torch.channels_last if new.is_contiguous(memory_format=torch.channels_last)
+                                                              else torch.contiguous_format)
+        return torch.cat([matching_features, new], 0)
+
     @torch.no_grad()
     def forward_2d(self, imgs, matching_features=None, join=False):
         """imgs [1,V,3,Hi,Wi] in 0..255 -> the camera-independent features.  ``join``: wait for the side stream before returning
-        (a captured hipGraph has to end with its streams joined)."""
+        (a captured hipGraph has to end with its streams joined).  ``matching_features``: see ``_matching``."""
         batch_size, views_num, _, height_img, width_img = imgs.shape
         assert views_num > 2  # the views_num should be larger than 2 (model_hybrid.py:123)
         if batch_size != 1:
@@ -278,13 +295,14 @@ class DepthNetHybrid(nn.Module):
                 sv = self.CostRegNet._semantic_vs(semantic_features).contiguous()     # [T,D,H,W] planes (the decoder's layout)
             for t_ in list(semantic_features) + [sv]:
                 t_.record_stream(main)
-            matching = matching_features if matching_features is not None else self.matchingFeature(flat)   # :128
+            matching = self._matching(flat, matching_features)                                             # :128
             if join:
                 main.wait_stream(side)
             sv_pre = (None if join else side, sv)
         else:
-            matching = matching_features if matching_features is not None else self.matchingFeature(flat)   # :128
+            matching = self._matching(flat, matching_features)                                             # :128
             semantic_features = self.semanticFeature(flat[1:1 + target_num])                               # :138-139 (batch 1)
+        self.last_matching = matching      # [V,32,H/4,W/4]: what a streaming caller slices its next call's ``matching_features`` from
         return {"matching": matching, "semantic_features": semantic_features, "sv_pre": sv_pre, "views_num": views_num,
                 "device": imgs.device, "dtype": imgs.dtype}
 
@@ -350,8 +368,9 @@ class DepthNetHybrid(nn.Module):
                 matching_features=None, cam_mats=None):
         """model_hybrid.py:110-184.  imgs [1,V,3,Hi,Wi] in 0..255; cam_poses [1,V,4,4] camera-to-world; cam_intr [1,3,3]
         full-resolution pixels; returns (outputs, cur_costs, cur_cam_poses) for inference modes.  Two optional extensions:
-        ``matching_features`` (estdepth_amd.streaming) = precomputed PSM features [V,32,H/4,W/4] of the frames, so overlapping
-        windows do not recompute them; ``cam_mats`` = the result of ``camera_matrices`` for these poses."""
+        ``matching_features`` (estdepth_amd.streaming) = PSM features [Vc,32,H/4,W/4] of the leading Vc <= V frames, so overlapping
+        windows / clips do not recompute them (the trailing frames are extracted in this call; ``last_matching`` holds the full stack
+        afterwards); ``cam_mats`` = the result of ``camera_matrices`` for these poses."""
         if mode == 'train' or self.training:
             raise RuntimeError("estdepth_amd implements the inference path (mode='val'/'test'); training is out of scope")
         pending = self.camera_begin(cam_poses, cam_intr, pre_cam_poses) if cam_mats is None else None

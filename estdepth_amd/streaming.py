@@ -6,28 +6,33 @@
     eval_hybrid_seq.py:76-120   lw2batch: stack the window on dim 1, build pre_costs / pre_cam_poses from the memory.
 
 SURVEY §8(f) rank 1: consecutive windows share lwindow-1 frames, and the PSM matching features of a frame do not
-depend on the window, so they are computed ONCE per frame and handed to ``DepthNetHybrid.forward`` through its
-``matching_features`` extension (406 of ~1320 GFLOP per depth frame at cfg3).  Everything else is the unchanged forward.
+depend on the window, so they are computed ONCE per frame: a window hands the features of its lwindow-1 old frames to
+``DepthNetHybrid.forward`` through the ``matching_features`` extension (406 of ~1320 GFLOP per depth frame at cfg3) and
+the forward extracts only the NEW frame's -- inside its stage A, on the matching stream BESIDE the semantic branch
+(round 5; before, a separate per-frame extraction ran in front of the window forward and exposed the ResNet / decoder
+time it used to hide: 7.62 vs 7.76 ms per window, 1.7 % for 31 % fewer FLOPs).  Everything else is the unchanged forward.
+
+``JointStream``: the same idea for the Joint protocol (eval_hybrid.py:229-243 with the clip sampling of
+data/general_eval.py:52: consecutive seq_len-frame clips at stride seq_len-2 share two frames): a clip hands over the
+features of its two leading frames and carries (costs, poses) of the previous clip as memory.
 """
 import torch
 
 
 class ESTMStream:
     def __init__(self, model, lwindow=3, memory_size=2, cache_features=True, graph=False):
-        """``graph=True``: replay captured hipGraphs instead of ~330 eager launches per window -- one graph per number of
-        memory volumes (0, 1, ..memory_size) for the window forward and one for the per-frame PSM extraction
-        (estdepth_amd.graph); same kernels, same results, returned ``outputs`` live until the next push.  The harness owns the
+        """``graph=True``: replay captured hipGraphs instead of ~330 eager launches per window -- one graph pair per (number of
+        memory volumes, cached frames, memory ring slot) (estdepth_amd.graph); same kernels, same results, returned ``outputs`` live
+        until the next push.  The harness owns the
         memory protocol, so the replay runs with ``zero_copy_memory=True``: the (costs, poses) a push returns lie in a ring of
         ``memory_size + 1`` buffers and are read back in place -- they stay valid for ``memory_size`` further pushes (as long as the
         harness itself uses them); clone them to keep them longer."""
         if lwindow < 3:
             raise RuntimeError("a window needs at least 3 frames (model_hybrid.py:123)")
-        self._psm = None                     # None = model.matchingFeature, looked up at call time
         if graph:
-            from .graph import GraphedForward, GraphedModule
+            from .graph import GraphedForward
             if not isinstance(model, GraphedForward):
                 model = GraphedForward(model, zero_copy_memory=True)
-            self._psm = GraphedModule(model.matchingFeature, owner=model.model)     # keyed on the model's weights epoch
         self.model = model
         self.lwindow = lwindow
         self.memory_size = memory_size
@@ -36,7 +41,8 @@ class ESTMStream:
 
     def reset(self):
         """start of a new sequence (eval_hybrid_seq.py:162-166)."""
-        self._frames = []          # dicts: img [1,3,H,W], pose [1,4,4], dmap, dmask, feat
+        self._frames = []          # dicts: img [1,3,H,W], pose [1,4,4], dmap, dmask
+        self._feats = None         # matching features [lwindow-1,32,H/4,W/4] of the frames the NEXT window shares with the last one
         self._mem_costs = []
         self._mem_poses = []
         self.windows = 0
@@ -50,13 +56,7 @@ class ESTMStream:
         hi, wi = img.shape[-2:]
         fr = {"img": img, "pose": pose,
               "dmap": dmap if dmap is not None else torch.ones(1, 1, hi, wi, device=img.device),
-              "dmask": dmask if dmask is not None else torch.ones(1, 1, hi, wi, device=img.device, dtype=torch.bool),
-              "feat": None}
-        if self.cache_features:
-            x = self.model.normalise_images(img)
-            if getattr(self.model, "_channels_last_2d", False):
-                x = x.contiguous(memory_format=torch.channels_last)
-            fr["feat"] = (self._psm or self.model.matchingFeature)(x)                                       # [1,32,H/4,W/4], once per frame
+              "dmask": dmask if dmask is not None else torch.ones(1, 1, hi, wi, device=img.device, dtype=torch.bool)}
         self._frames.append(fr)
         if len(self._frames) < self.lwindow:
             return None
@@ -70,9 +70,13 @@ class ESTMStream:
             pre_poses = [p[0] for p in self._mem_poses]
         else:
             pre_costs, pre_poses = None, None
-        feats = torch.cat([f["feat"] for f in win], 0) if self.cache_features else None
+        # the old frames' features (None for the first window: every frame is new); the forward extracts the new frame's in its stage A
+        feats = self._feats if self.cache_features else None
         outputs, costs, cposes = self.model(imgs, poses, cam_intr.reshape(1, 3, 3), sample, pre_costs, pre_poses,
                                             mode="val", matching_features=feats)
+        if self.cache_features:
+            # (a copy: under hipGraph replay ``last_matching`` is stage A's static buffer, rewritten by the next call of that capture)
+            self._feats = self.model.last_matching[1:].clone(memory_format=torch.preserve_format)
         self._mem_costs.append(costs)
         self._mem_poses.append(cposes)
         self._frames.pop(0)                                                     # eval_hybrid_seq.py:190
@@ -80,4 +84,54 @@ class ESTMStream:
             self._mem_costs.pop(0)
             self._mem_poses.pop(0)
         self.windows += 1
+        return outputs, costs, cposes
+
+
+class JointStream:
+    """The Joint protocol as a reusable class: consecutive ``seq_len``-frame clips at stride ``seq_len - 2`` (the clip sampling of
+    data/general_eval.py:52) through ``DepthNetHybrid.forward`` with the previous clip's (costs, poses) as memory
+    (eval_hybrid.py:229-243).  The two frames a clip shares with its predecessor keep their PSM matching features
+    (``cache_features``): 2 of 5 frames at the benchmark's configuration skip the extractor, everything else is the unchanged forward.
+    ``graph=True``: hipGraph replay with zero-copy memory (estdepth_amd.graph); the returned ``outputs`` then live until the next clip."""
+
+    def __init__(self, model, seq_len=5, cache_features=True, graph=False):
+        if seq_len < 3:
+            raise RuntimeError("a clip needs at least 3 frames (model_hybrid.py:123)")
+        if graph:
+            from .graph import GraphedForward
+            if not isinstance(model, GraphedForward):
+                model = GraphedForward(model, zero_copy_memory=True)
+        self.model = model
+        self.seq_len = seq_len
+        self.cache_features = cache_features
+        self.reset()
+
+    def reset(self):
+        """start of a new sequence: no memory, no cached features"""
+        self._feats = None
+        self._mem = (None, None)
+        self.clips = 0
+
+    @property
+    def stride(self):
+        return self.seq_len - 2
+
+    @torch.no_grad()
+    def push_clip(self, imgs, cam_poses, cam_intr, sample=None):
+        """imgs [seq_len,3,Hi,Wi] or [1,seq_len,3,Hi,Wi] in 0..255 (the clip's first two frames are the previous clip's last two);
+        cam_poses [seq_len,4,4]; cam_intr [3,3].  Returns (outputs, costs, poses) of the clip's seq_len - 2 targets."""
+        imgs = imgs.reshape(1, self.seq_len, *imgs.shape[-3:])
+        poses = cam_poses.reshape(1, self.seq_len, 4, 4)
+        hi, wi = imgs.shape[-2:]
+        if sample is None:
+            sample = {"dmaps": torch.ones(1, self.seq_len, 1, hi, wi, device=imgs.device),
+                      "dmasks": torch.ones(1, self.seq_len, 1, hi, wi, device=imgs.device, dtype=torch.bool)}
+        feats = self._feats if self.cache_features else None
+        pre_costs, pre_poses = self._mem
+        outputs, costs, cposes = self.model(imgs, poses, cam_intr.reshape(1, 3, 3), sample, pre_costs,
+                                            list(pre_poses) if pre_poses is not None else None, mode="val", matching_features=feats)
+        if self.cache_features:
+            self._feats = self.model.last_matching[self.seq_len - 2:].clone(memory_format=torch.preserve_format)
+        self._mem = (costs, cposes)
+        self.clips += 1
         return outputs, costs, cposes

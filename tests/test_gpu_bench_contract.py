@@ -80,7 +80,8 @@ def test_bench_headline_workload_roofline_fields_are_hardware_fractions():
     assert abs(r["replay"]["eager_over_replay"] - 1.0) <= 0.15
     assert sum(k["launches_per_step"] * k["avg_launch_ms"] for k in r["mfma_kernels"].values()) <= d["ms_per_step"]
     ow = d["other_workloads"]
-    assert set(ow) == {"estm", "cfg5", "stream"} and all(v.get("value", 0) > 0 for v in ow.values()), ow
+    assert set(ow) == {"estm", "cfg5", "stream", "joint_stream"} and all(v.get("value", 0) > 0 for v in ow.values()), ow
+    assert ow["joint_stream"]["value"] > d["value"] and ow["stream"]["value"] > ow["estm"]["value"]     # the feature caches pay
     assert ow["estm"]["workload"].startswith("cfg3") and ow["cfg5"]["workload"].startswith("cfg5")
     assert REQUIRED <= set(d) and d["config"]["workload"].startswith("cfg2")
     assert 0 < r["frac"] <= 1 and r["achieved"] <= r["peak"] and abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3

@@ -406,6 +406,38 @@ def test_channels_last_2d_backbones_keep_parity(golden_dir):
         _cmp_outputs(outputs, g, prefix="w%d|" % w)
 
 
+@pytest.mark.parametrize("cache,graph", [(False, False), (True, False), (True, True)])
+def test_joint_stream_reproduces_the_joint_carry_golden(golden_dir, cache, graph):
+    """JointStream (eval_hybrid.py:229-243 with the clip sampling of data/general_eval.py:52 as a class; with / without the cache of the two
+    shared frames' matching features, eagerly and under hipGraph replay) must reproduce the reference's two consecutive Joint calls (G9);
+    a third clip through the steady-state signature agrees between the cached and the plain path."""
+    from estdepth_amd.streaming import JointStream
+    g = _g(golden_dir, "g9_joint_carry.npz")
+    m = _stream_model()
+    imgs, poses, intr, sample = S.e2e_inputs(8, S.E2E_HI, S.E2E_WI, seed=1004)           # the golden's eight frames ...
+    i2, p2, _, s2 = S.e2e_inputs(3, S.E2E_HI, S.E2E_WI, seed=1005, first_frame=8)         # ... and three more for a third clip
+    imgs, poses = torch.cat([imgs, i2], 1).to(DEV), torch.cat([poses, p2], 1).to(DEV)
+    sample = {k: torch.cat([v, s2[k]], 1) for k, v in sample.items()}
+    intr = intr.to(DEV)
+    st = JointStream(m, seq_len=5, cache_features=cache, graph=graph)
+    ref = JointStream(m, seq_len=5, cache_features=False, graph=False)
+    for call in range(3):
+        sl = slice(3 * call, 3 * call + 5)
+        smp = {k: v[:, sl].to(DEV) for k, v in sample.items()}
+        outputs, costs, cposes = st.push_clip(imgs[0, sl], poses[0, sl], intr[0], smp)
+        outputs = {k: v.clone() for k, v in outputs.items()}
+        if call < 2:
+            _cmp_outputs(outputs, g, prefix="c%d|" % call, optional=("init_prob", ("depth", 1)))
+            assert np.array_equal(cposes[0].cpu().numpy(), g["c%d|pose" % call])
+            assert checksum_close(checksum(costs["values"][0].cpu().numpy()), g["c%d|value_ck" % call])
+        if cache:
+            assert st._feats is not None and st._feats.shape[0] == 2
+            o2, _, _ = ref.push_clip(imgs[0, sl], poses[0, sl], intr[0], smp)
+            for k in o2:                     # cached features = the features the plain call extracts from the same images
+                assert float((o2[k] - outputs[k]).abs().max()) < 2e-5, (call, k)
+    assert st.clips == 3
+
+
 @pytest.mark.parametrize("cache", [False, True])
 def test_streaming_harness_reproduces_estm_golden(golden_dir, cache):
     """ESTMStream (eval_hybrid_seq.py protocol as a class, with/without the per-frame PSM feature cache) fed frame by
