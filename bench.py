@@ -558,16 +558,52 @@ def main():
 
     from estdepth_amd.graph import GraphedForward
     zero_copy = args.graph_memory == "zero-copy"
-    fwd = model if args.no_graph else GraphedForward(model, zero_copy_memory=zero_copy)     # hipGraph replay of the same forward (same kernels)
-
-    state = {"pending": None, "fwd": fwd, "allgather": dist_on and not args.no_allgather, "notes": [], "bank": None}
+    state = {"pending": None, "fwd": None, "allgather": dist_on and not args.no_allgather, "notes": [], "bank": None}
     if force_dist:
         state["notes"].append("ESTD_FORCE_DIST=1: world-size-1 RCCL communicator on one GPU (code-path + overlap-cost measurement, not scaling)")
+    reserve = None
     if state["allgather"] and not oversub:
-        # the RCCL all-gather of step k runs on a few CUs WHILE step k+1 computes.  The convolutions launch one or two resident
+        # the RCCL exchange of step k runs on a few CUs WHILE step k+1 computes.  The convolutions launch one or two resident
         # workgroups per CU with static tile ranges: were all 256 CUs claimed, the workgroups displaced by the collective would
-        # queue behind the others and double the launch.  Leave one CU per XCD free (costs ~3 % of the convolution rate at N > 1).
-        state["reserved_cus"] = ops.set_reserved_cus(int(os.environ.get("ESTD_RESERVED_CUS", "8")))
+        # queue behind the others and double the launch.  Leave one CU per XCD free -- but only where the exchange runs: it starts
+        # when stage B of step k ends and overlaps stage A (the 2D networks, ~30 % of a step) of step k + 1; an exchange shorter than
+        # that (the direct exchange over xGMI: ~1 ms; the device-local copy of a world-size-1 run) needs no reserve in stage B, which
+        # holds the 3D convolutions the reserve costs most (0.6 ms per Joint step for the whole-step reserve).
+        n_res = int(os.environ.get("ESTD_RESERVED_CUS", "8"))
+        scope = os.environ.get("ESTD_RESERVE_SCOPE", "auto")          # auto | A | AB
+        probe = None
+        if scope == "auto" and not args.no_graph:
+            # one eager forward for a record, then the exchange alone (the algorithm the timed steps will use) against that step
+            with torch.no_grad():
+                model(x_imgs, x_poses, intr, x_sample, pre_costs, list(pre_poses) if pre_poses else None, mode="val")
+                torch.cuda.synchronize()
+                te = time.perf_counter()
+                _, c_, p_ = model(x_imgs, x_poses, intr, x_sample, pre_costs, list(pre_poses) if pre_poses else None, mode="val")
+                torch.cuda.synchronize()
+                t_step = time.perf_counter() - te
+                lg_ = model.CostRegNet.memory_logits
+                parallel.allgather_memory_bank_async(c_, p_, stage=False, logits=lg_).wait()
+                torch.cuda.synchronize()
+                dist.barrier()
+                te = time.perf_counter()
+                for _ in range(3):
+                    parallel.allgather_memory_bank_async(c_, p_, stage=False, logits=lg_).wait()
+                torch.cuda.synchronize()
+                t_x = torch.tensor([(time.perf_counter() - te) / 3, t_step], device=device, dtype=torch.float64)
+                dist.all_reduce(t_x, op=dist.ReduceOp.MAX)            # every rank decides on the same numbers
+                del c_, p_
+            probe = {"exchange_alone_ms": round(1e3 * float(t_x[0]), 3), "eager_step_ms": round(1e3 * float(t_x[1]), 3)}
+            scope = "A" if float(t_x[0]) < 0.25 * float(t_x[1]) else "AB"
+        elif scope == "auto":
+            scope = "AB"
+        if scope not in ("A", "AB"):
+            raise RuntimeError("ESTD_RESERVE_SCOPE must be auto, A or AB, got %r" % (scope,))
+        reserve = (n_res, n_res if scope == "AB" else 0)
+        state["reserved_cus"], state["reserve_scope"], state["reserve_probe"] = n_res, scope, probe
+        if args.no_graph:
+            ops.set_reserved_cus(n_res)                                # eager launches: the process-wide setting, every kernel
+    fwd = model if args.no_graph else GraphedForward(model, zero_copy_memory=zero_copy, reserve_cus=reserve)     # hipGraph replay of the same forward (same kernels)
+    state["fwd"] = fwd
     if oversub:
         state["notes"].append("%d ranks share %d GPU(s), gloo collectives: code-path check, not a scaling measurement" % (world, oversub))
 
@@ -646,8 +682,9 @@ def main():
                     parallel.allgather_memory_bank_async(last[1], last[2], stage=False, logits=state["logits"], algo=algo).wait()
                 barrier()
                 return (time.perf_counter() - ta) / reps
-            t_ag = exchange_alone(None)                     # the algorithm the timed steps used (ESTD_AG_ALGO, default: one all-gather)
-            other = "direct" if parallel.AG_ALGO == "collective" else "collective"
+            t_ag = exchange_alone(None)                     # the algorithm the timed steps used (ESTD_AG_ALGO; "auto" starts on the one all-gather)
+            used_algo = parallel.active_algo()
+            other = "direct" if used_algo == "collective" else "collective"
             # the other one beside it (ring-vs-direct on the xGMI mesh is the open question) is timed LAST, under a watchdog, when the
             # line is complete (other_algo_diagnostic below): it is the one call of a multi-GPU run that no timed step has exercised
             t_other = None
@@ -655,7 +692,7 @@ def main():
                 state["other_algo"] = (other, exchange_alone)
         nbytes = 4 * (last[1]["keys"][0].numel() + last[1]["values"][0].numel() + 16 + state["logits"].numel())
         ag = {"record": "K||V_fused (%d B) + pose (64 B) + initial logit volume (%d B)" % (4 * 2 * last[1]["keys"][0].numel(), 4 * state["logits"].numel()),
-              "bytes_sent_per_rank": nbytes, "algo": parallel.AG_ALGO, "ms_alone": round(1e3 * t_ag, 3),
+              "bytes_sent_per_rank": nbytes, "algo": used_algo, "algo_setting": parallel.AG_ALGO, "ms_alone": round(1e3 * t_ag, 3),
               "bus_gbs_per_rank": round((world - 1) * nbytes / t_ag / 1e9, 2),
               "other_algo": {"algo": other, "ms_alone": round(1e3 * t_other, 3), "bus_gbs_per_rank": round((world - 1) * nbytes / t_other / 1e9, 2)} if t_other else None,
               "local_copy_gbs": round(nbytes / t_ag / 1e9, 2) if world == 1 else None,
@@ -665,17 +702,45 @@ def main():
         if backend == "nccl" and rank == 0 and os.environ.get("NCCL_DEBUG_FILE"):
             ag["rccl"] = rccl_debug_summary(os.environ["NCCL_DEBUG_FILE"])
     state["allgather"] = False
-    if force_dist and gathered:
-        # the same K steps without the collective (CU reserve still in place): what the overlapped all-gather costs a step
+
+    def timed_plain(f=None):
+        """the same K steps (after W warm-up steps) with forward ``f`` and whatever state["allgather"] says; max over the ranks, seconds"""
         for _ in range(args.warmup):
-            step()
+            step(f)
         barrier()
         ta = time.perf_counter()
         for _ in range(args.steps):
-            step()
+            step(f)
+        drain()
         barrier()
-        ag["ms_per_step_without_collective"] = round(1e3 * (time.perf_counter() - ta) / args.steps, 3)
+        tl = time.perf_counter() - ta
+        if world > 1:
+            tt_ = torch.tensor([tl], device=device, dtype=torch.float64)
+            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            tl = float(tt_[0])
+        return tl
+
+    if dist_on and gathered:
+        # every N: the same K steps WITHOUT the collective (CU reserve still in place) -- what the overlapped exchange costs a step, and the
+        # figure that is comparable with the driver's N = 1 line
+        t_nc = timed_plain()
+        ag["ms_per_step_without_collective"] = round(1e3 * t_nc / args.steps, 3)
         ag["ms_per_step_with_collective"] = round(1e3 * elapsed / args.steps, 3)
+        ag["reserved_cus"], ag["reserve_scope"] = state.get("reserved_cus"), state.get("reserve_scope")
+        ag["reserve_scope_probe"] = state.get("reserve_probe")
+        if state.get("reserved_cus") and not args.no_graph and not oversub and os.environ.get("ESTD_RESERVE_COST", "1") != "0":
+            # ... and without the reserve either (a third set of captures with full grids): what leaving the CUs free costs a step
+            try:
+                f0 = GraphedForward(model, zero_copy_memory=zero_copy, reserve_cus=(0, 0))
+                for _ in range(GRAPH_PRIME):
+                    step(f0)
+                t_nr = timed_plain(f0)
+                ag["ms_per_step_without_collective_without_reserve"] = round(1e3 * t_nr / args.steps, 3)
+                ag["reserve_cost_ms"] = round(1e3 * (t_nc - t_nr) / args.steps, 3)
+                del f0
+            except Exception as e:
+                ag["reserve_cost_ms"] = None
+                state["notes"].append("reserve-cost loop failed (%s: %s)" % (type(e).__name__, str(e)[:80]))
 
     child = os.environ.get("ESTD_BENCH_CHILD") == "1"       # the traced child run of replay_profile(): the timed loop is all it is for
     if child:
@@ -785,7 +850,8 @@ def main():
                        "notes": state["notes"],
                        "per_rank_ms_per_step": per_rank_ms,
                        "parallelism": "1 sequence per GPU" + ("; RCCL all-gather of {K,V,pose} per step, overlapped with the next step" if gathered else "")
-                                      + (("; %d CUs left free for the collective" % state["reserved_cus"]) if state.get("reserved_cus") else "")},
+                                      + (("; %d CUs left free for the collective in stage %s" % (state["reserved_cus"], "A (2D networks)" if state.get("reserve_scope") == "A" else "A and B"))
+                                         if state.get("reserved_cus") else "")},
             # `achieved` / `frac` = MFMA FLOPs the dominant kernel actually EXECUTES per second against the fp32 matrix peak (<= 1 by
             # construction: the hardware fraction).  `algorithmic_*` = the direct convolution's 2*27*Cin*Cout FLOPs per voxel (SURVEY
             # §8d) over the same time -- above the peak when exact Winograd identities remove products.
@@ -910,6 +976,33 @@ def main():
             res = {"algo": other, "ms_alone": round(1e3 * t_other, 3), "bus_gbs_per_rank": round((world - 1) * nb / t_other / 1e9, 2)}
         except Exception as e:
             res = {"algo": other, "error": "%s: %s" % (type(e).__name__, str(e)[:80])}
+        # ESTD_AG_ALGO=auto (default): every rank has both figures now -- agree on them (MAX over the ranks) and, when the other algorithm
+        # wins by more than 10 %, run the K timed steps once more on it (still under the watchdog: the line as it stands is printed if
+        # this never returns) and report that as the result, the first pass beside it
+        if parallel.AG_ALGO == "auto" and "ms_alone" in res and world > 1 and os.environ.get("ESTD_AG_AUTO_RETIME", "1") != "0":
+            try:
+                tx = torch.tensor([ag["ms_alone"], res["ms_alone"]], device=device, dtype=torch.float64)
+                dist.all_reduce(tx, op=dist.ReduceOp.MAX)
+                switch = float(tx[1]) < 0.9 * float(tx[0])
+                auto = {"ms_alone": {used_algo: round(float(tx[0]), 3), other: round(float(tx[1]), 3)}, "chosen": other if switch else used_algo}
+                if switch:
+                    parallel._ACTIVE["algo"] = other
+                    state["allgather"] = True
+                    t2 = timed_plain()
+                    state["allgather"] = False
+                    auto["first_pass"] = {"algo": used_algo, "ms_per_step": round(1e3 * elapsed / args.steps, 3)}
+                    auto["second_pass"] = {"algo": other, "ms_per_step": round(1e3 * t2 / args.steps, 3)}
+                    if rank == 0 and t2 < elapsed:
+                        line["value"] = round(frames * world * args.steps / t2, 3)
+                        line["ms_per_step"] = round(1e3 * t2 / args.steps, 3)
+                        line["config"]["input_frames_per_s"] = round(x_imgs.shape[1] * world * args.steps / t2, 3)
+                        line["config"]["allgather"]["algo"] = other
+                        line["config"]["allgather"]["ms_per_step_with_collective"] = round(1e3 * t2 / args.steps, 3)
+                if rank == 0:
+                    line["config"]["allgather"]["auto"] = auto
+            except Exception as e:
+                if rank == 0:
+                    line["config"]["allgather"]["auto"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:80])}
         done.set()
         if rank == 0:
             line["config"]["allgather"]["other_algo"] = res

@@ -47,11 +47,16 @@ UPLOAD_STREAM = os.environ.get("ESTD_GRAPH_UPLOAD_STREAM", "side")      # A/B sw
 class GraphedForward:
     MAX_FOREIGN = 2          # zero-copy mode: address sets of memory records that do not lie in the ring, per call shape
 
-    def __init__(self, model, warmup=2, clone_outputs=False, zero_copy_memory=False):
+    def __init__(self, model, warmup=2, clone_outputs=False, zero_copy_memory=False, reserve_cus=None):
         """``clone_outputs=True``: the returned ``outputs`` dict holds fresh tensors (18 device copies of [1,1,Hi,Wi] maps per
         Joint call) instead of the graph's static output buffers -- a true drop-in for callers that keep outputs across calls.
-        ``zero_copy_memory=True``: see the module docstring."""
+        ``zero_copy_memory=True``: see the module docstring.
+        ``reserve_cus=(a, b)``: compute units the persistent convolution grids leave free (``estd_set_reserved_cus``) in stage A and in
+        stage B -- a grid size is baked into a capture.  A collective that overlaps the NEXT call (the memory-bank exchange of a multi-GPU
+        run) starts when stage B ends and runs beside stage A of the next call: an exchange shorter than stage A needs the reserve there
+        only, ``(8, 0)``; None = whatever the process-wide setting is at capture time."""
         self.model = model
+        self.reserve_cus = reserve_cus
         self.warmup = warmup
         self.clone_outputs = clone_outputs
         self.zero_copy_memory = zero_copy_memory
@@ -62,7 +67,7 @@ class GraphedForward:
         self._ring = {}                          # zero-copy mode: kv shape -> {"bufs": [...], "stamp": [...], "last": slot, "clock": n}
 
     def __getattr__(self, name):                 # normalise_images, matchingFeature, ndepths, ... of the wrapped model
-        if name in ("model", "warmup", "_graphs", "clone_outputs", "memory_logits", "zero_copy_memory", "_ring", "last_matching"):
+        if name in ("model", "warmup", "_graphs", "clone_outputs", "memory_logits", "zero_copy_memory", "_ring", "last_matching", "reserve_cus"):
             raise AttributeError(name)
         return getattr(self.model, name)
 
@@ -129,10 +134,19 @@ class GraphedForward:
         pending = m.camera_begin(cam_poses, cam_intr, pre_cam_poses)
         st["cam"] = camera.finish(pending) if pending is not None else None
 
+        from . import ops
+        prev_reserve = ops.get_reserved_cus() if self.reserve_cus is not None else None
+
+        def reserve(stage):                              # the persistent grids of this stage leave that many CUs free (baked into the capture)
+            if self.reserve_cus is not None:
+                ops.set_reserved_cus(self.reserve_cus[stage])
+
         def run_a():                                     # stage A: camera-independent 2D networks, streams joined at the end
+            reserve(0)
             return m.forward_2d(st["imgs"], st["feats"], join=True)
 
         def run_b(feats):                                # stage B: everything downstream of the plane sweep
+            reserve(1)
             pc, pp = None, None
             if pre_costs is not None:
                 pairs = [kv_views(kv) for kv in st["kv"]]
@@ -157,6 +171,8 @@ class GraphedForward:
             feats = run_a()
         with torch.no_grad(), torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
             out = run_b(feats)
+        if prev_reserve is not None:
+            ops.set_reserved_cus(prev_reserve)
         st["graph_a"], st["graph_b"], st["feats2d"], st["out"] = ga, gb, feats, out
         st["memory_logits"] = getattr(m.CostRegNet, "memory_logits", None)     # static buffer of graph B (rewritten by every replay)
         # the replay reads the packed-weight buffers that existed at capture time: keep them alive even if a PlanCache

@@ -116,6 +116,10 @@ def set_reserved_cus(n):
     return int(N.lib().estd_set_reserved_cus(int(n)))
 
 
+def get_reserved_cus():
+    return int(N.lib().estd_get_reserved_cus())
+
+
 def profile_mark(idx):
     if _use_torch():
         return T().profile_mark(int(idx))

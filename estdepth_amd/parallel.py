@@ -9,26 +9,64 @@ probability volume of `north_star` before its softmax, hybrid_depth_decoder.py:2
 bandwidth over xGMI is exercised and reported).  Backend "nccl" is RCCL on ROCm; CPU tests use gloo.
 
 Algorithm of the exchange (``ESTD_AG_ALGO`` / ``algo=``):
-  * ``collective`` (default): ONE ``all_gather_into_tensor`` per stream of the record (RCCL picks ring / direct itself);
+  * ``auto`` (default): ``collective`` until ``select_exchange_algo`` has timed both algorithms on the real communicator and every
+    rank has agreed on the faster one (bench.py does that once, behind its first complete set of timed steps and under a watchdog:
+    the untried algorithm of a machine nobody has run yet must not cost the measurement);
+  * ``collective``: ONE ``all_gather_into_tensor`` per stream of the record (RCCL picks ring / direct itself);
   * ``direct``: every rank posts a send to and a receive from every peer under ONE group
     (``batch_isend_irecv`` = ncclGroupStart{ncclSend/ncclRecv to all peers}ncclGroupEnd on RCCL) and copies its own shard
     locally: on the fully connected xGMI mesh of an MI355X node every one of the 7 links of a GPU carries exactly one
     157 MB message (~1 ms at 153 GB/s per link) where a ring all-gather pushes (N-1) x 157 MB through ONE link per GPU
-    (~7.2 ms at N = 8).  Same receive layout, bit-identical result.
+    (~7.2 ms at N = 8).  Same receive layout, bit-identical result.  Exercised on gloo (world 2 and 3) and on a
+    world-size-1 RCCL communicator only: experimental until a multi-GPU RCCL run has been through it.
 """
 import os
 
 import torch
 import torch.distributed as dist
 
-AG_ALGO = os.environ.get("ESTD_AG_ALGO", "collective")
+AG_ALGO = os.environ.get("ESTD_AG_ALGO", "auto")
+_ACTIVE = {"algo": "collective"}      # what "auto" resolves to (select_exchange_algo)
+
+
+def active_algo():
+    """the algorithm an exchange with ``algo=None`` runs now"""
+    return _ACTIVE["algo"] if AG_ALGO == "auto" else AG_ALGO
+
+
+def select_exchange_algo(costs, cam_poses, group=None, logits=None, reps=3, margin=0.9, sync=None):
+    """Time the memory-bank exchange alone with BOTH algorithms on this communicator (``reps`` exchanges each after one untimed
+    one), agree on the result across the ranks (every rank's times are reduced with MAX, so all ranks see the same two numbers) and
+    make the faster one what ``algo=None`` / ``ESTD_AG_ALGO=auto`` uses from now on -- ``direct`` only when it wins by more than
+    ``1 - margin``.  ``sync``: device synchronisation (``torch.cuda.synchronize``; None on CPU / gloo).  Returns
+    {"chosen", "ms_collective", "ms_direct"}.  Collective call: every rank must make it at the same point."""
+    import time
+    ms = {}
+    for algo in ("collective", "direct"):
+        allgather_memory_bank_async(costs, cam_poses, group=group, stage=False, logits=logits, algo=algo).wait()
+        if sync:
+            sync()
+        dist.barrier(group)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            allgather_memory_bank_async(costs, cam_poses, group=group, stage=False, logits=logits, algo=algo).wait()
+        if sync:
+            sync()
+        ms[algo] = 1e3 * (time.perf_counter() - t0) / reps
+    t = torch.tensor([ms["collective"], ms["direct"]], dtype=torch.float64, device=costs["keys"][0].device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    mc, md = float(t[0]), float(t[1])
+    _ACTIVE["algo"] = "direct" if md < margin * mc else "collective"
+    return {"chosen": _ACTIVE["algo"], "ms_collective": round(mc, 3), "ms_direct": round(md, 3)}
 
 
 def _gather_flat(recv, send, group, algo, async_op=True):
     """recv [world * n] <- every rank's send [n].  Returns a list of work handles (possibly empty)."""
-    algo = AG_ALGO if algo is None else algo
+    algo = active_algo() if algo is None else algo
+    if algo == "auto":
+        algo = _ACTIVE["algo"]
     if algo not in ("collective", "direct"):
-        raise RuntimeError("ESTD_AG_ALGO must be collective or direct, got %r" % (algo,))
+        raise RuntimeError("ESTD_AG_ALGO must be auto, collective or direct, got %r" % (algo,))
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if algo == "collective":
         w = dist.all_gather_into_tensor(recv, send, group=group, async_op=async_op)

@@ -106,7 +106,10 @@ def test_bench_world_size_one_rccl_communicator():
     ag = d["config"]["allgather"]
     assert d["n_gpus"] == 1 and ag["backend"].startswith("RCCL") and ag["own_shard_bit_equal"] is True
     assert ag["ms_alone"] > 0 and ag["ms_per_step_without_collective"] > 0 and "CUs left free" in d["config"]["parallelism"]
-    assert "logit volume" in ag["record"] and ag["algo"] == "collective"
+    assert "logit volume" in ag["record"] and ag["algo"] == "collective" and ag["algo_setting"] == "auto"
+    # the CU reserve is held only where the exchange runs (a device-local copy here: stage A), and its cost is measured
+    assert ag["reserve_scope"] == "A" and ag["reserved_cus"] == 8 and ag["reserve_scope_probe"]["exchange_alone_ms"] > 0
+    assert ag["ms_per_step_without_collective_without_reserve"] > 0 and abs(ag["reserve_cost_ms"]) < 0.5 * d["ms_per_step"]
     assert ag["rccl"].get("debug_lines", 0) > 0, ag["rccl"]           # RCCL's own account of its set-up was captured and summarised
 
 
@@ -122,6 +125,8 @@ def test_bench_direct_exchange_world_size_one_rccl():
 
 def _check_two_ranks(d):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["allgather"]["ms_per_step_without_collective"] > 0          # every N > 1 line carries the step time without the exchange
+    assert d["config"]["allgather"]["auto"]["chosen"] in ("collective", "direct")   # ESTD_AG_ALGO=auto: both timed, every rank agreed
     assert "all-gather" in d["config"]["parallelism"]
     assert len(d["config"]["per_rank_ms_per_step"]) == 2
     ag = d["config"]["allgather"]

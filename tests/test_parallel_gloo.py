@@ -118,6 +118,16 @@ def _worker3(rank, world, port, ret):
             rk, rv = kv_views(mk(300, r, 4, 3, 5, 32))
             ok = ok and torch.equal(bank[r][0]["keys"][0], rk) and torch.equal(bank[r][0]["values"][0], rv)
             ok = ok and torch.equal(bank[r][1][0], mk(400, r, 1, 4, 4)) and torch.equal(bank[r][0]["logits"][0], mk(500, r, 4, 3, 5))
+    # ESTD_AG_ALGO=auto: both algorithms timed on this communicator, every rank lands on the same choice, and that choice is what
+    # an exchange with algo=None runs afterwards
+    assert parallel.AG_ALGO == "auto" and parallel.active_algo() == "collective"
+    sel = parallel.select_exchange_algo({"keys": [k], "values": [v]}, [mk(400, rank, 1, 4, 4)], logits=mk(500, rank, 4, 3, 5), reps=2)
+    got = [None] * world
+    dist.all_gather_object(got, (sel["chosen"], sel["ms_collective"], sel["ms_direct"]))
+    ok = ok and all(g == got[0] for g in got) and sel["chosen"] in ("collective", "direct") and parallel.active_algo() == sel["chosen"]
+    bank = parallel.allgather_memory_bank_async({"keys": [k], "values": [v]}, [mk(400, rank, 1, 4, 4)], stage=False).wait()
+    for r in range(world):
+        ok = ok and torch.equal(bank[r][0]["values"][0], kv_views(mk(300, r, 4, 3, 5, 32))[1])
     ret[rank] = bool(ok)
     dist.destroy_process_group()
 
