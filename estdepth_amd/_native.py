@@ -31,6 +31,7 @@ class Conv3dDesc(ctypes.Structure):
         ("w_split", ctypes.c_void_p),
         ("w_wino", ctypes.c_void_p),
         ("w_wino2", ctypes.c_void_p),
+        ("gate_r", ctypes.c_void_p), ("gate_stats", ctypes.c_void_p), ("gate_gamma", ctypes.c_void_p), ("gate_beta", ctypes.c_void_p),
     ]
 
 

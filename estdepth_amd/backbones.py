@@ -110,11 +110,19 @@ def conv1x1_bn_gemm(conv, bn, x, relu):
 HIP_TAPS = os.environ.get("ESTD_HIP_TAPS", "1") == "1"
 
 
+def _fits_32bit(x, conv):
+    """the in-house NHWC kernels address a map with 32-bit byte offsets (buffer descriptors): N*H*W*C*4 of the wider side below 2 GiB;
+    larger maps stay on the library path instead of failing with ESTD_ERR_UNSUPPORTED"""
+    n, _, h, w = x.shape
+    ho, wo = (h + conv.stride[0] - 1) // conv.stride[0], (w + conv.stride[1] - 1) // conv.stride[1]
+    return max(n * h * w * conv.in_channels, n * ho * wo * conv.out_channels) * 4 < 0x7fffff00
+
+
 def _hip_taps_ok(conv):
     k = conv.kernel_size[0]
     return HIP_TAPS and conv.kernel_size == (k, k) and k in (3, 5) and conv.stride in ((1, 1), (2, 2)) and conv.dilation == (1, 1) \
         and conv.groups == 1 and conv.bias is None and conv.padding[0] == conv.padding[1] and conv.in_channels % 16 == 0 \
-        and conv.out_channels % 32 == 0 and conv.weight.is_cuda
+        and conv.out_channels % 32 == 0 and conv.weight.is_cuda and conv.padding_mode == "zeros"
 
 
 def _is_1x1(conv):
@@ -167,7 +175,7 @@ def conv_bn_act(conv, bn, x, relu, residual=None):
         rn = residual.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1) if residual is not None else None
         return plan.run(xn, residual=rn).permute(0, 3, 1, 2)
     if _is_1x1(conv) and conv.bias is None and conv.stride in ((1, 1), (2, 2)) and conv.in_channels % 16 == 0 \
-            and conv.out_channels % 32 == 0 and _hip_1x1_wanted(conv, residual):
+            and conv.out_channels % 32 == 0 and _hip_1x1_wanted(conv, residual) and _fits_32bit(x, conv):
         # conv + BN [+ residual] [+ ReLU] in ONE launch of csrc/conv1x1.hip (the ResNet bottlenecks' conv1 / conv3 / downsample)
         key = (conv.weight.device, conv.weight._version, conv.weight.data_ptr())
         c = conv.__dict__.get("_estd_w1x1")
@@ -178,7 +186,7 @@ def conv_bn_act(conv, bn, x, relu, residual=None):
         xn = x.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
         rn = residual.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1) if residual is not None else None
         return ops.conv1x1_nhwc(xn, c[1], sc, sh, conv.stride[0], relu, rn).permute(0, 3, 1, 2)
-    if _hip_taps_ok(conv):
+    if _hip_taps_ok(conv) and _fits_32bit(x, conv):
         # k x k, stride 1 | 2 (the stride-2 3x3 convolutions of layer2..4, 3x3 convolutions on maps too small for the tiled kernels):
         # conv + BN [+ residual] [+ ReLU] in ONE launch of csrc/conv2d_taps.hip
         from . import packing

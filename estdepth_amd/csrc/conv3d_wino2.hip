@@ -204,9 +204,14 @@ __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float
 // 4 weight reads and 8 packed FMAs in every other step -- folds its partial products m33[sd][sh] through both output transforms as the
 // depth transforms complete, and after the loop the lane groups (shuffles) and the two waves (1 KB through LDS, published by the tile's
 // post-loop barrier) add up; wave nh = 0 applies BN + activation and stores the 2 planes x 2 rows x 16 voxels to out_extra.
-template <int NW, int RBK, bool EXTRA, bool O16, bool XOUT = false>
+// GATE (O16 only): the ConvGRU's reset gate folded into the plane loads of the output convolution (transformer/epipolar_transformer.py:46,:51:
+// the convolution's input is cat[x, sigmoid(GN(r)) * h]): threads that own a 16-byte chunk of the h half (chunk index >= 4) also load the same
+// chunk of r (the gate convolution's raw output, channels 0..15 of gate_r) and scale their values when a plane arrives -- sigmoid on the
+// exp / rcp units, five VALU operations per value, ~170 per wave and tile against a 393 MB pass of its own (estd_gru_reset_apply: 70 us).
+template <int NW, int RBK, bool EXTRA, bool O16, bool XOUT = false, bool GATE = false>
 __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int dpairs, int total_tiles)
 {
+    static_assert(!GATE || (O16 && NW == 8), "GATE: the 32 -> 16 instance");
     // RBK: read-back streams of the epilogue.  0 none; 1 = running sum only (out += result: the second source view of pre1), deferred
     // epilogue like the plain instance; 2 = two residuals + scale (pre2 over both source views), deferred; 3 = any combination, epilogue
     // between the tiles.  (profiles/r4_wino2_rb.txt)
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
     float* lds_ss = reinterpret_cast<float*>(smem + 4 * SLICE_BYTES + RED_BYTES);  // scale[32] | shift[32]: read in the epilogue
     if (tid < 64) {                                                               // (a global load there is an exposed L2 round trip)
         const int c = tid & 31;
-        lds_ss[tid] = (O16 && c >= 16) ? 0.0f : (tid < 32 ? p.scale[c] : p.shift[c]);
+        if (!(GATE && c >= 16)) lds_ss[tid] = (O16 && c >= 16) ? 0.0f : (tid < 32 ? p.scale[c] : p.shift[c]);      // (GATE: the upper halves hold the gate constants)
     }
     // activation as a per-channel floor: ReLU = max(v, 0), none = max(v, -inf) -- two VALU operations per value in the epilogue
     // (fp32 MFMAs hide no VALU work: every epilogue instruction is paid in matrix-pipe time); tanh takes the generic path
@@ -285,6 +290,23 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
 #pragma unroll
         for (int c = 0; c < 2; ++c) rbase[kw][c] = row0 * (IN_W * 128) + lds_colkey_off(kw + pi, g + 4 * c);
 
+    // GATE: this thread's chunk of a voxel record is tid & 7 for every slice chunk it owns (NTHREADS is a multiple of 8); chunks 4..7 = h
+    const bool gate_lane = GATE && (tid & 4) != 0;
+    // sigmoid(GN(r)) = 1 / (1 + exp2(r * a + b)) with a = -log2(e) * rstd * gamma, b = -log2(e) * (beta - mean * rstd * gamma): the 16 (a, b) pairs
+    // lie in the upper halves of the scale / shift arrays of lds_ss, which the 16-output-channel instance does not use
+    if (GATE && tid < 16) {
+        const float mean = p.gate_stats[0], rstd = p.gate_stats[1];
+        const float ga = rstd * p.gate_gamma[tid], gb = p.gate_beta[tid] - mean * ga;
+        lds_ss[16 + tid] = -1.4426950408889634f * ga;
+        lds_ss[48 + tid] = -1.4426950408889634f * gb;
+    }
+    auto gate_chunk = [&](float4 x, float4 r) {
+        const float4 a4 = *reinterpret_cast<const float4*>(lds_ss + 16 + (tid & 3) * 4), b4 = *reinterpret_cast<const float4*>(lds_ss + 48 + (tid & 3) * 4);
+        return make_float4(x.x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(r.x, a4.x, b4.x))),
+                           x.y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(r.y, a4.y, b4.y))),
+                           x.z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(r.z, a4.z, b4.z))),
+                           x.w * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(r.w, a4.w, b4.w))));
+    };
     int tl_tile = 0;        // (timeline builds) tiles done by this workgroup
 #if ESTD_W2PRIO == 2
     if (NW == 8 && nh0 != 0) __builtin_amdgcn_s_setprio(1);
@@ -355,6 +377,23 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                              : make_float4(0.f, 0.f, 0.f, 0.f);
         };
 
+        __amdgpu_buffer_rsrc_t rs_gate = rs_in;
+        if (GATE) rs_gate = make_rsrc(p.gate_r + (size_t)n * vol * 32, vol * 32);
+        // GATE: the r chunk that belongs to this thread's h chunk lies 64 bytes in front of it in a record of the same stride (in_stride = 32)
+        auto gate_voff = [&](unsigned vo) { return gate_lane ? vo - 64u : OOB_OFFSET; };
+        auto load_plane_r = [&](int pd, float4 (&dst)[SIT]) {
+            const bool pv = (unsigned)pd < (unsigned)D;
+#pragma unroll
+            for (int it = 0; it < SIT; ++it)
+                dst[it] = pv ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_gate, gate_voff(chunk_voff(it)), pd * (HW * 32 * 4), 0))
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        auto gate_plane = [&](float4 (&x)[SIT], const float4 (&r)[SIT]) {
+            if (gate_lane) {
+#pragma unroll
+                for (int it = 0; it < SIT; ++it) x[it] = gate_chunk(x[it], r[it]);
+            }
+        };
         // The MFMAs run TRANSPOSED (weights as the A operand, voxels as B): D row = output channel, D column = voxel, so lane
         // (g, i) holds the four consecutive channels 16nh + 4g .. +3 of voxel pi(i) of a tile row -- one 16-byte store (and one
         // 16-byte read per residual stream) per plane, row and channel half instead of four 4-byte ones.
@@ -536,7 +575,16 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
             load_plane(d0, xb);
             load_plane(d0 + 1, xc);
             load_plane(d0 + 2, xd);
+            if (GATE) {
+                float4 ra[SIT], rb[SIT];
+                __syncthreads();                          // (the gate constants in lds_ss: written by threads 0..15 at kernel start)
+                load_plane_r(d0 - 1, ra); load_plane_r(d0, rb);
+                gate_plane(xa, ra); gate_plane(xb, rb);
+                load_plane_r(d0 + 1, ra); load_plane_r(d0 + 2, rb);
+                gate_plane(xc, ra); gate_plane(xd, rb);
+            }
         }
+        float4 rc[SIT], rd[SIT];                         // GATE: the r chunks of the two planes in flight
         float ea = 0.f, eb = 0.f, ec = 0.f, ed = 0.f;    // EXTRA: the scalar channel's four planes at this thread's voxel
         if (EXTRA) {
             const int d0 = 2 * dp;
@@ -720,6 +768,13 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
 #ifndef ESTD_W2SPREAD
 #define ESTD_W2SPREAD 0     // A/B: 1 = the rewrite of slices 0..2 one slice per step (steps RB_STEP .. RB_STEP + 2) instead of all nine writes at once
 #endif
+                if (GATE && has_next && step >= 2 && step < 2 + 2 * SIT) {      // the chunk requested two steps ago (steps 0..5 -> gated in steps 2..7 = RB_STEP)
+                    const int idx = step - 2, it = idx % SIT;
+                    if (gate_lane) {
+                        if (idx < SIT) xc[it] = gate_chunk(xc[it], rc[it]);
+                        else           xd[it] = gate_chunk(xd[it], rd[it]);
+                    }
+                }
                 if (has_next && step == RB_STEP) {
                     // slices 0..2 have been read for the last time by every wave (the rows of step 17 are fetched at the end of step
                     // 15); DEFER: this barrier also publishes slice 3, rewritten at the top of this tile and first read at the end of
@@ -753,6 +808,12 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
                             else           xd[it] = v1 ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, vo, (nd + 1) * in_slice_bytes, ESTD_W2_AUX_IN))
                                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (GATE) {
+                                if (idx < SIT) rc[it] = v0 ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_gate, gate_voff(vo), nd * (HW * 32 * 4), 0))
+                                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                                else           rd[it] = v1 ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_gate, gate_voff(vo), (nd + 1) * (HW * 32 * 4), 0))
+                                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                            }
                         }
                     }
                 }
@@ -1052,7 +1113,13 @@ extern "C" int estd_conv3d_k3_wino2(const estd_conv3d_desc* dp, estd_stream_t s)
         hipLaunchKernelGGL((conv3d_wino2_kernel<NWV, RBV, EXV, OV>), dim3(grid), dim3(64 * NWV), lds_bytes, estd_stream(s), d,       \
                            tiles_w, tiles_h, dpairs, (int)total);                                                                    \
     } while (0)
-    if (o16) {                                       // 8-wave form only
+    const bool gate = d.gate_r != nullptr;
+    if (gate && (!o16 || rb || !d.gate_stats || !d.gate_gamma || !d.gate_beta || d.in_stride != 32)) return ESTD_ERR_UNSUPPORTED;
+    if (o16 && gate) {
+        estd_allow_dynamic_lds<conv3d_wino2_kernel<8, 0, false, true, false, true>>(O16_LDS_BYTES);
+        hipLaunchKernelGGL((conv3d_wino2_kernel<8, 0, false, true, false, true>), dim3(grid), dim3(512), O16_LDS_BYTES, estd_stream(s), d,
+                           tiles_w, tiles_h, dpairs, (int)total);
+    } else if (o16) {                                // 8-wave form only
         if (rb) ESTD_W2_LAUNCH(8, 3, false, true); else ESTD_W2_LAUNCH(8, 0, false, true);
     } else if (xout) {
         estd_allow_dynamic_lds<conv3d_wino2_kernel<8, 0, true, false, true>>(XOUT_LDS_BYTES);

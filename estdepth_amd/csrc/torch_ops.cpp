@@ -151,7 +151,8 @@ void conv3d_k3(const Tensor& x, const OptTensor& x_extra, const Tensor& w_main, 
                int64_t in_stride, int64_t n_tiles, int64_t act_a, int64_t act_b, int64_t act_split, const OptTensor& out,
                int64_t out_stride, int64_t out_channels, const OptTensor& residual, const OptTensor& residual2, double out_scale,
                bool accumulate, const OptTensor& out_extra, const OptTensor& head_w, const OptTensor& head_b, const OptTensor& out_head,
-               const OptTensor& stats_partials, int64_t variant)
+               const OptTensor& stats_partials, int64_t variant, const OptTensor& gate_r, const OptTensor& gate_stats,
+               const OptTensor& gate_gamma, const OptTensor& gate_beta)
 {
     const OpScope scope(x);
     TORCH_CHECK(dims.size() == 4, "conv3d_k3: dims = (N, D, H, W)");
@@ -185,6 +186,17 @@ void conv3d_k3(const Tensor& x, const OptTensor& x_extra, const Tensor& w_main, 
         const int blocks = estd_conv3d_k3_grid(d.N, d.D, d.H, d.W);
         TORCH_CHECK(blocks > 0 && stats_partials->numel() >= (int64_t)blocks * 4, "conv3d_k3: stats_partials needs 4 doubles per tile");
         d.stats_partials = stats_partials->data_ptr<double>();
+    }
+    // reset gate folded into the loads of the 32 -> 16 two-axis Winograd instance (all four tensors or none)
+    d.gate_r = opt_fptr(gate_r, "gate r volume", false);
+    d.gate_stats = opt_fptr(gate_stats, "gate statistics");
+    d.gate_gamma = opt_fptr(gate_gamma, "gate gamma");
+    d.gate_beta = opt_fptr(gate_beta, "gate beta");
+    if (d.gate_r) {
+        TORCH_CHECK(d.gate_stats && d.gate_gamma && d.gate_beta, "conv3d_k3: the reset gate needs r, statistics, gamma and beta");
+        TORCH_CHECK(gate_r->numel() >= vox * 32 && gate_stats->numel() >= 2 && gate_gamma->numel() >= 16 && gate_beta->numel() >= 16,
+                    "conv3d_k3: reset-gate tensors too small");
+        TORCH_CHECK(variant == 3, "conv3d_k3: the reset gate exists in the two-axis Winograd kernel's 32 -> 16 instance only");
     }
     // variant: 0 = direct fp32 MFMA; 1 = exact 3 x bf16 operand split (w_alt = split weights); 2 = fp32 MFMA with the depth
     // axis in Winograd F(2,3) form (w_alt = transformed filters); 3 = depth and row axis in Winograd form (w_extra / w_xout in that kernel's packing)
@@ -703,7 +715,8 @@ TORCH_LIBRARY(estdepth_hip, m)
     m.def("conv3d_k3(Tensor x, Tensor? x_extra, Tensor w_main, Tensor? w_extra, Tensor? w_xout, Tensor? w_alt, Tensor scale, Tensor shift, "
           "int[] dims, int cin_main, int in_stride, int n_tiles, int act_a, int act_b, int act_split, Tensor(a!)? out, int out_stride, "
           "int out_channels, Tensor? residual, Tensor? residual2, float out_scale, bool accumulate, Tensor(b!)? out_extra, Tensor? head_w, "
-          "Tensor? head_b, Tensor(c!)? out_head, Tensor(d!)? stats_partials, int variant) -> ()");
+          "Tensor? head_b, Tensor(c!)? out_head, Tensor(d!)? stats_partials, int variant, Tensor? gate_r=None, Tensor? gate_stats=None, "
+          "Tensor? gate_gamma=None, Tensor? gate_beta=None) -> ()");
     m.def("conv2d_k3(Tensor x_nhwc, Tensor w, Tensor? w_alt, Tensor scale, Tensor shift, int cout, int dilation, int group_tiles, "
           "bool relu_before_residual, bool relu_after_residual, Tensor? residual, int variant) -> Tensor");
     m.def("groupnorm_finalize(Tensor partials, int n_blocks, float count, float eps) -> Tensor");

@@ -6,11 +6,16 @@ forward signature (transformer/epipolar_transformer.py:10-83), executed by HIP k
     GroupNorm(1,16) x3             -> estd_groupnorm_finalize + the two elementwise GRU kernels
     sigmoid / tanh / blend         -> estd_gru_reset_apply, estd_gru_blend
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from . import ops
 from .layers_op import PlanCache
+
+
+GATE_IN_CONV = os.environ.get("ESTD_GATE_IN_CONV", "1") == "1"      # A/B: 0 = the reset gate as a pass of its own (estd_gru_reset_apply)
 
 
 class EpipolarTransformer(nn.Module):
@@ -49,10 +54,16 @@ class EpipolarTransformer(nn.Module):
         ru = torch.empty((D, H, W, 32), device=xh.device, dtype=torch.float32)
         gate.run(xh, (1, D, H, W), out=ru, out_stride=32, stats_partials=part)                   # :36-37
         st_ru = ops.groupnorm_finalize(part, nblk, 16.0 * n_vox, self.reset_gate_norm.eps)       # :44-45 statistics
-        xrh = ops.gru_reset_apply(xh, ru, st_ru, self.reset_gate_norm.weight, self.reset_gate_norm.bias)   # :46,:51
         part2 = torch.empty(nblk * 4, device=xh.device, dtype=torch.float64)
         o_raw = torch.empty((D, H, W, 16), device=xh.device, dtype=torch.float32)
-        outp.run(xrh, (1, D, H, W), out=o_raw, out_stride=16, stats_partials=part2)              # :52
+        if GATE_IN_CONV and ops.CONV3D_ALGO == "wino2" and ops.CONV3D_ARITH == "f32":
+            # :46,:51 the reset gate sigmoid(GN(r)) * h is formed in the output convolution's own plane loads (no [x | r*h] volume: one
+            # 393 MB pass less per target)
+            outp.run(xh, (1, D, H, W), out=o_raw, out_stride=16, stats_partials=part2,
+                     gate=(ru, st_ru, self.reset_gate_norm.weight, self.reset_gate_norm.bias))       # :52
+        else:
+            xrh = ops.gru_reset_apply(xh, ru, st_ru, self.reset_gate_norm.weight, self.reset_gate_norm.bias)   # :46,:51
+            outp.run(xrh, (1, D, H, W), out=o_raw, out_stride=16, stats_partials=part2)              # :52
         st_o = ops.groupnorm_finalize(part2, nblk, 16.0 * n_vox, self.output_norm.eps)           # :53
         if before_write is not None:
             before_write()            # e.g. join a side stream that still reads the value half we are about to overwrite

@@ -173,6 +173,11 @@ class GraphedForward:
             out = run_b(feats)
         if prev_reserve is not None:
             ops.set_reserved_cus(prev_reserve)
+        if kv_out is not None:
+            # zero-copy contract: the record this capture hands out IS the ring slot it was told to write
+            rec = getattr(out[1]["values"][0], "_estd_kv", None)
+            if rec is None or rec.data_ptr() != kv_out[-1].data_ptr():
+                raise RuntimeError("zero-copy memory: the captured forward did not write its memory record into the ring buffer it was given")
         st["graph_a"], st["graph_b"], st["feats2d"], st["out"] = ga, gb, feats, out
         st["memory_logits"] = getattr(m.CostRegNet, "memory_logits", None)     # static buffer of graph B (rewritten by every replay)
         # the replay reads the packed-weight buffers that existed at capture time: keep them alive even if a PlanCache

@@ -268,7 +268,12 @@ class DepthHybridDecoder(nn.Module):
         # the kv records of the targets; GraphedForward(zero_copy_memory=True) names the buffer (one of its ring of output buffers:
         # the record handed on as memory then needs no copy out of the graph's static buffers)
         kv, self.kv_out = getattr(self, "kv_out", None), None
-        if kv is None or tuple(kv.shape) != (T, D, H, W, 32) or kv.device != dev or kv.dtype != torch.float32 or not kv.is_contiguous():
+        if kv is not None and (tuple(kv.shape) != (T, D, H, W, 32) or kv.device != dev or kv.dtype != torch.float32 or not kv.is_contiguous()):
+            # a caller that names the buffer relies on the record lying THERE afterwards (the zero-copy ring of estdepth_amd.graph): a
+            # quiet private allocation would hand out a graph-pool buffer the next replay overwrites
+            raise RuntimeError("kv_out must be a contiguous float32 tensor of shape %s on %s, got %s %s on %s"
+                               % ((T, D, H, W, 32), dev, tuple(kv.shape), kv.dtype, kv.device))
+        if kv is None:
             kv = torch.empty((T, D, H, W, 32), device=dev, dtype=torch.float32)
         P["kv"].run(a, dims, in_extra=extra, out=kv, out_stride=32)
         init_logits = torch.empty((T, D, H, W), device=dev, dtype=torch.float32)

@@ -260,8 +260,10 @@ class Conv3dPlan:
         return other
 
     def run(self, x, dims, in_stride=None, in_extra=None, out=None, out_stride=None, out_channels=None,
-            residual=None, residual2=None, out_scale=1.0, accumulate=False, out_extra=None, out_head=None, stats_partials=None):
-        """x: channels-last volume(s) [N,D,H,W,in_stride] (or a base view of it); dims = (N,D,H,W)."""
+            residual=None, residual2=None, out_scale=1.0, accumulate=False, out_extra=None, out_head=None, stats_partials=None, gate=None):
+        """x: channels-last volume(s) [N,D,H,W,in_stride] (or a base view of it); dims = (N,D,H,W).
+        ``gate`` = (ru [N,D,H,W,32], statistics [4], gamma [16], beta [16]): the ConvGRU's reset gate applied to input channels 16..31 in the
+        convolution's own loads (32 -> 16 instance of the two-axis Winograd kernel only; include/estd_hip.h ``gate_r``)."""
         Nn, D, H, W = dims
         if (in_extra is None) != (self.w_extra is None):
             raise RuntimeError("conv3d plan/extra-channel mismatch")
@@ -308,6 +310,9 @@ class Conv3dPlan:
             and (stats_partials is None or (residual is None and residual2 is None and not accumulate and float(out_scale) == 1.0))
         variant, w_alt = (1, self.w_split) if split else (3, self.w_wino2_c16) if c16 else (3, self.w_wino2_o16) if o16 else (4, self.w_wino2x) if wino2x \
             else (3, self.w_wino2) if wino2 else (2, self.w_wino) if wino else (0, None)
+        if gate is not None and not o16:
+            raise RuntimeError("the reset gate is folded into the 32 -> 16 instance of the two-axis Winograd kernel only")
+        g_r, g_st, g_ga, g_be = gate if gate is not None else (None, None, None, None)
         cin = self.cin_main + (1 if self.w_extra is not None else 0)
         with _Prof("conv3d:%d->%d" % (cin, self.n_out), 2.0 * 27 * cin * self.n_out * Nn * D * H * W):
             if _use_torch():
@@ -315,7 +320,7 @@ class Conv3dPlan:
                               self.w_wino2_xout if wino2 else self.w_wino_xout if wino else self.w_xout, w_alt, self.scale, self.shift,
                               (Nn, D, H, W), self.cin_main, in_stride, self.n_tiles, self.act_a, self.act_b, self.act_split, out,
                               out_stride, out_channels, residual, residual2, float(out_scale), bool(accumulate), out_extra, head_w, head_b,
-                              out_head, stats_partials, variant)
+                              out_head, stats_partials, variant, g_r, g_st, g_ga, g_be)
                 return
             d = N.Conv3dDesc()
             d.N, d.D, d.H, d.W = Nn, D, H, W
@@ -338,6 +343,8 @@ class Conv3dPlan:
             d.head_b = head_b.data_ptr() if head_b is not None else None
             d.out_head = out_head.data_ptr() if out_head is not None else None
             d.stats_partials = stats_partials.data_ptr() if stats_partials is not None else None
+            if gate is not None:
+                d.gate_r, d.gate_stats, d.gate_gamma, d.gate_beta = g_r.data_ptr(), g_st.data_ptr(), g_ga.data_ptr(), g_be.data_ptr()
             if split:
                 d.w_split = self.w_split.data_ptr()
                 N.check(N.lib().estd_conv3d_k3_split(ctypes.byref(d), _stream()), "estd_conv3d_k3_split")

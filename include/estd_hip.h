@@ -135,6 +135,15 @@ typedef struct estd_conv3d_desc {
     /* estd_conv3d_k3_wino2 only: the 32->32 filters with depth AND row axis in Winograd F(2,3) form, float32
      * [48 taps = (3 sd + kw) * 4 + sh][2 channel halves][2 quads][64 lanes][4] (packing.py::pack_conv3d_wino2), else NULL */
     const float* w_wino2;
+    /* estd_conv3d_k3_wino2, 32 -> 16 instance only (the ConvGRU's output convolution, transformer/epipolar_transformer.py:51-52): the reset
+     * gate applied in the convolution's plane loads instead of in a pass of its own (estd_gru_reset_apply): input channels 16..31 (h) are
+     * multiplied by sigmoid(GroupNorm(r)) with r = channels 0..15 of gate_r [N][D][H][W][32] (the gate convolution's raw output),
+     * gate_stats = {mean_r, rstd_r, ..} as estd_groupnorm_finalize writes them, gate_gamma / gate_beta [16] the affine of
+     * reset_gate_norm (:44,:46).  All four NULL = no gate. */
+    const float* gate_r;
+    const float* gate_stats;
+    const float* gate_gamma;
+    const float* gate_beta;
 } estd_conv3d_desc;
 
 int estd_conv3d_k3(const estd_conv3d_desc* desc, estd_stream_t stream);
