@@ -1,9 +1,11 @@
 #!/bin/bash
 # Profile collection on the GPU box (writes under gpurun_out/profiles_<round>/; copy what is kept into profiles/).
-#   bash tools/collect_profiles.sh [round prefix, default r4]
+#   bash tools/collect_profiles.sh [round prefix, default r5]
+# (default build: the superseded A/B kernels -- depth-only / row-only Winograd, bf16 operand split -- are not part of it; their lines
+#  of the round-4 collection are gone)
 set -u
 R=$PWD
-P=${1:-r4}
+P=${1:-r5}
 OUT=$R/gpurun_out/profiles_$P
 mkdir -p $OUT tools/bin
 cd /tmp && export TMPDIR=/tmp
@@ -18,7 +20,7 @@ for wl in joint estm cfg5; do
   [ -n "$S" ] && head -41 $S > $OUT/${P}_bench_${wl}_rocprof_stats_top40.csv
 done
 # PMC: dominant kernel (conv_bench: N = 3 volumes) per algorithm, separate --pmc passes
-for algo in wino2 wino direct; do
+for algo in wino2 direct; do
   ESTD_CONV3D_ALGO=$algo bash $R/tools/pmc_collect.sh "FETCH_SIZE WRITE_SIZE" $OUT/${P}_conv3d_${algo}_pmc.csv -- python $R/tools/conv_bench.py 3 10 > /dev/null 2>&1
 done
 python $R/tools/pmc_json.py $OUT $P          # ${P}_conv3d_pmc.json: what bench.py reads for roofline.traffic (from profiles/)
@@ -30,13 +32,15 @@ for b in "conv_bench.py 3 10" "conv_bench.py 1 10" "kv_bench.py" "head_bench.py"
 done
 cd $R
 python tools/hbm_bench.py > $OUT/${P}_hbm_bench.txt 2>&1
-for algo in wino2 wino direct; do
+for algo in wino2 direct; do
   echo "# ESTD_CONV3D_ALGO=$algo" >> $OUT/${P}_conv_bench.txt
   ESTD_CONV3D_ALGO=$algo CB_EPI=1 python tools/conv_bench.py 3 30 2>&1 | grep -v amdgpu >> $OUT/${P}_conv_bench.txt
   ESTD_CONV3D_ALGO=$algo python tools/conv_bench.py 1 30 2>&1 | grep -v amdgpu >> $OUT/${P}_conv_bench.txt
 done
 python tools/head_bench.py 2>&1 | grep -v amdgpu >> $OUT/${P}_conv_bench.txt
 python tools/kv_bench.py 2>&1 | grep -v amdgpu >> $OUT/${P}_conv_bench.txt
+python tools/w2x_bench.py 3 30 2>&1 | grep -v amdgpu > $OUT/${P}_w2x_bench.txt
+python tools/gate_bench.py 2>&1 | grep -v amdgpu > $OUT/${P}_gate_bench.txt
 python tools/conv2d_bench.py 2>&1 | grep -v amdgpu > $OUT/${P}_conv2d_bench.txt
 python tools/psm_small_bench.py 2>&1 | grep -v amdgpu > $OUT/${P}_psm_small_bench.txt
 python tools/conv1x1_bench.py 2>&1 | grep -v amdgpu > $OUT/${P}_conv1x1_bench.txt
@@ -51,17 +55,16 @@ python bench.py --workload estm 2>/dev/null | last > $OUT/${P}_bench_estm.json
 python bench.py --workload cfg1 2>/dev/null | last > $OUT/${P}_bench_cfg1.json
 python bench.py --workload cfg5 --steps 5 --warmup 2 2>/dev/null | last > $OUT/${P}_bench_cfg5.json
 python bench.py --workload stream --steps 20 2>/dev/null | last > $OUT/${P}_bench_stream.json
-python bench.py --conv3d-algo wino --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_wino1.json
+ESTD_W2X=1 python bench.py --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_w2x.json
+ESTD_GATE_IN_CONV=0 python bench.py --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_gate_pass.json
 python bench.py --conv3d-algo direct --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_direct_conv.json
 python bench.py --no-graph --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_eager.json
 ESTD_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-alt --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_rccl_world1.json
 ESTD_FORCE_DIST=1 python bench.py --workload estm --no-cpu-baseline --no-alt --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_estm_rccl_world1.json
 python bench.py --gpus 2 --workload cfg1 --steps 5 --warmup 2 2>/dev/null | last > $OUT/${P}_bench_gpus2_codepath.json
-ESTD_CONV2D_ALGO=wino python bench.py --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_conv2d_rowonly.json
 ESTD_HIP_1X1=0 python bench.py --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_lib1x1.json
 ESTD_HIP_TAPS=0 ESTD_HIP_POOL=0 ESTD_HIP_STEM7=0 python bench.py --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_lib2d.json
-ESTD_W2_XOUT=0 python bench.py --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_dres2_wino1.json
 python bench.py --graph-memory copy --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_graph_copy.json
 python bench.py --workload estm --graph-memory copy --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_estm_graph_copy.json
-timeout 1500 python -m pytest tests/ -q -m gpu > $OUT/${P}_gputests.log 2>&1
+timeout 2400 python -m pytest tests/ -q -m gpu > $OUT/${P}_gputests.log 2>&1
 ls -la $OUT
