@@ -42,6 +42,7 @@ from .layers_op import PlanCache
 
 
 UPLOAD_STREAM = os.environ.get("ESTD_GRAPH_UPLOAD_STREAM", "side")      # A/B switch, read once at import (see __call__)
+SHARE_POOL = os.environ.get("ESTD_GRAPH_SHARE_POOL", "1") == "1"        # one graph memory pool per call shape (0: one per capture)
 
 
 class GraphedForward:
@@ -64,16 +65,18 @@ class GraphedForward:
         self.last_matching = None                # after a call: the PSM features [V,32,H/4,W/4] of its frames (stage A's static buffer: valid until
                                                  # the next call; estdepth_amd.streaming copies the frames it shares with the next call out of it)
         self._graphs = {}
+        self._pools = {}                         # call shape (signature without placement / weights epoch) -> graph memory pool shared by its captures
         self._ring = {}                          # zero-copy mode: kv shape -> {"bufs": [...], "stamp": [...], "last": slot, "clock": n}
 
     def __getattr__(self, name):                 # normalise_images, matchingFeature, ndepths, ... of the wrapped model
-        if name in ("model", "warmup", "_graphs", "clone_outputs", "memory_logits", "zero_copy_memory", "_ring", "last_matching", "reserve_cus"):
+        if name in ("model", "warmup", "_graphs", "clone_outputs", "memory_logits", "zero_copy_memory", "_ring", "last_matching", "reserve_cus", "_pools"):
             raise AttributeError(name)
         return getattr(self.model, name)
 
     def invalidate(self):
         """drop every captured graph (after in-place edits of parameters, which no epoch counter can see)."""
         self._graphs.clear()
+        self._pools.clear()
 
     def _signature(self, imgs, pre_costs, mode, matching_features, placement=(None, None)):
         n_mem = 0 if pre_costs is None else len(pre_costs["keys"])
@@ -166,10 +169,19 @@ class GraphedForward:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        # ONE memory pool for every capture of a call shape (zero-copy mode makes one capture per (memory addresses, ring slot): the ESTM
+        # stream settles at 3 + the start-up signatures): the captures never run concurrently, so the intermediates of one replay may
+        # reuse the blocks of another's; what a capture hands out (outputs, 2D features, logits) stays allocated through the references
+        # ``st`` keeps.  Before: one private pool of a whole forward's activations per capture (tens of GB each at cfg5 size).
+        pool = self._pools.get(key[:-2]) if SHARE_POOL else None
+        if pool is None:
+            pool = torch.cuda.graph_pool_handle()
+            if SHARE_POOL:
+                self._pools[key[:-2]] = pool
         # thread_local: other threads (e.g. the RCCL watchdog polling events) may keep issuing HIP calls during capture
-        with torch.no_grad(), torch.cuda.graph(ga, capture_error_mode="thread_local"):
+        with torch.no_grad(), torch.cuda.graph(ga, pool=pool, capture_error_mode="thread_local"):
             feats = run_a()
-        with torch.no_grad(), torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
+        with torch.no_grad(), torch.cuda.graph(gb, pool=pool, capture_error_mode="thread_local"):
             out = run_b(feats)
         if prev_reserve is not None:
             ops.set_reserved_cus(prev_reserve)
