@@ -192,6 +192,10 @@ class GraphedForward:
                 raise RuntimeError("zero-copy memory: the captured forward did not write its memory record into the ring buffer it was given")
         st["graph_a"], st["graph_b"], st["feats2d"], st["out"] = ga, gb, feats, out
         st["memory_logits"] = getattr(m.CostRegNet, "memory_logits", None)     # static buffer of graph B (rewritten by every replay)
+        # the logit volumes a caller asked the decoder to keep (``keep_logits``): buffers of THIS capture -- the decoder's attribute is pointed
+        # at them again after every replay (it would otherwise name the buffers of whichever capture was made last, which a shared pool
+        # lets other captures reuse)
+        st["last_logits"] = getattr(m.CostRegNet, "last_logits", None) if getattr(m.CostRegNet, "keep_logits", False) else None
         # the replay reads the packed-weight buffers that existed at capture time: keep them alive even if a PlanCache
         # is rebuilt later (stale-but-valid until the epoch check re-captures), never a use-after-free
         st["keepalive"] = [c._plans for c in (getattr(mod, "_cache", None) for mod in m.modules()) if isinstance(c, PlanCache)]
@@ -266,6 +270,8 @@ class GraphedForward:
         st["graph_b"].replay()
         outputs, costs, cposes = st["out"]
         self.last_matching = st["feats2d"]["matching"]
+        if st.get("last_logits") is not None:
+            self.model.CostRegNet.last_logits = st["last_logits"]
         # the logit volume that travels with the memory bank (parallel.allgather_memory_bank*): a fresh 4.9 MB tensor, like the memory
         ml = st.get("memory_logits")
         self.memory_logits = ml.clone() if ml is not None else None

@@ -11,7 +11,8 @@ import re
 from collections import defaultdict
 
 # family names are ops._Prof's group names (estdepth_amd/ops.py), so that amounts (FLOPs / bytes per launch) recorded there apply
-_W2 = re.compile(r"conv3d_wino2_kernel<\s*(\d+),\s*(\d+|true|false),\s*(true|false),\s*(true|false)(?:,\s*(true|false))?\s*>")
+_W2 = re.compile(r"conv3d_wino2_kernel<\s*(\d+),\s*(\d+|true|false),\s*(true|false),\s*(true|false)(?:,\s*(true|false))?(?:,\s*(true|false))?\s*>")
+_W2X = re.compile(r"conv3d_wino2x_kernel<")          # the operand-reuse form of the 32 -> 32 instance (csrc/conv3d_wino2x.hip, opt-in)
 _W2H = re.compile(r"conv3d_wino2_c16_kernel")
 _W1 = re.compile(r"conv3d_wino_kernel<\s*(true|false),\s*(true|false)\s*>")
 _K3 = re.compile(r"conv3d_k3_kernel<\s*(\d+),\s*(\d+),\s*(true|false),\s*(true|false)\s*>")
@@ -28,6 +29,8 @@ def family_of(kernel_name):
             return "conv3d:32->16"
         if extra:
             return "conv3d:33->33" if xout else "conv3d:33->32"
+        return "conv3d:32->32"
+    if _W2X.search(n):
         return "conv3d:32->32"
     if _W2H.search(n):
         return "conv3d:16->16"
