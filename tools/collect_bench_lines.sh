@@ -1,0 +1,25 @@
+#!/bin/bash
+# The bench.py JSON lines of a round (default command per workload + the A/B lines), without the traces / PMC passes of tools/collect_profiles.sh.
+#   bash tools/collect_bench_lines.sh [round prefix, default r5]
+set -u
+R=$PWD
+P=${1:-r5}
+OUT=$R/gpurun_out/profiles_$P
+mkdir -p $OUT
+last() { grep "^{" | tail -1; }
+python bench.py 2>/dev/null | last > $OUT/${P}_bench_joint.json
+python bench.py --workload estm 2>/dev/null | last > $OUT/${P}_bench_estm.json
+python bench.py --workload cfg1 2>/dev/null | last > $OUT/${P}_bench_cfg1.json
+python bench.py --workload cfg5 --steps 5 --warmup 2 2>/dev/null | last > $OUT/${P}_bench_cfg5.json
+python bench.py --workload stream --steps 20 2>/dev/null | last > $OUT/${P}_bench_stream.json
+AB="--no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads"
+for rep in 1 2; do
+  python bench.py $AB 2>/dev/null | last > $OUT/${P}_ab_default_$rep.json
+  ESTD_W2X=1 python bench.py $AB 2>/dev/null | last > $OUT/${P}_ab_w2x_$rep.json
+  ESTD_GATE_IN_CONV=0 python bench.py $AB 2>/dev/null | last > $OUT/${P}_ab_gate_pass_$rep.json
+done
+ESTD_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-alt --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_rccl_world1.json
+ESTD_FORCE_DIST=1 ESTD_RESERVE_SCOPE=AB python bench.py --no-cpu-baseline --no-alt --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_rccl_world1_reserve_ab.json
+ESTD_FORCE_DIST=1 python bench.py --workload estm --no-cpu-baseline --no-alt --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_estm_rccl_world1.json
+python bench.py --gpus 2 --workload cfg1 --steps 5 --warmup 2 2>/dev/null | last > $OUT/${P}_bench_gpus2_codepath.json
+ls -la $OUT | tail -20
