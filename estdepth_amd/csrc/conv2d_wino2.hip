@@ -69,6 +69,13 @@ constexpr int NSTEP = 8;                             // steps per 32-channel chu
 #ifndef ESTD_C2W2_INLOOP_W0
 #define ESTD_C2W2_INLOOP_W0 4
 #endif
+// ESTD_C2W2_SCHED = 1 (round 5): the step's memory requests (weights two steps ahead, the next brick's rows, the in-loop LDS writes of the next chunk) are issued
+// BETWEEN its MFMAs -- one vector-memory read, one LDS write and up to four VALU instructions per pair of MFMAs -- instead of in a cluster in front of them (a 16-byte
+// store costs the LDS store path 13 cycles, a vector-memory request ~16 of issue: a cluster of 5 + 4 of them in front of 16 x 32 matrix cycles left the pipe idle
+// while it was issued; same finding as csrc/conv3d_wino2x.hip, profiles/r5_wino2x_table.txt)
+#ifndef ESTD_C2W2_SCHED
+#define ESTD_C2W2_SCHED 2
+#endif
 constexpr int WD = ESTD_C2W2_WD, WR = 4;             // weight stream: WD steps ahead, ring slot = step % WR (8 % WR == 0, WD < WR)
 
 __device__ __forceinline__ float4 as_float4(u32x4 v) { float4 f; __builtin_memcpy(&f, &v, 16); return f; }
@@ -216,6 +223,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino2_kernel(const estd_conv2d_
                 }
             }
         };
+        // one of the four transformed rows (index sh) of row pair w: a quarter of write_rows(slot, w, w + 1)
+        auto write_row_sh = [&](char* slot, int w, int sh_) {
+            if (loader && !(ESTD_C2W2ABL & 2)) {
+                const int a = DIL == 1 ? 2 * w : (w & 1) + 4 * (w >> 1);
+                const float4 d0 = pf[a], d1 = pf[a + DIL], d2 = pf[a + 2 * DIL], d3 = pf[a + 3 * DIL];
+                const float4 v = sh_ == 0 ? f4_sub(d0, d2) : sh_ == 1 ? f4_add(d1, d2) : sh_ == 2 ? f4_sub(d2, d1) : f4_sub(d1, d3);
+                *reinterpret_cast<float4*>(slot + wbase + (sh_ * 4 + w) * PITCH * 128) = v;
+            }
+        };
         auto chunk_body = [&](auto first_c, const int c) {
             constexpr bool FIRST = decltype(first_c)::value;
             const int sb = (k & 1) * SLOT_BYTES;
@@ -262,6 +278,46 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino2_kernel(const estd_conv2d_
 #pragma clang loop unroll(full)
             for (int st = 0; st < NSTEP; ++st) {
                 const int sh = st >> 1;
+                f32x2 Tn[2][4];
+                if (ESTD_C2W2_SCHED == 2) {
+                    // the step in four quarters of 4 MFMAs (128 matrix cycles each): in front of quarter k one weight request (tap sw = k of step st + WD), a share of the
+                    // next brick's rows and ONE 16-byte LDS write (+ its four adds) of the next chunk's transform; scheduling barriers pin the quarters
+                    constexpr int PFS = INLOOP ? ESTD_C2W2_INLOOP_PFS : ESTD_C2W2_PFS;
+                    const int r0 = PFS != 8 ? (st < PFS ? st * IN_H / PFS : IN_H) : DIL == 1 ? (st == 0 ? 0 : st + 1) : (3 * st + 1) / 2;
+                    const int r1 = PFS != 8 ? (st < PFS ? (st + 1) * IN_H / PFS : IN_H)
+                                            : DIL == 1 ? ((st == 0 || st == NSTEP - 1) ? r0 + 2 : r0 + 1) : (3 * (st + 1) + 1) / 2;
+                    const bool wr = INLOOP && st >= ESTD_C2W2_INLOOP_W0 && (!last_chunk || has_next_item);
+                    constexpr int WN = NSTEP - ESTD_C2W2_INLOOP_W0;
+                    static_assert(!INLOOP || WN == 4, "quarter schedule: one row pair of the next chunk per step");
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int qk = 2 * h + e;
+                            if (!(ESTD_C2W2ABL & 8)) {
+                                const int tgt = st + WD;
+                                bq[tgt % WR][qk] = tgt < NSTEP
+                                    ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, (wbase_q + tgt * 4 + qk) * 2048, 0))
+                                    : as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_wx, wlane, (wnext_q + (tgt - NSTEP) * 4 + qk) * 2048, 0));
+                            }
+#pragma unroll
+                            for (int r = r0 + (r1 - r0) * qk / 4; r < r0 + (r1 - r0) * (qk + 1) / 4; ++r)
+                                pf[r] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, voff[r], pf_soff, 0));
+                            if (wr) write_row_sh(smem + (((k + 1) & 1) * SLOT_BYTES), st - ESTD_C2W2_INLOOP_W0, qk);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int sw = 0; sw < 4; ++sw) {
+                                const float4 b4 = bq[(ESTD_C2W2ABL & 8) ? 0 : st % WR][sw];
+                                const float b = h == 0 ? (e == 0 ? b4.x : b4.y) : (e == 0 ? b4.z : b4.w);
+                                const bool first_product = FIRST && (st & 1) == 0 && h == 0 && e == 0;
+                                const f32x4 c_in = first_product ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[sh][sw];
+                                acc[sh][sw] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, T[h][sw][e], c_in, 0, 0, 0);
+                            }
+                            if (e == 1 && st + 1 < NSTEP) xform2(R, h, Tn[h]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                } else {
                 // weights of step st + WD (this chunk's, or the first steps of the next chunk / next item's first chunk)
                 if (!(ESTD_C2W2ABL & 8)) {
                     const int tgt = st + WD;
@@ -286,8 +342,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino2_kernel(const estd_conv2d_
                     const int i0 = (st - ESTD_C2W2_INLOOP_W0) * 4 / WN, i1 = (st - ESTD_C2W2_INLOOP_W0 + 1) * 4 / WN;
                     write_rows(smem + (((k + 1) & 1) * SLOT_BYTES), i0, i1);
                 }
-                __builtin_amdgcn_sched_barrier(0);      // memory requests in front of the step's MFMAs
-                f32x2 Tn[2][4];
+                if (!ESTD_C2W2_SCHED) __builtin_amdgcn_sched_barrier(0);      // memory requests in front of the step's MFMAs
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -302,13 +357,27 @@ __global__ __launch_bounds__(256, 2) void conv2d_wino2_kernel(const estd_conv2d_
                         }
                     if (st + 1 < NSTEP) xform2(R, h, Tn[h]);
                 }
-                if (st + 2 < NSTEP) load_rows(st + 2, R);
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {            // order of the region: the MFMAs of two k-steps, then the next step's 4 transforms
-                    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                if (st + 2 < NSTEP) load_rows(st + 2, R);
+                if (ESTD_C2W2_SCHED == 2) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                } else if (ESTD_C2W2_SCHED) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // two MFMAs
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // one vector-memory read (weights / brick rows)
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // one LDS write (the next chunk's transformed rows)
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // transform arithmetic
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                } else {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {            // order of the region: the MFMAs of two k-steps, then the next step's 4 transforms
+                        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                }
                 if (st + 1 < NSTEP) {
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
