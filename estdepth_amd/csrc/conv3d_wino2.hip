@@ -57,6 +57,9 @@
 #ifndef ESTD_W2_AUX_OUT
 #define ESTD_W2_AUX_OUT 0    // cache policy of the output stores (A/B: 2 = non-temporal)
 #endif
+#ifndef ESTD_W2_QSCHED
+#define ESTD_W2_QSCHED 0   // A/B (round 5): the four weight requests of a step one per quarter of its 16 MFMAs (the schedule that pays in csrc/conv2d_wino2.hip): +-0.1 % here, 33 -> 33 +0.7 % (profiles/r5_conv3d_wino2_qsched.txt)
+#endif
 #ifndef ESTD_W2FOLD
 #define ESTD_W2FOLD 0   // 1: the products of a depth transform are folded into the output planes as soon as it is complete (32 accumulator registers less)
 #endif
@@ -729,6 +732,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
 #endif                  // + residual 0.862 -> 0.847, two residuals 0.911 -> 0.893, 33 -> 32 0.861 -> 0.850, 32 -> 16 0.158 -> 0.155 (profiles/r4_wino2_ablation.txt)
             // the 33 -> 33 instance keeps one step of cover: with two it spills (0.982 -> 1.124 ms)
             constexpr int BD = NW == 4 ? 3 : XOUT ? 2 : ESTD_W2BD;  // weight buffers in flight
+            constexpr bool QSCHED = ESTD_W2_QSCHED != 0 && NW == 8;
             float4 bq[BD][4][NHW];                       // [buffer][sh][channel half]: one step's quad of the four taps of a group
             f32x2 T[2][4];                               // [component pair][sh]
             float4 R[4];
@@ -793,7 +797,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                     for (int t = 0; t < 4; ++t) xw[t] = *reinterpret_cast<const float4*>(lds_wxo + ((step * 4 + t) * 4) * 16 + g * 16);
                 }
                 // weights of step + BD - 1
-                if (step + BD - 1 < NSTEPS && !(ESTD_W2ABL & 8)) load_b(step + BD - 1, bq[(step + BD - 1) % BD]);
+                if (!QSCHED && step + BD - 1 < NSTEPS && !(ESTD_W2ABL & 8)) load_b(step + BD - 1, bq[(step + BD - 1) % BD]);
                 if (RB_EARLY && step == NSTEPS - 2) epi_issue(d0, el0);
                 if (RB_EARLY && step == NSTEPS - 1 && d0 + 1 < D) epi_issue(d0 + 1, el1);
                 // chunks of the NEXT tile's two new planes: spread over the first steps (their offsets were read from the LDS table
@@ -834,7 +838,18 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {            // the products rotate: no MFMA waits for its own predecessor
 #pragma unroll
-                    for (int e = 0; e < 2; ++e)
+                    for (int e = 0; e < 2; ++e) {
+                        if (QSCHED) {
+                            // ESTD_W2_QSCHED (round 5, from csrc/conv2d_wino2.hip): the step in four quarters of 4 MFMAs, ONE weight request (tap t = quarter) of step
+                            // + BD - 1 in front of each instead of four in a cluster in front of the step; a scheduling barrier pins the quarter
+                            const int qk = 2 * h + e, tstep = step + BD - 1;
+                            if (tstep < NSTEPS && !(ESTD_W2ABL & 8)) {
+                                const int ng = O16 ? tstep : tstep >> 1, nc = O16 ? cw : (tstep & 1);
+#pragma unroll
+                                for (int x = 0; x < NHW; ++x) bq[tstep % BD][qk][x] = load_w(4 * ng + qk, nc, x);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
 #pragma unroll
                         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -845,6 +860,8 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                                 const f32x4 c_in = first_product ? (f32x4){0.f, 0.f, 0.f, 0.f} : acc[FOLD ? 0 : sd][t][x];
                                 acc[FOLD ? 0 : sd][t][x] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, T[h][t][e], c_in, 0, 0, 0);
                             }
+                        if (QSCHED && e == 0) __builtin_amdgcn_sched_barrier(0);
+                    }
                     if (ESTD_W2PK == 1) __builtin_amdgcn_sched_barrier(0);   // the MFMAs of two components, then the next step's 4 packed transforms
                     if (step + 1 < NSTEPS) xform2(R, h, Tn[h]);
                     if (ESTD_W2PK == 1 && h == 0) __builtin_amdgcn_sched_barrier(0);
@@ -865,7 +882,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
                     if (step == 0) epi_issue(pd0 + cw, pl);
                     else epi_finish(py0, pd0 + cw, pl);
                 }
-                if (ESTD_W2PK == 0) {
+                if (ESTD_W2PK == 0 && !QSCHED) {
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {        // order of the region: the MFMAs of two components, then the next step's 4 transforms
                         __builtin_amdgcn_sched_group_barrier(0x008, 8 * NHW, 0);
