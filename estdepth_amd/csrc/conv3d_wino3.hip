@@ -1,0 +1,487 @@
+// conv3d_wino3.hip -- the plain 32 -> 32 3x3x3 convolution with ALL THREE axes in Winograd F(2,3) form on gfx950 fp32 MFMA:
+// F(2x2x2, 3x3x3), 64 products per 8 outputs = 8/27 of the direct MFMA work (two axes, csrc/conv3d_wino2.hip: 12/27).
+//
+// Same operator and descriptor as estd_conv3d_k3_wino2 (networks/layers_op.py:16-39 as used at hybrid_models/model_hybrid.py:59-60,:95 and
+// hybrid_models/hybrid_depth_decoder.py:84-95).
+//
+//   2 x 2 x 2 outputs (planes d, d+1; rows y, y+1; columns x, x+1) from the 4 x 4 x 4 input patch:
+//       T = B^T x B on the depth axis, the row axis and the column axis   (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1])
+//       U = G g G^T on kd, kh, kw                                         (float64 on the host, rounded once: packing.pack_conv3d_wino3)
+//       m[sd][sh][sw] = sum over input channels of U[sd][sh][sw] * T[sd][sh][sw]      64 products, each a chain of v_mfma_f32_16x16x4_f32
+//       y = A^T m A on the three axes                                     (A^T = [1 1 1 0; 0 1 -1 -1])
+//
+// Work decomposition (what it shares with the two-axis kernel: 512 threads = 8 waves, ONE workgroup per CU, output tile 2 x 8 x 16 voxels, persistent
+// XCD-contiguous ranges of the column-major tile list, the four DEPTH-transformed slices of 10 x 18 voxels x 32 channels in LDS, raw planes carried in
+// registers along a depth column, the next tile's slices written inside the tap loop):
+//   * an MFMA column is a 2 x 2 output BLOCK (row pair, column pair) of the tile instead of a voxel; wave (rq, nh, shh) owns the 16 blocks of tile rows
+//     4rq .. 4rq+3 (two row pairs x eight column pairs) x the 16 output channels of half nh x the row-transform indices sh = 2shh, 2shh+1:
+//     8 products m[sh][sw] of the CURRENT depth transform (32 accumulator registers), 256 MFMAs per tile and wave (two-axis kernel: 384);
+//   * the ROW and the COLUMN transform run in registers between LDS and the MFMA: a sub-step (sd, channel chunk, sh) reads two halo rows x four columns of
+//     its block (the row the two sh of a wave share stays in registers: 12 ds_read_b128 per two sub-steps), forms the row combination (4 packed adds per
+//     channel pair) and its four column combinations (4 more), and multiplies them with the four taps sw of (sd, sh): 16 MFMAs, 2 VALU per MFMA;
+//   * when a depth transform is complete its 8 products go through the column and row halves of the output transform and are added into the partial sums
+//     of the two output planes (32 registers); the two waves of a SIMD (shh = 0, 1: the two halves of the row transform) exchange one plane's partial sums
+//     through LDS at the end of the tile and finish one plane each (the structure of the two-axis kernel's 32 -> 16 instance);
+//   * LDS rows are 18 records + 64 bytes long: halo rows two apart (the two row pairs of a wave) then lie in opposite halves of a 256-byte bank row, and
+//     with the column-keyed chunk swizzle and MFMA column i <-> block (row pair = 4 <= i < 12, column pair = i < 4 ? i : i < 12 ? i - 4 : i - 8) every
+//     ds_read_b128 of a patch position is conflict-free under the hardware's 16-lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
+
+#include "estd_hip.h"
+#include "estd_common.h"
+
+#ifndef ESTD_W3BD
+#define ESTD_W3BD 4         // weight buffers in flight (half-sub-steps of 8 MFMAs): 4 = requested three half-sub-steps (~800 cycles) ahead
+#endif
+#ifndef ESTD_W3ABL
+#define ESTD_W3ABL 0        // timing ablations only (results are wrong): 1 no output stores, 2 no slice writes, 8 no weight stream, 16 no next-plane prefetch,
+#endif                      // 32 no fold, 128 no transforms
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
+
+constexpr int TH = 8, TW = 16;
+constexpr int IN_H = TH + 2, IN_W = TW + 2;
+constexpr int SL_VOX = IN_H * IN_W;                 // 180 records per input slice (with halo)
+constexpr int SL_CHUNKS = SL_VOX * 8;               // 16-byte chunks per slice: 1440
+// LDS lines: line (halo row r, depth slice sd) = 18 records + 16 bytes at (4r + sd) * LINE_BYTES -- the four slices of a row are neighbours, so
+// every (slice, row) of a block's patch is a 16-bit immediate on ONE per-lane base register; 8 lines = 128 (mod 256): halo rows two apart (the two
+// row pairs of a wave) lie in opposite halves of a 256-byte bank row
+constexpr int LINE_BYTES = IN_W * 128 + 16;         // 2320
+constexpr int ROW_BYTES = 4 * LINE_BYTES;           // 9280: next halo row, same slice
+constexpr int SLICE_BYTES = LINE_BYTES;             // next slice, same halo row
+constexpr int SLICES_BYTES = IN_H * ROW_BYTES;      // 92 800
+constexpr int NTHREADS = 512, SIT = 3;              // chunks per thread and slice
+constexpr int RED_BYTES = 512;
+constexpr int SS_BYTES = 3 * 32 * 4;                // folded BN scale | shift | activation floor
+constexpr int VTAB_BYTES = SIT * NTHREADS * 4;      // per-thread global offsets of the slice chunks
+constexpr int XCH_BYTES = 8 * 4 * 64 * 16;          // [wave][4 quads][64 lanes] float4: one plane's partial sums per wave
+constexpr int NTAPS = 64, TAP_BYTES = 4096;         // [block = ((4 sd + sh) * 2 + cc) * 2 + hh][2 halves nh][2 tap pairs][64 lanes][4]: packing.pack_conv3d_wino3
+constexpr int LDS_BYTES = SLICES_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + XCH_BYTES;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;        // beyond num_records of any descriptor: loads return 0, stores are dropped
+
+__device__ __forceinline__ float4 as_float4(u32x4 v)
+{
+    float4 f;
+    __builtin_memcpy(&f, &v, 16);
+    return f;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, size_t elems)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(elems * 4), 0x00020000);
+}
+// workgroup barrier that only orders LDS traffic (no vmcnt drain: prefetches and output stores stay in flight)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ int lds_colkey_off(int col, int c) { return col * 128 + ((c ^ ((col >> 1) & 7)) << 4); }
+__device__ __forceinline__ float tanh_fast(float x)
+{
+    const float t = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(t + 1.0f);
+}
+__device__ __forceinline__ float act_apply(float v, int act)
+{
+    if (act == ESTD_ACT_RELU) return v > 0.0f ? v : 0.0f;
+    if (act == ESTD_ACT_TANH) return tanh_fast(v);
+    return v;
+}
+__device__ __forceinline__ float4 f4_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// RB: the launch has read-back streams in its epilogue (residual, residual2 + scale, running sum)
+template <bool RB>
+__global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int dpairs, int total_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rq = wave & 1;            // tile rows 4rq .. 4rq+3
+    const int nh = (wave >> 1) & 1;     // output channel half
+    const int shh = wave >> 2;          // row-transform indices 2shh, 2shh+1; finishes output plane d0 + shh.  (waves w, w + 4 share a SIMD)
+    const int g = lane >> 4;            // k index inside an MFMA
+    const int i = lane & 15;            // MFMA column = block
+    const int rpl = (i >= 4 && i < 12) ? 1 : 0;          // row pair of the block inside the wave's four rows
+    const int cb = i < 4 ? i : i < 12 ? i - 4 : i - 8;   // column pair
+    const int D = p.D, H = p.H, W = p.W;
+    const int HW = H * W;
+    const size_t vol = (size_t)D * HW;
+
+    int u, u_end;
+    {
+        const int G = gridDim.x, bid = blockIdx.x;
+        const int r = ((G & 7) == 0) ? (bid & 7) * (G >> 3) + (bid >> 3) : bid;       // XCD x owns a contiguous block of ranges
+        u = (int)((long long)total_tiles * r / G);
+        u_end = (int)((long long)total_tiles * (r + 1) / G);
+    }
+    if (u >= u_end) return;
+
+    float* lds_ss = reinterpret_cast<float*>(smem + SLICES_BYTES + RED_BYTES);
+    if (tid < 64) lds_ss[tid] = tid < 32 ? p.scale[tid & 31] : p.shift[tid & 31];
+    if (tid >= 64 && tid < 96) lds_ss[tid] = ((tid - 64) < p.act_split ? p.act_a : p.act_b) == ESTD_ACT_RELU ? 0.0f : ESTD_NO_FLOOR;
+    const bool any_tanh = p.act_a == ESTD_ACT_TANH || p.act_b == ESTD_ACT_TANH;                     // uniform
+    unsigned* lds_vt = reinterpret_cast<unsigned*>(smem + SLICES_BYTES + RED_BYTES + SS_BYTES);     // [it][thread]
+    float4* lds_xch = reinterpret_cast<float4*>(smem + SLICES_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES);
+
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w_wino2, (size_t)NTAPS * 1024);
+    const int wlane = lane * 16 + nh * 2048;
+    // byte offset of (halo row 4rq + 2rpl, halo column 2cb + j, chunk g + 4cc) of slice 0
+    // + the channel pair of half-sub-step half hh: 8 bytes further for hh ^ (g & 1) -- lane groups g, g + 1 read opposite 8-byte halves of their
+    // 16-byte slots, so the 32 lanes of a ds_read_b64 pass touch 32 different 8-byte units of a bank row
+    int cbase[4][2][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) cbase[j][cc][hh] = (4 * rq + 2 * rpl) * ROW_BYTES + lds_colkey_off(2 * cb + j, g + 4 * cc) + 8 * (hh ^ (g & 1));
+
+    while (u < u_end) {
+        // ---- column segment [u, seg_end): same (n, h-tile, w-tile), consecutive depth pairs ----
+        const int col = u / dpairs;
+        int dp = u - col * dpairs;
+        const int twi = col % tiles_w, c2 = col / tiles_w;
+        const int thi = c2 % tiles_h, n = c2 / tiles_h;
+        const int tw0 = twi * TW, th0 = thi * TH;
+        const int seg_end = min(u_end, (col + 1) * dpairs);
+
+        const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in_main + (size_t)n * vol * p.in_stride, vol * p.in_stride);
+        __amdgpu_buffer_rsrc_t rs_res = rs_in, rs_res2 = rs_in;
+        const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(p.out_main + (size_t)n * vol * p.out_stride, vol * p.out_stride);
+        if (RB && p.residual) rs_res = make_rsrc(p.residual + (size_t)n * vol * p.out_stride, vol * p.out_stride);
+        if (RB && p.residual2) rs_res2 = make_rsrc(p.residual2 + (size_t)n * vol * p.out_stride, vol * p.out_stride);
+        const int in_slice_bytes = HW * p.in_stride * 4;
+        const int out_plane_bytes = HW * p.out_stride * 4;
+
+        // per-thread slice chunks: chunk it of a slice = chunk tid + it * NTHREADS; global offsets in a per-thread LDS table (own entries only)
+#pragma unroll
+        for (int it = 0; it < SIT; ++it) {
+            const int e = tid + it * NTHREADS;
+            const int vs = e >> 3, c = e & 7;
+            const int zy = vs / IN_W, zx = vs % IN_W;
+            const int gy = th0 - 1 + zy, gx = tw0 - 1 + zx;
+            const bool ok = e < SL_CHUNKS && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            lds_vt[it * NTHREADS + tid] = ok ? (unsigned)((gy * W + gx) * p.in_stride + c * 4) * 4u : OOB_OFFSET;
+        }
+        auto chunk_voff = [&](int it) {
+            const int l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            return lds_vt[it * NTHREADS + wave * 64 + l];
+        };
+        int loffk[SIT];
+#pragma unroll
+        for (int it = 0; it < SIT; ++it) {
+            const int vs = (tid >> 3) + it * (NTHREADS / 8);
+            loffk[it] = (vs / IN_W) * ROW_BYTES + lds_colkey_off(vs % IN_W, tid & 7);
+        }
+        const bool last_ok = tid + (SIT - 1) * NTHREADS < SL_CHUNKS;
+        auto load_plane = [&](int pd, float4 (&dst)[SIT]) {
+            const bool pv = (unsigned)pd < (unsigned)D;        // wave-uniform; planes outside the volume are zero padding
+#pragma unroll
+            for (int it = 0; it < SIT; ++it)
+                dst[it] = pv ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, chunk_voff(it), pd * in_slice_bytes, 0)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        // lane (g, i) holds the four consecutive channels 16nh + 4g .. +3 of the 2 x 2 voxels of its block, in the plane its wave finishes
+        unsigned eoff[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int y = th0 + 4 * rq + 2 * rpl + m, x = tw0 + 2 * cb + c;
+                eoff[m][c] = (y < H && x < W) ? (unsigned)((y * W + x) * p.out_stride + 16 * nh + 4 * g) * 4u : OOB_OFFSET;
+            }
+        auto bn_act = [&](const f32x4& a, int chb, float4& v) {
+            const float4 sc4 = *reinterpret_cast<const float4*>(lds_ss + chb), sh4 = *reinterpret_cast<const float4*>(lds_ss + 32 + chb);
+            if (!any_tanh) {
+                const float4 lo = *reinterpret_cast<const float4*>(lds_ss + 64 + chb);
+                v.x = fmaxf(a[0] * sc4.x + sh4.x, lo.x);
+                v.y = fmaxf(a[1] * sc4.y + sh4.y, lo.y);
+                v.z = fmaxf(a[2] * sc4.z + sh4.z, lo.z);
+                v.w = fmaxf(a[3] * sc4.w + sh4.w, lo.w);
+                return;
+            }
+            v.x = act_apply(a[0] * sc4.x + sh4.x, chb + 0 < p.act_split ? p.act_a : p.act_b);
+            v.y = act_apply(a[1] * sc4.y + sh4.y, chb + 1 < p.act_split ? p.act_a : p.act_b);
+            v.z = act_apply(a[2] * sc4.z + sh4.z, chb + 2 < p.act_split ? p.act_a : p.act_b);
+            v.w = act_apply(a[3] * sc4.w + sh4.w, chb + 3 < p.act_split ? p.act_a : p.act_b);
+        };
+        // epilogue of this wave's plane: 2 x 2 voxels x 4 channels per lane
+        auto epi_plane = [&](const f32x4 (&a)[2][2], int dd) {
+            const int so = dd * out_plane_bytes;
+            float4 r1[2][2], r2[2][2], ro[2][2];
+            if (RB && p.residual) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) r1[m][c] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_res, eoff[m][c], so, 0));
+            }
+            if (RB && p.residual2) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) r2[m][c] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_res2, eoff[m][c], so, 0));
+            }
+            if (RB && p.accumulate) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) ro[m][c] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_out, eoff[m][c], so, 0));
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    float4 v;
+                    bn_act(a[m][c], 16 * nh + 4 * g, v);
+                    if (RB && p.residual) v = f4_add(v, r1[m][c]);
+                    if (RB && p.residual2) v = f4_add(v, r2[m][c]);
+                    if (RB) v = make_float4(v.x * p.out_scale, v.y * p.out_scale, v.z * p.out_scale, v.w * p.out_scale);
+                    if (RB && p.accumulate) v = f4_add(v, ro[m][c]);
+                    u32x4 bits;
+                    __builtin_memcpy(&bits, &v, 16);
+                    if (!(ESTD_W3ABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(bits, rs_out, eoff[m][c], so, 0);
+                }
+        };
+
+        // raw planes in registers: xa = x[d0-1], xb = x[d0], xc = x[d0+1], xd = x[d0+2]
+        float4 xa[SIT], xb[SIT], xc[SIT], xd[SIT];
+        {
+            const int d0 = 2 * dp;
+            load_plane(d0 - 1, xa);
+            load_plane(d0, xb);
+            load_plane(d0 + 1, xc);
+            load_plane(d0 + 2, xd);
+        }
+        // depth transform B^T x of the planes in (xa, xb, xc, xd), straight into LDS slice sl
+        auto write_slice = [&](int sl) {
+#pragma unroll
+            for (int it = 0; it < SIT; ++it) {
+                if ((it < SIT - 1 || last_ok) && !(ESTD_W3ABL & 2)) {
+                    const float4 v = sl == 0 ? f4_sub(xa[it], xc[it]) : sl == 1 ? f4_add(xb[it], xc[it])
+                                   : sl == 2 ? f4_sub(xc[it], xb[it]) : f4_sub(xb[it], xd[it]);
+                    *reinterpret_cast<float4*>(smem + loffk[it] + sl * SLICE_BYTES) = v;
+                }
+            }
+        };
+        auto shift_planes = [&]() {                      // planes d0+1, d0+2 are planes d0'-1, d0' of the next tile
+#pragma unroll
+            for (int it = 0; it < SIT; ++it) { xa[it] = xc[it]; xb[it] = xd[it]; }
+        };
+        bool first = true;
+
+        for (; u < seg_end; ++u, ++dp) {
+            const int d0 = 2 * dp;
+            if (first) {
+                lds_barrier();                          // every wave is done reading the previous segment's slices
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) write_slice(sl);
+                shift_planes();
+                lds_barrier();
+                first = false;
+            }
+            const bool has_next = (u + 1 < seg_end);     // wave-uniform
+            const int nd = d0 + 3;                       // new planes of the next tile: nd, nd + 1
+            const bool v0 = nd < D, v1 = nd + 1 < D;
+
+            f32x4 P[2][2][2];                            // partial sums [plane][row][column] of this wave's two row-transform indices
+
+            // one tile's tap loop for the waves of row-transform half SHH (compile-time: rows, signs and the output-transform rows differ)
+            auto tap_loop = [&](auto shh_c) {
+                constexpr int SHH = decltype(shh_c)::value;
+                // half-sub-step q = (sd = q >> 3, channel chunk cc = (q >> 2) & 1, channel-pair half hh = (q >> 1) & 1, sl = q & 1): 8 MFMAs =
+                // 4 taps sw x 2 k-steps e.  (Registers: a 16-MFMA unit on 16-byte fragment reads needs 56 more -- it spilled 128.)
+                constexpr int NQ = 32;
+                constexpr int BD = ESTD_W3BD;
+                // halo rows (relative to the block's first) of the two raw rows of a half-sub-step: even q: A = RA0, B = RSH; odd q: A = RA1, B stays
+                //   SHH 0: sh 0 = r0 - r2, sh 1 = r1 + r2       SHH 1: sh 2 = r2 - r1, sh 3 = r1 - r3
+                constexpr int RA0 = SHH == 0 ? 0 : 2, RSH = SHH == 0 ? 2 : 1, RA1 = SHH == 0 ? 1 : 3;
+                f32x4 m[2][4];                           // products [sl][sw] of the current depth transform
+                float4 bq[BD][2];                        // [buffer][tap pair]: (sw 2p, e 0), (2p, 1), (2p + 1, 0), (2p + 1, 1)
+                f32x2 RA[4], RBs[4];                     // raw rows (four block columns, one channel pair) of the next half-sub-step
+                f32x2 T[4];                              // [sw], components = k-steps e
+
+                auto load_w = [&](int q, float4 (&b)[2]) {
+                    const int sd = q >> 3, cc = (q >> 2) & 1, hh = (q >> 1) & 1, sh = 2 * SHH + (q & 1);
+#pragma unroll
+                    for (int sp = 0; sp < 2; ++sp)
+                        b[sp] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, ((((sd * 4 + sh) * 2 + cc) * 2 + hh) * TAP_BYTES) + sp * 1024, 0));
+                };
+                auto load_rowA = [&](int q) {
+                    const int sd = q >> 3, cc = (q >> 2) & 1, hh = (q >> 1) & 1, r = (q & 1) ? RA1 : RA0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) RA[j] = *reinterpret_cast<const f32x2*>(smem + cbase[j][cc][hh] + sd * SLICE_BYTES + r * ROW_BYTES);
+                };
+                auto load_rowB = [&](int q) {
+                    const int sd = q >> 3, cc = (q >> 2) & 1, hh = (q >> 1) & 1;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) RBs[j] = *reinterpret_cast<const f32x2*>(smem + cbase[j][cc][hh] + sd * SLICE_BYTES + RSH * ROW_BYTES);
+                };
+                // the four transformed operands (two k-steps each) of half-sub-step q from its raw rows: row combination, then the column transform
+                auto xform = [&](int q, f32x2 (&o)[4]) {
+                    f32x2 X[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (ESTD_W3ABL & 128) X[j] = RA[j];
+                        else if ((q & 1) == 0) X[j] = RA[j] - RBs[j];
+                        else X[j] = SHH == 0 ? RA[j] + RBs[j] : RBs[j] - RA[j];
+                    }
+                    if (ESTD_W3ABL & 128) { o[0] = X[0]; o[1] = X[1]; o[2] = X[2]; o[3] = X[3]; }
+                    else { o[0] = X[0] - X[2]; o[1] = X[1] + X[2]; o[2] = X[2] - X[1]; o[3] = X[1] - X[3]; }
+                };
+
+#pragma unroll
+                for (int b = 0; b < BD - 1; ++b) load_w(b, bq[b]);
+                load_rowA(0);
+                load_rowB(0);
+                xform(0, T);
+                load_rowA(1);
+                unsigned vo_next = 0;
+                constexpr int PF_Q = 4;                  // next-plane prefetch: one chunk per two half-sub-steps, q = 4, 6, .. 14
+                constexpr int RW_Q = 22;                 // slices 0..2 of the next tile: every read of them has been issued (rows are fetched two half-sub-steps ahead)
+                __builtin_amdgcn_sched_barrier(0);
+
+#pragma clang loop unroll(full)
+                for (int q = 0; q < NQ; ++q) {
+                    const int sd = q >> 3, sl = q & 1;
+                    if (q == RW_Q) lds_barrier();        // (also on a segment's last tile: it separates the partner's read of the exchange buffer from this tile's write)
+                    if (has_next && q >= RW_Q && q < RW_Q + 9 && !(ESTD_W3ABL & 2)) {      // one 16-byte chunk of the next tile's slices 0..2 per half-sub-step
+                        const int sl_w = (q - RW_Q) / SIT, it = (q - RW_Q) % SIT;
+                        if (it < SIT - 1 || last_ok) {
+                            const float4 v = sl_w == 0 ? f4_sub(xa[it], xc[it]) : sl_w == 1 ? f4_add(xb[it], xc[it]) : f4_sub(xc[it], xb[it]);
+                            *reinterpret_cast<float4*>(smem + loffk[it] + sl_w * SLICE_BYTES) = v;
+                        }
+                    }
+                    if (q + BD - 1 < NQ && !(ESTD_W3ABL & 8)) load_w(q + BD - 1, bq[(q + BD - 1) % BD]);
+                    if (has_next && q >= PF_Q && q < PF_Q + 12 && ((q - PF_Q) & 1) == 0 && !(ESTD_W3ABL & 16)) {
+                        const int idx = (q - PF_Q) >> 1, it = idx % SIT;
+                        if (idx < SIT) xc[it] = v0 ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, vo_next, nd * in_slice_bytes, 0)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        else           xd[it] = v1 ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, vo_next, (nd + 1) * in_slice_bytes, 0)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int cur = (ESTD_W3ABL & 8) ? 0 : q % BD;
+                    f32x2 Tn[4];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int sw = 0; sw < 4; ++sw) {
+                            const float4 b4 = bq[cur][sw >> 1];
+                            const float b = (sw & 1) == 0 ? (e == 0 ? b4.x : b4.y) : (e == 0 ? b4.z : b4.w);
+                            const bool first_product = (q & 7) < 2 && e == 0;       // channel chunk 0, pair half 0, k-step 0 of the depth transform
+                            const f32x4 c_in = first_product ? (f32x4){0.f, 0.f, 0.f, 0.f} : m[sl][sw];
+                            m[sl][sw] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, T[sw][e], c_in, 0, 0, 0);
+                        }
+                    if (q + 1 < NQ) xform(q + 1, Tn);
+                    if (q + 2 < NQ) {
+                        load_rowA(q + 2);
+                        if (((q + 2) & 1) == 0) load_rowB(q + 2);
+                    }
+                    if (has_next && q + 1 >= PF_Q && q + 1 < PF_Q + 12 && ((q + 1 - PF_Q) & 1) == 0 && !(ESTD_W3ABL & 16)) vo_next = chunk_voff(((q + 1 - PF_Q) >> 1) % SIT);
+                    // order of the region: four MFMAs, half the next half-sub-step's transform, four MFMAs, the other half, the fragment reads
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                    if (q + 1 < NQ) {
+#pragma unroll
+                        for (int sw = 0; sw < 4; ++sw) T[sw] = Tn[sw];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if ((q & 7) == 7 && !(ESTD_W3ABL & 32)) {
+                        // depth transform sd complete: column half, then this wave's part of the row half of the output transform, then the planes
+                        f32x4 z[2][2];                   // [row][column]
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const f32x4 v0_ = c == 0 ? m[0][0] + m[0][1] + m[0][2] : m[0][1] - m[0][2] - m[0][3];
+                            const f32x4 v1_ = c == 0 ? m[1][0] + m[1][1] + m[1][2] : m[1][1] - m[1][2] - m[1][3];
+                            if (SHH == 0) { z[0][c] = v0_ + v1_; z[1][c] = v1_; }                  // rows: y0 = t0 + t1 (+ t2), y1 = t1 (- t2 - t3)
+                            else          { z[0][c] = v0_;       z[1][c] = -(v0_ + v1_); }         //       y0 = (..) + t2,      y1 = (..) - t2 - t3
+                        }
+#pragma unroll
+                        for (int r = 0; r < 2; ++r)
+#pragma unroll
+                            for (int c = 0; c < 2; ++c) {
+                                if (sd == 0) P[0][r][c] = z[r][c];
+                                else if (sd == 1) { P[0][r][c] += z[r][c]; P[1][r][c] = z[r][c]; }
+                                else if (sd == 2) { P[0][r][c] += z[r][c]; P[1][r][c] -= z[r][c]; }
+                                else P[1][r][c] -= z[r][c];
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (ESTD_W3ABL & 32) {
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) { P[0][r][c] = m[0][2 * r + c]; P[1][r][c] = m[1][2 * r + c]; }
+                }
+                // the other plane's partial sums go to the partner wave (wave ^ 4: same rows and channels, the other half of the row transform)
+                float4* xw = lds_xch + (wave * 4) * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const f32x4 snd = P[1 - SHH][r][c];
+                        xw[(2 * r + c) * 64] = make_float4(snd[0], snd[1], snd[2], snd[3]);
+                    }
+                lds_barrier();                            // every wave has read slice 3 for the last time; the exchange is visible
+                const float4* xr = lds_xch + ((wave ^ 4) * 4) * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const float4 o = xr[(2 * r + c) * 64];
+                        P[0][r][c] = P[SHH][r][c] + (f32x4){o.x, o.y, o.z, o.w};           // P[0] now = the finished outputs of plane d0 + SHH
+                    }
+            };
+            if (shh == 0) tap_loop(std::integral_constant<int, 0>{});
+            else tap_loop(std::integral_constant<int, 1>{});
+
+            if (has_next) {                               // slice 3 of the next tile (published by the next tile's in-loop barrier: first read at the end of its sub-step 10)
+                write_slice(3);
+                shift_planes();
+            }
+            if (d0 + shh < D) epi_plane(P[0], d0 + shh);
+        }
+    }
+}
+
+constexpr int PERSISTENT_WGS = 256;     // one 512-thread workgroup per CU (LDS-limited)
+
+}  // namespace
+
+extern "C" int estd_conv3d_k3_wino3(const estd_conv3d_desc* dp, estd_stream_t s)
+{
+    if (!dp) return ESTD_ERR_ARG;
+    const estd_conv3d_desc& d = *dp;
+    if (d.N <= 0 || d.D <= 0 || d.H <= 0 || d.W <= 0) return ESTD_ERR_ARG;
+    if (!d.in_main || !d.w_wino2 || !d.scale || !d.shift || !d.out_main) return ESTD_ERR_ARG;
+    // 32 -> 32 only: no scalar channels, no fused head, no GroupNorm partial sums, no gate
+    if (d.cin_main != 32 || d.n_tiles != 2 || d.out_head || d.in_extra || d.w_extra || d.out_extra || d.stats_partials || d.gate_r) return ESTD_ERR_UNSUPPORTED;
+    if (d.in_stride < 32 || (d.in_stride & 3) || d.out_stride < 32 || (d.out_stride & 3) || (d.act_split & 1)) return ESTD_ERR_ARG;
+    const int tiles_w = (d.W + TW - 1) / TW, tiles_h = (d.H + TH - 1) / TH, dpairs = (d.D + 1) / 2;
+    const long long total = (long long)d.N * dpairs * tiles_h * tiles_w;
+    if (total > 0x7fffffffLL) return ESTD_ERR_ARG;
+    {   // buffer descriptors address one volume of the batch with 32-bit byte offsets
+        const long long vox = (long long)d.D * d.H * d.W;
+        const int widest = d.in_stride > d.out_stride ? d.in_stride : d.out_stride;
+        if (vox * widest * 4 >= 0x7fffff00LL) return ESTD_ERR_UNSUPPORTED;
+    }
+    const int slots = estd_persistent_wgs(PERSISTENT_WGS / 256);
+    int grid = total < slots ? (int)total : slots;
+    if (grid >= 8) grid &= ~7;
+    const bool rb = d.residual || d.residual2 || d.out_scale != 1.0f || d.accumulate;
+    if (rb) {
+        estd_allow_dynamic_lds<conv3d_wino3_kernel<true>>(LDS_BYTES);
+        hipLaunchKernelGGL((conv3d_wino3_kernel<true>), dim3(grid), dim3(NTHREADS), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h, dpairs, (int)total);
+    } else {
+        estd_allow_dynamic_lds<conv3d_wino3_kernel<false>>(LDS_BYTES);
+        hipLaunchKernelGGL((conv3d_wino3_kernel<false>), dim3(grid), dim3(NTHREADS), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h, dpairs, (int)total);
+    }
+    return ESTD_LAUNCH_CHECK();
+}

@@ -219,6 +219,9 @@ void conv3d_k3(const Tensor& x, const OptTensor& x_extra, const Tensor& w_main, 
     } else if (variant == 4) {          // the 32 -> 32 instance on the operand-reuse kernel (w_alt = packing.pack_conv3d_wino2x)
         d.w_wino2 = fptr(*w_alt, "2-axis Winograd-packed weights (reuse form)");
         check_status(estd_conv3d_k3_wino2x(&d, cur_stream()), "estd_conv3d_k3_wino2x");
+    } else if (variant == 5) {          // the 32 -> 32 instance with all three axes in Winograd form (w_alt = packing.pack_conv3d_wino3)
+        d.w_wino2 = fptr(*w_alt, "3-axis Winograd-packed weights");
+        check_status(estd_conv3d_k3_wino3(&d, cur_stream()), "estd_conv3d_k3_wino3");
     } else {
         TORCH_CHECK(variant == 0, "conv3d_k3: unknown variant ", variant);
         check_status(estd_conv3d_k3(&d, cur_stream()), "estd_conv3d_k3");

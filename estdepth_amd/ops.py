@@ -83,6 +83,8 @@ W2_XOUT = os.environ.get("ESTD_W2_XOUT", "1") != "0"
 # the plain 32 -> 32 instances of the two-axis Winograd kernel on the operand-reuse form (csrc/conv3d_wino2x.hip: one wave per SIMD,
 # 32x32x2 MFMAs, transforms in front of the LDS); opt-in ("1"): at parity with the 8-wave kernel of csrc/conv3d_wino2.hip, not faster (profiles/r5_wino2x_table.txt)
 W2X = os.environ.get("ESTD_W2X", "0") != "0"
+# the plain 32 -> 32 instances (no scalar channel, no GroupNorm partials) with ALL THREE axes in Winograd form (csrc/conv3d_wino3.hip: 8/27 of the direct products)
+W3 = os.environ.get("ESTD_W3", "0") != "0"
 # same choice for the 3x3 / dilation-1 NHWC convolutions: row axis in Winograd F(2,3) form (csrc/conv2d_wino.hip) or direct
 CONV2D_ALGO = os.environ.get("ESTD_CONV2D_ALGO", "wino2")
 CONV2D_NT = os.environ.get("ESTD_CONV2D_NT", "auto")
@@ -231,6 +233,8 @@ class Conv3dPlan:
         self.w_wino2 = packing.pack_conv3d_wino2(weight, main_idx, out_idx[:32]).to(device) if wino_ok else None
         self.w_wino2x = packing.pack_conv3d_wino2x(weight, main_idx, out_idx[:32]).to(device) \
             if (wino_ok and n_tiles == 2 and extra_idx is None) else None
+        self.w_wino3 = packing.pack_conv3d_wino3(weight, main_idx, out_idx[:32]).to(device) \
+            if (wino_ok and n_tiles == 2 and extra_idx is None) else None
         self.w_wino2_extra = packing.pack_conv3d_wino2_extra(weight, extra_idx, out_idx[:32]).to(device) \
             if (wino_ok and extra_idx is not None) else None
         # 33 -> 33 (dres2): the 33rd output channel of the wino2 kernel's XOUT instance
@@ -308,7 +312,10 @@ class Conv3dPlan:
         # 32 -> 32 without a scalar channel and without tanh: the operand-reuse kernel (GroupNorm partials only without read-back streams)
         wino2x = wino2 and W2X and self.w_wino2x is not None and in_extra is None and self.n_tiles == 2 and not tanh \
             and (stats_partials is None or (residual is None and residual2 is None and not accumulate and float(out_scale) == 1.0))
-        variant, w_alt = (1, self.w_split) if split else (3, self.w_wino2_c16) if c16 else (3, self.w_wino2_o16) if o16 else (4, self.w_wino2x) if wino2x \
+        wino3 = wino2 and W3 and self.w_wino3 is not None and in_extra is None and self.n_tiles == 2 and stats_partials is None
+        wino2x = wino2x and not wino3
+        variant, w_alt = (1, self.w_split) if split else (3, self.w_wino2_c16) if c16 else (3, self.w_wino2_o16) if o16 else (5, self.w_wino3) if wino3 \
+            else (4, self.w_wino2x) if wino2x \
             else (3, self.w_wino2) if wino2 else (2, self.w_wino) if wino else (0, None)
         if gate is not None and not o16:
             raise RuntimeError("the reset gate is folded into the 32 -> 16 instance of the two-axis Winograd kernel only")
@@ -354,6 +361,9 @@ class Conv3dPlan:
             elif o16:
                 d.w_wino2 = self.w_wino2_o16.data_ptr()
                 N.check(N.lib().estd_conv3d_k3_wino2(ctypes.byref(d), _stream()), "estd_conv3d_k3_wino2")
+            elif wino3:
+                d.w_wino2 = self.w_wino3.data_ptr()
+                N.check(N.lib().estd_conv3d_k3_wino3(ctypes.byref(d), _stream()), "estd_conv3d_k3_wino3")
             elif wino2x:
                 d.w_wino2 = self.w_wino2x.data_ptr()
                 N.check(N.lib().estd_conv3d_k3_wino2x(ctypes.byref(d), _stream()), "estd_conv3d_k3_wino2x")

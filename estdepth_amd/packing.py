@@ -341,6 +341,30 @@ def pack_conv3d_wino2x(weight, main_idx, out_idx):
     return torch.from_numpy(out.reshape(4 * 3 * 2 * 2, 4, 64, 4))
 
 
+def pack_conv3d_wino3(weight, main_idx, out_idx):
+    """32 -> 32 filters for csrc/conv3d_wino3.hip: ALL THREE axes in Winograd F(2,3) form, U = G g G^T applied on kd, kh and kw (float64, rounded
+    once to float32): 64 products (sd, sh, sw) of [32 out][32 in].  Packed as float32 [block = ((4 sd + sh) * 2 + cc) * 2 + hh][2 halves nh][2 tap
+    pairs sp][64 lanes][4]: element f of lane (g, j) = U[sd][sh][sw = 2 sp + (f >> 1)][out_idx[16 nh + j]][main_idx[16 cc + 4 g + 2 (hh ^ (g & 1)) + (f & 1)]] --
+    a block is what one half-sub-step of 8 MFMAs (4 taps sw x 2 k-steps) reads; lane groups g, g + 1 take the two channel pairs of their 16-byte
+    chunk in opposite order (their 8-byte fragment reads then fall into different LDS banks)."""
+    assert len(main_idx) == 32 and len(out_idx) == 32
+    w = weight.detach().double().cpu().numpy()                       # [Cout, Cin, kd, kh, kw]
+    G = np.array([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
+    U = np.einsum("sd,th,uw,oidhw->stuoi", G, G, G, w).astype(np.float32)      # [4 sd, 4 sh, 4 sw, Cout, Cin]
+    oi, mi = np.asarray(out_idx), np.asarray(main_idx)
+    out = np.zeros((4, 4, 2, 2, 2, 2, 64, 4), np.float32)            # [sd][sh][cc][hh][nh][sp][lane][f]
+    for lane in range(64):
+        g, j = lane >> 4, lane & 15
+        for cc in range(2):
+            for hh in range(2):
+                for nh in range(2):
+                    for sp in range(2):
+                        for f in range(4):
+                            ci = mi[16 * cc + 4 * g + 2 * (hh ^ (g & 1)) + (f & 1)]
+                            out[:, :, cc, hh, nh, sp, lane, f] = U[:, :, 2 * sp + (f >> 1), oi[16 * nh + j], ci]
+    return torch.from_numpy(out.reshape(64, 2, 2, 64, 4))
+
+
 def pack_conv3d_wino2_c16(weight, main_idx, out_idx):
     """16 -> 16 filters (the stereo heads) for csrc/conv3d_wino2_c16.hip: U = G g G^T over (kd, kh) as in pack_conv3d_wino2, packed as
     float32 [48 taps = (3 sd + kw) * 4 + sh][64 lanes][4]: element e of lane (g, j) = U[sd][sh][out_idx[j]][main_idx[4 g + e]][kw] -- output

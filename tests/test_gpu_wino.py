@@ -28,9 +28,10 @@ def _plan(seed, act="relu"):
 
 def _run(plan, algo, x, dims, **kw):
     from estdepth_amd import ops
-    old, old_x = ops.CONV3D_ALGO, ops.W2X
-    # "wino2x" = the two-axis form on the operand-reuse kernel (csrc/conv3d_wino2x.hip, opt-in: ESTD_W2X=1) for the plain 32 -> 32 instance
-    ops.CONV3D_ALGO, ops.W2X = ("wino2", True) if algo == "wino2x" else (algo, False)
+    old, old_x, old_3 = ops.CONV3D_ALGO, ops.W2X, ops.W3
+    # "wino2x" = the two-axis form on the operand-reuse kernel (csrc/conv3d_wino2x.hip, opt-in: ESTD_W2X=1) for the plain 32 -> 32 instance;
+    # "wino3" = all three axes in Winograd form (csrc/conv3d_wino3.hip, ESTD_W3=1; launches with GroupNorm partials stay on the two-axis kernel)
+    ops.CONV3D_ALGO, ops.W2X, ops.W3 = ("wino2", True, False) if algo == "wino2x" else ("wino2", False, True) if algo == "wino3" else (algo, False, False)
     try:
         out = kw.pop("out", None)
         if out is None:
@@ -39,7 +40,7 @@ def _run(plan, algo, x, dims, **kw):
         torch.cuda.synchronize()
         return out
     finally:
-        ops.CONV3D_ALGO, ops.W2X = old, old_x
+        ops.CONV3D_ALGO, ops.W2X, ops.W3 = old, old_x, old_3
 
 
 def _has_ab():
@@ -52,7 +53,7 @@ def _has_ab():
 
 # depth and row axis in Winograd form (default); "wino" = depth axis only (csrc/conv3d_wino.hip: part of the ESTD_BUILD_AB=1 build)
 ALGOS = ("wino2",) + (("wino",) if _has_ab() else ())
-ALGOS_PLAIN = ALGOS + ("wino2x",)      # instances without a scalar channel: + the operand-reuse kernel
+ALGOS_PLAIN = ALGOS + ("wino2x", "wino3")      # instances without a scalar channel: + the operand-reuse kernel, + the three-axis kernel
 
 
 @pytest.mark.parametrize("algo", ALGOS_PLAIN)

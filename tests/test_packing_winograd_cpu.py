@@ -65,6 +65,40 @@ def test_pack_conv3d_wino2x_reproduces_the_direct_convolution():
     assert np.abs(y - ref).max() < 1e-5 * np.abs(ref).max()
 
 
+def test_pack_conv3d_wino3_reproduces_the_direct_convolution():
+    """csrc/conv3d_wino3.hip: F(2x2x2, 3x3x3).  Block ((4 sd + sh) * 2 + cc) * 2 + hh, half nh, tap pair sp: element f of lane (g, j) multiplies record
+    position 16 cc + 4 g + 2 (hh ^ (g & 1)) + (f & 1) into output position 16 nh + j for the tap sw = 2 sp + (f >> 1)."""
+    rng = np.random.default_rng(6)
+    w = rng.standard_normal((32, 32, 3, 3, 3)) * 0.1
+    main_idx, out_idx = list(rng.permutation(32)), list(rng.permutation(32))
+    packed = packing.pack_conv3d_wino3(torch.from_numpy(w).float(), main_idx, out_idx).numpy().reshape(4, 4, 2, 2, 2, 2, 64, 4)   # [sd][sh][cc][hh][nh][sp][lane][f]
+    U = np.zeros((4, 4, 4, 32, 32), np.float32)               # [sd][sh][sw][output position][record position]
+    seen = np.zeros((32, 32), int)
+    for lane in range(64):
+        g, j = lane >> 4, lane & 15
+        for cc in range(2):
+            for hh in range(2):
+                for nh in range(2):
+                    for sp in range(2):
+                        for f in range(4):
+                            pos = 16 * cc + 4 * g + 2 * (hh ^ (g & 1)) + (f & 1)
+                            U[:, :, 2 * sp + (f >> 1), 16 * nh + j, pos] = packed[:, :, cc, hh, nh, sp, lane, f]
+                            seen[16 * nh + j, pos] += 1
+    assert (seen == 4).all()                                  # every (output, input) pair once per tap sw
+    D, H, W = 4, 6, 6
+    x = rng.standard_normal((32, D, H, W))
+    xp = np.zeros((32, D + 2, H + 2, W + 2)); xp[:, 1:-1, 1:-1, 1:-1] = x
+    y = np.zeros((32, D, H, W))
+    for d0 in range(0, D, 2):
+        for h0 in range(0, H, 2):
+            for w0 in range(0, W, 2):
+                T = np.einsum("sd,th,uw,cdhw->stuc", BT, BT, BT, xp[:, d0:d0 + 4, h0:h0 + 4, w0:w0 + 4])
+                m = np.einsum("stuoc,stuc->stuo", U.astype(np.float64), T)
+                y[:, d0:d0 + 2, h0:h0 + 2, w0:w0 + 2] = np.einsum("ds,et,fu,stuo->odef", AT, AT, AT, m)
+    ref = _direct3d(x, w[:, main_idx][out_idx])
+    assert np.abs(y - ref).max() < 1e-5 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("n_out", [32, 16])
 def test_pack_conv3d_wino2_reproduces_the_direct_convolution(n_out):
     rng = np.random.default_rng(3)
