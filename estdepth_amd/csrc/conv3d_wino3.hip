@@ -63,7 +63,8 @@ constexpr int SS_BYTES = 3 * 32 * 4;                // folded BN scale | shift |
 constexpr int VTAB_BYTES = SIT * NTHREADS * 4;      // per-thread global offsets of the slice chunks
 constexpr int XCH_BYTES = 8 * 4 * 64 * 16;          // [wave][4 quads][64 lanes] float4: one plane's partial sums per wave
 constexpr int NTAPS = 64, TAP_BYTES = 4096;         // [block = ((4 sd + sh) * 2 + cc) * 2 + hh][2 halves nh][2 tap pairs][64 lanes][4]: packing.pack_conv3d_wino3
-constexpr int LDS_BYTES = SLICES_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + XCH_BYTES;
+constexpr int DUMMY_BYTES = 96 * 16 + 2 * LINE_BYTES; // where the threads without a third chunk of a slice (1440 = 2 x 512 + 416) put their in-loop writes: the tap loop has no branch
+constexpr int LDS_BYTES = SLICES_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + XCH_BYTES + DUMMY_BYTES;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;        // beyond num_records of any descriptor: loads return 0, stores are dropped
 
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
     float4* lds_xch = reinterpret_cast<float4*>(smem + SLICES_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES);
 
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w_wino2, (size_t)NTAPS * 1024);
+    const __amdgpu_buffer_rsrc_t rs_null = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w_wino2), 0, 0, 0x00020000);     // num_records 0: loads return 0
     const int wlane = lane * 16 + nh * 2048;
     // byte offset of (halo row 4rq + 2rpl, halo column 2cb + j, chunk g + 4cc) of slice 0
     // + the channel pair of half-sub-step half hh: 8 bytes further for hh ^ (g & 1) -- lane groups g, g + 1 read opposite 8-byte halves of their
@@ -180,6 +182,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
             loffk[it] = (vs / IN_W) * ROW_BYTES + lds_colkey_off(vs % IN_W, tid & 7);
         }
         const bool last_ok = tid + (SIT - 1) * NTHREADS < SL_CHUNKS;
+        // in-loop writes: the same for every slice (slices 0..2 only: a thread without a third chunk writes into the dummy area, which also holds its offsets of sl = 1, 2)
+        int loffw[SIT];
+#pragma unroll
+        for (int it = 0; it < SIT; ++it) loffw[it] = (it < SIT - 1 || last_ok) ? loffk[it] : (SLICES_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + XCH_BYTES + (tid - 416) * 16);
         auto load_plane = [&](int pd, float4 (&dst)[SIT]) {
             const bool pv = (unsigned)pd < (unsigned)D;        // wave-uniform; planes outside the volume are zero padding
 #pragma unroll
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
             }
             const bool has_next = (u + 1 < seg_end);     // wave-uniform
             const int nd = d0 + 3;                       // new planes of the next tile: nd, nd + 1
-            const bool v0 = nd < D, v1 = nd + 1 < D;
+            const __amdgpu_buffer_rsrc_t rs_pf0 = (has_next && nd < D) ? rs_in : rs_null, rs_pf1 = (has_next && nd + 1 < D) ? rs_in : rs_null;
 
             f32x4 P[2][2][2];                            // partial sums [plane][row][column] of this wave's two row-transform indices
 
@@ -349,18 +355,16 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
                 for (int q = 0; q < NQ; ++q) {
                     const int sd = q >> 3, sl = q & 1;
                     if (q == RW_Q) lds_barrier();        // (also on a segment's last tile: it separates the partner's read of the exchange buffer from this tile's write)
-                    if (has_next && q >= RW_Q && q < RW_Q + 9 && !(ESTD_W3ABL & 2)) {      // one 16-byte chunk of the next tile's slices 0..2 per half-sub-step
+                    if (q >= RW_Q && q < RW_Q + 9 && !(ESTD_W3ABL & 2)) {      // one 16-byte chunk of the next tile's slices 0..2 per half-sub-step (no next tile: dead slices, harmless)
                         const int sl_w = (q - RW_Q) / SIT, it = (q - RW_Q) % SIT;
-                        if (it < SIT - 1 || last_ok) {
-                            const float4 v = sl_w == 0 ? f4_sub(xa[it], xc[it]) : sl_w == 1 ? f4_add(xb[it], xc[it]) : f4_sub(xc[it], xb[it]);
-                            *reinterpret_cast<float4*>(smem + loffk[it] + sl_w * SLICE_BYTES) = v;
-                        }
+                        const float4 v = sl_w == 0 ? f4_sub(xa[it], xc[it]) : sl_w == 1 ? f4_add(xb[it], xc[it]) : f4_sub(xc[it], xb[it]);
+                        *reinterpret_cast<float4*>(smem + loffw[it] + sl_w * SLICE_BYTES) = v;
                     }
                     if (q + BD - 1 < NQ && !(ESTD_W3ABL & 8)) load_w(q + BD - 1, bq[(q + BD - 1) % BD]);
-                    if (has_next && q >= PF_Q && q < PF_Q + 12 && ((q - PF_Q) & 1) == 0 && !(ESTD_W3ABL & 16)) {
+                    if (q >= PF_Q && q < PF_Q + 12 && ((q - PF_Q) & 1) == 0 && !(ESTD_W3ABL & 16)) {      // (no next tile / plane outside the volume: null descriptor, zeros)
                         const int idx = (q - PF_Q) >> 1, it = idx % SIT;
-                        if (idx < SIT) xc[it] = v0 ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, vo_next, nd * in_slice_bytes, 0)) : make_float4(0.f, 0.f, 0.f, 0.f);
-                        else           xd[it] = v1 ? as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, vo_next, (nd + 1) * in_slice_bytes, 0)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (idx < SIT) xc[it] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_pf0, vo_next, nd * in_slice_bytes, 0));
+                        else           xd[it] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_pf1, vo_next, (nd + 1) * in_slice_bytes, 0));
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     const int cur = (ESTD_W3ABL & 8) ? 0 : q % BD;
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
                         load_rowA(q + 2);
                         if (((q + 2) & 1) == 0) load_rowB(q + 2);
                     }
-                    if (has_next && q + 1 >= PF_Q && q + 1 < PF_Q + 12 && ((q + 1 - PF_Q) & 1) == 0 && !(ESTD_W3ABL & 16)) vo_next = chunk_voff(((q + 1 - PF_Q) >> 1) % SIT);
+                    if (q + 1 >= PF_Q && q + 1 < PF_Q + 12 && ((q + 1 - PF_Q) & 1) == 0 && !(ESTD_W3ABL & 16)) vo_next = chunk_voff(((q + 1 - PF_Q) >> 1) % SIT);
                     // order of the region: four MFMAs, half the next half-sub-step's transform, four MFMAs, the other half, the fragment reads
                     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
