@@ -95,10 +95,16 @@ __device__ __forceinline__ float act_apply(float v, int act)
 __device__ __forceinline__ float4 f4_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-// RB: the launch has read-back streams in its epilogue (residual, residual2 + scale, running sum)
-template <bool RB>
+// RBK: read-back streams of the epilogue.  0 none; 1 = running sum only (out += result); 2 = residual (+ residual2) + scale; 3 = both.
+// Absent streams of a kind (no residual2) read through a null descriptor (zeros, no memory access): the tap loop has no branch.
+#ifndef ESTD_W3DEFER
+#define ESTD_W3DEFER 1      // 1: the epilogue of tile k runs inside the first half-sub-steps of tile k + 1 (A/B: 0 = between the tiles)
+#endif
+template <int RBK>
 __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int dpairs, int total_tiles)
 {
+    constexpr bool RB_ACC = RBK == 1 || RBK == 3, RB_RES = RBK == 2 || RBK == 3;
+    constexpr bool DEFER = ESTD_W3DEFER != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -156,8 +162,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
         const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(p.in_main + (size_t)n * vol * p.in_stride, vol * p.in_stride);
         __amdgpu_buffer_rsrc_t rs_res = rs_in, rs_res2 = rs_in;
         const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(p.out_main + (size_t)n * vol * p.out_stride, vol * p.out_stride);
-        if (RB && p.residual) rs_res = make_rsrc(p.residual + (size_t)n * vol * p.out_stride, vol * p.out_stride);
-        if (RB && p.residual2) rs_res2 = make_rsrc(p.residual2 + (size_t)n * vol * p.out_stride, vol * p.out_stride);
+        rs_res = (RB_RES && p.residual) ? make_rsrc(p.residual + (size_t)n * vol * p.out_stride, vol * p.out_stride) : rs_null;
+        rs_res2 = (RB_RES && p.residual2) ? make_rsrc(p.residual2 + (size_t)n * vol * p.out_stride, vol * p.out_stride) : rs_null;
         const int in_slice_bytes = HW * p.in_stride * 4;
         const int out_plane_bytes = HW * p.out_stride * 4;
 
@@ -216,43 +222,48 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
             v.z = act_apply(a[2] * sc4.z + sh4.z, chb + 2 < p.act_split ? p.act_a : p.act_b);
             v.w = act_apply(a[3] * sc4.w + sh4.w, chb + 3 < p.act_split ? p.act_a : p.act_b);
         };
-        // epilogue of this wave's plane: 2 x 2 voxels x 4 channels per lane
+        // epilogue of this wave's plane (2 x 2 voxels x 4 channels per lane) in two halves m = block row: the read-back loads of a half back to back,
+        // waited for once.  The descriptors are arguments: the deferred form passes null descriptors when there is no previous tile.
+        struct EpiLoads { float4 r1[2], r2[2], ro[2]; };
+        auto epi_issue = [&](int m, int so, const __amdgpu_buffer_rsrc_t& q1, const __amdgpu_buffer_rsrc_t& q2, const __amdgpu_buffer_rsrc_t& qo, EpiLoads& L) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (RB_RES) L.r1[c] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(q1, eoff[m][c], so, 0));
+                if (RB_RES) L.r2[c] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(q2, eoff[m][c], so, 0));
+                if (RB_ACC) L.ro[c] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(qo, eoff[m][c], so, 0));
+            }
+        };
+        auto epi_finish = [&](const f32x4 (&a)[2], int m, int so, const __amdgpu_buffer_rsrc_t& qo, const EpiLoads& L) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float4 v;
+                bn_act(a[c], 16 * nh + 4 * g, v);
+                if (RB_RES) {
+                    v = f4_add(f4_add(v, L.r1[c]), L.r2[c]);
+                    v = make_float4(v.x * p.out_scale, v.y * p.out_scale, v.z * p.out_scale, v.w * p.out_scale);
+                }
+                if (RB_ACC) v = f4_add(v, L.ro[c]);
+                u32x4 bits;
+                __builtin_memcpy(&bits, &v, 16);
+                if (!(ESTD_W3ABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(bits, qo, eoff[m][c], so, 0);
+            }
+        };
         auto epi_plane = [&](const f32x4 (&a)[2][2], int dd) {
             const int so = dd * out_plane_bytes;
-            float4 r1[2][2], r2[2][2], ro[2][2];
-            if (RB && p.residual) {
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) r1[m][c] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_res, eoff[m][c], so, 0));
-            }
-            if (RB && p.residual2) {
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) r2[m][c] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_res2, eoff[m][c], so, 0));
-            }
-            if (RB && p.accumulate) {
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c) ro[m][c] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_out, eoff[m][c], so, 0));
-            }
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    float4 v;
-                    bn_act(a[m][c], 16 * nh + 4 * g, v);
-                    if (RB && p.residual) v = f4_add(v, r1[m][c]);
-                    if (RB && p.residual2) v = f4_add(v, r2[m][c]);
-                    if (RB) v = make_float4(v.x * p.out_scale, v.y * p.out_scale, v.z * p.out_scale, v.w * p.out_scale);
-                    if (RB && p.accumulate) v = f4_add(v, ro[m][c]);
-                    u32x4 bits;
-                    __builtin_memcpy(&bits, &v, 16);
-                    if (!(ESTD_W3ABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(bits, rs_out, eoff[m][c], so, 0);
-                }
+            EpiLoads L0, L1;
+            epi_issue(0, so, rs_res, rs_res2, rs_out, L0);
+            epi_issue(1, so, rs_res, rs_res2, rs_out, L1);
+            epi_finish(a[0], 0, so, rs_out, L0);
+            epi_finish(a[1], 1, so, rs_out, L1);
         };
+        // DEFER: the finished plane of the previous tile of this column segment and where it goes
+        f32x4 py[2][2];
+        int pso = 0;
+        bool have_prev = false;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) py[m][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         // raw planes in registers: xa = x[d0-1], xb = x[d0], xc = x[d0+1], xd = x[d0+2]
         float4 xa[SIT], xb[SIT], xc[SIT], xd[SIT];
@@ -295,6 +306,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
             const __amdgpu_buffer_rsrc_t rs_pf0 = (has_next && nd < D) ? rs_in : rs_null, rs_pf1 = (has_next && nd + 1 < D) ? rs_in : rs_null;
 
             f32x4 P[2][2][2];                            // partial sums [plane][row][column] of this wave's two row-transform indices
+            // the previous tile's plane leaves inside this tile's first half-sub-steps (no previous tile: null descriptors, the stores are dropped)
+            const __amdgpu_buffer_rsrc_t rp_out = have_prev ? rs_out : rs_null, rp_res = have_prev ? rs_res : rs_null, rp_res2 = have_prev ? rs_res2 : rs_null;
 
             // one tile's tap loop for the waves of row-transform half SHH (compile-time: rows, signs and the output-transform rows differ)
             auto tap_loop = [&](auto shh_c) {
@@ -347,6 +360,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
                 xform(0, T);
                 load_rowA(1);
                 unsigned vo_next = 0;
+                EpiLoads pl;
                 constexpr int PF_Q = 4;                  // next-plane prefetch: one chunk per two half-sub-steps, q = 4, 6, .. 14
                 constexpr int RW_Q = 22;                 // slices 0..2 of the next tile: every read of them has been issued (rows are fetched two half-sub-steps ahead)
                 __builtin_amdgcn_sched_barrier(0);
@@ -365,6 +379,13 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
                         const int idx = (q - PF_Q) >> 1, it = idx % SIT;
                         if (idx < SIT) xc[it] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_pf0, vo_next, nd * in_slice_bytes, 0));
                         else           xd[it] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_pf1, vo_next, (nd + 1) * in_slice_bytes, 0));
+                    }
+                    if (DEFER) {                          // read-back instances: half m requested at q = 0 | 2, finished at q = 2 | 4; else finished at q = 1 | 2
+                        constexpr bool RB = RBK != 0;
+                        if (RB && q == 0) epi_issue(0, pso, rp_res, rp_res2, rp_out, pl);
+                        if (q == (RB ? 2 : 1)) epi_finish(py[0], 0, pso, rp_out, pl);
+                        if (RB && q == 2) epi_issue(1, pso, rp_res, rp_res2, rp_out, pl);
+                        if (q == (RB ? 4 : 2)) epi_finish(py[1], 1, pso, rp_out, pl);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     const int cur = (ESTD_W3ABL & 8) ? 0 : q % BD;
@@ -450,7 +471,17 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
                 write_slice(3);
                 shift_planes();
             }
-            if (d0 + shh < D) epi_plane(P[0], d0 + shh);
+            if (DEFER && has_next) {                      // (a tile with a successor is never the odd last plane pair: d0 + shh < D)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) py[m][c] = P[0][m][c];
+                pso = (d0 + shh) * out_plane_bytes;
+                have_prev = true;
+            } else {
+                if (d0 + shh < D) epi_plane(P[0], d0 + shh);
+                have_prev = false;
+            }
         }
     }
 }
@@ -479,13 +510,21 @@ extern "C" int estd_conv3d_k3_wino3(const estd_conv3d_desc* dp, estd_stream_t s)
     const int slots = estd_persistent_wgs(PERSISTENT_WGS / 256);
     int grid = total < slots ? (int)total : slots;
     if (grid >= 8) grid &= ~7;
-    const bool rb = d.residual || d.residual2 || d.out_scale != 1.0f || d.accumulate;
-    if (rb) {
-        estd_allow_dynamic_lds<conv3d_wino3_kernel<true>>(LDS_BYTES);
-        hipLaunchKernelGGL((conv3d_wino3_kernel<true>), dim3(grid), dim3(NTHREADS), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h, dpairs, (int)total);
-    } else {
-        estd_allow_dynamic_lds<conv3d_wino3_kernel<false>>(LDS_BYTES);
-        hipLaunchKernelGGL((conv3d_wino3_kernel<false>), dim3(grid), dim3(NTHREADS), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h, dpairs, (int)total);
+    // read-back kind of the launch (the scale multiply lives in the residual instances)
+    const bool res_any = d.residual || d.residual2 || d.out_scale != 1.0f;
+    const int rbk = (!res_any && !d.accumulate) ? 0 : (!res_any ? 1 : (!d.accumulate ? 2 : 3));
+#define ESTD_W3_LAUNCH(RBV)                                                                                                           \
+    do {                                                                                                                             \
+        estd_allow_dynamic_lds<conv3d_wino3_kernel<RBV>>(LDS_BYTES);                                                                 \
+        hipLaunchKernelGGL((conv3d_wino3_kernel<RBV>), dim3(grid), dim3(NTHREADS), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h,   \
+                           dpairs, (int)total);                                                                                      \
+    } while (0)
+    switch (rbk) {
+    case 0: ESTD_W3_LAUNCH(0); break;
+    case 1: ESTD_W3_LAUNCH(1); break;
+    case 2: ESTD_W3_LAUNCH(2); break;
+    default: ESTD_W3_LAUNCH(3); break;
     }
+#undef ESTD_W3_LAUNCH
     return ESTD_LAUNCH_CHECK();
 }
