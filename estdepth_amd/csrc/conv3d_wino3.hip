@@ -36,6 +36,15 @@
 #ifndef ESTD_W3BD
 #define ESTD_W3BD 4         // weight buffers in flight (half-sub-steps of 8 MFMAs): 4 = requested three half-sub-steps (~800 cycles) ahead
 #endif
+#ifndef ESTD_W3_SCHED
+#define ESTD_W3_SCHED 1     // issue order of a half-sub-step: 0 = requests, then {4 MFMAs, 4 transforms} x 2, then the fragment reads; 1 = {2 MFMAs, transforms, 2 fragment
+#endif                      // reads, every other time one weight request} x 4 (what paid in csrc/conv2d_wino2.hip: a cluster of requests drains the matrix pipe)
+#ifndef ESTD_W3_WRING
+#define ESTD_W3_WRING 0     // (A/B; slower: 0.69 vs 0.653 ms, the ring's registers spill at the tile boundary) 1: the weight ring runs on across the tiles of a column segment (the last half-sub-steps of a tile request the next tile's first blocks)
+#endif
+#ifndef ESTD_W3_SCHED_VALU
+#define ESTD_W3_SCHED_VALU 8
+#endif
 #ifndef ESTD_W3ABL
 #define ESTD_W3ABL 0        // timing ablations only (results are wrong): 1 no output stores, 2 no slice writes, 8 no weight stream, 16 no next-plane prefetch,
 #endif                      // 32 no fold, 128 no transforms
@@ -78,6 +87,23 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, s
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(elems * 4), 0x00020000);
 }
+// sum of a double over the 16 lanes of a DPP row, every lane gets the total (as in csrc/conv3d_wino2.hip)
+template <int CTRL>
+__device__ __forceinline__ double dpp_add_f64(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, false);
+    return v + __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double row16_sum_f64(double v)
+{
+    v = dpp_add_f64<0xB1>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add_f64<0x4E>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add_f64<0x124>(v);     // row_ror:4
+    v = dpp_add_f64<0x128>(v);     // row_ror:8
+    return v;
+}
 // workgroup barrier that only orders LDS traffic (no vmcnt drain: prefetches and output stores stay in flight)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ int lds_colkey_off(int col, int c) { return col * 128 + ((c ^ ((col >> 1) & 7)) << 4); }
@@ -100,7 +126,9 @@ __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float
 #ifndef ESTD_W3DEFER
 #define ESTD_W3DEFER 1      // 1: the epilogue of tile k runs inside the first half-sub-steps of tile k + 1 (A/B: 0 = between the tiles)
 #endif
-template <int RBK>
+// STATS: GroupNorm(1 group per channel half) partial sums of the raw outputs (the ConvGRU's gate convolution, transformer/epipolar_transformer.py:21): one
+// more barrier per tile.
+template <int RBK, bool STATS>
 __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int dpairs, int total_tiles)
 {
     constexpr bool RB_ACC = RBK == 1 || RBK == 3, RB_RES = RBK == 2 || RBK == 3;
@@ -150,6 +178,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) cbase[j][cc][hh] = (4 * rq + 2 * rpl) * ROW_BYTES + lds_colkey_off(2 * cb + j, g + 4 * cc) + 8 * (hh ^ (g & 1));
 
+    constexpr int BD = ESTD_W3BD;
+    static_assert(32 % BD == 0, "the weight ring runs on across tiles");
     while (u < u_end) {
         // ---- column segment [u, seg_end): same (n, h-tile, w-tile), consecutive depth pairs ----
         const int col = u / dpairs;
@@ -290,6 +320,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
             for (int it = 0; it < SIT; ++it) { xa[it] = xc[it]; xb[it] = xd[it]; }
         };
         bool first = true;
+        int stats_parity = 0;
+        float4 bq[BD][2];                                // weight ring: [buffer][tap pair]: (sw 2p, e 0), (2p, 1), (2p + 1, 0), (2p + 1, 1) of a half-sub-step
+        bool w_primed = false;                           // (per column segment: held across its setup code the ring spills)
 
         for (; u < seg_end; ++u, ++dp) {
             const int d0 = 2 * dp;
@@ -315,12 +348,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
                 // half-sub-step q = (sd = q >> 3, channel chunk cc = (q >> 2) & 1, channel-pair half hh = (q >> 1) & 1, sl = q & 1): 8 MFMAs =
                 // 4 taps sw x 2 k-steps e.  (Registers: a 16-MFMA unit on 16-byte fragment reads needs 56 more -- it spilled 128.)
                 constexpr int NQ = 32;
-                constexpr int BD = ESTD_W3BD;
                 // halo rows (relative to the block's first) of the two raw rows of a half-sub-step: even q: A = RA0, B = RSH; odd q: A = RA1, B stays
                 //   SHH 0: sh 0 = r0 - r2, sh 1 = r1 + r2       SHH 1: sh 2 = r2 - r1, sh 3 = r1 - r3
                 constexpr int RA0 = SHH == 0 ? 0 : 2, RSH = SHH == 0 ? 2 : 1, RA1 = SHH == 0 ? 1 : 3;
                 f32x4 m[2][4];                           // products [sl][sw] of the current depth transform
-                float4 bq[BD][2];                        // [buffer][tap pair]: (sw 2p, e 0), (2p, 1), (2p + 1, 0), (2p + 1, 1)
                 f32x2 RA[4], RBs[4];                     // raw rows (four block columns, one channel pair) of the next half-sub-step
                 f32x2 T[4];                              // [sw], components = k-steps e
 
@@ -353,8 +384,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
                     else { o[0] = X[0] - X[2]; o[1] = X[1] + X[2]; o[2] = X[2] - X[1]; o[3] = X[1] - X[3]; }
                 };
 
+                if (!ESTD_W3_WRING || !w_primed) {                         // the weight stream runs on across tiles (every tile reads the same 64 blocks): filled once per column segment
 #pragma unroll
-                for (int b = 0; b < BD - 1; ++b) load_w(b, bq[b]);
+                    for (int b = 0; b < BD - 1; ++b) load_w(b, bq[b]);
+                    w_primed = true;
+                }
                 load_rowA(0);
                 load_rowB(0);
                 xform(0, T);
@@ -374,7 +408,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
                         const float4 v = sl_w == 0 ? f4_sub(xa[it], xc[it]) : sl_w == 1 ? f4_add(xb[it], xc[it]) : f4_sub(xc[it], xb[it]);
                         *reinterpret_cast<float4*>(smem + loffw[it] + sl_w * SLICE_BYTES) = v;
                     }
-                    if (q + BD - 1 < NQ && !(ESTD_W3ABL & 8)) load_w(q + BD - 1, bq[(q + BD - 1) % BD]);
+                    if ((ESTD_W3_WRING || q + BD - 1 < NQ) && !(ESTD_W3ABL & 8)) load_w((q + BD - 1) % NQ, bq[(q + BD - 1) % BD]);      // (the last ones: the next tile's first blocks)
                     if (q >= PF_Q && q < PF_Q + 12 && ((q - PF_Q) & 1) == 0 && !(ESTD_W3ABL & 16)) {      // (no next tile / plane outside the volume: null descriptor, zeros)
                         const int idx = (q - PF_Q) >> 1, it = idx % SIT;
                         if (idx < SIT) xc[it] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_pf0, vo_next, nd * in_slice_bytes, 0));
@@ -387,7 +421,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
                         if (RB && q == 2) epi_issue(1, pso, rp_res, rp_res2, rp_out, pl);
                         if (q == (RB ? 4 : 2)) epi_finish(py[1], 1, pso, rp_out, pl);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    if (ESTD_W3_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
                     const int cur = (ESTD_W3ABL & 8) ? 0 : q % BD;
                     f32x2 Tn[4];
 #pragma unroll
@@ -406,12 +440,23 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
                         if (((q + 2) & 1) == 0) load_rowB(q + 2);
                     }
                     if (q + 1 >= PF_Q && q + 1 < PF_Q + 12 && ((q + 1 - PF_Q) & 1) == 0 && !(ESTD_W3ABL & 16)) vo_next = chunk_voff(((q + 1 - PF_Q) >> 1) % SIT);
-                    // order of the region: four MFMAs, half the next half-sub-step's transform, four MFMAs, the other half, the fragment reads
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                    if (ESTD_W3_SCHED == 0) {
+                        // order of the region: four MFMAs, half the next half-sub-step's transform, four MFMAs, the other half, the fragment reads
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                    } else {
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // one vector-memory read (weights, next plane, read-back)
+                            __builtin_amdgcn_sched_group_barrier(0x002, ESTD_W3_SCHED_VALU, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // (q >= 22: the slice chunk)
+                        }
+                    }
                     if (q + 1 < NQ) {
 #pragma unroll
                         for (int sw = 0; sw < 4; ++sw) T[sw] = Tn[sw];
@@ -467,6 +512,37 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
             if (shh == 0) tap_loop(std::integral_constant<int, 0>{});
             else tap_loop(std::integral_constant<int, 1>{});
 
+            if (STATS) {
+                // fixed-order reduction -> deterministic: the lanes of a wave by DPP moves + two shuffles, the two row quads of a (plane, channel half)
+                // through LDS.  Partial index = canonical tile id (n, d, thi, twi) of each plane, as the direct kernel writes it.
+                double* red = reinterpret_cast<double*>(smem + SLICES_BYTES) + (stats_parity ? 32 : 0);      // [plane][channel half][row quad][sum, sumsq]
+                stats_parity ^= 1;
+                double v0_ = 0.0, v1_ = 0.0;
+                const int chb = 16 * nh + 4 * g;
+                const float4 sc4 = *reinterpret_cast<const float4*>(lds_ss + chb), sh4 = *reinterpret_cast<const float4*>(lds_ss + 32 + chb);
+                const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+                        if (eoff[m][c] != OOB_OFFSET) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { const double uu = (double)(P[0][m][c][r] * scv[r] + shv[r]); v0_ += uu; v1_ += uu * uu; }
+                        }
+                v0_ = row16_sum_f64(v0_); v1_ = row16_sum_f64(v1_);
+#pragma unroll
+                for (int o = 16; o <= 32; o <<= 1) { v0_ += __shfl_xor(v0_, o); v1_ += __shfl_xor(v1_, o); }
+                if (lane == 0) { red[((shh * 2 + nh) * 2 + rq) * 2] = v0_; red[((shh * 2 + nh) * 2 + rq) * 2 + 1] = v1_; }
+                __syncthreads();
+                if (tid < 8) {                                       // (plane, channel half, {sum, sumsq})
+                    const int pl_ = tid >> 2, grp = (tid >> 1) & 1, qq = tid & 1;
+                    if (d0 + pl_ < D) {                              // (odd D: the last pair has one plane)
+                        const double tot = red[((pl_ * 2 + grp) * 2 + 0) * 2 + qq] + red[((pl_ * 2 + grp) * 2 + 1) * 2 + qq];
+                        const size_t tile_id = (((size_t)n * D + d0 + pl_) * tiles_h + thi) * tiles_w + twi;
+                        p.stats_partials[tile_id * 4 + grp * 2 + qq] = tot;
+                    }
+                }
+            }
             if (has_next) {                               // slice 3 of the next tile (published by the next tile's in-loop barrier: first read at the end of its sub-step 10)
                 write_slice(3);
                 shift_planes();
@@ -497,7 +573,7 @@ extern "C" int estd_conv3d_k3_wino3(const estd_conv3d_desc* dp, estd_stream_t s)
     if (d.N <= 0 || d.D <= 0 || d.H <= 0 || d.W <= 0) return ESTD_ERR_ARG;
     if (!d.in_main || !d.w_wino2 || !d.scale || !d.shift || !d.out_main) return ESTD_ERR_ARG;
     // 32 -> 32 only: no scalar channels, no fused head, no GroupNorm partial sums, no gate
-    if (d.cin_main != 32 || d.n_tiles != 2 || d.out_head || d.in_extra || d.w_extra || d.out_extra || d.stats_partials || d.gate_r) return ESTD_ERR_UNSUPPORTED;
+    if (d.cin_main != 32 || d.n_tiles != 2 || d.out_head || d.in_extra || d.w_extra || d.out_extra || d.gate_r) return ESTD_ERR_UNSUPPORTED;
     if (d.in_stride < 32 || (d.in_stride & 3) || d.out_stride < 32 || (d.out_stride & 3) || (d.act_split & 1)) return ESTD_ERR_ARG;
     const int tiles_w = (d.W + TW - 1) / TW, tiles_h = (d.H + TH - 1) / TH, dpairs = (d.D + 1) / 2;
     const long long total = (long long)d.N * dpairs * tiles_h * tiles_w;
@@ -513,17 +589,18 @@ extern "C" int estd_conv3d_k3_wino3(const estd_conv3d_desc* dp, estd_stream_t s)
     // read-back kind of the launch (the scale multiply lives in the residual instances)
     const bool res_any = d.residual || d.residual2 || d.out_scale != 1.0f;
     const int rbk = (!res_any && !d.accumulate) ? 0 : (!res_any ? 1 : (!d.accumulate ? 2 : 3));
-#define ESTD_W3_LAUNCH(RBV)                                                                                                           \
+    if (d.stats_partials && rbk != 0) return ESTD_ERR_UNSUPPORTED;       // GroupNorm partial sums: without read-back streams (the gate convolution has none)
+#define ESTD_W3_LAUNCH(RBV, STV)                                                                                                           \
     do {                                                                                                                             \
-        estd_allow_dynamic_lds<conv3d_wino3_kernel<RBV>>(LDS_BYTES);                                                                 \
-        hipLaunchKernelGGL((conv3d_wino3_kernel<RBV>), dim3(grid), dim3(NTHREADS), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h,   \
+        estd_allow_dynamic_lds<conv3d_wino3_kernel<RBV, STV>>(LDS_BYTES);                                                                 \
+        hipLaunchKernelGGL((conv3d_wino3_kernel<RBV, STV>), dim3(grid), dim3(NTHREADS), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h,   \
                            dpairs, (int)total);                                                                                      \
     } while (0)
     switch (rbk) {
-    case 0: ESTD_W3_LAUNCH(0); break;
-    case 1: ESTD_W3_LAUNCH(1); break;
-    case 2: ESTD_W3_LAUNCH(2); break;
-    default: ESTD_W3_LAUNCH(3); break;
+    case 0: if (d.stats_partials) ESTD_W3_LAUNCH(0, true); else ESTD_W3_LAUNCH(0, false); break;
+    case 1: ESTD_W3_LAUNCH(1, false); break;
+    case 2: ESTD_W3_LAUNCH(2, false); break;
+    default: ESTD_W3_LAUNCH(3, false); break;
     }
 #undef ESTD_W3_LAUNCH
     return ESTD_LAUNCH_CHECK();

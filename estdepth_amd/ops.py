@@ -312,7 +312,8 @@ class Conv3dPlan:
         # 32 -> 32 without a scalar channel and without tanh: the operand-reuse kernel (GroupNorm partials only without read-back streams)
         wino2x = wino2 and W2X and self.w_wino2x is not None and in_extra is None and self.n_tiles == 2 and not tanh \
             and (stats_partials is None or (residual is None and residual2 is None and not accumulate and float(out_scale) == 1.0))
-        wino3 = wino2 and W3 and self.w_wino3 is not None and in_extra is None and self.n_tiles == 2 and stats_partials is None
+        wino3 = wino2 and W3 and self.w_wino3 is not None and in_extra is None and self.n_tiles == 2 \
+            and (stats_partials is None or (residual is None and residual2 is None and not accumulate and float(out_scale) == 1.0))
         wino2x = wino2x and not wino3
         variant, w_alt = (1, self.w_split) if split else (3, self.w_wino2_c16) if c16 else (3, self.w_wino2_o16) if o16 else (5, self.w_wino3) if wino3 \
             else (4, self.w_wino2x) if wino2x \

@@ -178,8 +178,8 @@ int estd_conv3d_k3_wino2(const estd_conv3d_desc* desc, estd_stream_t stream);
  * operand blocks.  Reads desc->w_wino2, which must then hold the packing of packing.py::pack_conv3d_wino2x: float32
  * [4 sd][3 kw][2 chunks][2 q][4 sh][64 lanes][4].  ESTD_ERR_UNSUPPORTED for any other shape (callers fall back to estd_conv3d_k3_wino2). */
 int estd_conv3d_k3_wino2x(const estd_conv3d_desc* desc, estd_stream_t stream);
-/* The 32 -> 32 instance of estd_conv3d_k3_wino2 (cin_main = 32, n_tiles = 2, no in_extra / out_extra / head / GroupNorm partials / gate; BN,
- * activation, residuals, scale, running sum) with ALL THREE axes in Winograd F(2,3) form -- F(2x2x2, 3x3x3), 8/27 of the direct products
+/* The 32 -> 32 instance of estd_conv3d_k3_wino2 (cin_main = 32, n_tiles = 2, no in_extra / out_extra / head / gate; BN,
+ * activation, residuals, scale, running sum; GroupNorm partials without read-back streams) with ALL THREE axes in Winograd F(2,3) form -- F(2x2x2, 3x3x3), 8/27 of the direct products
  * (csrc/conv3d_wino3.hip).  Reads desc->w_wino2, which must then hold the packing of packing.py::pack_conv3d_wino3: float32
  * [64 blocks ((4 sd + sh) * 2 + cc) * 2 + hh][2 halves][2 tap pairs][64 lanes][4].  ESTD_ERR_UNSUPPORTED for any other shape (callers fall back to
  * estd_conv3d_k3_wino2). */
