@@ -30,7 +30,7 @@ PEAK_FP32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f
 PEAK_BF16_MATRIX_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak; the 3xbf16 split spends 6 bf16 FLOPs per fp32 FLOP
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E spec peak (about 6.3 TB/s is achievable by a copy)
 # fraction of the direct convolution's 27-tap MFMA products a kernel actually issues (the rest is removed by exact Winograd identities)
-EXECUTED_FACTOR = {"direct": 1.0, "wino": 18.0 / 27.0, "wino2": 12.0 / 27.0}
+EXECUTED_FACTOR = {"direct": 1.0, "wino": 18.0 / 27.0, "wino2": 12.0 / 27.0, "wino3": 8.0 / 27.0}
 
 #            name:  (views, Hi,  Wi,   D,  resnet, EST,   description)
 WORKLOADS = {
@@ -423,6 +423,8 @@ def conv3d_algo_of(group, algo, arith):
     from estdepth_amd import ops
     if arith != "f32":
         return "direct"
+    if group == "conv3d:32->32" and algo == "wino2" and ops.W3:      # all three axes in Winograd form (csrc/conv3d_wino3.hip: 8/27 of the products)
+        return "wino3"
     if group in ("conv3d:32->32", "conv3d:33->32"):      # the key || value convolution (33 -> 32) has a wino2 instance as well
         return algo
     if group == "conv3d:33->33":
@@ -830,7 +832,8 @@ def main():
                                                    n=10, device=device, peak_gbs=HBM_PEAK_GBS)
             except Exception as e:
                 hbm_alone = {"error": "%s: %s" % (type(e).__name__, str(e)[:100])}
-        kname = {"wino2": "conv3d_wino2_kernel (3x3x3 conv 32->32, fp32 MFMA 16x16x4, depth and row axis in Winograd F(2,3) form: 12/27 of the products)",
+        kname = {"wino3": "conv3d_wino3_kernel (3x3x3 conv 32->32, fp32 MFMA 16x16x4, all three axes in Winograd F(2,3) form: 8/27 of the products)",
+                 "wino2": "conv3d_wino2_kernel (3x3x3 conv 32->32, fp32 MFMA 16x16x4, depth and row axis in Winograd F(2,3) form: 12/27 of the products)",
                  "wino": "conv3d_wino_kernel (3x3x3 conv 32->32, fp32 MFMA 16x16x4, depth axis in Winograd F(2,3) form: 18/27 of the products)",
                  "direct": "conv3d_k3_kernel<32,2> (3x3x3 conv 32->32, fp32 MFMA 16x16x4)"}[kalgo]
         line = {
@@ -846,7 +849,7 @@ def main():
                        "launch": "eager" if (args.no_graph or state["fwd"] is model) else "hipGraph replay",
                        "graph_memory": None if (args.no_graph or state["fwd"] is model) else args.graph_memory,
                        "conv3d_arith": args.conv3d_arith, "conv2d_arith": args.conv2d_arith,
-                       "conv3d_algo_32to32": args.conv3d_algo if args.conv3d_arith == "f32" else "direct",
+                       "conv3d_algo_32to32": kalgo,
                        "notes": state["notes"],
                        "per_rank_ms_per_step": per_rank_ms,
                        "parallelism": "1 sequence per GPU" + ("; RCCL all-gather of {K,V,pose} per step, overlapped with the next step" if gathered else "")

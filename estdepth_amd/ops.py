@@ -83,8 +83,9 @@ W2_XOUT = os.environ.get("ESTD_W2_XOUT", "1") != "0"
 # the plain 32 -> 32 instances of the two-axis Winograd kernel on the operand-reuse form (csrc/conv3d_wino2x.hip: one wave per SIMD,
 # 32x32x2 MFMAs, transforms in front of the LDS); opt-in ("1"): at parity with the 8-wave kernel of csrc/conv3d_wino2.hip, not faster (profiles/r5_wino2x_table.txt)
 W2X = os.environ.get("ESTD_W2X", "0") != "0"
-# the plain 32 -> 32 instances (no scalar channel, no GroupNorm partials) with ALL THREE axes in Winograd form (csrc/conv3d_wino3.hip: 8/27 of the direct products)
-W3 = os.environ.get("ESTD_W3", "0") != "0"
+# the 32 -> 32 instances without a scalar channel (BN / activation / residuals / running sum / GroupNorm partials) with ALL THREE axes in Winograd form
+# (csrc/conv3d_wino3.hip: F(2x2x2, 3x3x3), 8/27 of the direct products; default since round 5: 0.65 vs 0.81 ms for 3 volumes, Joint step 16.9 -> 15.8 ms; "0": two-axis kernel)
+W3 = os.environ.get("ESTD_W3", "1") != "0"
 # same choice for the 3x3 / dilation-1 NHWC convolutions: row axis in Winograd F(2,3) form (csrc/conv2d_wino.hip) or direct
 CONV2D_ALGO = os.environ.get("ESTD_CONV2D_ALGO", "wino2")
 CONV2D_NT = os.environ.get("ESTD_CONV2D_NT", "auto")

@@ -20,8 +20,10 @@ for wl in joint estm cfg5; do
   [ -n "$S" ] && head -41 $S > $OUT/${P}_bench_${wl}_rocprof_stats_top40.csv
 done
 # PMC: dominant kernel (conv_bench: N = 3 volumes) per algorithm, separate --pmc passes
-for algo in wino2 direct; do
-  ESTD_CONV3D_ALGO=$algo bash $R/tools/pmc_collect.sh "FETCH_SIZE WRITE_SIZE" $OUT/${P}_conv3d_${algo}_pmc.csv -- python $R/tools/conv_bench.py 3 10 > /dev/null 2>&1
+# (wino3 = ESTD_CONV3D_ALGO=wino2 with ESTD_W3=1, the default: the 32 -> 32 instances on csrc/conv3d_wino3.hip; wino2 = ESTD_W3=0)
+algo_env() { case $1 in wino3) echo "ESTD_CONV3D_ALGO=wino2 ESTD_W3=1";; wino2) echo "ESTD_CONV3D_ALGO=wino2 ESTD_W3=0";; *) echo "ESTD_CONV3D_ALGO=$1";; esac; }
+for algo in wino3 wino2 direct; do
+  env $(algo_env $algo) bash $R/tools/pmc_collect.sh "FETCH_SIZE WRITE_SIZE" $OUT/${P}_conv3d_${algo}_pmc.csv -- python $R/tools/conv_bench.py 3 10 > /dev/null 2>&1
 done
 python $R/tools/pmc_json.py $OUT $P          # ${P}_conv3d_pmc.json: what bench.py reads for roofline.traffic (from profiles/)
 bash $R/tools/pmc_collect.sh "FETCH_SIZE WRITE_SIZE" $OUT/${P}_hbm_kernels_pmc.csv -- python $R/tools/hbm_bench.py > /dev/null 2>&1
@@ -32,14 +34,15 @@ for b in "conv_bench.py 3 10" "conv_bench.py 1 10" "kv_bench.py" "head_bench.py"
 done
 cd $R
 python tools/hbm_bench.py > $OUT/${P}_hbm_bench.txt 2>&1
-for algo in wino2 direct; do
-  echo "# ESTD_CONV3D_ALGO=$algo" >> $OUT/${P}_conv_bench.txt
-  ESTD_CONV3D_ALGO=$algo CB_EPI=1 python tools/conv_bench.py 3 30 2>&1 | grep -v amdgpu >> $OUT/${P}_conv_bench.txt
-  ESTD_CONV3D_ALGO=$algo python tools/conv_bench.py 1 30 2>&1 | grep -v amdgpu >> $OUT/${P}_conv_bench.txt
+for algo in wino3 wino2 direct; do
+  echo "# $algo: $(algo_env $algo)" >> $OUT/${P}_conv_bench.txt
+  env $(algo_env $algo) CB_EPI=1 python tools/conv_bench.py 3 30 2>&1 | grep -v amdgpu >> $OUT/${P}_conv_bench.txt
+  env $(algo_env $algo) python tools/conv_bench.py 1 30 2>&1 | grep -v amdgpu >> $OUT/${P}_conv_bench.txt
 done
 python tools/head_bench.py 2>&1 | grep -v amdgpu >> $OUT/${P}_conv_bench.txt
 python tools/kv_bench.py 2>&1 | grep -v amdgpu >> $OUT/${P}_conv_bench.txt
-python tools/w2x_bench.py 3 30 2>&1 | grep -v amdgpu > $OUT/${P}_w2x_bench.txt
+python tools/w3_bench.py 3 30 2>&1 | grep -v amdgpu > $OUT/${P}_w3_bench.txt
+ESTD_W3=0 python tools/w2x_bench.py 3 30 2>&1 | grep -v amdgpu > $OUT/${P}_w2x_bench.txt
 python tools/gate_bench.py 2>&1 | grep -v amdgpu > $OUT/${P}_gate_bench.txt
 python tools/conv2d_bench.py 2>&1 | grep -v amdgpu > $OUT/${P}_conv2d_bench.txt
 python tools/psm_small_bench.py 2>&1 | grep -v amdgpu > $OUT/${P}_psm_small_bench.txt
@@ -55,7 +58,8 @@ python bench.py --workload estm 2>/dev/null | last > $OUT/${P}_bench_estm.json
 python bench.py --workload cfg1 2>/dev/null | last > $OUT/${P}_bench_cfg1.json
 python bench.py --workload cfg5 --steps 5 --warmup 2 2>/dev/null | last > $OUT/${P}_bench_cfg5.json
 python bench.py --workload stream --steps 20 2>/dev/null | last > $OUT/${P}_bench_stream.json
-ESTD_W2X=1 python bench.py --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_w2x.json
+ESTD_W3=0 python bench.py --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_two_axis.json
+ESTD_W3=0 ESTD_W2X=1 python bench.py --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_w2x.json
 ESTD_GATE_IN_CONV=0 python bench.py --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_gate_pass.json
 python bench.py --conv3d-algo direct --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_direct_conv.json
 python bench.py --no-graph --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_eager.json

@@ -11,7 +11,7 @@ from estdepth_amd import ops
 from estdepth_amd import _native
 DEV = torch.device("cuda:0")
 AB = _native.has_ab()                                         # depth-only / row-only Winograd kernels: ESTD_BUILD_AB=1 builds only
-WINO3D = ("wino", "wino2") if AB else ("wino2",)
+WINO3D = (("wino", "wino2") if AB else ("wino2",)) + ("wino3",)     # "wino3": the 32 -> 32 instances on csrc/conv3d_wino3.hip (ops.W3, the default); "wino2": ops.W3 = False
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
@@ -22,7 +22,7 @@ def rnd(*shape, scale=1.0):
 
 
 def run3d(plan, algo, x, dims, **kw):
-    ops.CONV3D_ALGO = algo
+    ops.CONV3D_ALGO, ops.W3 = ("wino2", True) if algo == "wino3" else (algo, False)
     out = kw.pop("out")
     plan.run(x, dims, out=out, **kw)
     torch.cuda.synchronize()
@@ -117,12 +117,12 @@ def case_conv2d():
     x = rnd(N, H, W, cin)
     res = rnd(N, H, W, cout) if rng.integers(2) else None
     outs = {}
-    for algo in ("direct",) + WINO3D:            # two-axis Winograd (the default; + row-only in an ESTD_BUILD_AB=1 build) against the direct kernel
+    for algo in ("direct",) + tuple(a for a in WINO3D if a != "wino3"):            # two-axis Winograd (the default; + row-only in an ESTD_BUILD_AB=1 build) against the direct kernel
         ops.CONV2D_ALGO = algo
         outs[algo] = plan.run(x, residual=res)
         torch.cuda.synchronize()
     a = outs["direct"]
-    d = max(float((a - outs[alg]).abs().max()) for alg in WINO3D)
+    d = max(float((a - outs[alg]).abs().max()) for alg in WINO3D if alg != "wino3")
     return (d == d) and d < 4e-5 * max(1.0, float(a.abs().max())), ("conv2d", (N, H, W), cin, cout, dil, rb, ra, res is not None, d)
 
 

@@ -7,7 +7,7 @@ ALG = 64 * 120 * 160 * (32 + 32) * 4                      # read 32 + write 32 c
 out = {"how": "tools/pmc_collect.sh \"FETCH_SIZE WRITE_SIZE\" -- python tools/conv_bench.py 3 10 (separate --pmc passes; values in KiB; gfx950: "
               "FETCH_SIZE counts 64-byte units as 32 -> x2, MI355X_MICROARCH.md); 3 volumes of 64x120x160 per launch",
        "algorithmic_bytes_per_volume": ALG, "hbm_bytes_per_volume_by_algo": {}, "detail": {}}
-for algo, pat in (("wino2", "conv3d_wino2_kernel"), ("wino", "conv3d_wino_kernel"), ("direct", "conv3d_k3_kernel")):
+for algo, pat in (("wino3", "conv3d_wino3_kernel"), ("wino2", "conv3d_wino2_kernel"), ("wino", "conv3d_wino_kernel"), ("direct", "conv3d_k3_kernel")):
     if not os.path.exists(os.path.join(d, "%s_conv3d_%s_pmc.csv" % (RND, algo))):      # (the depth-only kernel: ESTD_BUILD_AB=1 builds only)
         continue
     with open(os.path.join(d, "%s_conv3d_%s_pmc.csv" % (RND, algo))) as f:
