@@ -42,6 +42,9 @@
 #ifndef ESTD_W3_WRING
 #define ESTD_W3_WRING 0     // (A/B; slower: 0.69 vs 0.653 ms, the ring's registers spill at the tile boundary) 1: the weight ring runs on across the tiles of a column segment (the last half-sub-steps of a tile request the next tile's first blocks)
 #endif
+#ifndef ESTD_W3_RBQ
+#define ESTD_W3_RBQ 5       // half-sub-step at which the deferred epilogue of a read-back instance consumes its loads (requested at 0, 1)
+#endif
 #ifndef ESTD_W3_SCHED_VALU
 #define ESTD_W3_SCHED_VALU 8
 #endif
@@ -73,7 +76,8 @@ constexpr int VTAB_BYTES = SIT * NTHREADS * 4;      // per-thread global offsets
 constexpr int XCH_BYTES = 8 * 4 * 64 * 16;          // [wave][4 quads][64 lanes] float4: one plane's partial sums per wave
 constexpr int NTAPS = 64, TAP_BYTES = 4096;         // [block = ((4 sd + sh) * 2 + cc) * 2 + hh][2 halves nh][2 tap pairs][64 lanes][4]: packing.pack_conv3d_wino3
 constexpr int DUMMY_BYTES = 96 * 16 + 2 * LINE_BYTES; // where the threads without a third chunk of a slice (1440 = 2 x 512 + 416) put their in-loop writes: the tap loop has no branch
-constexpr int LDS_BYTES = SLICES_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + XCH_BYTES + DUMMY_BYTES;
+constexpr int XSL_BYTES = 4 * SL_VOX * 4;            // EXTRA: the four depth-transformed slices of the scalar 33rd input channel ([sd][180] floats)
+constexpr int LDS_BYTES = SLICES_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + XCH_BYTES + DUMMY_BYTES + XSL_BYTES;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;        // beyond num_records of any descriptor: loads return 0, stores are dropped
 
@@ -128,7 +132,10 @@ __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float
 #endif
 // STATS: GroupNorm(1 group per channel half) partial sums of the raw outputs (the ConvGRU's gate convolution, transformer/epipolar_transformer.py:21): one
 // more barrier per tile.
-template <int RBK, bool STATS>
+// EXTRA: a scalar 33rd INPUT channel (the key || value convolution, hybrid_depth_decoder.py:190-191 on cat[dres2 output]): its four depth-transformed slices
+// in 2.9 KB of LDS; in the middle of every depth transform ONE more k-step per product m[sh][sw] -- lane group g = 0 carries the scalar channel's row- and
+// column-transformed patch, groups 1..3 read zero weights (out-of-range offsets of the weight load) -- i.e. 32 more MFMAs per tile and wave.
+template <int RBK, bool STATS, bool EXTRA>
 __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int dpairs, int total_tiles)
 {
     constexpr bool RB_ACC = RBK == 1 || RBK == 3, RB_RES = RBK == 2 || RBK == 3;
@@ -163,9 +170,14 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
     const bool any_tanh = p.act_a == ESTD_ACT_TANH || p.act_b == ESTD_ACT_TANH;                     // uniform
     unsigned* lds_vt = reinterpret_cast<unsigned*>(smem + SLICES_BYTES + RED_BYTES + SS_BYTES);     // [it][thread]
     float4* lds_xch = reinterpret_cast<float4*>(smem + SLICES_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES);
+    const __amdgpu_buffer_rsrc_t rs_null = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w_wino2), 0, 0, 0x00020000);     // num_records 0: loads return 0
+    float* lds_x = reinterpret_cast<float*>(smem + SLICES_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + XCH_BYTES + DUMMY_BYTES);      // [4][SL_VOX] (EXTRA)
+    // EXTRA: weights [4 sd][4 sh][2 halves][16 output channels][4 sw] (packing.pack_conv3d_wino3_extra): lane (g = 0, i) reads its 16 bytes, g > 0 zeros
+    const __amdgpu_buffer_rsrc_t rs_wx = EXTRA ? make_rsrc(p.w_extra, (size_t)4 * 4 * 2 * 16 * 4) : rs_null;
+    const unsigned wxlane = g == 0 ? (unsigned)(nh * 256 + i * 16) : OOB_OFFSET;
+    const int xbase = ((4 * rq + 2 * rpl) * IN_W + 2 * cb) * 4;       // byte offset of the block's patch origin in a scalar slice
 
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w_wino2, (size_t)NTAPS * 1024);
-    const __amdgpu_buffer_rsrc_t rs_null = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w_wino2), 0, 0, 0x00020000);     // num_records 0: loads return 0
     const int wlane = lane * 16 + nh * 2048;
     // byte offset of (halo row 4rq + 2rpl, halo column 2cb + j, chunk g + 4cc) of slice 0
     // + the channel pair of half-sub-step half hh: 8 bytes further for hh ^ (g & 1) -- lane groups g, g + 1 read opposite 8-byte halves of their
@@ -194,6 +206,17 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
         const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(p.out_main + (size_t)n * vol * p.out_stride, vol * p.out_stride);
         rs_res = (RB_RES && p.residual) ? make_rsrc(p.residual + (size_t)n * vol * p.out_stride, vol * p.out_stride) : rs_null;
         rs_res2 = (RB_RES && p.residual2) ? make_rsrc(p.residual2 + (size_t)n * vol * p.out_stride, vol * p.out_stride) : rs_null;
+        const __amdgpu_buffer_rsrc_t rs_ex = EXTRA ? make_rsrc(p.in_extra + (size_t)n * vol, vol) : rs_null;
+        // EXTRA: thread t < 180 owns voxel t of the scalar channel's haloed slices
+        unsigned xoff = OOB_OFFSET;
+        if (EXTRA && tid < SL_VOX) {
+            const int zy = tid / IN_W, zx = tid % IN_W;
+            const int gy = th0 - 1 + zy, gx = tw0 - 1 + zx;
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) xoff = (unsigned)(gy * W + gx) * 4u;
+        }
+        auto load_x = [&](int pd) {
+            return (unsigned)pd < (unsigned)D ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ex, xoff, pd * HW * 4, 0)) : 0.0f;
+        };
         const int in_slice_bytes = HW * p.in_stride * 4;
         const int out_plane_bytes = HW * p.out_stride * 4;
 
@@ -304,6 +327,16 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
             load_plane(d0 + 1, xc);
             load_plane(d0 + 2, xd);
         }
+        float ea = 0.f, eb = 0.f, ec = 0.f, ed = 0.f;    // EXTRA: the scalar channel's four planes at this thread's voxel
+        if (EXTRA) {
+            const int d0 = 2 * dp;
+            ea = load_x(d0 - 1); eb = load_x(d0); ec = load_x(d0 + 1); ed = load_x(d0 + 2);
+        }
+        // (threads without a voxel write into the dummy area: no branch in the tap loop)
+        char* xw_ptr = tid < SL_VOX ? reinterpret_cast<char*>(lds_x) + tid * 4 : smem + SLICES_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + XCH_BYTES + (tid & 63) * 4;
+        auto write_x_slice = [&](int sl) {
+            if (EXTRA) *reinterpret_cast<float*>(xw_ptr + sl * (SL_VOX * 4)) = sl == 0 ? ea - ec : sl == 1 ? eb + ec : sl == 2 ? ec - eb : eb - ed;
+        };
         // depth transform B^T x of the planes in (xa, xb, xc, xd), straight into LDS slice sl
         auto write_slice = [&](int sl) {
 #pragma unroll
@@ -318,6 +351,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
         auto shift_planes = [&]() {                      // planes d0+1, d0+2 are planes d0'-1, d0' of the next tile
 #pragma unroll
             for (int it = 0; it < SIT; ++it) { xa[it] = xc[it]; xb[it] = xd[it]; }
+            if (EXTRA) { ea = ec; eb = ed; }
         };
         bool first = true;
         int stats_parity = 0;
@@ -330,6 +364,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
                 lds_barrier();                          // every wave is done reading the previous segment's slices
 #pragma unroll
                 for (int sl = 0; sl < 4; ++sl) write_slice(sl);
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) write_x_slice(sl);
                 shift_planes();
                 lds_barrier();
                 first = false;
@@ -337,6 +373,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
             const bool has_next = (u + 1 < seg_end);     // wave-uniform
             const int nd = d0 + 3;                       // new planes of the next tile: nd, nd + 1
             const __amdgpu_buffer_rsrc_t rs_pf0 = (has_next && nd < D) ? rs_in : rs_null, rs_pf1 = (has_next && nd + 1 < D) ? rs_in : rs_null;
+            const __amdgpu_buffer_rsrc_t rs_px0 = (EXTRA && has_next && nd < D) ? rs_ex : rs_null, rs_px1 = (EXTRA && has_next && nd + 1 < D) ? rs_ex : rs_null;
 
             f32x4 P[2][2][2];                            // partial sums [plane][row][column] of this wave's two row-transform indices
             // the previous tile's plane leaves inside this tile's first half-sub-steps (no previous tile: null descriptors, the stores are dropped)
@@ -394,7 +431,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
                 xform(0, T);
                 load_rowA(1);
                 unsigned vo_next = 0;
-                EpiLoads pl;
+                EpiLoads pl, pl1;
+                float4 wx[2];                            // EXTRA: the scalar channel's weights [sl], components = sw
+                f32x2 xpt[3][2];                         // EXTRA: its patch: rows RA0, shared, RA1 x column pairs
                 constexpr int PF_Q = 4;                  // next-plane prefetch: one chunk per two half-sub-steps, q = 4, 6, .. 14
                 constexpr int RW_Q = 22;                 // slices 0..2 of the next tile: every read of them has been issued (rows are fetched two half-sub-steps ahead)
                 __builtin_amdgcn_sched_barrier(0);
@@ -414,12 +453,51 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
                         if (idx < SIT) xc[it] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_pf0, vo_next, nd * in_slice_bytes, 0));
                         else           xd[it] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_pf1, vo_next, (nd + 1) * in_slice_bytes, 0));
                     }
-                    if (DEFER) {                          // read-back instances: half m requested at q = 0 | 2, finished at q = 2 | 4; else finished at q = 1 | 2
+                    if (EXTRA) {
+                        // the scalar channel's k-step of depth transform sd: weights requested at (q & 7) == 1, patch read at 2, transformed + multiplied at 4;
+                        // its next planes requested at q = 16, 17, its slices 0..2 rewritten behind the barrier (q = 22..24: read for the last time at q = 18)
+                        if ((q & 7) == 1) {
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; ++s2)
+                                wx[s2] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_wx, wxlane, ((sd * 4 + 2 * SHH + s2) * 2) * 256, 0));
+                        }
+                        if ((q & 7) == 2) {
+#pragma unroll
+                            for (int r3 = 0; r3 < 3; ++r3)
+#pragma unroll
+                                for (int jp = 0; jp < 2; ++jp) {
+                                    const int row = r3 == 0 ? RA0 : r3 == 1 ? RSH : RA1;
+                                    xpt[r3][jp] = *reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(lds_x) + xbase + sd * (SL_VOX * 4) + row * (IN_W * 4) + jp * 8);
+                                }
+                        }
+                        if (q == 16) ec = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_px0, xoff, nd * HW * 4, 0));
+                        if (q == 17) ed = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_px1, xoff, (nd + 1) * HW * 4, 0));
+                        if (q >= RW_Q && q < RW_Q + 3) write_x_slice(q - RW_Q);
+                        if ((q & 7) == 4) {
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; ++s2) {
+                                // row combination of transform index sh = 2 SHH + s2 (rows: xpt[0] = RA0, xpt[1] = the shared row, xpt[2] = RA1), then the column transform
+                                const f32x2 a0 = s2 == 0 ? xpt[0][0] : xpt[2][0], a1 = s2 == 0 ? xpt[0][1] : xpt[2][1];
+                                const f32x2 X01 = s2 == 0 ? a0 - xpt[1][0] : (SHH == 0 ? a0 + xpt[1][0] : xpt[1][0] - a0);
+                                const f32x2 X23 = s2 == 0 ? a1 - xpt[1][1] : (SHH == 0 ? a1 + xpt[1][1] : xpt[1][1] - a1);
+                                const float t0 = X01.x - X23.x, t1 = X01.y + X23.x, t2 = X23.x - X01.y, t3 = X01.y - X23.y;
+                                m[s2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[s2].x, t0, m[s2][0], 0, 0, 0);
+                                m[s2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[s2].y, t1, m[s2][1], 0, 0, 0);
+                                m[s2][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[s2].z, t2, m[s2][2], 0, 0, 0);
+                                m[s2][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[s2].w, t3, m[s2][3], 0, 0, 0);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                    if (DEFER) {
+                        // read-back instances: the two halves requested at q = 0, 1 and finished at q = RBQ, RBQ + 1 -- vector-memory loads return in
+                        // order: a weight request behind a read-back load waits for HBM with it, and the loads' first use waits for them; else finished at q = 1, 2
                         constexpr bool RB = RBK != 0;
+                        constexpr int RBQ = ESTD_W3_RBQ;
                         if (RB && q == 0) epi_issue(0, pso, rp_res, rp_res2, rp_out, pl);
-                        if (q == (RB ? 2 : 1)) epi_finish(py[0], 0, pso, rp_out, pl);
-                        if (RB && q == 2) epi_issue(1, pso, rp_res, rp_res2, rp_out, pl);
-                        if (q == (RB ? 4 : 2)) epi_finish(py[1], 1, pso, rp_out, pl);
+                        if (RB && q == 1) epi_issue(1, pso, rp_res, rp_res2, rp_out, pl1);
+                        if (q == (RB ? RBQ : 1)) epi_finish(py[0], 0, pso, rp_out, pl);
+                        if (q == (RB ? RBQ + 1 : 2)) epi_finish(py[1], 1, pso, rp_out, pl1);
                     }
                     if (ESTD_W3_SCHED == 0) __builtin_amdgcn_sched_barrier(0);
                     const int cur = (ESTD_W3ABL & 8) ? 0 : q % BD;
@@ -545,6 +623,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
             }
             if (has_next) {                               // slice 3 of the next tile (published by the next tile's in-loop barrier: first read at the end of its sub-step 10)
                 write_slice(3);
+                write_x_slice(3);
                 shift_planes();
             }
             if (DEFER && has_next) {                      // (a tile with a successor is never the odd last plane pair: d0 + shh < D)
@@ -573,7 +652,9 @@ extern "C" int estd_conv3d_k3_wino3(const estd_conv3d_desc* dp, estd_stream_t s)
     if (d.N <= 0 || d.D <= 0 || d.H <= 0 || d.W <= 0) return ESTD_ERR_ARG;
     if (!d.in_main || !d.w_wino2 || !d.scale || !d.shift || !d.out_main) return ESTD_ERR_ARG;
     // 32 -> 32 only: no scalar channels, no fused head, no GroupNorm partial sums, no gate
-    if (d.cin_main != 32 || d.n_tiles != 2 || d.out_head || d.in_extra || d.w_extra || d.out_extra || d.gate_r) return ESTD_ERR_UNSUPPORTED;
+    if (d.cin_main != 32 || d.n_tiles != 2 || d.out_head || d.out_extra || d.gate_r) return ESTD_ERR_UNSUPPORTED;
+    const bool extra = d.in_extra != nullptr;
+    if (extra != (d.w_extra != nullptr)) return ESTD_ERR_ARG;
     if (d.in_stride < 32 || (d.in_stride & 3) || d.out_stride < 32 || (d.out_stride & 3) || (d.act_split & 1)) return ESTD_ERR_ARG;
     const int tiles_w = (d.W + TW - 1) / TW, tiles_h = (d.H + TH - 1) / TH, dpairs = (d.D + 1) / 2;
     const long long total = (long long)d.N * dpairs * tiles_h * tiles_w;
@@ -590,17 +671,18 @@ extern "C" int estd_conv3d_k3_wino3(const estd_conv3d_desc* dp, estd_stream_t s)
     const bool res_any = d.residual || d.residual2 || d.out_scale != 1.0f;
     const int rbk = (!res_any && !d.accumulate) ? 0 : (!res_any ? 1 : (!d.accumulate ? 2 : 3));
     if (d.stats_partials && rbk != 0) return ESTD_ERR_UNSUPPORTED;       // GroupNorm partial sums: without read-back streams (the gate convolution has none)
-#define ESTD_W3_LAUNCH(RBV, STV)                                                                                                           \
+#define ESTD_W3_LAUNCH(RBV, STV, EXV)                                                                                                           \
     do {                                                                                                                             \
-        estd_allow_dynamic_lds<conv3d_wino3_kernel<RBV, STV>>(LDS_BYTES);                                                                 \
-        hipLaunchKernelGGL((conv3d_wino3_kernel<RBV, STV>), dim3(grid), dim3(NTHREADS), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h,   \
+        estd_allow_dynamic_lds<conv3d_wino3_kernel<RBV, STV, EXV>>(LDS_BYTES);                                                                 \
+        hipLaunchKernelGGL((conv3d_wino3_kernel<RBV, STV, EXV>), dim3(grid), dim3(NTHREADS), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h,   \
                            dpairs, (int)total);                                                                                      \
     } while (0)
+    if (extra && (rbk != 0 || d.stats_partials)) return ESTD_ERR_UNSUPPORTED;       // the key || value convolution has neither
     switch (rbk) {
-    case 0: if (d.stats_partials) ESTD_W3_LAUNCH(0, true); else ESTD_W3_LAUNCH(0, false); break;
-    case 1: ESTD_W3_LAUNCH(1, false); break;
-    case 2: ESTD_W3_LAUNCH(2, false); break;
-    default: ESTD_W3_LAUNCH(3, false); break;
+    case 0: if (extra) ESTD_W3_LAUNCH(0, false, true); else if (d.stats_partials) ESTD_W3_LAUNCH(0, true, false); else ESTD_W3_LAUNCH(0, false, false); break;
+    case 1: ESTD_W3_LAUNCH(1, false, false); break;
+    case 2: ESTD_W3_LAUNCH(2, false, false); break;
+    default: ESTD_W3_LAUNCH(3, false, false); break;
     }
 #undef ESTD_W3_LAUNCH
     return ESTD_LAUNCH_CHECK();

@@ -234,8 +234,9 @@ class Conv3dPlan:
         self.w_wino2 = packing.pack_conv3d_wino2(weight, main_idx, out_idx[:32]).to(device) if wino_ok else None
         self.w_wino2x = packing.pack_conv3d_wino2x(weight, main_idx, out_idx[:32]).to(device) \
             if (wino_ok and n_tiles == 2 and extra_idx is None) else None
-        self.w_wino3 = packing.pack_conv3d_wino3(weight, main_idx, out_idx[:32]).to(device) \
-            if (wino_ok and n_tiles == 2 and extra_idx is None) else None
+        self.w_wino3 = packing.pack_conv3d_wino3(weight, main_idx, out_idx[:32]).to(device) if (wino_ok and n_tiles == 2) else None
+        self.w_wino3_extra = packing.pack_conv3d_wino3_extra(weight, extra_idx, out_idx[:32]).to(device) \
+            if (wino_ok and n_tiles == 2 and extra_idx is not None) else None
         self.w_wino2_extra = packing.pack_conv3d_wino2_extra(weight, extra_idx, out_idx[:32]).to(device) \
             if (wino_ok and extra_idx is not None) else None
         # 33 -> 33 (dres2): the 33rd output channel of the wino2 kernel's XOUT instance
@@ -313,8 +314,9 @@ class Conv3dPlan:
         # 32 -> 32 without a scalar channel and without tanh: the operand-reuse kernel (GroupNorm partials only without read-back streams)
         wino2x = wino2 and W2X and self.w_wino2x is not None and in_extra is None and self.n_tiles == 2 and not tanh \
             and (stats_partials is None or (residual is None and residual2 is None and not accumulate and float(out_scale) == 1.0))
-        wino3 = wino2 and W3 and self.w_wino3 is not None and in_extra is None and self.n_tiles == 2 \
-            and (stats_partials is None or (residual is None and residual2 is None and not accumulate and float(out_scale) == 1.0))
+        plain_epi = residual is None and residual2 is None and not accumulate and float(out_scale) == 1.0
+        wino3 = wino2 and W3 and self.w_wino3 is not None and self.n_tiles == 2 and (stats_partials is None or plain_epi) \
+            and (in_extra is None or (self.w_wino3_extra is not None and plain_epi and stats_partials is None))
         wino2x = wino2x and not wino3
         variant, w_alt = (1, self.w_split) if split else (3, self.w_wino2_c16) if c16 else (3, self.w_wino2_o16) if o16 else (5, self.w_wino3) if wino3 \
             else (4, self.w_wino2x) if wino2x \
@@ -325,7 +327,7 @@ class Conv3dPlan:
         cin = self.cin_main + (1 if self.w_extra is not None else 0)
         with _Prof("conv3d:%d->%d" % (cin, self.n_out), 2.0 * 27 * cin * self.n_out * Nn * D * H * W):
             if _use_torch():
-                T().conv3d_k3(x, in_extra, self.w_main, self.w_wino2_extra if wino2 else self.w_wino_extra if wino else self.w_extra,
+                T().conv3d_k3(x, in_extra, self.w_main, self.w_wino3_extra if wino3 else self.w_wino2_extra if wino2 else self.w_wino_extra if wino else self.w_extra,
                               self.w_wino2_xout if wino2 else self.w_wino_xout if wino else self.w_xout, w_alt, self.scale, self.shift,
                               (Nn, D, H, W), self.cin_main, in_stride, self.n_tiles, self.act_a, self.act_b, self.act_split, out,
                               out_stride, out_channels, residual, residual2, float(out_scale), bool(accumulate), out_extra, head_w, head_b,
@@ -365,6 +367,7 @@ class Conv3dPlan:
                 N.check(N.lib().estd_conv3d_k3_wino2(ctypes.byref(d), _stream()), "estd_conv3d_k3_wino2")
             elif wino3:
                 d.w_wino2 = self.w_wino3.data_ptr()
+                d.w_extra = self.w_wino3_extra.data_ptr() if (in_extra is not None) else None
                 N.check(N.lib().estd_conv3d_k3_wino3(ctypes.byref(d), _stream()), "estd_conv3d_k3_wino3")
             elif wino2x:
                 d.w_wino2 = self.w_wino2x.data_ptr()

@@ -365,6 +365,21 @@ def pack_conv3d_wino3(weight, main_idx, out_idx):
     return torch.from_numpy(out.reshape(64, 2, 2, 64, 4))
 
 
+def pack_conv3d_wino3_extra(weight, extra_idx, out_idx):
+    """the scalar 33rd input channel of a 33 -> 32 convolution for csrc/conv3d_wino3.hip<EXTRA>: float32 [4 sd][4 sh][2 halves nh][16 output channels j][4 sw] =
+    U[sd][sh][sw][out_idx[16 nh + j]][extra_idx], U = G g G^T on kd, kh and kw as in pack_conv3d_wino3 (lane (g = 0, j) reads its 16 bytes)."""
+    assert len(out_idx) == 32
+    w = weight.detach().double().cpu().numpy()[:, extra_idx]         # [Cout, kd, kh, kw]
+    G = np.array([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
+    U = np.einsum("sd,th,uw,odhw->stuo", G, G, G, w).astype(np.float32)        # [4 sd, 4 sh, 4 sw, Cout]
+    oi = np.asarray(out_idx)
+    out = np.zeros((4, 4, 2, 16, 4), np.float32)
+    for nh in range(2):
+        for j in range(16):
+            out[:, :, nh, j, :] = U[:, :, :, oi[16 * nh + j]]
+    return torch.from_numpy(out)
+
+
 def pack_conv3d_wino2_c16(weight, main_idx, out_idx):
     """16 -> 16 filters (the stereo heads) for csrc/conv3d_wino2_c16.hip: U = G g G^T over (kd, kh) as in pack_conv3d_wino2, packed as
     float32 [48 taps = (3 sd + kw) * 4 + sh][64 lanes][4]: element e of lane (g, j) = U[sd][sh][out_idx[j]][main_idx[4 g + e]][kw] -- output

@@ -144,7 +144,7 @@ def test_wino_full_size_linearity_and_match(algo):
     assert float((c - zero + 2.0 * (b - zero)).abs().max()) < 2e-5 * float(b.abs().max())
 
 
-@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("algo", ALGOS + ("wino3",))
 @pytest.mark.parametrize("dims", [(1, 4, 8, 32), (3, 5, 13, 50), (2, 1, 9, 33), (1, 64, 24, 32)])
 def test_wino_extra_input_channel_matches_direct_kernel_and_fp64(dims, algo):
     """the key || value convolution's shape: 32 channels-last inputs + a scalar 33rd input volume -> 32 outputs (ReLU)."""

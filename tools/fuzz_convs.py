@@ -77,6 +77,10 @@ def case_conv3d():
         d2 = float((a - b2).abs().max())
         if not ((d2 == d2) and d2 < 4e-5 * max(1.0, float(a.abs().max()))):
             return False, ("conv3d", "extra/wino2", dims, d2)
+        b3 = run3d(plan, "wino3", x, dims, in_extra=e, out=torch.empty_like(x))
+        d3 = float((a - b3).abs().max())
+        if not ((d3 == d3) and d3 < 4e-5 * max(1.0, float(a.abs().max()))):
+            return False, ("conv3d", "extra/wino3", dims, d3)
     else:
         w = rnd(33, 33, 3, 3, 3, scale=0.06).cpu()
         plan = ops.Conv3dPlan(w, list(range(1, 33)), 0, list(range(33)), 3, torch.rand(33, generator=g) + 0.5, torch.randn(33, generator=g) * 0.1,
