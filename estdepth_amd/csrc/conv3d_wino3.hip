@@ -432,8 +432,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
                 load_rowA(1);
                 unsigned vo_next = 0;
                 EpiLoads pl, pl1;
-                float4 wx[2];                            // EXTRA: the scalar channel's weights [sl], components = sw
-                f32x2 xpt[3][2];                         // EXTRA: its patch: rows RA0, shared, RA1 x column pairs
+                float4 wx[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};                            // EXTRA: the scalar channel's weights [sl], components = sw
+                float tx[2][4] = {};                     // EXTRA: its transformed operands [sl][sw]
+                f32x2 xpt[3][2] = {};                         // EXTRA: its patch: rows RA0, shared, RA1 x column pairs
                 constexpr int PF_Q = 4;                  // next-plane prefetch: one chunk per two half-sub-steps, q = 4, 6, .. 14
                 constexpr int RW_Q = 22;                 // slices 0..2 of the next tile: every read of them has been issued (rows are fetched two half-sub-steps ahead)
                 __builtin_amdgcn_sched_barrier(0);
@@ -456,12 +457,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
                     if (EXTRA) {
                         // the scalar channel's k-step of depth transform sd: weights requested at (q & 7) == 1, patch read at 2, transformed + multiplied at 4;
                         // its next planes requested at q = 16, 17, its slices 0..2 rewritten behind the barrier (q = 22..24: read for the last time at q = 18)
-                        if ((q & 7) == 1) {
+                        if ((q & 7) == 1 && !(ESTD_W3ABL & 1024)) {
 #pragma unroll
                             for (int s2 = 0; s2 < 2; ++s2)
                                 wx[s2] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_wx, wxlane, ((sd * 4 + 2 * SHH + s2) * 2) * 256, 0));
                         }
-                        if ((q & 7) == 2) {
+                        if ((q & 7) == 2 && !(ESTD_W3ABL & 512)) {
 #pragma unroll
                             for (int r3 = 0; r3 < 3; ++r3)
 #pragma unroll
@@ -473,20 +474,26 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
                         if (q == 16) ec = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_px0, xoff, nd * HW * 4, 0));
                         if (q == 17) ed = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_px1, xoff, (nd + 1) * HW * 4, 0));
                         if (q >= RW_Q && q < RW_Q + 3) write_x_slice(q - RW_Q);
-                        if ((q & 7) == 4) {
+                        if ((q & 7) == 3 && !(ESTD_W3ABL & 256)) {
+                            // operands one half-sub-step before their MFMAs (formed right in front of them, every MFMA waited for its own VALU instruction
+                            // and every VALU instruction for the previous MFMA's operand read: 0.84 instead of 0.70 ms)
 #pragma unroll
                             for (int s2 = 0; s2 < 2; ++s2) {
                                 // row combination of transform index sh = 2 SHH + s2 (rows: xpt[0] = RA0, xpt[1] = the shared row, xpt[2] = RA1), then the column transform
                                 const f32x2 a0 = s2 == 0 ? xpt[0][0] : xpt[2][0], a1 = s2 == 0 ? xpt[0][1] : xpt[2][1];
                                 const f32x2 X01 = s2 == 0 ? a0 - xpt[1][0] : (SHH == 0 ? a0 + xpt[1][0] : xpt[1][0] - a0);
                                 const f32x2 X23 = s2 == 0 ? a1 - xpt[1][1] : (SHH == 0 ? a1 + xpt[1][1] : xpt[1][1] - a1);
-                                const float t0 = X01.x - X23.x, t1 = X01.y + X23.x, t2 = X23.x - X01.y, t3 = X01.y - X23.y;
-                                m[s2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[s2].x, t0, m[s2][0], 0, 0, 0);
-                                m[s2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[s2].y, t1, m[s2][1], 0, 0, 0);
-                                m[s2][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[s2].z, t2, m[s2][2], 0, 0, 0);
-                                m[s2][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[s2].w, t3, m[s2][3], 0, 0, 0);
+                                tx[s2][0] = X01.x - X23.x; tx[s2][1] = X01.y + X23.x; tx[s2][2] = X23.x - X01.y; tx[s2][3] = X01.y - X23.y;
                             }
-                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if ((q & 7) == 4 && !(ESTD_W3ABL & 256)) {
+#pragma unroll
+                            for (int s2 = 0; s2 < 2; ++s2) {
+                                m[s2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[s2].x, tx[s2][0], m[s2][0], 0, 0, 0);
+                                m[s2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[s2].y, tx[s2][1], m[s2][1], 0, 0, 0);
+                                m[s2][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[s2].z, tx[s2][2], m[s2][2], 0, 0, 0);
+                                m[s2][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[s2].w, tx[s2][3], m[s2][3], 0, 0, 0);
+                            }
                         }
                     }
                     if (DEFER) {
@@ -528,7 +535,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
                     } else {
 #pragma unroll
                         for (int gq = 0; gq < 4; ++gq) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                            if (EXTRA && (q & 7) == 4) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      // (+ the scalar channel's 8 MFMAs)
+                            else __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);       // one vector-memory read (weights, next plane, read-back)
                             __builtin_amdgcn_sched_group_barrier(0x002, ESTD_W3_SCHED_VALU, 0);
                             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);

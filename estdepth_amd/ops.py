@@ -86,6 +86,9 @@ W2X = os.environ.get("ESTD_W2X", "0") != "0"
 # the 32 -> 32 instances without a scalar channel (BN / activation / residuals / running sum / GroupNorm partials) with ALL THREE axes in Winograd form
 # (csrc/conv3d_wino3.hip: F(2x2x2, 3x3x3), 8/27 of the direct products; default since round 5: 0.65 vs 0.81 ms for 3 volumes, Joint step 16.9 -> 15.8 ms; "0": two-axis kernel)
 W3 = os.environ.get("ESTD_W3", "1") != "0"
+# A/B: the key || value convolution (33 -> 32) on the three-axis kernel's scalar-channel instance as well.  Off: correct (tests/test_gpu_wino.py) but not faster
+# yet -- 0.84-0.86 vs 0.855 ms, the scalar channel's 30 extra registers spill inside the tap loop (profiles/r5_wino3_table.txt)
+W3_EXTRA = os.environ.get("ESTD_W3_EXTRA", "0") != "0"
 # same choice for the 3x3 / dilation-1 NHWC convolutions: row axis in Winograd F(2,3) form (csrc/conv2d_wino.hip) or direct
 CONV2D_ALGO = os.environ.get("ESTD_CONV2D_ALGO", "wino2")
 CONV2D_NT = os.environ.get("ESTD_CONV2D_NT", "auto")
@@ -316,7 +319,7 @@ class Conv3dPlan:
             and (stats_partials is None or (residual is None and residual2 is None and not accumulate and float(out_scale) == 1.0))
         plain_epi = residual is None and residual2 is None and not accumulate and float(out_scale) == 1.0
         wino3 = wino2 and W3 and self.w_wino3 is not None and self.n_tiles == 2 and (stats_partials is None or plain_epi) \
-            and (in_extra is None or (self.w_wino3_extra is not None and plain_epi and stats_partials is None))
+            and (in_extra is None or (W3_EXTRA and self.w_wino3_extra is not None and plain_epi and stats_partials is None))
         wino2x = wino2x and not wino3
         variant, w_alt = (1, self.w_split) if split else (3, self.w_wino2_c16) if c16 else (3, self.w_wino2_o16) if o16 else (5, self.w_wino3) if wino3 \
             else (4, self.w_wino2x) if wino2x \

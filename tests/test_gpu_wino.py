@@ -28,7 +28,8 @@ def _plan(seed, act="relu"):
 
 def _run(plan, algo, x, dims, **kw):
     from estdepth_amd import ops
-    old, old_x, old_3 = ops.CONV3D_ALGO, ops.W2X, ops.W3
+    old, old_x, old_3, old_3x = ops.CONV3D_ALGO, ops.W2X, ops.W3, ops.W3_EXTRA
+    ops.W3_EXTRA = algo == "wino3"                      # (the scalar-channel instance of the three-axis kernel is opt-in)
     # "wino2x" = the two-axis form on the operand-reuse kernel (csrc/conv3d_wino2x.hip, opt-in: ESTD_W2X=1) for the plain 32 -> 32 instance;
     # "wino3" = all three axes in Winograd form (csrc/conv3d_wino3.hip, ESTD_W3=1; launches with GroupNorm partials stay on the two-axis kernel)
     ops.CONV3D_ALGO, ops.W2X, ops.W3 = ("wino2", True, False) if algo == "wino2x" else ("wino2", False, True) if algo == "wino3" else (algo, False, False)
@@ -40,7 +41,7 @@ def _run(plan, algo, x, dims, **kw):
         torch.cuda.synchronize()
         return out
     finally:
-        ops.CONV3D_ALGO, ops.W2X, ops.W3 = old, old_x, old_3
+        ops.CONV3D_ALGO, ops.W2X, ops.W3, ops.W3_EXTRA = old, old_x, old_3, old_3x
 
 
 def _has_ab():

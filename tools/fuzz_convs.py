@@ -23,6 +23,7 @@ def rnd(*shape, scale=1.0):
 
 def run3d(plan, algo, x, dims, **kw):
     ops.CONV3D_ALGO, ops.W3 = ("wino2", True) if algo == "wino3" else (algo, False)
+    ops.W3_EXTRA = ops.W3
     out = kw.pop("out")
     plan.run(x, dims, out=out, **kw)
     torch.cuda.synchronize()
