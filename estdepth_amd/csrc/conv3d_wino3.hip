@@ -77,7 +77,8 @@ constexpr int XCH_BYTES = 8 * 4 * 64 * 16;          // [wave][4 quads][64 lanes]
 constexpr int NTAPS = 64, TAP_BYTES = 4096;         // [block = ((4 sd + sh) * 2 + cc) * 2 + hh][2 halves nh][2 tap pairs][64 lanes][4]: packing.pack_conv3d_wino3
 constexpr int DUMMY_BYTES = 96 * 16 + 2 * LINE_BYTES; // where the threads without a third chunk of a slice (1440 = 2 x 512 + 416) put their in-loop writes: the tap loop has no branch
 constexpr int XSL_BYTES = 4 * SL_VOX * 4;            // EXTRA: the four depth-transformed slices of the scalar 33rd input channel ([sd][180] floats)
-constexpr int LDS_BYTES = SLICES_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + XCH_BYTES + DUMMY_BYTES + XSL_BYTES;
+constexpr int XW_BYTES = 2 * 4 * 2 * 64 * 16;        // EXTRA: its weights [2 planes][4 sh][2 halves][64 lanes][4 sw] (packing.pack_conv3d_wino3_extra)
+constexpr int LDS_BYTES = SLICES_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + XCH_BYTES + DUMMY_BYTES + XSL_BYTES + XW_BYTES;
 static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;        // beyond num_records of any descriptor: loads return 0, stores are dropped
 
@@ -133,8 +134,10 @@ __device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float
 // STATS: GroupNorm(1 group per channel half) partial sums of the raw outputs (the ConvGRU's gate convolution, transformer/epipolar_transformer.py:21): one
 // more barrier per tile.
 // EXTRA: a scalar 33rd INPUT channel (the key || value convolution, hybrid_depth_decoder.py:190-191 on cat[dres2 output]): its four depth-transformed slices
-// in 2.9 KB of LDS; in the middle of every depth transform ONE more k-step per product m[sh][sw] -- lane group g = 0 carries the scalar channel's row- and
-// column-transformed patch, groups 1..3 read zero weights (out-of-range offsets of the weight load) -- i.e. 32 more MFMAs per tile and wave.
+// in 2.9 KB of LDS, its weights in 16 KB.  At the TOP of a tile (registers are free there, and the first weight blocks of the main stream are still on their way)
+// lane group g row- and column-transforms its block's patch of slice sd = g; per output plane ONE MFMA per (sh, sw) sums the four depth transforms with the plane's
+// output-transform coefficients folded into the weights (plane 0: 1 1 1 0, plane 1: 0 1 -1 -1) -- 16 MFMAs per tile and wave -- and the products go through the column
+// and row halves of the output transform straight into the partial sums P, which the depth transforms of the main channels then add to.
 template <int RBK, bool STATS, bool EXTRA>
 __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int dpairs, int total_tiles)
 {
@@ -172,10 +175,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
     float4* lds_xch = reinterpret_cast<float4*>(smem + SLICES_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES);
     const __amdgpu_buffer_rsrc_t rs_null = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w_wino2), 0, 0, 0x00020000);     // num_records 0: loads return 0
     float* lds_x = reinterpret_cast<float*>(smem + SLICES_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + XCH_BYTES + DUMMY_BYTES);      // [4][SL_VOX] (EXTRA)
-    // EXTRA: weights [4 sd][4 sh][2 halves][16 output channels][4 sw] (packing.pack_conv3d_wino3_extra): lane (g = 0, i) reads its 16 bytes, g > 0 zeros
-    const __amdgpu_buffer_rsrc_t rs_wx = EXTRA ? make_rsrc(p.w_extra, (size_t)4 * 4 * 2 * 16 * 4) : rs_null;
-    const unsigned wxlane = g == 0 ? (unsigned)(nh * 256 + i * 16) : OOB_OFFSET;
-    const int xbase = ((4 * rq + 2 * rpl) * IN_W + 2 * cb) * 4;       // byte offset of the block's patch origin in a scalar slice
+    // EXTRA: the scalar channel's weights in LDS (copied once per workgroup; visible after the first tile's barriers)
+    char* lds_wx = smem + SLICES_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + XCH_BYTES + DUMMY_BYTES + XSL_BYTES;
+    if (EXTRA) {
+        for (int e = tid; e < XW_BYTES / 16; e += NTHREADS) reinterpret_cast<float4*>(lds_wx)[e] = reinterpret_cast<const float4*>(p.w_extra)[e];
+    }
+    const int xbase = ((4 * rq + 2 * rpl) * IN_W + 2 * cb) * 4 + g * (SL_VOX * 4);       // byte offset of the block's patch origin in the scalar slice sd = g (the lane group's k index)
 
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(p.w_wino2, (size_t)NTAPS * 1024);
     const int wlane = lane * 16 + nh * 2048;
@@ -430,11 +435,52 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
                 load_rowB(0);
                 xform(0, T);
                 load_rowA(1);
+                if (EXTRA && !(ESTD_W3ABL & 256)) {
+                    f32x2 xpt[3][2];                     // the block's patch of scalar slice sd = g: rows RA0, shared, RA1 x column pairs
+#pragma unroll
+                    for (int r3 = 0; r3 < 3; ++r3)
+#pragma unroll
+                        for (int jp = 0; jp < 2; ++jp) {
+                            const int row = r3 == 0 ? RA0 : r3 == 1 ? RSH : RA1;
+                            xpt[r3][jp] = *reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(lds_x) + xbase + row * (IN_W * 4) + jp * 8);
+                        }
+                    float tx[2][4];
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const f32x2 a0 = s2 == 0 ? xpt[0][0] : xpt[2][0], a1 = s2 == 0 ? xpt[0][1] : xpt[2][1];
+                        const f32x2 X01 = s2 == 0 ? a0 - xpt[1][0] : (SHH == 0 ? a0 + xpt[1][0] : xpt[1][0] - a0);
+                        const f32x2 X23 = s2 == 0 ? a1 - xpt[1][1] : (SHH == 0 ? a1 + xpt[1][1] : xpt[1][1] - a1);
+                        tx[s2][0] = X01.x - X23.x; tx[s2][1] = X01.y + X23.x; tx[s2][2] = X23.x - X01.y; tx[s2][3] = X01.y - X23.y;
+                    }
+#pragma unroll
+                    for (int pl_ = 0; pl_ < 2; ++pl_) {
+                        f32x4 mx[2][4];
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const float4 w4 = *reinterpret_cast<const float4*>(lds_wx + ((pl_ * 4 + 2 * SHH + s2) * 2 + nh) * 1024 + lane * 16);
+                            mx[s2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.x, tx[s2][0], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                            mx[s2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.y, tx[s2][1], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                            mx[s2][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.z, tx[s2][2], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                            mx[s2][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4.w, tx[s2][3], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const f32x4 v0_ = c == 0 ? mx[0][0] + mx[0][1] + mx[0][2] : mx[0][1] - mx[0][2] - mx[0][3];
+                            const f32x4 v1_ = c == 0 ? mx[1][0] + mx[1][1] + mx[1][2] : mx[1][1] - mx[1][2] - mx[1][3];
+                            if (SHH == 0) { P[pl_][0][c] = v0_ + v1_; P[pl_][1][c] = v1_; }
+                            else          { P[pl_][0][c] = v0_;       P[pl_][1][c] = -(v0_ + v1_); }
+                        }
+                    }
+                } else if (EXTRA) {
+#pragma unroll
+                    for (int pl_ = 0; pl_ < 2; ++pl_)
+#pragma unroll
+                        for (int r = 0; r < 2; ++r)
+#pragma unroll
+                            for (int c = 0; c < 2; ++c) P[pl_][r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
                 unsigned vo_next = 0;
                 EpiLoads pl, pl1;
-                float4 wx[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};                            // EXTRA: the scalar channel's weights [sl], components = sw
-                float tx[2][4] = {};                     // EXTRA: its transformed operands [sl][sw]
-                f32x2 xpt[3][2] = {};                         // EXTRA: its patch: rows RA0, shared, RA1 x column pairs
                 constexpr int PF_Q = 4;                  // next-plane prefetch: one chunk per two half-sub-steps, q = 4, 6, .. 14
                 constexpr int RW_Q = 22;                 // slices 0..2 of the next tile: every read of them has been issued (rows are fetched two half-sub-steps ahead)
                 __builtin_amdgcn_sched_barrier(0);
@@ -455,46 +501,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
                         else           xd[it] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_pf1, vo_next, (nd + 1) * in_slice_bytes, 0));
                     }
                     if (EXTRA) {
-                        // the scalar channel's k-step of depth transform sd: weights requested at (q & 7) == 1, patch read at 2, transformed + multiplied at 4;
-                        // its next planes requested at q = 16, 17, its slices 0..2 rewritten behind the barrier (q = 22..24: read for the last time at q = 18)
-                        if ((q & 7) == 1 && !(ESTD_W3ABL & 1024)) {
-#pragma unroll
-                            for (int s2 = 0; s2 < 2; ++s2)
-                                wx[s2] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_wx, wxlane, ((sd * 4 + 2 * SHH + s2) * 2) * 256, 0));
-                        }
-                        if ((q & 7) == 2 && !(ESTD_W3ABL & 512)) {
-#pragma unroll
-                            for (int r3 = 0; r3 < 3; ++r3)
-#pragma unroll
-                                for (int jp = 0; jp < 2; ++jp) {
-                                    const int row = r3 == 0 ? RA0 : r3 == 1 ? RSH : RA1;
-                                    xpt[r3][jp] = *reinterpret_cast<const f32x2*>(reinterpret_cast<const char*>(lds_x) + xbase + sd * (SL_VOX * 4) + row * (IN_W * 4) + jp * 8);
-                                }
-                        }
+                        // the scalar channel: its next planes requested at q = 16, 17, ALL FOUR of its slices rewritten behind the barrier (they are read at the top of a tile only)
                         if (q == 16) ec = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_px0, xoff, nd * HW * 4, 0));
                         if (q == 17) ed = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_px1, xoff, (nd + 1) * HW * 4, 0));
-                        if (q >= RW_Q && q < RW_Q + 3) write_x_slice(q - RW_Q);
-                        if ((q & 7) == 3 && !(ESTD_W3ABL & 256)) {
-                            // operands one half-sub-step before their MFMAs (formed right in front of them, every MFMA waited for its own VALU instruction
-                            // and every VALU instruction for the previous MFMA's operand read: 0.84 instead of 0.70 ms)
-#pragma unroll
-                            for (int s2 = 0; s2 < 2; ++s2) {
-                                // row combination of transform index sh = 2 SHH + s2 (rows: xpt[0] = RA0, xpt[1] = the shared row, xpt[2] = RA1), then the column transform
-                                const f32x2 a0 = s2 == 0 ? xpt[0][0] : xpt[2][0], a1 = s2 == 0 ? xpt[0][1] : xpt[2][1];
-                                const f32x2 X01 = s2 == 0 ? a0 - xpt[1][0] : (SHH == 0 ? a0 + xpt[1][0] : xpt[1][0] - a0);
-                                const f32x2 X23 = s2 == 0 ? a1 - xpt[1][1] : (SHH == 0 ? a1 + xpt[1][1] : xpt[1][1] - a1);
-                                tx[s2][0] = X01.x - X23.x; tx[s2][1] = X01.y + X23.x; tx[s2][2] = X23.x - X01.y; tx[s2][3] = X01.y - X23.y;
-                            }
-                        }
-                        if ((q & 7) == 4 && !(ESTD_W3ABL & 256)) {
-#pragma unroll
-                            for (int s2 = 0; s2 < 2; ++s2) {
-                                m[s2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[s2].x, tx[s2][0], m[s2][0], 0, 0, 0);
-                                m[s2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[s2].y, tx[s2][1], m[s2][1], 0, 0, 0);
-                                m[s2][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[s2].z, tx[s2][2], m[s2][2], 0, 0, 0);
-                                m[s2][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[s2].w, tx[s2][3], m[s2][3], 0, 0, 0);
-                            }
-                        }
+                        if (q >= RW_Q && q < RW_Q + 4) write_x_slice(q - RW_Q);
                     }
                     if (DEFER) {
                         // read-back instances: the two halves requested at q = 0, 1 and finished at q = RBQ, RBQ + 1 -- vector-memory loads return in
@@ -562,8 +572,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
                         for (int r = 0; r < 2; ++r)
 #pragma unroll
                             for (int c = 0; c < 2; ++c) {
-                                if (sd == 0) P[0][r][c] = z[r][c];
-                                else if (sd == 1) { P[0][r][c] += z[r][c]; P[1][r][c] = z[r][c]; }
+                                if (sd == 0) { if (EXTRA) P[0][r][c] += z[r][c]; else P[0][r][c] = z[r][c]; }
+                                else if (sd == 1) { P[0][r][c] += z[r][c]; if (EXTRA) P[1][r][c] += z[r][c]; else P[1][r][c] = z[r][c]; }
                                 else if (sd == 2) { P[0][r][c] += z[r][c]; P[1][r][c] -= z[r][c]; }
                                 else P[1][r][c] -= z[r][c];
                             }
@@ -631,7 +641,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
             }
             if (has_next) {                               // slice 3 of the next tile (published by the next tile's in-loop barrier: first read at the end of its sub-step 10)
                 write_slice(3);
-                write_x_slice(3);
                 shift_planes();
             }
             if (DEFER && has_next) {                      // (a tile with a successor is never the odd last plane pair: d0 + shh < D)

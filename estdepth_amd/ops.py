@@ -86,9 +86,8 @@ W2X = os.environ.get("ESTD_W2X", "0") != "0"
 # the 32 -> 32 instances without a scalar channel (BN / activation / residuals / running sum / GroupNorm partials) with ALL THREE axes in Winograd form
 # (csrc/conv3d_wino3.hip: F(2x2x2, 3x3x3), 8/27 of the direct products; default since round 5: 0.65 vs 0.81 ms for 3 volumes, Joint step 16.9 -> 15.8 ms; "0": two-axis kernel)
 W3 = os.environ.get("ESTD_W3", "1") != "0"
-# A/B: the key || value convolution (33 -> 32) on the three-axis kernel's scalar-channel instance as well.  Off: correct (tests/test_gpu_wino.py) but not faster
-# yet -- 0.84-0.86 vs 0.855 ms, the scalar channel's 30 extra registers spill inside the tap loop (profiles/r5_wino3_table.txt)
-W3_EXTRA = os.environ.get("ESTD_W3_EXTRA", "0") != "0"
+# the key || value convolution (33 -> 32) on the three-axis kernel's scalar-channel instance as well (0.73 vs 0.85 ms for 3 volumes; "0": two-axis kernel)
+W3_EXTRA = os.environ.get("ESTD_W3_EXTRA", "1") != "0"
 # same choice for the 3x3 / dilation-1 NHWC convolutions: row axis in Winograd F(2,3) form (csrc/conv2d_wino.hip) or direct
 CONV2D_ALGO = os.environ.get("ESTD_CONV2D_ALGO", "wino2")
 CONV2D_NT = os.environ.get("ESTD_CONV2D_NT", "auto")

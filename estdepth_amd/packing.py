@@ -366,17 +366,22 @@ def pack_conv3d_wino3(weight, main_idx, out_idx):
 
 
 def pack_conv3d_wino3_extra(weight, extra_idx, out_idx):
-    """the scalar 33rd input channel of a 33 -> 32 convolution for csrc/conv3d_wino3.hip<EXTRA>: float32 [4 sd][4 sh][2 halves nh][16 output channels j][4 sw] =
-    U[sd][sh][sw][out_idx[16 nh + j]][extra_idx], U = G g G^T on kd, kh and kw as in pack_conv3d_wino3 (lane (g = 0, j) reads its 16 bytes)."""
+    """the scalar 33rd input channel of a 33 -> 32 convolution for csrc/conv3d_wino3.hip<EXTRA>: float32 [2 output planes][4 sh][2 halves nh][64 lanes][4 sw].
+    Element sw of lane (g, j) = A^T[plane][g] * U[sd = g][sh][sw][out_idx[16 nh + j]][extra_idx] with U = G g G^T on kd, kh and kw as in pack_conv3d_wino3 and
+    A^T = [[1, 1, 1, 0], [0, 1, -1, -1]] the depth axis' output transform: the kernel sums the four depth transforms of the scalar channel inside ONE MFMA per
+    (plane, sh, sw) -- the k index of the MFMA is the depth-transform index."""
     assert len(out_idx) == 32
     w = weight.detach().double().cpu().numpy()[:, extra_idx]         # [Cout, kd, kh, kw]
     G = np.array([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
-    U = np.einsum("sd,th,uw,odhw->stuo", G, G, G, w).astype(np.float32)        # [4 sd, 4 sh, 4 sw, Cout]
+    AT = np.array([[1.0, 1.0, 1.0, 0.0], [0.0, 1.0, -1.0, -1.0]])
+    U = np.einsum("sd,th,uw,odhw->stuo", G, G, G, w)                 # [4 sd, 4 sh, 4 sw, Cout]
     oi = np.asarray(out_idx)
-    out = np.zeros((4, 4, 2, 16, 4), np.float32)
-    for nh in range(2):
-        for j in range(16):
-            out[:, :, nh, j, :] = U[:, :, :, oi[16 * nh + j]]
+    out = np.zeros((2, 4, 2, 64, 4), np.float32)
+    for lane in range(64):
+        g, j = lane >> 4, lane & 15
+        for nh in range(2):
+            for pl in range(2):
+                out[pl, :, nh, lane, :] = (AT[pl, g] * U[g, :, :, oi[16 * nh + j]]).astype(np.float32)
     return torch.from_numpy(out)
 
 

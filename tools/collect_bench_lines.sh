@@ -15,11 +15,13 @@ python bench.py --workload stream --steps 20 2>/dev/null | last > $OUT/${P}_benc
 AB="--no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads"
 for rep in 1 2; do
   python bench.py $AB 2>/dev/null | last > $OUT/${P}_ab_default_$rep.json
-  ESTD_W2X=1 python bench.py $AB 2>/dev/null | last > $OUT/${P}_ab_w2x_$rep.json
+  ESTD_W3=0 python bench.py $AB 2>/dev/null | last > $OUT/${P}_ab_two_axis_$rep.json      # 32 -> 32 convolutions on the two-axis kernel (csrc/conv3d_wino2.hip)
+  ESTD_W3=0 ESTD_W2X=1 python bench.py $AB 2>/dev/null | last > $OUT/${P}_ab_w2x_$rep.json
   ESTD_GATE_IN_CONV=0 python bench.py $AB 2>/dev/null | last > $OUT/${P}_ab_gate_pass_$rep.json
 done
 ESTD_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-alt --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_rccl_world1.json
 ESTD_FORCE_DIST=1 ESTD_RESERVE_SCOPE=AB python bench.py --no-cpu-baseline --no-alt --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_rccl_world1_reserve_ab.json
 ESTD_FORCE_DIST=1 python bench.py --workload estm --no-cpu-baseline --no-alt --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_estm_rccl_world1.json
 python bench.py --gpus 2 --workload cfg1 --steps 5 --warmup 2 2>/dev/null | last > $OUT/${P}_bench_gpus2_codepath.json
+timeout 2400 python -m pytest tests/ -q -m gpu > $OUT/${P}_gputests.log 2>&1
 ls -la $OUT | tail -20

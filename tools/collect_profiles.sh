@@ -51,6 +51,8 @@ python tools/taps_bench.py 2>&1 | grep -v amdgpu > $OUT/${P}_taps_bench.txt
 # (built here, before the gpurun call: /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/src/mfma_valu_overlap.hip -o tools/bin/mfma_valu_overlap)
 [ -x tools/bin/mfma_valu_overlap ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/src/mfma_valu_overlap.hip -o tools/bin/mfma_valu_overlap
 tools/bin/mfma_valu_overlap > $OUT/${P}_mfma_valu_overlap.txt 2>&1
+# (ESTD_COLLECT_LINES=0: stop here -- copy ${P}_conv3d_pmc.json into profiles/ first, so that the bench lines of tools/collect_bench_lines.sh carry this round's roofline.traffic)
+[ "${ESTD_COLLECT_LINES:-1}" = 1 ] || { ls -la $OUT; exit 0; }
 # default bench lines (with cpu_baseline + parity) of every workload; algorithm A/B; the world-size-1 RCCL run
 last() { grep "^{" | tail -1; }
 python bench.py 2>/dev/null | last > $OUT/${P}_bench_joint.json
