@@ -78,8 +78,16 @@ constexpr int NTAPS = 64, TAP_BYTES = 4096;         // [block = ((4 sd + sh) * 2
 constexpr int DUMMY_BYTES = 96 * 16 + 2 * LINE_BYTES; // where the threads without a third chunk of a slice (1440 = 2 x 512 + 416) put their in-loop writes: the tap loop has no branch
 constexpr int XSL_BYTES = 4 * SL_VOX * 4;            // EXTRA: the four depth-transformed slices of the scalar 33rd input channel ([sd][180] floats)
 constexpr int XW_BYTES = 2 * 4 * 2 * 64 * 16;        // EXTRA: its weights [2 planes][4 sh][2 halves][64 lanes][4 sw] (packing.pack_conv3d_wino3_extra)
-constexpr int LDS_BYTES = SLICES_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + XCH_BYTES + DUMMY_BYTES + XSL_BYTES + XW_BYTES;
-static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+constexpr int LDS_BASE_BYTES = SLICES_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + XCH_BYTES + DUMMY_BYTES;
+// instances without a scalar channel: the weight blocks of half-sub-steps WL_Q0 .. WL_Q0 + 2 (both row-transform halves: 6 x 4 KB) live in LDS -- the requests a
+// read-back instance would issue right behind its read-back loads (vector-memory loads return in order: they would wait for HBM with them)
+#ifndef ESTD_W3_WLDS
+#define ESTD_W3_WLDS 1
+#endif
+constexpr int WL_Q0 = 4, WL_N = 3;
+constexpr int WL_BYTES = 2 * WL_N * 4096;
+constexpr int LDS_BYTES_EXTRA = LDS_BASE_BYTES + XSL_BYTES + XW_BYTES, LDS_BYTES_PLAIN = LDS_BASE_BYTES + (ESTD_W3_WLDS ? WL_BYTES : 0);
+static_assert(LDS_BYTES_EXTRA <= 160 * 1024 && LDS_BYTES_PLAIN <= 160 * 1024, "LDS budget");
 constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;        // beyond num_records of any descriptor: loads return 0, stores are dropped
 
 __device__ __forceinline__ float4 as_float4(u32x4 v)
@@ -179,6 +187,15 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
     char* lds_wx = smem + SLICES_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES + XCH_BYTES + DUMMY_BYTES + XSL_BYTES;
     if (EXTRA) {
         for (int e = tid; e < XW_BYTES / 16; e += NTHREADS) reinterpret_cast<float4*>(lds_wx)[e] = reinterpret_cast<const float4*>(p.w_extra)[e];
+    }
+    constexpr bool WL = ESTD_W3_WLDS != 0 && !EXTRA;
+    char* lds_wl = smem + LDS_BASE_BYTES;                // [row-transform half][WL_N half-sub-steps][4096] (shares the scalar channel's place)
+    if (WL) {
+        for (int e = tid; e < WL_BYTES / 16; e += NTHREADS) {
+            const int blk = e >> 8, q_ = WL_Q0 + blk % WL_N, sh_ = 2 * (blk / WL_N) + (q_ & 1);
+            const int src = ((((q_ >> 3) * 4 + sh_) * 2 + ((q_ >> 2) & 1)) * 2 + ((q_ >> 1) & 1));
+            reinterpret_cast<float4*>(lds_wl)[e] = reinterpret_cast<const float4*>(p.w_wino2)[src * 256 + (e & 255)];
+        }
     }
     const int xbase = ((4 * rq + 2 * rpl) * IN_W + 2 * cb) * 4 + g * (SL_VOX * 4);       // byte offset of the block's patch origin in the scalar slice sd = g (the lane group's k index)
 
@@ -400,8 +417,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
                 auto load_w = [&](int q, float4 (&b)[2]) {
                     const int sd = q >> 3, cc = (q >> 2) & 1, hh = (q >> 1) & 1, sh = 2 * SHH + (q & 1);
 #pragma unroll
-                    for (int sp = 0; sp < 2; ++sp)
-                        b[sp] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, ((((sd * 4 + sh) * 2 + cc) * 2 + hh) * TAP_BYTES) + sp * 1024, 0));
+                    for (int sp = 0; sp < 2; ++sp) {
+                        if (WL && q >= WL_Q0 && q < WL_Q0 + WL_N) b[sp] = *reinterpret_cast<const float4*>(lds_wl + (SHH * WL_N + q - WL_Q0) * 4096 + sp * 1024 + wlane);
+                        else b[sp] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane, ((((sd * 4 + sh) * 2 + cc) * 2 + hh) * TAP_BYTES) + sp * 1024, 0));
+                    }
                 };
                 auto load_rowA = [&](int q) {
                     const int sd = q >> 3, cc = (q >> 2) & 1, hh = (q >> 1) & 1, r = (q & 1) ? RA1 : RA0;
@@ -690,8 +709,8 @@ extern "C" int estd_conv3d_k3_wino3(const estd_conv3d_desc* dp, estd_stream_t s)
     if (d.stats_partials && rbk != 0) return ESTD_ERR_UNSUPPORTED;       // GroupNorm partial sums: without read-back streams (the gate convolution has none)
 #define ESTD_W3_LAUNCH(RBV, STV, EXV)                                                                                                           \
     do {                                                                                                                             \
-        estd_allow_dynamic_lds<conv3d_wino3_kernel<RBV, STV, EXV>>(LDS_BYTES);                                                                 \
-        hipLaunchKernelGGL((conv3d_wino3_kernel<RBV, STV, EXV>), dim3(grid), dim3(NTHREADS), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h,   \
+        estd_allow_dynamic_lds<conv3d_wino3_kernel<RBV, STV, EXV>>(EXV ? LDS_BYTES_EXTRA : LDS_BYTES_PLAIN);                                                                 \
+        hipLaunchKernelGGL((conv3d_wino3_kernel<RBV, STV, EXV>), dim3(grid), dim3(NTHREADS), EXV ? LDS_BYTES_EXTRA : LDS_BYTES_PLAIN, estd_stream(s), d, tiles_w, tiles_h,   \
                            dpairs, (int)total);                                                                                      \
     } while (0)
     if (extra && (rbk != 0 || d.stats_partials)) return ESTD_ERR_UNSUPPORTED;       // the key || value convolution has neither
