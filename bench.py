@@ -423,8 +423,8 @@ def conv3d_algo_of(group, algo, arith):
     from estdepth_amd import ops
     if arith != "f32":
         return "direct"
-    if group == "conv3d:32->32" and algo == "wino2" and ops.W3:      # all three axes in Winograd form (csrc/conv3d_wino3.hip: 8/27 of the products)
-        return "wino3"
+    if algo == "wino2" and ops.W3 and (group == "conv3d:32->32" or (group == "conv3d:33->32" and ops.W3_EXTRA)):
+        return "wino3"                                   # all three axes in Winograd form (csrc/conv3d_wino3.hip: 8/27 of the products)
     if group in ("conv3d:32->32", "conv3d:33->32"):      # the key || value convolution (33 -> 32) has a wino2 instance as well
         return algo
     if group == "conv3d:33->33":

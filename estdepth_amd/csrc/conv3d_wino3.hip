@@ -1,4 +1,4 @@
-// conv3d_wino3.hip -- the plain 32 -> 32 3x3x3 convolution with ALL THREE axes in Winograd F(2,3) form on gfx950 fp32 MFMA:
+// conv3d_wino3.hip -- the 32 -> 32 (and 33 -> 32) 3x3x3 convolution with ALL THREE axes in Winograd F(2,3) form on gfx950 fp32 MFMA:
 // F(2x2x2, 3x3x3), 64 products per 8 outputs = 8/27 of the direct MFMA work (two axes, csrc/conv3d_wino2.hip: 12/27).
 //
 // Same operator and descriptor as estd_conv3d_k3_wino2 (networks/layers_op.py:16-39 as used at hybrid_models/model_hybrid.py:59-60,:95 and
@@ -16,15 +16,20 @@
 //   * an MFMA column is a 2 x 2 output BLOCK (row pair, column pair) of the tile instead of a voxel; wave (rq, nh, shh) owns the 16 blocks of tile rows
 //     4rq .. 4rq+3 (two row pairs x eight column pairs) x the 16 output channels of half nh x the row-transform indices sh = 2shh, 2shh+1:
 //     8 products m[sh][sw] of the CURRENT depth transform (32 accumulator registers), 256 MFMAs per tile and wave (two-axis kernel: 384);
-//   * the ROW and the COLUMN transform run in registers between LDS and the MFMA: a sub-step (sd, channel chunk, sh) reads two halo rows x four columns of
-//     its block (the row the two sh of a wave share stays in registers: 12 ds_read_b128 per two sub-steps), forms the row combination (4 packed adds per
-//     channel pair) and its four column combinations (4 more), and multiplies them with the four taps sw of (sd, sh): 16 MFMAs, 2 VALU per MFMA;
+//   * the ROW and the COLUMN transform run in registers between LDS and the MFMA: a half-sub-step (sd, channel chunk, channel pair, sh) reads two halo rows x four
+//     columns of its block, 8 bytes = one channel pair each (the row the two sh of a wave share stays in registers: 12 ds_read_b64 per two half-sub-steps), forms the
+//     row combination (4 packed adds) and its four column combinations (4 more), and multiplies them with the four taps sw of (sd, sh): 8 MFMAs, 2 VALU per MFMA.
+//     (A 16-MFMA unit on 16-byte reads needs 56 registers more: it spilled 128.)  Lane groups g, g + 1 read opposite 8-byte halves of their 16-byte slot -- the weights
+//     are packed for that k order -- so the 32 lanes of a ds_read_b64 pass touch 32 different 8-byte units of a bank row;
 //   * when a depth transform is complete its 8 products go through the column and row halves of the output transform and are added into the partial sums
 //     of the two output planes (32 registers); the two waves of a SIMD (shh = 0, 1: the two halves of the row transform) exchange one plane's partial sums
 //     through LDS at the end of the tile and finish one plane each (the structure of the two-axis kernel's 32 -> 16 instance);
-//   * LDS rows are 18 records + 64 bytes long: halo rows two apart (the two row pairs of a wave) then lie in opposite halves of a 256-byte bank row, and
-//     with the column-keyed chunk swizzle and MFMA column i <-> block (row pair = 4 <= i < 12, column pair = i < 4 ? i : i < 12 ? i - 4 : i - 8) every
-//     ds_read_b128 of a patch position is conflict-free under the hardware's 16-lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...
+//   * LDS lines: line (halo row r, slice sd) = 18 records + 16 bytes at (4r + sd) * 2320 -- the four slices of a row are neighbours (every patch address is an
+//     immediate on one per-lane base) and 8 lines = 128 (mod 256): halo rows two apart (the two row pairs of a wave) lie in opposite halves of a 256-byte bank row; with
+//     the column-keyed chunk swizzle and MFMA column i <-> block (row pair = 4 <= i < 12, column pair = i < 4 ? i : i < 12 ? i - 4 : i - 8) every fragment read is conflict-free;
+//   * NO BRANCH inside the unrolled tap loop (scheduling regions end at branches: with them the allocator spilled 150 registers): absent planes read through a null
+//     buffer descriptor, threads without a third chunk of a slice write into a dummy LDS slot, a segment's first tile "stores" its deferred epilogue through the null descriptor.
+// profiles/r5_wino3_table.txt: 0.65 ms against 0.81 ms (two-axis kernel) for 3 volumes of 64x120x160, error against fp64 below the two-axis kernel's.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

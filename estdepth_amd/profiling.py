@@ -13,7 +13,7 @@ from collections import defaultdict
 # family names are ops._Prof's group names (estdepth_amd/ops.py), so that amounts (FLOPs / bytes per launch) recorded there apply
 _W2 = re.compile(r"conv3d_wino2_kernel<\s*(\d+),\s*(\d+|true|false),\s*(true|false),\s*(true|false)(?:,\s*(true|false))?(?:,\s*(true|false))?\s*>")
 _W2X = re.compile(r"conv3d_wino2x_kernel<")          # the operand-reuse form of the 32 -> 32 instance (csrc/conv3d_wino2x.hip, opt-in)
-_W3 = re.compile(r"conv3d_wino3_kernel<")            # the 32 -> 32 instances with all three axes in Winograd form (csrc/conv3d_wino3.hip, default since round 5)
+_W3 = re.compile(r"conv3d_wino3_kernel<\s*(\d+),\s*(true|false),\s*(true|false)\s*>")            # the 32 -> 32 instances with all three axes in Winograd form (csrc/conv3d_wino3.hip, default since round 5)
 _W2H = re.compile(r"conv3d_wino2_c16_kernel")
 _W1 = re.compile(r"conv3d_wino_kernel<\s*(true|false),\s*(true|false)\s*>")
 _K3 = re.compile(r"conv3d_k3_kernel<\s*(\d+),\s*(\d+),\s*(true|false),\s*(true|false)\s*>")
@@ -31,7 +31,10 @@ def family_of(kernel_name):
         if extra:
             return "conv3d:33->33" if xout else "conv3d:33->32"
         return "conv3d:32->32"
-    if _W2X.search(n) or _W3.search(n):
+    m = _W3.search(n)
+    if m:
+        return "conv3d:33->32" if m.group(3) == "true" else "conv3d:32->32"      # <read-back kind, GroupNorm partials, scalar 33rd input channel>
+    if _W2X.search(n):
         return "conv3d:32->32"
     if _W2H.search(n):
         return "conv3d:16->16"

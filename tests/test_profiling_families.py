@@ -13,6 +13,10 @@ NAMES = {
     "void (anonymous namespace)::conv3d_wino2_kernel<8, 0, false, false, false, false>(estd_conv3d_desc, int, int, int, int)": "conv3d:32->32",
     "void (anonymous namespace)::conv3d_wino2_kernel<8, 0, true, false, true, false>(estd_conv3d_desc, int, int, int, int)": "conv3d:33->33",
     "void (anonymous namespace)::conv3d_wino2x_kernel<0, false>(estd_conv3d_desc, int, int, int, int)": "conv3d:32->32",
+    "void (anonymous namespace)::conv3d_wino3_kernel<0, false, false>(estd_conv3d_desc, int, int, int, int)": "conv3d:32->32",     # three-axis kernel: <read-back kind, GroupNorm, scalar channel>
+    "void (anonymous namespace)::conv3d_wino3_kernel<2, false, false>(estd_conv3d_desc, int, int, int, int)": "conv3d:32->32",
+    "void (anonymous namespace)::conv3d_wino3_kernel<0, true, false>(estd_conv3d_desc, int, int, int, int)": "conv3d:32->32",
+    "void (anonymous namespace)::conv3d_wino3_kernel<0, false, true>(estd_conv3d_desc, int, int, int, int)": "conv3d:33->32",
     "(anonymous namespace)::conv3d_wino2_c16_kernel(estd_conv3d_desc, int, int, int, int)": "conv3d:16->16",
     "void (anonymous namespace)::conv3d_wino_kernel<true, true>(estd_conv3d_desc, int, int, int, int)": "conv3d:33->33",
     "void (anonymous namespace)::conv3d_k3_kernel<16, 1, false, false>(estd_conv3d_desc, int, int, int)": "conv3d:16->16",
