@@ -89,7 +89,10 @@ constexpr int LDS_BASE_BYTES = SLICES_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES 
 #ifndef ESTD_W3_WLDS
 #define ESTD_W3_WLDS 1
 #endif
-constexpr int WL_Q0 = 4, WL_N = 3;
+#ifndef ESTD_W3_WLQ0_PLAIN
+#define ESTD_W3_WLQ0_PLAIN 0     // launches without read-back streams: the FIRST three blocks of a tile instead (no L2 round trip in front of a tile's first MFMA)
+#endif
+constexpr int WL_N = 3;
 constexpr int WL_BYTES = 2 * WL_N * 4096;
 constexpr int LDS_BYTES_EXTRA = LDS_BASE_BYTES + XSL_BYTES + XW_BYTES, LDS_BYTES_PLAIN = LDS_BASE_BYTES + (ESTD_W3_WLDS ? WL_BYTES : 0);
 static_assert(LDS_BYTES_EXTRA <= 160 * 1024 && LDS_BYTES_PLAIN <= 160 * 1024, "LDS budget");
@@ -194,6 +197,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
         for (int e = tid; e < XW_BYTES / 16; e += NTHREADS) reinterpret_cast<float4*>(lds_wx)[e] = reinterpret_cast<const float4*>(p.w_extra)[e];
     }
     constexpr bool WL = ESTD_W3_WLDS != 0 && !EXTRA;
+    constexpr int WL_Q0 = RBK == 0 ? ESTD_W3_WLQ0_PLAIN : 4;
     char* lds_wl = smem + LDS_BASE_BYTES;                // [row-transform half][WL_N half-sub-steps][4096] (shares the scalar channel's place)
     if (WL) {
         for (int e = tid; e < WL_BYTES / 16; e += NTHREADS) {
