@@ -90,7 +90,7 @@ constexpr int LDS_BASE_BYTES = SLICES_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES 
 #define ESTD_W3_WLDS 1
 #endif
 #ifndef ESTD_W3_WLQ0_PLAIN
-#define ESTD_W3_WLQ0_PLAIN 0     // launches without read-back streams: the FIRST three blocks of a tile instead (no L2 round trip in front of a tile's first MFMA)
+#define ESTD_W3_WLQ0_PLAIN 4     // (A/B) launches without read-back streams: 0 = the FIRST three blocks of a tile instead -- measured the same (0.692 / 0.694 vs 0.690 / 0.689 ms): the other wave of the SIMD covers a tile's first L2 round trip
 #endif
 constexpr int WL_N = 3;
 constexpr int WL_BYTES = 2 * WL_N * 4096;
