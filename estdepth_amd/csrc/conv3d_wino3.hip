@@ -50,6 +50,9 @@
 #ifndef ESTD_W3_RBQ
 #define ESTD_W3_RBQ 5       // half-sub-step at which the deferred epilogue of a read-back instance consumes its loads (requested at 0, 1)
 #endif
+#ifndef ESTD_W3PK
+#define ESTD_W3PK 0          // A/B: the transforms as v_pk_add_f32 by inline assembly
+#endif
 #ifndef ESTD_W3_SCHED_VALU
 #define ESTD_W3_SCHED_VALU 8
 #endif
@@ -444,6 +447,15 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
                 // the four transformed operands (two k-steps each) of half-sub-step q from its raw rows: row combination, then the column transform
                 auto xform = [&](int q, f32x2 (&o)[4]) {
                     f32x2 X[4];
+                    if (ESTD_W3PK && !(ESTD_W3ABL & 128)) {
+                        // inline assembly: left to itself the compiler emits ~60 % of these as two plain adds each (a heuristic for the bf16 matrix pipe)
+                        auto pk_sub = [](f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; };
+                        auto pk_add = [](f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) X[j] = (q & 1) == 0 ? pk_sub(RA[j], RBs[j]) : SHH == 0 ? pk_add(RA[j], RBs[j]) : pk_sub(RBs[j], RA[j]);
+                        o[0] = pk_sub(X[0], X[2]); o[1] = pk_add(X[1], X[2]); o[2] = pk_sub(X[2], X[1]); o[3] = pk_sub(X[1], X[3]);
+                        return;
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (ESTD_W3ABL & 128) X[j] = RA[j];

@@ -1,5 +1,5 @@
 # parameter variants of csrc/conv3d_wino3.hip: one library per variant (built here, run on the GPU box)
 for v in base $W3_VARIANTS; do
-  lib="X=1"; [ "$v" != base ] && lib="ESTD_LIB=$PWD/estdepth_amd/lib/libestd_hip_w3_$(echo $v | tr -d '=').so"
-  echo "== $v"; env $lib ESTD_BINDING=ctypes W3_NOCHECK=1 python tools/w3_bench.py 3 30 2>&1 | grep "plain\|accumulate\|residual" | tail -4 | cut -c1-120
+  lib="X=1"; [ "$v" != base ] && lib="ESTD_LIB=$PWD/estdepth_amd/lib/libestd_hip_w3_$v.so"
+  echo "== $v"; env $lib ESTD_BINDING=ctypes W3_NOCHECK=1 python tools/w3_bench.py 3 30 2>&1 | grep "plain\|accumulate" | tail -2 | cut -c1-120
 done
