@@ -50,6 +50,9 @@
 #ifndef ESTD_W3_RBQ
 #define ESTD_W3_RBQ 5       // half-sub-step at which the deferred epilogue of a read-back instance consumes its loads (requested at 0, 1)
 #endif
+#ifndef ESTD_W3_TANH_HALVES
+#define ESTD_W3_TANH_HALVES 1   // (A/B: 0 = per-element activation select in the tanh launches)
+#endif
 #ifndef ESTD_W3PK
 #define ESTD_W3PK 0          // A/B: the transforms as v_pk_add_f32 by inline assembly
 #endif
@@ -190,6 +193,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
     if (tid < 64) lds_ss[tid] = tid < 32 ? p.scale[tid & 31] : p.shift[tid & 31];
     if (tid >= 64 && tid < 96) lds_ss[tid] = ((tid - 64) < p.act_split ? p.act_a : p.act_b) == ESTD_ACT_RELU ? 0.0f : ESTD_NO_FLOOR;
     const bool any_tanh = p.act_a == ESTD_ACT_TANH || p.act_b == ESTD_ACT_TANH;                     // uniform
+    const bool tanh_halves = ESTD_W3_TANH_HALVES && any_tanh && (p.act_split & 15) == 0;            // uniform
+    const int wave_act = __builtin_amdgcn_readfirstlane(16 * nh < p.act_split ? p.act_a : p.act_b);   // the activation of this wave's 16 output channels (tanh_halves)
     unsigned* lds_vt = reinterpret_cast<unsigned*>(smem + SLICES_BYTES + RED_BYTES + SS_BYTES);     // [it][thread]
     float4* lds_xch = reinterpret_cast<float4*>(smem + SLICES_BYTES + RED_BYTES + SS_BYTES + VTAB_BYTES);
     const __amdgpu_buffer_rsrc_t rs_null = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w_wino2), 0, 0, 0x00020000);     // num_records 0: loads return 0
@@ -302,6 +307,13 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
                 v.y = fmaxf(a[1] * sc4.y + sh4.y, lo.y);
                 v.z = fmaxf(a[2] * sc4.z + sh4.z, lo.z);
                 v.w = fmaxf(a[3] * sc4.w + sh4.w, lo.w);
+                return;
+            }
+            if (tanh_halves) {     // the 16 channels of a wave share the activation (split is a multiple of 16): a wave-uniform choice, tanh from the exp / rcp units
+                const float u0 = a[0] * sc4.x + sh4.x, u1 = a[1] * sc4.y + sh4.y, u2 = a[2] * sc4.z + sh4.z, u3 = a[3] * sc4.w + sh4.w;
+                if (wave_act == ESTD_ACT_TANH) { v.x = tanh_fast(u0); v.y = tanh_fast(u1); v.z = tanh_fast(u2); v.w = tanh_fast(u3); }
+                else if (wave_act == ESTD_ACT_RELU) { v.x = fmaxf(u0, 0.f); v.y = fmaxf(u1, 0.f); v.z = fmaxf(u2, 0.f); v.w = fmaxf(u3, 0.f); }
+                else { v.x = u0; v.y = u1; v.z = u2; v.w = u3; }
                 return;
             }
             v.x = act_apply(a[0] * sc4.x + sh4.x, chb + 0 < p.act_split ? p.act_a : p.act_b);

@@ -1,8 +1,6 @@
-for rep in 1 2; do for v in main f0 fd1; do
-  lib="X=1"; [ $v != main ] && lib="ESTD_LIB=$PWD/estdepth_amd/lib/libestd_hip_$v.so"
-  echo "== $v"; env $lib ESTD_BINDING=ctypes python tools/conv2d_bench.py 2>&1 | grep -v amdgpu | grep -v residual | cut -c1-60
-done; done
-for rep in 1 2; do for v in main f0; do
+timeout 600 python -m pytest tests/test_gpu_wino.py tests/test_gpu_parity.py -x -q 2>&1 | tail -2
+timeout 100 python tools/fuzz_convs.py 60 3 2>&1 | tail -1
+for rep in 1 2 3; do for v in main th0; do
   lib="X=1"; [ $v != main ] && lib="ESTD_LIB=$PWD/estdepth_amd/lib/libestd_hip_$v.so"
   env $lib ESTD_BINDING=ctypes python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | tail -1 | python -c "import json,sys; d=json.load(sys.stdin); print('$v:', d['value'], d['ms_per_step'])"
 done; done
