@@ -53,6 +53,15 @@
 #ifndef ESTD_W3_TANH_HALVES
 #define ESTD_W3_TANH_HALVES 1   // (A/B: 0 = per-element activation select in the tanh launches)
 #endif
+#ifndef ESTD_W3_PFQ
+#define ESTD_W3_PFQ 4
+#endif
+#ifndef ESTD_W3_PFQ_RB
+#define ESTD_W3_PFQ_RB 8
+#endif
+#ifndef ESTD_W3PRIO
+#define ESTD_W3PRIO 0        // A/B: 1 = static priority 1 for the waves of the second row-transform half (the two waves of a SIMD run the same instruction stream)
+#endif
 #ifndef ESTD_W3PK
 #define ESTD_W3PK 0          // A/B: the transforms as v_pk_add_f32 by inline assembly
 #endif
@@ -231,6 +240,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
 
     constexpr int BD = ESTD_W3BD;
     static_assert(32 % BD == 0, "the weight ring runs on across tiles");
+    if (ESTD_W3PRIO == 1 && shh != 0) __builtin_amdgcn_s_setprio(1);
     while (u < u_end) {
         // ---- column segment [u, seg_end): same (n, h-tile, w-tile), consecutive depth pairs ----
         const int col = u / dpairs;
@@ -533,7 +543,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void conv3d_wino3_kernel(const estd_co
                 }
                 unsigned vo_next = 0;
                 EpiLoads pl, pl1;
-                constexpr int PF_Q = 4;                  // next-plane prefetch: one chunk per two half-sub-steps, q = 4, 6, .. 14
+                constexpr int PF_Q = RBK != 0 ? ESTD_W3_PFQ_RB : ESTD_W3_PFQ;    // (read-back launches: later, clear of the read-back loads of half-sub-steps 0, 1: running sum 0.735 -> 0.710 ms)
+                // next-plane prefetch: one chunk per two half-sub-steps, q = PF_Q, PF_Q + 2, .. PF_Q + 10
                 constexpr int RW_Q = 22;                 // slices 0..2 of the next tile: every read of them has been issued (rows are fetched two half-sub-steps ahead)
                 __builtin_amdgcn_sched_barrier(0);
 
