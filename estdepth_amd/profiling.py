@@ -94,3 +94,120 @@ def replay_families(trace_csv, steps):
             for k, (c, t) in sorted(agg.items())}
     info = {"ms_per_step": round(span / 1e6 / steps, 3), "gpu_busy_pct": round(100.0 * busy / span, 1), "kernels_per_step": len(region) // max(steps, 1)}
     return fams, info
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Shader clock / board power beside a long timed loop (bench.py --sustained-s): a host thread that reads the amdgpu sysfs nodes of the
+# device (no process spawn, no HIP call: nothing enters the timed stream), falling back to one `rocm-smi` / `amd-smi` call per sample.
+class GpuSampler:
+    """samples (t, sclk MHz, power W) every ``period`` seconds between start() and stop(); summary() -> dict or {"error": ...}"""
+
+    def __init__(self, device_index=0, period=0.25):
+        import threading
+        self.period = period
+        self.samples = []
+        self._stop = threading.Event()
+        self._thread = None
+        self.source = None
+        self._card = self._find_card(device_index)
+
+    @staticmethod
+    def _find_card(index):
+        import glob
+        import os
+        cards = []
+        for c in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
+            dev = os.path.join(c, "device")
+            if os.path.basename(c).count("-") == 0 and os.path.exists(os.path.join(dev, "pp_dpm_sclk")):
+                cards.append(dev)
+        return cards[index] if index < len(cards) else (cards[0] if cards else None)
+
+    def _read_sysfs(self):
+        import glob
+        import os
+        if self._card is None:
+            return None
+        sclk, power = None, None
+        try:
+            for line in open(os.path.join(self._card, "pp_dpm_sclk")):
+                if line.rstrip().endswith("*"):
+                    sclk = float(re.search(r"(\d+)\s*Mhz", line, re.I).group(1))
+        except (OSError, AttributeError):
+            pass
+        for hw in glob.glob(os.path.join(self._card, "hwmon", "hwmon*")):
+            if sclk is None:
+                try:
+                    sclk = float(open(os.path.join(hw, "freq1_input")).read()) / 1e6
+                except (OSError, ValueError):
+                    pass
+            for node in ("power1_average", "power1_input"):
+                try:
+                    power = float(open(os.path.join(hw, node)).read()) / 1e6
+                    break
+                except (OSError, ValueError):
+                    pass
+        if sclk is None and power is None:
+            return None
+        return sclk, power
+
+    def _read_smi(self):
+        import shutil
+        import subprocess
+        exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+        try:
+            r = subprocess.run([exe, "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+        except Exception:
+            return None
+        m = re.search(r"GPU\[\d+\]\s*:\s*sclk clock level[^(]*\((\d+)Mhz\)", r)
+        p = re.search(r"GPU\[\d+\]\s*:\s*[^\n]*Power \(W\):\s*([\d.]+)", r)
+        if not m and not p:
+            return None
+        return (float(m.group(1)) if m else None), (float(p.group(1)) if p else None)
+
+    def _run(self):
+        import time
+        read = self._read_sysfs
+        if read() is None:
+            read, self.source = self._read_smi, "rocm-smi --showclocks --showpower (one call per sample)"
+            self.period = max(self.period, 1.0)
+        else:
+            self.source = "amdgpu sysfs (%s: pp_dpm_sclk / hwmon freq1_input, power1_average)" % self._card
+        t0 = time.perf_counter()
+        while not self._stop.is_set():
+            s = read()
+            if s is not None:
+                self.samples.append((time.perf_counter() - t0, s[0], s[1]))
+            self._stop.wait(self.period)
+
+    def start(self):
+        import threading
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout=15)
+        return self
+
+    def summary(self, bucket_edges=None):
+        if not self.samples:
+            return {"error": "no shader-clock / power reading (no amdgpu sysfs node and no rocm-smi output)", "source": self.source}
+
+        def stat(vals):
+            vals = [v for v in vals if v is not None]
+            if not vals:
+                return None
+            return {"min": round(min(vals), 1), "mean": round(sum(vals) / len(vals), 1), "max": round(max(vals), 1)}
+        out = {"source": self.source, "samples": len(self.samples), "period_s": self.period,
+               "sclk_mhz": stat([s[1] for s in self.samples]), "power_w": stat([s[2] for s in self.samples])}
+        if bucket_edges:
+            per = []
+            for a, b in zip(bucket_edges[:-1], bucket_edges[1:]):
+                inb = [s for s in self.samples if a <= s[0] < b]
+                sc = [s[1] for s in inb if s[1] is not None]
+                pw = [s[2] for s in inb if s[2] is not None]
+                per.append([round(sum(sc) / len(sc)) if sc else None, round(sum(pw) / len(pw)) if pw else None])
+            out["per_bucket_sclk_mhz_power_w"] = per
+        return out

@@ -5,6 +5,8 @@ BASELINE.json configs[1] (cfg2): seq_len=5, 480x640, D=64, ResNet-50, Joint-mode
       side-stream semantic branch and heads, hipGraph replay) vs the plain eager path: all outputs within 5e-5;
   (b) plain path and accelerated path vs the CPU ORACLE on the same inputs: every ("depth", t, s) within 1e-4 abs
       (north_star tolerance) -- one oracle forward at full size, ~1 min on the box's host cores.
+  (e) round 6: the MEMORY-LESS call of both protocols at full size (Joint call 1, ESTM window 0 => forward_notransformer) vs the
+      oracle: outputs, both logit volumes, the key / value record and the pose the call hands on.
 BASELINE.json configs[2] (cfg3): the steady-state ESTM window at 480x640, D=64, ResNet-50 vs the oracle (1e-4).
 BASELINE.json configs[4] (cfg5): 960x1280, D=128 ESTM steady-state window (2 memory volumes)
   (d) the whole window vs the oracle (1e-4), the fused warp+attention identity / permutation properties and the
@@ -55,16 +57,21 @@ def _np(t):
     return t.detach().float().cpu().contiguous().numpy()
 
 
-def _oracle_forward(workload, x_imgs, x_poses, intr, pre_costs, pre_poses):
+def _oracle_forward(workload, x_imgs, x_poses, intr, pre_costs, pre_poses, memory=False):
     import bench as B
     from oracle import ref_model as M, ref_ops as O
     from oracle.nets2d import Nets2D, sd_numpy
     n = torch.get_num_threads()
     O.set_num_threads(n)
     cpu_model = B.build_model(workload, "cpu")
-    pc = {"keys": [_np(k) for k in pre_costs["keys"]], "values": [_np(v) for v in pre_costs["values"]]}
-    ref, _, _ = M.model_forward(sd_numpy(cpu_model), _np(x_imgs), _np(x_poses), _np(intr), pc, [_np(p) for p in pre_poses],
-                                Nets2D(model=cpu_model), ndepths=B.WORKLOADS[workload][3], depth_min=0.1, depth_max=10.0)
+    pc, pp = None, None
+    if pre_costs is not None:
+        pc = {"keys": [_np(k) for k in pre_costs["keys"]], "values": [_np(v) for v in pre_costs["values"]]}
+        pp = [_np(p) for p in pre_poses]
+    ref, costs, cposes = M.model_forward(sd_numpy(cpu_model), _np(x_imgs), _np(x_poses), _np(intr), pc, pp,
+                                         Nets2D(model=cpu_model), ndepths=B.WORKLOADS[workload][3], depth_min=0.1, depth_max=10.0)
+    if memory:
+        return ref, costs, cposes
     return ref
 
 
@@ -127,6 +134,72 @@ def _assert_logits(tag, diffs):
 def test_cfg2_logit_volumes_match_the_oracle(cfg2_joint):
     """3 targets x 64 x 120 x 160 logits of both heads, accelerated + hipGraph path vs the oracle (same inputs, same memory)"""
     _assert_logits("cfg2", cfg2_joint[3])
+
+
+# ---- the memory-less call at full size: forward_notransformer (hybrid_depth_decoder.py:294-417, dispatch :423) ----
+# Joint call 1 (eval_hybrid.py:229-243: pre_costs=None for the first clip of every scene) and ESTM window 0 (eval_hybrid_seq.py:171-193).
+# Bars: every depth within 1e-4 m (north_star), probabilities within 5e-5, both logit volumes within TOL_LOGIT (unchanged), and the memory
+# record the call hands on -- key (ReLU output) and value (tanh output) of the LAST target, [1,16,D,H,W] -- within TOL_KV_REL x the
+# record's own scale, pose bit-equal.  Key and value are the two halves of ONE 33 -> 32 convolution behind seven others (864-term fp32
+# sums each; a single convolution is held to 3e-6 x its magnitude in test_gpu_wino.py): bar = TOL_KV_REL x the KEY's range for both
+# halves -- the value is tanh (1-Lipschitz) of a pre-activation of the key's scale, so its absolute error is the key's, not one relative
+# to its own +-1 range.  Measured (round 6, cfg2 call 1): key 6.3e-5 on a range of 29.9 (2.1e-6 relative), value 4.1e-5.
+TOL_KV_REL = 4e-6
+
+
+def _memoryless(workload, sl):
+    import bench as B
+    from estdepth_amd.graph import GraphedForward
+    dev = torch.device(DEV)
+    model = B.build_model(workload, dev)                             # exactly what bench.py times
+    model.CostRegNet.keep_logits = True
+    imgs, poses, intr, sample = B.make_inputs(workload, 0, dev)
+    x_imgs, x_poses = imgs[:, sl].contiguous(), poses[:, sl].contiguous()
+    x_sample = {k: v[:, sl] for k, v in sample.items()}
+    fwd = GraphedForward(model, zero_copy_memory=True)               # (bench.py's default launch path)
+    with torch.no_grad():
+        for _ in range(3):                                           # one capture per ring buffer, then a pure replay
+            out, costs, cposes = fwd(x_imgs, x_poses, intr, x_sample, None, None, mode="val")
+    out = {k: v.clone() for k, v in out.items()}
+    mem = {"key": _np(costs["keys"][0]), "value": _np(costs["values"][0]), "pose": _np(cposes[0])}
+    torch.cuda.synchronize()
+    ref, rcosts, rposes = _oracle_forward(workload, x_imgs, x_poses, intr, None, None, memory=True)
+    ldiff = _logit_diffs(model.CostRegNet, ref)
+    del fwd, model
+    torch.cuda.empty_cache()
+    return out, mem, ref, rcosts, rposes, ldiff
+
+
+def _assert_memoryless(tag, n_targets, res):
+    out, mem, ref, rcosts, rposes, ldiff = res
+    assert len(out) == 6 * n_targets and set(out) == {k for k in ref if k[0] in ("depth", "init_prob", "fused_prob")}
+    for k, v in out.items():
+        d = float(np.abs(_np(v) - ref[k]).max())
+        assert np.isfinite(d) and d < (TOL_DEPTH if k[0] == "depth" else 5e-5), (tag, k, d)
+    _assert_logits(tag, ldiff)
+    bar = TOL_KV_REL * max(float(np.abs(rcosts["keys"][0]).max()), 1.0)
+    for name, r in (("key", rcosts["keys"][0]), ("value", rcosts["values"][0])):
+        g = mem[name]
+        assert g.shape == r.shape and g.shape[:2] == (1, 16), (tag, name, g.shape, r.shape)
+        rng = float(np.abs(r).max())
+        d = float(np.abs(g - r).max())
+        cs_g, cs_r = float(g.astype(np.float64).sum()), float(r.astype(np.float64).sum())
+        print("%s memory %s: max |HIP - oracle| = %.3g (bar %.3g) on a range of %.3g; checksum %.9g vs %.9g" % (tag, name, d, bar, rng, cs_g, cs_r))
+        assert rng > 0.05 and np.isfinite(d) and d < bar, (tag, name, d, rng, bar)
+        assert abs(cs_g - cs_r) <= 1e-6 * float(np.abs(r).astype(np.float64).sum()) + 1e-3, (tag, name, cs_g, cs_r)
+    assert np.array_equal(mem["pose"], np.asarray(rposes[0])), tag     # the pose of the LAST target, handed on untouched (:417)
+
+
+def test_cfg2_call1_notransformer_matches_the_oracle():
+    """BASELINE.json configs[1], FIRST Joint call of a scene (5 frames, no memory => forward_notransformer, 3 targets) at 480x640 /
+    D = 64 / ResNet-50 through every accelerator + hipGraph replay (zero-copy ring) vs the CPU oracle: 18 outputs, both logit
+    volumes, the returned key / value record and pose."""
+    _assert_memoryless("cfg2 call 1", 3, _memoryless("joint", slice(0, 5)))
+
+
+def test_cfg3_window0_notransformer_matches_the_oracle():
+    """BASELINE.json configs[2], ESTM window 0 (3 frames, no memory => forward_notransformer, 1 target) at full size."""
+    _assert_memoryless("cfg3 window 0", 1, _memoryless("estm", slice(0, 3)))
 
 
 def test_semantic_encoder_resnet50_fused_path_vs_torch_cpu():
