@@ -69,6 +69,11 @@ def parse():
                     help="skip the rocprofv3 kernel trace of a short child run (per-kernel durations INSIDE the hipGraph replay)")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip the short timed loops of the other single-GPU workloads (ESTM window, cfg5, stream) reported beside the headline")
+    ap.add_argument("--sustained-s", type=float, default=float(os.environ.get("ESTD_SUSTAINED_S", "20")),
+                    help="after the K timed steps: the same step for about this many seconds in buckets of --sustained-bucket steps, shader clock and "
+                         "board power sampled beside it by a host thread (config.sustained, config.sustained_ms_per_step, "
+                         "config.sustained_over_timed); 0 = skip.  `value` stays the K-step figure of the contract")
+    ap.add_argument("--sustained-bucket", type=int, default=200)
     ap.add_argument("--conv2d-arith", default=os.environ.get("ESTD_CONV2D_ARITH", "f32"), choices=["f32", "bf16x3"],
                     help="same choice for the 3x3 NHWC convolutions of the PSM extractor / 2D decoder (opt-in)")
     return ap.parse_args()
@@ -199,10 +204,45 @@ def _cpu_model_name():
     return "unknown"
 
 
+def _socket_cpus(package=None):
+    """one hardware thread per physical core of ONE socket (the first sibling of every core of ``package``; default: the socket
+    with the most cores allowed to this process) from /sys/devices/system/cpu/*/topology; [] if the topology cannot be read."""
+    import glob
+    allowed = os.sched_getaffinity(0)
+    cores = {}
+    for d in glob.glob("/sys/devices/system/cpu/cpu[0-9]*"):
+        try:
+            cpu = int(os.path.basename(d)[3:])
+            pkg = int(open(os.path.join(d, "topology", "physical_package_id")).read())
+            core = int(open(os.path.join(d, "topology", "core_id")).read())
+        except (OSError, ValueError):
+            continue
+        if cpu in allowed:
+            cores.setdefault(pkg, {}).setdefault(core, []).append(cpu)
+    if not cores:
+        return []
+    if package is None:
+        package = max(cores, key=lambda p: (len(cores[p]), -p))
+    return sorted(min(sib) for sib in cores.get(package, {}).values())
+
+
+def _set_affinity_all_threads(cpus):
+    """the affinity mask of EVERY thread of this process (the OpenMP / oneDNN workers that exist already keep their own mask otherwise;
+    threads created later inherit their creator's).  Returns the number of threads moved."""
+    n = 0
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            os.sched_setaffinity(int(tid), cpus)
+            n += 1
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 _DEFAULT_TORCH_THREADS = [0]        # torch's own default (= the physical cores of the box), recorded before anything changes it
 
 
-def cpu_baseline(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses, gpu_outputs, frames, gpu_logits=None, kind="port"):
+def cpu_baseline(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses, gpu_outputs, frames, gpu_logits=None, kind="port", pin_socket=False):
     """A CPU restatement of the reference timed on ONE full step of the same workload on the box's host cores: the whole
     DepthNetHybrid.forward of the timed step -- PSM, ResNet, plane sweeps, every 3D convolution, the 2N volume warps + attention +
     ConvGRU per target, soft-argmin, 2D refinement -- on the very inputs (and carried memory) of the GPU step.  Nothing is extrapolated.
@@ -217,6 +257,17 @@ def cpu_baseline(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses,
     from oracle.nets2d import Nets2D, sd_numpy
     ncores = os.cpu_count() or 1
     threads = _DEFAULT_TORCH_THREADS[0] if threads <= 0 else min(threads, ncores)
+    pinned, full_mask = None, None
+    if pin_socket:
+        # ``threads`` workers confined to the physical cores of ONE socket (one hardware thread per core): an unpinned oneDNN run across two
+        # sockets is SLOWER at 128 threads than at 8 (round 5: 0.115 vs 0.206 depth frames/s) -- not what the box's CPU path can do
+        cpus = _socket_cpus()
+        if cpus:
+            threads = min(threads, len(cpus))
+            full_mask = os.sched_getaffinity(0)
+            use = cpus[:threads]
+            _set_affinity_all_threads(use)
+            pinned = "%d threads on cpus %d-%d of one socket (%d physical cores on it; sched_setaffinity of every thread)" % (threads, use[0], use[-1], len(cpus))
     O.set_num_threads(threads)
     torch.set_num_threads(threads)
     D = WORKLOADS[workload][3]
@@ -235,6 +286,8 @@ def cpu_baseline(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses,
         ref, _, _ = M.model_forward(P, a_imgs, a_poses, a_intr, pc, pp, nets, ndepths=D, depth_min=0.1, depth_max=10.0,
                                     IF_EST_transformer=WORKLOADS[workload][5])
     dt = time.time() - t0
+    if full_mask is not None:
+        _set_affinity_all_threads(full_mask)
     worst, arel = {}, {}
     for k, v in gpu_outputs.items():
         if k[0] == "depth":
@@ -243,7 +296,7 @@ def cpu_baseline(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses,
             # abs_rel(pred, ref) = mean(|ref - pred| / ref) (metric.py:131-150, model_hybrid.py:306) of the GPU depth against the CPU depth
             arel.setdefault(k[2], []).append(float(np.mean(np.abs(ref[k] - g) / ref[k])))
     how = "C/OpenMP oracle" if kind == "port" else "torch-CPU operators (oneDNN conv3d, ATen grid_sample / group_norm)"
-    base = {"value": round(frames / dt, 4), "unit": "depth frames/s", "cores": threads, "kind": kind, "wall_s": round(dt, 2),
+    base = {"value": round(frames / dt, 4), "unit": "depth frames/s", "cores": threads, "kind": kind, "wall_s": round(dt, 2), "pinned": pinned,
             "cpu": "%s (%d hardware threads on the box)" % (_cpu_model_name(), ncores),
             "sample": "ONE full step of this workload (%d depth frames: 2D networks on torch-CPU + %s for the whole 3D "
                       "hot path incl. volume warps, attention, ConvGRU), %.1f s wall, %d threads" % (frames, how, dt, threads)}
@@ -339,6 +392,49 @@ def joint_stream_bench(steps, warmup, device, no_graph=False):
                         "(3 of 5 frames extracted per step), 480x640, D=64, ResNet-50, %s" % ("eager launches" if no_graph else "hipGraph replay"),
             "value": round(3 * steps / dt, 3), "unit": "depth frames/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps, "warmup": warmup,
             "depth_frames_per_step": 3, "untimed_priming_calls": c0}
+
+
+def sustained_loop(step, drain, barrier, args, elapsed, device, dist, device_index):
+    """The timed step once more, for about ``--sustained-s`` seconds: buckets of ``--sustained-bucket`` steps, each between two device
+    synchronisations (one host wait per bucket), while a host thread samples shader clock and board power (estdepth_amd.profiling.GpuSampler:
+    sysfs reads, nothing on a HIP stream).  The number of buckets is fixed BEFORE the loop from the K-step time (MAX over the ranks), so
+    every rank of an N > 1 run makes the same number of calls (the exchange is a collective).  Returns the config.sustained dict."""
+    import torch
+    from estdepth_amd.profiling import GpuSampler
+    t_step = elapsed / max(args.steps, 1)
+    if dist is not None:
+        tt = torch.tensor([t_step], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_step = float(tt[0])
+    bucket = max(1, args.sustained_bucket)
+    nb = max(2, int(round(args.sustained_s / (bucket * t_step))))
+    barrier()
+    sampler = GpuSampler(device_index).start()
+    t0 = time.perf_counter()
+    edges, per = [0.0], []
+    for _ in range(nb):
+        tb = time.perf_counter()
+        for _ in range(bucket):
+            step()
+        drain()
+        torch.cuda.synchronize()
+        te = time.perf_counter()
+        per.append(1e3 * (te - tb) / bucket)
+        edges.append(te - t0)
+    barrier()
+    total = time.perf_counter() - t0
+    sampler.stop()
+    if dist is not None:
+        tt = torch.tensor([total], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        total = float(tt[0])
+    ms = 1e3 * total / (nb * bucket)
+    return {"seconds": round(total, 2), "steps": nb * bucket, "bucket_steps": bucket, "ms_per_step": round(ms, 3),
+            "ms_per_step_per_bucket": [round(x, 3) for x in per], "slowest_bucket_ms": round(max(per), 3), "fastest_bucket_ms": round(min(per), 3),
+            "timed_ms_per_step": round(1e3 * t_step, 3), "timed_over_sustained": round(1e3 * t_step / ms, 4),
+            "clocks": sampler.summary(edges),
+            "how": "after the K timed steps: %d buckets of %d steps of the same call, one device synchronisation per bucket, wall clock; "
+                   "shader clock / power from a host thread" % (nb, bucket)}
 
 
 GRAPH_PRIME = 2      # untimed calls in front of the warm-up steps of a hipGraph run: zero-copy memory alternates between two captures
@@ -671,6 +767,11 @@ def main():
         if not bank_ok:
             raise RuntimeError("rank %d: the all-gathered memory bank differs from the tensors this rank sent" % rank)
 
+    # ---- is the K-step figure a sustained one?  The same step (same launch path, same overlapped exchange) for tens of seconds ----
+    sustained = None
+    if args.sustained_s > 0 and os.environ.get("ESTD_BENCH_CHILD") != "1":
+        sustained = sustained_loop(step, drain, barrier, args, elapsed, device, dist if world > 1 else None, local_rank)
+
     # ---- the collective alone (N > 1): bytes per rank and achieved bus bandwidth ----
     ag = None
     if dist_on and gathered:
@@ -851,6 +952,10 @@ def main():
                        "conv3d_arith": args.conv3d_arith, "conv2d_arith": args.conv2d_arith,
                        "conv3d_algo_32to32": kalgo,
                        "notes": state["notes"],
+                       # the K-step figure against tens of seconds of the same step (timed / sustained: 1.0 = the headline IS a sustained rate)
+                       "sustained_ms_per_step": sustained["ms_per_step"] if sustained else None,
+                       "sustained_over_timed": sustained["timed_over_sustained"] if sustained else None,
+                       "sustained": sustained,
                        "per_rank_ms_per_step": per_rank_ms,
                        "parallelism": "1 sequence per GPU" + ("; RCCL all-gather of {K,V,pose} per step, overlapped with the next step" if gathered else "")
                                       + (("; %d CUs left free for the collective in stage %s" % (state["reserved_cus"], "A (2D networks)" if state.get("reserve_scope") == "A" else "A and B"))
@@ -917,12 +1022,18 @@ def main():
             # two CPU restatements on the box's host cores -- the C/OpenMP port (the parity checker, 8 threads: it
             # does not scale further) and the torch-operator leg (oneDNN / ATen, what the reference itself would run: 8 threads for
             # comparability with BASELINE.md section 2 AND torch's default = all physical cores); headline entry = the fastest
-            legs = [("port", args.cpu_threads)] if args.cpu_threads > 0 else [("port", 8), ("torch-ops", 8), ("torch-ops", 0)]
+            # round 6: + the torch-operator leg at 32 and 64 threads PINNED to one socket (the unpinned all-core leg crosses sockets and loses to 8 threads)
+            legs = [("port", args.cpu_threads, False)] if args.cpu_threads > 0 else \
+                [("port", 8, False), ("torch-ops", 8, False), ("torch-ops", 0, False), ("torch-ops", 32, True), ("torch-ops", 64, True)]
             if args.cpu_threads > 0:
-                legs.append(("torch-ops", args.cpu_threads))
+                legs.append(("torch-ops", args.cpu_threads, False))
+            if args.workload == "cfg5" and args.cpu_threads <= 0:
+                legs = legs[:3]                        # (one cfg5 step is ~1 min of CPU work per leg)
             runs, parity, parity_t = [], None, None
-            for kind, th in legs:
-                base, par = cpu_baseline(args.workload, th, x_imgs, x_poses, intr, pre_costs, pre_poses, gpu_outputs, frames, gpu_logits, kind=kind)
+            for kind, th, pin in legs:
+                if pin and len(_socket_cpus()) < 16:
+                    continue                           # (a box without a 16-core socket: the unpinned legs say it all)
+                base, par = cpu_baseline(args.workload, th, x_imgs, x_poses, intr, pre_costs, pre_poses, gpu_outputs, frames, gpu_logits, kind=kind, pin_socket=pin)
                 runs.append(base)
                 if kind == "port":
                     parity = par
@@ -930,7 +1041,7 @@ def main():
                     parity_t = par
             best = max(runs, key=lambda b: b["value"])
             line["cpu_baseline"] = dict(best)
-            line["cpu_baseline"]["all_runs"] = [{"kind": b["kind"], "cores": b["cores"], "value": b["value"], "wall_s": b["wall_s"]} for b in runs]
+            line["cpu_baseline"]["all_runs"] = [{"kind": b["kind"], "cores": b["cores"], "value": b["value"], "wall_s": b["wall_s"], "pinned": b["pinned"]} for b in runs]
             if parity_t is not None:      # the torch-operator leg's own view of the GPU depth (a second, independent CPU arithmetic)
                 parity["vs_torch_ops"] = {"max_abs_depth_diff_m": parity_t["max_abs_depth_diff_vs_oracle_m"], "abs_rel": parity_t["abs_rel_vs_oracle"]}
             line["parity"] = parity

@@ -29,7 +29,7 @@ def _last_json(out):
 
 
 def test_bench_single_gpu_line():
-    out = subprocess.run([sys.executable, "bench.py", "--workload", "cfg1", "--steps", "3", "--warmup", "1", "--no-replay-profile"], cwd=ROOT,
+    out = subprocess.run([sys.executable, "bench.py", "--workload", "cfg1", "--steps", "3", "--warmup", "1", "--sustained-s", "1", "--sustained-bucket", "50", "--no-replay-profile"], cwd=ROOT,
                          capture_output=True, text=True, timeout=900)
     d = _last_json(out.stdout)
     assert REQUIRED <= set(d) and "cpu_baseline" in d
@@ -39,7 +39,11 @@ def test_bench_single_gpu_line():
     assert d["cpu_baseline"]["kind"] in ("port", "torch-ops") and d["cpu_baseline"]["cores"] >= 1
     runs = d["cpu_baseline"]["all_runs"]     # the C/OpenMP port at 8 threads, the torch-operator leg at 8 threads and at the box's default; headline = the fastest
     assert [(r["kind"], r["cores"] == 8) for r in runs[:2]] == [("port", True), ("torch-ops", True)] and runs[2]["kind"] == "torch-ops"
-    assert len(runs) == 3 and d["cpu_baseline"]["value"] == max(r["value"] for r in runs)
+    assert len(runs) in (3, 5) and d["cpu_baseline"]["value"] == max(r["value"] for r in runs)
+    if len(runs) == 5:     # a box with a >= 16-core socket: + the torch-operator leg at 32 and 64 threads pinned to the physical cores of one socket
+        assert [(r["kind"], bool(r["pinned"])) for r in runs[3:]] == [("torch-ops", True)] * 2 and runs[3]["cores"] <= 32 < runs[4]["cores"] <= 64 \
+            or runs[3]["cores"] == runs[4]["cores"]           # (a socket with <= 32 cores runs both legs on all of them)
+    assert all(not r["pinned"] for r in runs[:3])
     assert d["parity"]["within_tolerance"] and max(d["parity"]["max_abs_depth_diff_vs_oracle_m"].values()) <= 1e-4
     # SURVEY section 8(d) "Metric": abs_rel(depth_gpu, depth_cpu) per output scale beside the max-abs figure, against both CPU arithmetics
     assert d["parity"]["oracle_kind"] == "port" and set(d["parity"]["abs_rel_vs_oracle"]) == set(d["parity"]["max_abs_depth_diff_vs_oracle_m"])
@@ -62,7 +66,7 @@ def test_bench_headline_workload_roofline_fields_are_hardware_fractions():
     hipGraph REPLAY that produced `value` (rocprofv3 kernel trace of a child run), the dominant kernel's live HIP-event brackets
     agree with it within 15 %, and every family whose eager bracket is further off is named.  The other single-GPU workloads
     (ESTM window, cfg5, stream) are timed in the same run."""
-    out = subprocess.run([sys.executable, "bench.py", "--workload", "joint", "--steps", "5", "--warmup", "2", "--no-alt", "--no-cpu-baseline"],
+    out = subprocess.run([sys.executable, "bench.py", "--workload", "joint", "--steps", "5", "--warmup", "2", "--no-alt", "--no-cpu-baseline", "--sustained-s", "6"],
                          cwd=ROOT, capture_output=True, text=True, timeout=1500)
     d = _last_json(out.stdout)
     r = d["roofline"]
@@ -93,6 +97,12 @@ def test_bench_headline_workload_roofline_fields_are_hardware_fractions():
     assert {"homo_warp_costvol", "warp_attention N=3", "gru_blend", "softargmin_up (T=3)"} <= set(alone)
     assert all(0 < v["frac"] <= 1 for v in alone.values())
     assert d["value"] > 50.0                               # north_star: >= 50 depth frames/s on one MI355X
+    # the headline against seconds of the same step (round 6): per-bucket ms/step, the ratio timed / sustained, clocks and power beside it
+    su = d["config"]["sustained"]
+    assert su["steps"] == su["bucket_steps"] * len(su["ms_per_step_per_bucket"]) >= 2 * su["bucket_steps"] and su["seconds"] > 3
+    assert d["config"]["sustained_ms_per_step"] == su["ms_per_step"] and d["config"]["sustained_over_timed"] == su["timed_over_sustained"]
+    assert 0.9 < su["timed_over_sustained"] < 1.1, su                  # a 5-step figure on a cold box may be off by more than the 20-step one
+    assert "error" in su["clocks"] or su["clocks"]["samples"] >= 3, su["clocks"]
 
 
 def test_bench_world_size_one_rccl_communicator():
@@ -100,7 +110,7 @@ def test_bench_world_size_one_rccl_communicator():
     channel cap, CU reserve, the asynchronous all-gather overlapped with the next step, the own-shard bit-equality check."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["ESTD_FORCE_DIST"] = "1"
-    out = subprocess.run([sys.executable, "bench.py", "--workload", "cfg1", "--steps", "3", "--warmup", "1", "--no-alt", "--no-cpu-baseline"],
+    out = subprocess.run([sys.executable, "bench.py", "--workload", "cfg1", "--steps", "3", "--warmup", "1", "--sustained-s", "1", "--sustained-bucket", "50", "--no-alt", "--no-cpu-baseline"],
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     d = _last_json(out.stdout)
     ag = d["config"]["allgather"]
@@ -117,7 +127,7 @@ def test_bench_direct_exchange_world_size_one_rccl():
     """ESTD_AG_ALGO=direct on the world-size-1 RCCL communicator (the all-to-all send/recv list is empty there: own-shard copy only)"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(ESTD_FORCE_DIST="1", ESTD_AG_ALGO="direct")
-    out = subprocess.run([sys.executable, "bench.py", "--workload", "cfg1", "--steps", "3", "--warmup", "1", "--no-alt", "--no-cpu-baseline"],
+    out = subprocess.run([sys.executable, "bench.py", "--workload", "cfg1", "--steps", "3", "--warmup", "1", "--sustained-s", "1", "--sustained-bucket", "50", "--no-alt", "--no-cpu-baseline"],
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     d = _last_json(out.stdout)
     assert d["config"]["allgather"]["algo"] == "direct" and d["config"]["allgather"]["own_shard_bit_equal"] is True
@@ -139,7 +149,7 @@ def test_bench_gpus_flag_launches_the_ranks_itself():
     """the driver's command line: `python bench.py --gpus N` with NO launcher and no WORLD_SIZE -> bench.py re-executes
     itself under torch.distributed.run with N ranks (here: 2 ranks sharing the single test GPU, gloo instead of RCCL)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--workload", "cfg1", "--steps", "3", "--warmup", "1"],
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--workload", "cfg1", "--steps", "3", "--warmup", "1", "--sustained-s", "1", "--sustained-bucket", "50"],
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     d = _last_json(out.stdout)
     _check_two_ranks(d)
@@ -149,7 +159,7 @@ def test_bench_gpus_flag_launches_the_ranks_itself():
 def test_bench_two_ranks_under_an_external_launcher():
     env = dict(os.environ, ESTD_FORCE_DEVICE="0", ESTD_DIST_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--workload", "cfg1", "--steps", "3", "--warmup", "1"]
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--workload", "cfg1", "--steps", "3", "--warmup", "1", "--sustained-s", "1", "--sustained-bucket", "50"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     _check_two_ranks(_last_json(out.stdout))
 
@@ -159,7 +169,7 @@ def test_bench_line_survives_a_hanging_exchange_diagnostic():
     place on every rank) rank 0 still prints the complete line, says so in `other_algo`, and every rank exits with status 0"""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(ESTD_AG_DIAG_TEST_HANG="1", ESTD_AG_DIAG_TIMEOUT="5")
-    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--workload", "cfg1", "--steps", "3", "--warmup", "1"],
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--workload", "cfg1", "--steps", "3", "--warmup", "1", "--sustained-s", "1", "--sustained-bucket", "50"],
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     d = _last_json(out.stdout)
