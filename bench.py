@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="host threads of the cpu_baseline leg (0 = torch's default = the physical cores of the box; SMT siblings slow both "
                          "the OpenMP oracle and the oneDNN convolutions of the 2D networks down)")
+    ap.add_argument("--cpu-leg-child", default=None, help=argparse.SUPPRESS)          # internal: the pinned child of cpu_leg_pinned()
+    ap.add_argument("--cpu-leg-kind", default="torch-ops", help=argparse.SUPPRESS)
     ap.add_argument("--no-allgather", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--graph-memory", default=os.environ.get("ESTD_GRAPH_MEMORY", "zero-copy"), choices=["zero-copy", "copy"],
@@ -59,11 +61,11 @@ def parse():
                          "(two 157 MB device copies per Joint step)")
     ap.add_argument("--conv3d-arith", default=os.environ.get("ESTD_CONV3D_ARITH", "f32"), choices=["f32", "bf16x3"],
                     help="products of the plain 32->32 3D convolutions: native fp32 MFMA (default) or the exact 3-way bf16 "
-                         "operand split with six bf16 MFMAs per product block (fp32-level error, opt-in)")
+                         "operand split with six bf16 MFMAs per product block (fp32-level error; ESTD_BUILD_AB=1 builds only)")
     ap.add_argument("--conv3d-algo", default=os.environ.get("ESTD_CONV3D_ALGO", "wino2"), choices=["wino2", "wino", "direct"],
                     help="3D convolutions under f32 arithmetic: wino2 = depth and row axis of the plain 32->32 instance in Winograd F(2,3) "
                          "form (0.444 of the fp32 MFMA products, csrc/conv3d_wino2.hip: every 32/33-channel instance, 32->16 and the 16->16 heads; default), "
-                         "wino = depth axis only (2/3 of the products, csrc/conv3d_wino.hip), direct = 27-tap implicit GEMM (csrc/conv3d_mfma.hip)")
+                         "wino = depth axis only (2/3 of the products, csrc/conv3d_wino.hip; ESTD_BUILD_AB=1 builds only), direct = 27-tap implicit GEMM (csrc/conv3d_mfma.hip)")
     ap.add_argument("--no-alt", action="store_true", help="skip the second timed loop with the other convolution arithmetic")
     ap.add_argument("--no-replay-profile", action="store_true",
                     help="skip the rocprofv3 kernel trace of a short child run (per-kernel durations INSIDE the hipGraph replay)")
@@ -226,17 +228,80 @@ def _socket_cpus(package=None):
     return sorted(min(sib) for sib in cores.get(package, {}).values())
 
 
-def _set_affinity_all_threads(cpus):
-    """the affinity mask of EVERY thread of this process (the OpenMP / oneDNN workers that exist already keep their own mask otherwise;
-    threads created later inherit their creator's).  Returns the number of threads moved."""
-    n = 0
-    for tid in os.listdir("/proc/self/task"):
-        try:
-            os.sched_setaffinity(int(tid), cpus)
-            n += 1
-        except (OSError, ValueError):
-            pass
-    return n
+def cpu_leg_pinned(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses, frames, kind):
+    """One CPU leg in a CHILD process confined to the physical cores of ONE socket: ``threads`` OpenMP / oneDNN workers, one per core,
+    affinity set before the child creates its first thread (so every worker inherits it; memory is first-touched on that socket),
+    OMP_PROC_BIND=close / OMP_PLACES=cores.  An unpinned run across both sockets is SLOWER at 128 threads than at 8 (round 5: 0.115 vs
+    0.206 depth frames/s): the box's CPU path deserves the pinned figure beside it.  The inputs (and carried memory) of the GPU step
+    travel through an .npz in the temporary directory; the child times the same model_forward call as the in-process legs."""
+    import subprocess
+    import tempfile
+    import numpy as np
+    cpus = _socket_cpus()
+    threads = max(1, min(threads, len(cpus)))
+    use = cpus[:threads]
+    np_ = lambda t: t.detach().float().cpu().contiguous().numpy()
+    arrays = {"imgs": np_(x_imgs), "poses": np_(x_poses), "intr": np_(intr)}
+    if pre_costs is not None:
+        for i, (k, v, p) in enumerate(zip(pre_costs["keys"], pre_costs["values"], pre_poses)):
+            arrays["key%d" % i], arrays["value%d" % i], arrays["pose%d" % i] = np_(k), np_(v), np_(p)
+    tmp = tempfile.mkdtemp(prefix="estd_cpuleg_")
+    path = os.path.join(tmp, "step.npz")
+    try:
+        np.savez(path, **arrays)
+        env = dict(os.environ, ESTD_CPU_LEG_CPUS=",".join(str(c) for c in use), OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads),
+                   OMP_PROC_BIND="close", OMP_PLACES="cores", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "ESTD_FORCE_DIST", "ESTD_BENCH_CHILD"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg-child", path, "--cpu-leg-kind", kind, "--workload", workload,
+                            "--cpu-threads", str(threads)], env=env, capture_output=True, text=True, timeout=1800)
+        res = None
+        for line in reversed(r.stdout.splitlines()):
+            if line.startswith("{"):
+                res = json.loads(line)
+                break
+        if r.returncode != 0 or res is None:
+            return {"value": 0.0, "unit": "depth frames/s", "cores": threads, "kind": kind, "wall_s": None, "pinned": None,
+                    "error": "child failed (rc %d): %s" % (r.returncode, (r.stderr or "")[-300:])}
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    dt = res["wall_s"]
+    how = "C/OpenMP oracle" if kind == "port" else "torch-CPU operators (oneDNN conv3d, ATen grid_sample / group_norm)"
+    return {"value": round(frames / dt, 4), "unit": "depth frames/s", "cores": threads, "kind": kind, "wall_s": round(dt, 2),
+            "pinned": "child process, %d threads on cpus %d-%d = physical cores of ONE socket (%d on it), affinity set before the first thread, "
+                      "OMP_PROC_BIND=close OMP_PLACES=cores; torch reports %d threads" % (threads, use[0], use[-1], len(cpus), res["torch_threads"]),
+            "cpu": "%s (%d hardware threads on the box)" % (_cpu_model_name(), os.cpu_count() or 1),
+            "sample": "ONE full step of this workload (%d depth frames: 2D networks on torch-CPU + %s for the whole 3D hot path), %.1f s wall, "
+                      "%d threads pinned to one socket" % (frames, how, dt, threads)}
+
+
+def cpu_leg_child(args):
+    """the child of cpu_leg_pinned(): affinity first (before numpy / torch create a thread), then the timed forward; prints one JSON line"""
+    cpus = [int(c) for c in os.environ.get("ESTD_CPU_LEG_CPUS", "").split(",") if c]
+    if cpus:
+        os.sched_setaffinity(0, cpus)
+    import contextlib
+    import numpy as np
+    import torch
+    from oracle import ref_model as M, ref_ops as O, torch_ops as TO
+    from oracle.nets2d import Nets2D, sd_numpy
+    torch.set_num_threads(args.cpu_threads)
+    O.set_num_threads(args.cpu_threads)
+    z = np.load(args.cpu_leg_child)
+    n_mem = sum(1 for k in z.files if k.startswith("key"))
+    pc = {"keys": [z["key%d" % i] for i in range(n_mem)], "values": [z["value%d" % i] for i in range(n_mem)]} if n_mem else None
+    pp = [z["pose%d" % i] for i in range(n_mem)] if n_mem else None
+    cpu_model = build_model(args.workload, "cpu")
+    P, nets = sd_numpy(cpu_model), Nets2D(model=cpu_model)
+    a_imgs, a_poses, a_intr = z["imgs"], z["poses"], z["intr"]
+    t0 = time.time()
+    with (M.use_ops(TO) if args.cpu_leg_kind == "torch-ops" else contextlib.nullcontext()):
+        ref, _, _ = M.model_forward(P, a_imgs, a_poses, a_intr, pc, pp, nets, ndepths=WORKLOADS[args.workload][3], depth_min=0.1, depth_max=10.0,
+                                    IF_EST_transformer=WORKLOADS[args.workload][5])
+    dt = time.time() - t0
+    print(json.dumps({"wall_s": dt, "torch_threads": torch.get_num_threads(), "affinity": len(os.sched_getaffinity(0)),
+                      "depth0_checksum": float(np.asarray(ref[("depth", 0, 0)], np.float64).sum())}), flush=True)
 
 
 _DEFAULT_TORCH_THREADS = [0]        # torch's own default (= the physical cores of the box), recorded before anything changes it
@@ -257,17 +322,9 @@ def cpu_baseline(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses,
     from oracle.nets2d import Nets2D, sd_numpy
     ncores = os.cpu_count() or 1
     threads = _DEFAULT_TORCH_THREADS[0] if threads <= 0 else min(threads, ncores)
-    pinned, full_mask = None, None
     if pin_socket:
-        # ``threads`` workers confined to the physical cores of ONE socket (one hardware thread per core): an unpinned oneDNN run across two
-        # sockets is SLOWER at 128 threads than at 8 (round 5: 0.115 vs 0.206 depth frames/s) -- not what the box's CPU path can do
-        cpus = _socket_cpus()
-        if cpus:
-            threads = min(threads, len(cpus))
-            full_mask = os.sched_getaffinity(0)
-            use = cpus[:threads]
-            _set_affinity_all_threads(use)
-            pinned = "%d threads on cpus %d-%d of one socket (%d physical cores on it; sched_setaffinity of every thread)" % (threads, use[0], use[-1], len(cpus))
+        return cpu_leg_pinned(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses, frames, kind), None
+    pinned = None
     O.set_num_threads(threads)
     torch.set_num_threads(threads)
     D = WORKLOADS[workload][3]
@@ -286,8 +343,6 @@ def cpu_baseline(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses,
         ref, _, _ = M.model_forward(P, a_imgs, a_poses, a_intr, pc, pp, nets, ndepths=D, depth_min=0.1, depth_max=10.0,
                                     IF_EST_transformer=WORKLOADS[workload][5])
     dt = time.time() - t0
-    if full_mask is not None:
-        _set_affinity_all_threads(full_mask)
     worst, arel = {}, {}
     for k, v in gpu_outputs.items():
         if k[0] == "depth":
@@ -582,6 +637,15 @@ def summarize(prof, peak_tf, algo="direct", arith="f32", replay=None):
 
 def main():
     args = parse()
+    if args.cpu_leg_child:
+        return cpu_leg_child(args)
+    if "bf16x3" in (args.conv3d_arith, args.conv2d_arith) or args.conv3d_algo == "wino":
+        # the superseded A/B kernels are not part of the default library: say so here, once, instead of in the middle of the first step
+        from estdepth_amd import _native
+        if not _native.has_ab():
+            raise SystemExit("bench.py: --conv3d-arith/--conv2d-arith bf16x3 and --conv3d-algo wino run on the superseded A/B kernels, which the "
+                             "default build does not carry: rebuild with ESTD_BUILD_AB=1 (`ESTD_BUILD_AB=1 python -m estdepth_amd.build`) and "
+                             "run with ESTD_BUILD_AB=1 in the environment")
     self_launch_if_needed(args)
     if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("ESTD_FORCE_DIST", "0") == "1") \
             and os.environ.get("ESTD_DIST_BACKEND", "nccl") == "nccl" and os.environ.get("ESTD_RCCL_DEBUG", "1") == "1":
@@ -1035,13 +1099,16 @@ def main():
                     continue                           # (a box without a 16-core socket: the unpinned legs say it all)
                 base, par = cpu_baseline(args.workload, th, x_imgs, x_poses, intr, pre_costs, pre_poses, gpu_outputs, frames, gpu_logits, kind=kind, pin_socket=pin)
                 runs.append(base)
+                if pin:
+                    continue
                 if kind == "port":
                     parity = par
                 else:
                     parity_t = par
             best = max(runs, key=lambda b: b["value"])
             line["cpu_baseline"] = dict(best)
-            line["cpu_baseline"]["all_runs"] = [{"kind": b["kind"], "cores": b["cores"], "value": b["value"], "wall_s": b["wall_s"], "pinned": b["pinned"]} for b in runs]
+            line["cpu_baseline"]["all_runs"] = [{"kind": b["kind"], "cores": b["cores"], "value": b["value"], "wall_s": b["wall_s"], "pinned": b["pinned"],
+                                                 **({"error": b["error"]} if "error" in b else {})} for b in runs]
             if parity_t is not None:      # the torch-operator leg's own view of the GPU depth (a second, independent CPU arithmetic)
                 parity["vs_torch_ops"] = {"max_abs_depth_diff_m": parity_t["max_abs_depth_diff_vs_oracle_m"], "abs_rel": parity_t["abs_rel_vs_oracle"]}
             line["parity"] = parity
@@ -1091,8 +1158,9 @@ def main():
         except Exception as e:
             res = {"algo": other, "error": "%s: %s" % (type(e).__name__, str(e)[:80])}
         # ESTD_AG_ALGO=auto (default): every rank has both figures now -- agree on them (MAX over the ranks) and, when the other algorithm
-        # wins by more than 10 %, run the K timed steps once more on it (still under the watchdog: the line as it stands is printed if
-        # this never returns) and report that as the result, the first pass beside it
+        # wins the exchange alone by more than 10 %, it is the CHOSEN algorithm: the K timed steps run once more on it (still under the
+        # watchdog: the line as it stands is printed if this never returns) and THAT pass is the line's value -- whichever way the
+        # step time moved (no minimum over the two passes); the first pass is reported beside it
         if parallel.AG_ALGO == "auto" and "ms_alone" in res and world > 1 and os.environ.get("ESTD_AG_AUTO_RETIME", "1") != "0":
             try:
                 tx = torch.tensor([ag["ms_alone"], res["ms_alone"]], device=device, dtype=torch.float64)
@@ -1100,13 +1168,13 @@ def main():
                 switch = float(tx[1]) < 0.9 * float(tx[0])
                 auto = {"ms_alone": {used_algo: round(float(tx[0]), 3), other: round(float(tx[1]), 3)}, "chosen": other if switch else used_algo}
                 if switch:
-                    parallel._ACTIVE["algo"] = other
+                    parallel.set_active_algo(other)
                     state["allgather"] = True
                     t2 = timed_plain()
                     state["allgather"] = False
                     auto["first_pass"] = {"algo": used_algo, "ms_per_step": round(1e3 * elapsed / args.steps, 3)}
                     auto["second_pass"] = {"algo": other, "ms_per_step": round(1e3 * t2 / args.steps, 3)}
-                    if rank == 0 and t2 < elapsed:
+                    if rank == 0:
                         line["value"] = round(frames * world * args.steps / t2, 3)
                         line["ms_per_step"] = round(1e3 * t2 / args.steps, 3)
                         line["config"]["input_frames_per_s"] = round(x_imgs.shape[1] * world * args.steps / t2, 3)

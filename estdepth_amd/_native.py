@@ -141,7 +141,7 @@ _SIGNATURES = {
 }
 
 # the superseded A/B kernels: exported only by a library built with ESTD_BUILD_AB=1 (estdepth_amd/build.py)
-AB_SYMBOLS = ("estd_conv3d_k3_split", "estd_conv3d_k3_wino", "estd_conv2d_k3_split", "estd_conv2d_k3_wino")
+AB_SYMBOLS = ("estd_conv3d_k3_split", "estd_conv3d_k3_wino", "estd_conv2d_k3_split", "estd_conv2d_k3_wino", "estd_conv3d_k3_wino2x")
 EXPORTED_SYMBOLS = tuple(k for k in _SIGNATURES if k not in AB_SYMBOLS)
 
 _lib = None

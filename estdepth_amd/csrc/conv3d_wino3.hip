@@ -731,7 +731,8 @@ extern "C" int estd_conv3d_k3_wino3(const estd_conv3d_desc* dp, estd_stream_t s)
     const estd_conv3d_desc& d = *dp;
     if (d.N <= 0 || d.D <= 0 || d.H <= 0 || d.W <= 0) return ESTD_ERR_ARG;
     if (!d.in_main || !d.w_wino2 || !d.scale || !d.shift || !d.out_main) return ESTD_ERR_ARG;
-    // 32 -> 32 only: no scalar channels, no fused head, no GroupNorm partial sums, no gate
+    // 32 output channels: 32 -> 32 with every read-back epilogue, 32 -> 32 + GroupNorm partial sums and 33 -> 32 (scalar input channel) without
+    // read-back streams; no 33rd output channel, no fused head, no gate (include/estd_hip.h)
     if (d.cin_main != 32 || d.n_tiles != 2 || d.out_head || d.out_extra || d.gate_r) return ESTD_ERR_UNSUPPORTED;
     const bool extra = d.in_extra != nullptr;
     if (extra != (d.w_extra != nullptr)) return ESTD_ERR_ARG;

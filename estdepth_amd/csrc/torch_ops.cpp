@@ -146,7 +146,7 @@ void homo_warp_costvol(const Tensor& src_mix, const Tensor& ref_mix, const Tenso
 // ------------------------------------------------------------------------------------------------ conv3d / conv2d
 // Volumes are addressed as base pointers + strides (views into wider channels-last records are allowed), so only device
 // and dtype are checked for them; the C ABI validates the stride / channel combinations.
-void conv3d_k3(const Tensor& x, const OptTensor& x_extra, const Tensor& w_main, const OptTensor& w_extra, const OptTensor& w_xout,
+void conv3d_k3(const Tensor& x, const OptTensor& x_extra, const OptTensor& w_main, const OptTensor& w_extra, const OptTensor& w_xout,
                const OptTensor& w_alt, const Tensor& scale, const Tensor& shift, at::IntArrayRef dims, int64_t cin_main,
                int64_t in_stride, int64_t n_tiles, int64_t act_a, int64_t act_b, int64_t act_split, const OptTensor& out,
                int64_t out_stride, int64_t out_channels, const OptTensor& residual, const OptTensor& residual2, double out_scale,
@@ -163,7 +163,8 @@ void conv3d_k3(const Tensor& x, const OptTensor& x_extra, const Tensor& w_main, 
     d.in_main = fptr(x, "conv3d input", false);
     d.in_extra = opt_fptr(x_extra, "conv3d extra input channel");
     if (d.in_extra) TORCH_CHECK(x_extra->numel() >= vox, "conv3d_k3: extra input channel smaller than N*D*H*W");
-    d.w_main = fptr(w_main, "packed weights");
+    d.w_main = opt_fptr(w_main, "packed weights");      // the direct kernel reads it (variant 0); the Winograd variants read w_alt
+    TORCH_CHECK(variant != 0 || d.w_main, "conv3d_k3: the direct kernel (variant 0) needs w_main");
     d.w_extra = opt_fptr(w_extra, "packed extra-channel weights");
     d.w_xout = opt_fptr(w_xout, "packed 33rd-output weights");
     TORCH_CHECK((d.in_extra == nullptr) == (d.w_extra == nullptr), "conv3d plan/extra-channel mismatch");
@@ -217,8 +218,12 @@ void conv3d_k3(const Tensor& x, const OptTensor& x_extra, const Tensor& w_main, 
         d.w_wino2 = fptr(*w_alt, "2-axis Winograd-packed weights");
         check_status(estd_conv3d_k3_wino2(&d, cur_stream()), "estd_conv3d_k3_wino2");
     } else if (variant == 4) {          // the 32 -> 32 instance on the operand-reuse kernel (w_alt = packing.pack_conv3d_wino2x)
+#ifdef ESTD_BUILD_AB
         d.w_wino2 = fptr(*w_alt, "2-axis Winograd-packed weights (reuse form)");
         check_status(estd_conv3d_k3_wino2x(&d, cur_stream()), "estd_conv3d_k3_wino2x");
+#else
+        TORCH_CHECK(false, "conv3d_k3: variant 4 (operand-reuse two-axis Winograd kernel) needs a library built with ESTD_BUILD_AB=1");
+#endif
     } else if (variant == 5) {          // the 32 -> 32 instance with all three axes in Winograd form (w_alt = packing.pack_conv3d_wino3)
         d.w_wino2 = fptr(*w_alt, "3-axis Winograd-packed weights");
         check_status(estd_conv3d_k3_wino3(&d, cur_stream()), "estd_conv3d_k3_wino3");
@@ -228,7 +233,7 @@ void conv3d_k3(const Tensor& x, const OptTensor& x_extra, const Tensor& w_main, 
     }
 }
 
-Tensor conv2d_k3(const Tensor& x_nhwc, const Tensor& w, const OptTensor& w_alt, const Tensor& scale, const Tensor& shift,
+Tensor conv2d_k3(const Tensor& x_nhwc, const OptTensor& w, const OptTensor& w_alt, const Tensor& scale, const Tensor& shift,
                  int64_t cout, int64_t dilation, int64_t group_tiles, bool relu_before_residual, bool relu_after_residual,
                  const OptTensor& residual, int64_t variant)
 {
@@ -238,7 +243,8 @@ Tensor conv2d_k3(const Tensor& x_nhwc, const Tensor& w, const OptTensor& w_alt, 
     d.N = (int)x_nhwc.size(0); d.H = (int)x_nhwc.size(1); d.W = (int)x_nhwc.size(2); d.cin = (int)x_nhwc.size(3);
     d.cout = (int)cout; d.dilation = (int)dilation; d.group_tiles = (int)group_tiles;
     d.in = fptr(x_nhwc, "conv2d input");
-    d.w = fptr(w, "packed conv2d weights");
+    d.w = opt_fptr(w, "packed conv2d weights");         // the direct kernel reads it (variant 0); the other variants read w_alt
+    TORCH_CHECK(variant != 0 || d.w, "conv2d_k3: the direct kernel (variant 0) needs w");
     d.scale = fptr(scale, "scale"); d.shift = fptr(shift, "shift");
     TORCH_CHECK(scale.numel() == cout && shift.numel() == cout, "conv2d_k3: scale/shift must have Cout entries");
     d.relu_before_residual = relu_before_residual; d.relu_after_residual = relu_after_residual;
@@ -715,12 +721,12 @@ TORCH_LIBRARY(estdepth_hip, m)
     m.def("homo_warping_px(Tensor src_fea, Tensor proj12, Tensor depth_dhw) -> Tensor");
     m.def("mix1x1(Tensor feature, Tensor weight, Tensor? bias) -> Tensor");
     m.def("homo_warp_costvol(Tensor src_mix, Tensor ref_mix, Tensor proj12, Tensor depth_values, int D, Tensor(a!) out) -> ()");
-    m.def("conv3d_k3(Tensor x, Tensor? x_extra, Tensor w_main, Tensor? w_extra, Tensor? w_xout, Tensor? w_alt, Tensor scale, Tensor shift, "
+    m.def("conv3d_k3(Tensor x, Tensor? x_extra, Tensor? w_main, Tensor? w_extra, Tensor? w_xout, Tensor? w_alt, Tensor scale, Tensor shift, "
           "int[] dims, int cin_main, int in_stride, int n_tiles, int act_a, int act_b, int act_split, Tensor(a!)? out, int out_stride, "
           "int out_channels, Tensor? residual, Tensor? residual2, float out_scale, bool accumulate, Tensor(b!)? out_extra, Tensor? head_w, "
           "Tensor? head_b, Tensor(c!)? out_head, Tensor(d!)? stats_partials, int variant, Tensor? gate_r=None, Tensor? gate_stats=None, "
           "Tensor? gate_gamma=None, Tensor? gate_beta=None) -> ()");
-    m.def("conv2d_k3(Tensor x_nhwc, Tensor w, Tensor? w_alt, Tensor scale, Tensor shift, int cout, int dilation, int group_tiles, "
+    m.def("conv2d_k3(Tensor x_nhwc, Tensor? w, Tensor? w_alt, Tensor scale, Tensor shift, int cout, int dilation, int group_tiles, "
           "bool relu_before_residual, bool relu_after_residual, Tensor? residual, int variant) -> Tensor");
     m.def("groupnorm_finalize(Tensor partials, int n_blocks, float count, float eps) -> Tensor");
     m.def("softargmin_up(Tensor logits, Tensor depth_values, int scale) -> (Tensor, Tensor)");

@@ -80,9 +80,11 @@ class GraphedForward:
 
     def _signature(self, imgs, pre_costs, mode, matching_features, placement=(None, None)):
         n_mem = 0 if pre_costs is None else len(pre_costs["keys"])
-        from . import ops
+        from . import ops, epipolar_transformer as ET
         return (tuple(imgs.shape), n_mem, None if matching_features is None else int(matching_features.shape[0]), mode, ops.CONV3D_ARITH, ops.CONV2D_ARITH,
-                ops.CONV3D_ALGO, getattr(ops, "CONV2D_ALGO", None), getattr(ops, "CONV2D_NT", None),      # a graph bakes the kernel choice in
+                ops.CONV3D_ALGO, getattr(ops, "CONV2D_ALGO", None), getattr(ops, "CONV2D_NT", None),      # a graph bakes the kernel choice in:
+                # ... the module-level kernel switches tests and tools flip at run time, and the grid sizes of the two stages
+                (ops.W3, ops.W3_EXTRA, ops.W2X, ops.W2_XOUT, ET.GATE_IN_CONV), self.reserve_cus,
                 self.model.camera_algebra,
                 placement,                                         # zero-copy mode: (addresses of the memory records, output ring slot)
                 getattr(self.model, "_estd_weights_epoch", 0))     # (last) a captured graph bakes kernel choice and weight buffers in
@@ -161,13 +163,29 @@ class GraphedForward:
             finally:
                 m.CostRegNet.kv_out = None
 
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(self.warmup):      # MIOpen algorithm search, hipFuncSetAttribute, plan packing: all before capture
-                run_b(run_a())
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(self.warmup):      # hipFuncSetAttribute, plan packing (weight forms are packed on first use): all before capture
+                    run_b(run_a())
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            ga, gb, feats, out = self._capture_graphs(key, run_a, run_b)
+        finally:
+            # the stage reserves are process-wide state (estd_set_reserved_cus): restored whether or not warm-up / capture succeeded --
+            # an exception in there must not leave every later eager launch and capture on the wrong grid size
+            if prev_reserve is not None:
+                ops.set_reserved_cus(prev_reserve)
+        if kv_out is not None:
+            # zero-copy contract: the record this capture hands out IS the ring slot it was told to write
+            rec = getattr(out[1]["values"][0], "_estd_kv", None)
+            if rec is None or rec.data_ptr() != kv_out[-1].data_ptr():
+                raise RuntimeError("zero-copy memory: the captured forward did not write its memory record into the ring buffer it was given")
+        st["graph_a"], st["graph_b"], st["feats2d"], st["out"] = ga, gb, feats, out
+        return self._finish_capture(key, st)
+
+    def _capture_graphs(self, key, run_a, run_b):
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # ONE memory pool for every capture of a call shape (zero-copy mode makes one capture per (memory addresses, ring slot): the ESTM
         # stream settles at 3 + the start-up signatures): the captures never run concurrently, so the intermediates of one replay may
@@ -183,14 +201,10 @@ class GraphedForward:
             feats = run_a()
         with torch.no_grad(), torch.cuda.graph(gb, pool=pool, capture_error_mode="thread_local"):
             out = run_b(feats)
-        if prev_reserve is not None:
-            ops.set_reserved_cus(prev_reserve)
-        if kv_out is not None:
-            # zero-copy contract: the record this capture hands out IS the ring slot it was told to write
-            rec = getattr(out[1]["values"][0], "_estd_kv", None)
-            if rec is None or rec.data_ptr() != kv_out[-1].data_ptr():
-                raise RuntimeError("zero-copy memory: the captured forward did not write its memory record into the ring buffer it was given")
-        st["graph_a"], st["graph_b"], st["feats2d"], st["out"] = ga, gb, feats, out
+        return ga, gb, feats, out
+
+    def _finish_capture(self, key, st):
+        m = self.model
         st["memory_logits"] = getattr(m.CostRegNet, "memory_logits", None)     # static buffer of graph B (rewritten by every replay)
         # the logit volumes a caller asked the decoder to keep (``keep_logits``): buffers of THIS capture -- the decoder's attribute is pointed
         # at them again after every replay (it would otherwise name the buffers of whichever capture was made last, which a shared pool

@@ -213,44 +213,87 @@ def homo_warp_costvol(src_mix, ref_mix, proj12, depth_values, D, out=None):
 
 
 # ---------------------------------------------------------------------------------- conv3d
+class _Packs:
+    """Weight forms of a plan, packed and uploaded on first use (``define`` registers how, ``has`` says whether the plan's shape admits the
+    form, ``get`` packs once).  Shared by the copies ``with_shift_scaled`` makes."""
+
+    def __init__(self, device):
+        self.device, self._fns, self._vals = device, {}, {}
+
+    def define(self, name, fn):
+        self._fns[name] = fn
+
+    def has(self, name):
+        return name in self._fns
+
+    def get(self, name):
+        if name not in self._vals:
+            fn = self._fns.get(name)
+            self._vals[name] = fn().to(self.device) if fn is not None else None
+        return self._vals[name]
+
+    def packed(self):
+        """names of the forms that have been packed so far"""
+        return sorted(k for k, v in self._vals.items() if v is not None)
+
+
 class Conv3dPlan:
     """Packed weights + epilogue constants of one 3x3x3 convolution, resident on a device."""
 
+    def __getattr__(self, name):                     # self.w_<form>: packed on first use (None when the plan's shape has no such form)
+        if name.startswith("w_") and "_packs" in self.__dict__:
+            return self._packs.get(name)
+        raise AttributeError(name)
+
     def __init__(self, weight, main_idx, extra_idx, out_idx, n_tiles, scale, shift, act_a="none", act_b=None,
                  act_split=0, head_w=None, head_b=None, device="cuda"):
-        wm, wx = packing.pack_conv3d(weight, main_idx, extra_idx, out_idx, n_tiles)
-        self.w_xout = packing.pack_xout(weight, main_idx, extra_idx, out_idx[32]).to(device) if n_tiles == 3 else None
         self.cin_main = len(main_idx)
         self.n_tiles = n_tiles
         self.n_out = len(out_idx)
+        self.has_extra = extra_idx is not None
+        weight = weight.detach()
+        # Weight forms are packed ON FIRST USE (``self.w_<form>``, ``_Packs``): a plan carries only what the kernels it is actually run on
+        # read -- under the default switches one Winograd form per plan, the direct kernel's ``w_main`` only where a launch falls back to it.
+        # (Every launch of a captured forward has run eagerly first: GraphedForward warms up before it captures.)
+        P = self._packs = _Packs(device)
+        P.define("w_main", lambda: packing.pack_conv3d(weight, main_idx, extra_idx, out_idx, n_tiles)[0])
+        if extra_idx is not None:
+            P.define("w_extra", lambda: packing.pack_conv3d(weight, main_idx, extra_idx, out_idx, n_tiles)[1])
+        if n_tiles == 3:
+            P.define("w_xout", lambda: packing.pack_xout(weight, main_idx, extra_idx, out_idx[32]))
         splittable = len(main_idx) == 32 and head_w is None and \
             (n_tiles == 2 or (n_tiles == 3 and extra_idx is not None) or (n_tiles == 1 and extra_idx is None))
-        ab = N.has_ab()      # the superseded A/B kernels (bf16 operand split, depth-only Winograd): only in a library built with ESTD_BUILD_AB=1
-        self.w_split = packing.pack_conv3d_split(weight, main_idx, out_idx, extra_idx, n_tiles).to(device) if (splittable and ab) else None
+        # the superseded A/B kernels (bf16 operand split, depth-only Winograd, operand-reuse wino2x): only in a library built with ESTD_BUILD_AB=1
+        ab = N.has_ab()
+        if splittable and ab:
+            P.define("w_split", lambda: packing.pack_conv3d_split(weight, main_idx, out_idx, extra_idx, n_tiles))
         wino_ok = len(main_idx) == 32 and head_w is None and \
             ((n_tiles == 2 and len(out_idx) == 32) or (n_tiles == 3 and len(out_idx) == 33 and extra_idx is not None))
         self.wino_ok = wino_ok
-        self.w_wino = packing.pack_conv3d_wino(weight, main_idx, out_idx[:32]).to(device) if (wino_ok and ab) else None
-        self.w_wino_extra = packing.pack_conv3d_wino_extra(weight, extra_idx, out_idx[:32]).to(device) if (wino_ok and ab and extra_idx is not None) else None
-        self.w_wino_xout = packing.pack_conv3d_wino_xout(weight, main_idx, extra_idx, out_idx[32]).to(device) if (wino_ok and ab and n_tiles == 3) else None
-        self.w_wino2 = packing.pack_conv3d_wino2(weight, main_idx, out_idx[:32]).to(device) if wino_ok else None
-        self.w_wino2x = packing.pack_conv3d_wino2x(weight, main_idx, out_idx[:32]).to(device) \
-            if (wino_ok and n_tiles == 2 and extra_idx is None) else None
-        self.w_wino3 = packing.pack_conv3d_wino3(weight, main_idx, out_idx[:32]).to(device) if (wino_ok and n_tiles == 2) else None
-        self.w_wino3_extra = packing.pack_conv3d_wino3_extra(weight, extra_idx, out_idx[:32]).to(device) \
-            if (wino_ok and n_tiles == 2 and extra_idx is not None) else None
-        self.w_wino2_extra = packing.pack_conv3d_wino2_extra(weight, extra_idx, out_idx[:32]).to(device) \
-            if (wino_ok and extra_idx is not None) else None
-        # 33 -> 33 (dres2): the 33rd output channel of the wino2 kernel's XOUT instance
-        self.w_wino2_xout = packing.pack_conv3d_wino2_xout(weight, main_idx, extra_idx, out_idx[32]).to(device) if (wino_ok and n_tiles == 3) else None
+        if wino_ok and ab:
+            P.define("w_wino", lambda: packing.pack_conv3d_wino(weight, main_idx, out_idx[:32]))
+            if extra_idx is not None:
+                P.define("w_wino_extra", lambda: packing.pack_conv3d_wino_extra(weight, extra_idx, out_idx[:32]))
+            if n_tiles == 3:
+                P.define("w_wino_xout", lambda: packing.pack_conv3d_wino_xout(weight, main_idx, extra_idx, out_idx[32]))
+            if n_tiles == 2 and extra_idx is None:
+                P.define("w_wino2x", lambda: packing.pack_conv3d_wino2x(weight, main_idx, out_idx[:32]))
+        if wino_ok:
+            P.define("w_wino2", lambda: packing.pack_conv3d_wino2(weight, main_idx, out_idx[:32]))
+            if n_tiles == 2:
+                P.define("w_wino3", lambda: packing.pack_conv3d_wino3(weight, main_idx, out_idx[:32]))
+                if extra_idx is not None:
+                    P.define("w_wino3_extra", lambda: packing.pack_conv3d_wino3_extra(weight, extra_idx, out_idx[:32]))
+            if extra_idx is not None:
+                P.define("w_wino2_extra", lambda: packing.pack_conv3d_wino2_extra(weight, extra_idx, out_idx[:32]))
+            if n_tiles == 3:       # 33 -> 33 (dres2): the 33rd output channel of the wino2 kernel's XOUT instance
+                P.define("w_wino2_xout", lambda: packing.pack_conv3d_wino2_xout(weight, main_idx, extra_idx, out_idx[32]))
         # 32 -> 16 (the GRU output convolution): the wino2 kernel's 16-output-channel instance
-        self.w_wino2_o16 = packing.pack_conv3d_wino2(weight, main_idx, out_idx[:16]).to(device) \
-            if (len(main_idx) == 32 and n_tiles == 1 and len(out_idx) == 16 and extra_idx is None and head_w is None) else None
+        if len(main_idx) == 32 and n_tiles == 1 and len(out_idx) == 16 and extra_idx is None and head_w is None:
+            P.define("w_wino2_o16", lambda: packing.pack_conv3d_wino2(weight, main_idx, out_idx[:16]))
         # 16 -> 16 + 1x1x1 head (the stereo heads): csrc/conv3d_wino2_c16.hip
-        self.w_wino2_c16 = packing.pack_conv3d_wino2_c16(weight, main_idx, out_idx[:16]).to(device) \
-            if (len(main_idx) == 16 and n_tiles == 1 and len(out_idx) == 16 and extra_idx is None and head_w is not None) else None
-        self.w_main = wm.to(device)
-        self.w_extra = wx.to(device) if wx is not None else None
+        if len(main_idx) == 16 and n_tiles == 1 and len(out_idx) == 16 and extra_idx is None and head_w is not None:
+            P.define("w_wino2_c16", lambda: packing.pack_conv3d_wino2_c16(weight, main_idx, out_idx[:16]))
         self.scale = scale.float().contiguous().to(device)
         self.shift = shift.float().contiguous().to(device)
         self.act_a = ACT[act_a]
@@ -273,8 +316,9 @@ class Conv3dPlan:
         ``gate`` = (ru [N,D,H,W,32], statistics [4], gamma [16], beta [16]): the ConvGRU's reset gate applied to input channels 16..31 in the
         convolution's own loads (32 -> 16 instance of the two-axis Winograd kernel only; include/estd_hip.h ``gate_r``)."""
         Nn, D, H, W = dims
-        if (in_extra is None) != (self.w_extra is None):
+        if (in_extra is None) == self.has_extra:
             raise RuntimeError("conv3d plan/extra-channel mismatch")
+        has = self._packs.has
         if CONV3D_ARITH not in ("f32", "bf16x3"):
             raise RuntimeError("ESTD_CONV3D_ARITH must be f32 or bf16x3, got %r" % (CONV3D_ARITH,))
         in_stride = in_stride if in_stride is not None else self.cin_main
@@ -287,49 +331,54 @@ class Conv3dPlan:
         if self.n_tiles == 3:
             inst = not tanh and stats_partials is None
         elif self.n_tiles == 1:
-            inst = not tanh and self.w_extra is None
-        elif self.w_extra is not None:
+            inst = not tanh and not self.has_extra
+        elif self.has_extra:
             inst = stats_partials is None
         else:
             inst = not tanh
         if CONV3D_ARITH == "bf16x3":
             N.require_ab("ESTD_CONV3D_ARITH=bf16x3 (csrc/conv3d_split_bf16.hip)")
-        split = CONV3D_ARITH == "bf16x3" and self.w_split is not None and out is not None and inst
+        split = CONV3D_ARITH == "bf16x3" and has("w_split") and out is not None and inst
         if CONV3D_ALGO not in ("wino2", "wino", "direct"):
             raise RuntimeError("ESTD_CONV3D_ALGO must be wino2, wino or direct, got %r" % (CONV3D_ALGO,))
         if CONV3D_ALGO == "wino":
             N.require_ab("ESTD_CONV3D_ALGO=wino (csrc/conv3d_wino.hip)")
         wino_shape = (not split) and CONV3D_ALGO in ("wino", "wino2") and self.wino_ok and out is not None \
             and (out_extra is not None) == (self.n_tiles == 3) and out_head is None and out_channels == 32 \
-            and (stats_partials is None or self.w_extra is None)
-        wino2 = wino_shape and CONV3D_ALGO == "wino2" and self.w_wino2 is not None and (in_extra is None or stats_partials is None)
+            and (stats_partials is None or not self.has_extra)
+        wino2 = wino_shape and CONV3D_ALGO == "wino2" and has("w_wino2") and (in_extra is None or stats_partials is None)
         if self.n_tiles == 3:                             # the XOUT instance has no read-back streams / statistics (dres2 needs none)
             wino2 = wino2 and W2_XOUT and residual is None and residual2 is None and not accumulate and float(out_scale) == 1.0 and stats_partials is None
         # the depth-only kernel: ESTD_CONV3D_ALGO=wino, or dres2 with ESTD_W2_XOUT=0 -- where the library carries it (else the direct kernel)
-        wino = wino_shape and not wino2 and self.w_wino is not None
-        o16 = (not split) and CONV3D_ALGO == "wino2" and self.w_wino2_o16 is not None and out is not None and out_head is None \
+        wino = wino_shape and not wino2 and has("w_wino")
+        o16 = (not split) and CONV3D_ALGO == "wino2" and has("w_wino2_o16") and out is not None and out_head is None \
             and in_extra is None and out_channels == 16 and out_extra is None
         # the stereo heads: only the head's logit volume leaves the kernel, no tanh
-        c16 = (not split) and CONV3D_ALGO == "wino2" and self.w_wino2_c16 is not None and out is None and out_head is not None \
+        c16 = (not split) and CONV3D_ALGO == "wino2" and has("w_wino2_c16") and out is None and out_head is not None \
             and in_extra is None and out_extra is None and residual is None and residual2 is None and not accumulate \
             and stats_partials is None and float(out_scale) == 1.0 and not tanh
         # 32 -> 32 without a scalar channel and without tanh: the operand-reuse kernel (GroupNorm partials only without read-back streams)
-        wino2x = wino2 and W2X and self.w_wino2x is not None and in_extra is None and self.n_tiles == 2 and not tanh \
+        wino2x = wino2 and W2X and has("w_wino2x") and in_extra is None and self.n_tiles == 2 and not tanh \
             and (stats_partials is None or (residual is None and residual2 is None and not accumulate and float(out_scale) == 1.0))
         plain_epi = residual is None and residual2 is None and not accumulate and float(out_scale) == 1.0
-        wino3 = wino2 and W3 and self.w_wino3 is not None and self.n_tiles == 2 and (stats_partials is None or plain_epi) \
-            and (in_extra is None or (W3_EXTRA and self.w_wino3_extra is not None and plain_epi and stats_partials is None))
+        wino3 = wino2 and W3 and has("w_wino3") and self.n_tiles == 2 and (stats_partials is None or plain_epi) \
+            and (in_extra is None or (W3_EXTRA and has("w_wino3_extra") and plain_epi and stats_partials is None))
         wino2x = wino2x and not wino3
-        variant, w_alt = (1, self.w_split) if split else (3, self.w_wino2_c16) if c16 else (3, self.w_wino2_o16) if o16 else (5, self.w_wino3) if wino3 \
-            else (4, self.w_wino2x) if wino2x \
-            else (3, self.w_wino2) if wino2 else (2, self.w_wino) if wino else (0, None)
+        variant, alt = (1, "w_split") if split else (3, "w_wino2_c16") if c16 else (3, "w_wino2_o16") if o16 else (5, "w_wino3") if wino3 \
+            else (4, "w_wino2x") if wino2x \
+            else (3, "w_wino2") if wino2 else (2, "w_wino") if wino else (0, None)
+        if W2X:
+            N.require_ab("ESTD_W2X=1 (csrc/conv3d_wino2x.hip)")
+        w_alt = self._packs.get(alt) if alt is not None else None
         if gate is not None and not o16:
             raise RuntimeError("the reset gate is folded into the 32 -> 16 instance of the two-axis Winograd kernel only")
         g_r, g_st, g_ga, g_be = gate if gate is not None else (None, None, None, None)
-        cin = self.cin_main + (1 if self.w_extra is not None else 0)
+        cin = self.cin_main + (1 if self.has_extra else 0)
         with _Prof("conv3d:%d->%d" % (cin, self.n_out), 2.0 * 27 * cin * self.n_out * Nn * D * H * W):
             if _use_torch():
-                T().conv3d_k3(x, in_extra, self.w_main, self.w_wino3_extra if wino3 else self.w_wino2_extra if wino2 else self.w_wino_extra if wino else self.w_extra,
+                direct = variant in (0, 1)          # (the operand-split kernel reads the direct form's scalar-channel / 33rd-output weights)
+                T().conv3d_k3(x, in_extra, self.w_main if direct else None,
+                              self.w_wino3_extra if wino3 else self.w_wino2_extra if wino2 else self.w_wino_extra if wino else self.w_extra,
                               self.w_wino2_xout if wino2 else self.w_wino_xout if wino else self.w_xout, w_alt, self.scale, self.shift,
                               (Nn, D, H, W), self.cin_main, in_stride, self.n_tiles, self.act_a, self.act_b, self.act_split, out,
                               out_stride, out_channels, residual, residual2, float(out_scale), bool(accumulate), out_extra, head_w, head_b,
@@ -340,9 +389,10 @@ class Conv3dPlan:
             d.cin_main, d.in_stride, d.n_tiles = self.cin_main, in_stride, self.n_tiles
             d.in_main = x.data_ptr()
             d.in_extra = in_extra.data_ptr() if in_extra is not None else None
-            d.w_main = self.w_main.data_ptr()
-            d.w_extra = self.w_extra.data_ptr() if self.w_extra is not None else None
-            d.w_xout = self.w_xout.data_ptr() if self.w_xout is not None else None
+            if variant in (0, 1):
+                d.w_main = self.w_main.data_ptr()
+                d.w_extra = self.w_extra.data_ptr() if self.has_extra else None
+                d.w_xout = self.w_xout.data_ptr() if self.n_tiles == 3 else None
             d.scale, d.shift = self.scale.data_ptr(), self.shift.data_ptr()
             d.act_a, d.act_b, d.act_split = self.act_a, self.act_b, self.act_split
             d.out_main = out.data_ptr() if out is not None else None
@@ -376,13 +426,13 @@ class Conv3dPlan:
                 N.check(N.lib().estd_conv3d_k3_wino2x(ctypes.byref(d), _stream()), "estd_conv3d_k3_wino2x")
             elif wino2:
                 d.w_wino2 = self.w_wino2.data_ptr()
-                d.w_extra = self.w_wino2_extra.data_ptr() if self.w_wino2_extra is not None else None
-                d.w_xout = self.w_wino2_xout.data_ptr() if self.w_wino2_xout is not None else None
+                d.w_extra = self.w_wino2_extra.data_ptr() if self.has_extra else None
+                d.w_xout = self.w_wino2_xout.data_ptr() if self.n_tiles == 3 else None
                 N.check(N.lib().estd_conv3d_k3_wino2(ctypes.byref(d), _stream()), "estd_conv3d_k3_wino2")
             elif wino:
                 d.w_wino = self.w_wino.data_ptr()
-                d.w_extra = self.w_wino_extra.data_ptr() if self.w_wino_extra is not None else None
-                d.w_xout = self.w_wino_xout.data_ptr() if self.w_wino_xout is not None else None
+                d.w_extra = self.w_wino_extra.data_ptr() if self.has_extra else None
+                d.w_xout = self.w_wino_xout.data_ptr() if self.n_tiles == 3 else None
                 N.check(N.lib().estd_conv3d_k3_wino(ctypes.byref(d), _stream()), "estd_conv3d_k3_wino")
             else:
                 N.check(N.lib().estd_conv3d_k3(ctypes.byref(d), _stream()), "estd_conv3d_k3")
@@ -403,19 +453,28 @@ class Conv2dPlan:
         self.cin, self.cout, self.dil = conv.in_channels, conv.out_channels, conv.dilation[0]
         # output channels per work item: 64 (NT = 4: the input brick feeds twice the MFMAs) unless that leaves the 512 resident
         # workgroups badly balanced (e.g. 64 -> 64 on 5 x 120x160: 750 items = 1.46 rounds, 87 TFLOP/s; NT = 2: 1500 items, 103)
-        self.w_nt = {2: packing.pack_conv2d(conv.weight, 2).to(dev)}
-        if self.cout % 64 == 0:
-            self.w_nt[4] = packing.pack_conv2d(conv.weight, 4).to(dev)
-        ab = N.has_ab()      # row-only Winograd / bf16 operand split: only in a library built with ESTD_BUILD_AB=1
-        self.w_split = packing.pack_conv2d_split(conv.weight).to(dev) if ab else None
-        self.w_wino = {nt: packing.pack_conv2d_wino(conv.weight, nt).to(dev) for nt in self.w_nt} if ab else {}
-        self.w_wino2 = packing.pack_conv2d_wino2(conv.weight).to(dev)      # F(2x2, 3x3): csrc/conv2d_wino2.hip (dilation 1 and 2)
+        # weight forms packed on first use (see Conv3dPlan): the default path reads w_wino2 only
+        w = conv.weight.detach()
+        P = self._packs = _Packs(dev)
+        self.nts = (2, 4) if self.cout % 64 == 0 else (2,)
+        for nt in self.nts:
+            P.define("w_nt%d" % nt, lambda nt=nt: packing.pack_conv2d(w, nt))
+        if N.has_ab():       # row-only Winograd / bf16 operand split: only in a library built with ESTD_BUILD_AB=1
+            P.define("w_split", lambda: packing.pack_conv2d_split(w))
+            for nt in self.nts:
+                P.define("w_wino_nt%d" % nt, lambda nt=nt: packing.pack_conv2d_wino(w, nt))
+        P.define("w_wino2", lambda: packing.pack_conv2d_wino2(w))      # F(2x2, 3x3): csrc/conv2d_wino2.hip (dilation 1 and 2)
         sc, sh = packing.fold_bn_fp32(bn, list(range(self.cout)))
         self.scale, self.shift = sc.to(dev), sh.to(dev)
         self.relu_before, self.relu_after = int(relu_before), int(relu_after)
 
+    def __getattr__(self, name):                     # self.w_<form>: packed on first use (None when the plan has no such form)
+        if name.startswith("w_") and "_packs" in self.__dict__:
+            return self._packs.get(name)
+        raise AttributeError(name)
+
     def _pick_nt(self, n, h, w):
-        if 4 not in self.w_nt:
+        if 4 not in self.nts:
             return 2
         if CONV2D_NT in ("2", "4"):               # A/B switch (ESTD_CONV2D_NT): force the work-item width
             return int(CONV2D_NT)
@@ -438,33 +497,36 @@ class Conv2dPlan:
             N.require_ab("ESTD_CONV2D_ARITH=bf16x3 (csrc/conv2d_split_bf16.hip)")
         if CONV2D_ALGO == "wino":
             N.require_ab("ESTD_CONV2D_ALGO=wino (csrc/conv2d_wino.hip)")
-        split = CONV2D_ARITH == "bf16x3" and self.w_split is not None
+        has = self._packs.has
+        split = CONV2D_ARITH == "bf16x3" and has("w_split")
         if self.dil == 2 and not split and CONV2D_ALGO in ("wino", "wino2"):
             nt = 2        # the 64-channel work item of the dilated Winograd kernel spills registers into its MFMA loop (5x slower)
         if CONV2D_ALGO not in ("wino2", "wino", "direct"):
             raise RuntimeError("ESTD_CONV2D_ALGO must be wino2, wino or direct, got %r" % (CONV2D_ALGO,))
-        wino2 = (not split) and CONV2D_ALGO == "wino2" and self.w_wino2 is not None and (self.dil == 1 or C2W2_DIL2)
-        wino = (not split) and not wino2 and CONV2D_ALGO in ("wino", "wino2") and nt in self.w_wino
-        variant, w_alt = (1, self.w_split) if split else (3, self.w_wino2) if wino2 else (2, self.w_wino[nt]) if wino else (0, None)
+        wino2 = (not split) and CONV2D_ALGO == "wino2" and (self.dil == 1 or C2W2_DIL2)
+        wino = (not split) and not wino2 and CONV2D_ALGO in ("wino", "wino2") and has("w_wino_nt%d" % nt)
+        variant, alt = (1, "w_split") if split else (3, "w_wino2") if wino2 else (2, "w_wino_nt%d" % nt) if wino else (0, None)
+        w_alt = self._packs.get(alt) if alt is not None else None
+        w_direct = self._packs.get("w_nt%d" % nt) if variant in (0, 1) else None      # (the operand-split kernel validates d.w as well)
         if _use_torch():
-            return T().conv2d_k3(x_nhwc, self.w_nt[nt], w_alt, self.scale, self.shift, self.cout, self.dil, nt,
+            return T().conv2d_k3(x_nhwc, w_direct, w_alt, self.scale, self.shift, self.cout, self.dil, nt,
                                  bool(self.relu_before), bool(self.relu_after), residual, variant)
         out = torch.empty((Nn, H, W, self.cout), device=x_nhwc.device, dtype=torch.float32)
         d = N.Conv2dDesc()
         d.N, d.H, d.W, d.cin, d.cout, d.dilation, d.group_tiles = Nn, H, W, self.cin, self.cout, self.dil, nt
         d.in_ = _chk(x_nhwc, "conv2d input").data_ptr()
-        d.w, d.scale, d.shift = self.w_nt[nt].data_ptr(), self.scale.data_ptr(), self.shift.data_ptr()
+        d.w, d.scale, d.shift = (w_direct.data_ptr() if w_direct is not None else None), self.scale.data_ptr(), self.shift.data_ptr()
         d.relu_before_residual, d.relu_after_residual = self.relu_before, self.relu_after
         d.residual = residual.data_ptr() if residual is not None else None
         d.out = out.data_ptr()
         if split:
-            d.w_split = self.w_split.data_ptr()
+            d.w_split = w_alt.data_ptr()
             N.check(N.lib().estd_conv2d_k3_split(ctypes.byref(d), _stream()), "estd_conv2d_k3_split")
         elif wino2:
-            d.w_wino = self.w_wino2.data_ptr()
+            d.w_wino = w_alt.data_ptr()
             N.check(N.lib().estd_conv2d_k3_wino2(ctypes.byref(d), _stream()), "estd_conv2d_k3_wino2")
         elif wino:
-            d.w_wino = self.w_wino[nt].data_ptr()
+            d.w_wino = w_alt.data_ptr()
             N.check(N.lib().estd_conv2d_k3_wino(ctypes.byref(d), _stream()), "estd_conv2d_k3_wino")
         else:
             N.check(N.lib().estd_conv2d_k3(ctypes.byref(d), _stream()), "estd_conv2d_k3")

@@ -9,9 +9,10 @@ probability volume of `north_star` before its softmax, hybrid_depth_decoder.py:2
 bandwidth over xGMI is exercised and reported).  Backend "nccl" is RCCL on ROCm; CPU tests use gloo.
 
 Algorithm of the exchange (``ESTD_AG_ALGO`` / ``algo=``):
-  * ``auto`` (default): ``collective`` until ``select_exchange_algo`` has timed both algorithms on the real communicator and every
-    rank has agreed on the faster one (bench.py does that once, behind its first complete set of timed steps and under a watchdog:
-    the untried algorithm of a machine nobody has run yet must not cost the measurement);
+  * ``auto`` (default): ``collective`` until the faster algorithm is known.  ``select_exchange_algo`` times both on the real
+    communicator, agrees on the result across the ranks and switches; bench.py times the two itself (the untried one last and under a
+    watchdog: the untried algorithm of a machine nobody has run yet must not cost the measurement), agrees across the ranks the same
+    way and switches with ``set_active_algo``;
   * ``collective``: ONE ``all_gather_into_tensor`` per stream of the record (RCCL picks ring / direct itself);
   * ``direct``: every rank posts a send to and a receive from every peer under ONE group
     (``batch_isend_irecv`` = ncclGroupStart{ncclSend/ncclRecv to all peers}ncclGroupEnd on RCCL) and copies its own shard
@@ -27,6 +28,14 @@ import torch.distributed as dist
 
 AG_ALGO = os.environ.get("ESTD_AG_ALGO", "auto")
 _ACTIVE = {"algo": "collective"}      # what "auto" resolves to (select_exchange_algo)
+
+
+def set_active_algo(algo):
+    """what ``ESTD_AG_ALGO=auto`` / ``algo=None`` resolves to from now on.  Every rank must make the same call (bench.py: after an
+    all-reduce of the two exchange times)."""
+    if algo not in ("collective", "direct"):
+        raise RuntimeError("exchange algorithm must be collective or direct, got %r" % (algo,))
+    _ACTIVE["algo"] = algo
 
 
 def active_algo():
@@ -56,7 +65,7 @@ def select_exchange_algo(costs, cam_poses, group=None, logits=None, reps=3, marg
     t = torch.tensor([ms["collective"], ms["direct"]], dtype=torch.float64, device=costs["keys"][0].device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     mc, md = float(t[0]), float(t[1])
-    _ACTIVE["algo"] = "direct" if md < margin * mc else "collective"
+    set_active_algo("direct" if md < margin * mc else "collective")
     return {"chosen": _ACTIVE["algo"], "ms_collective": round(mc, 3), "ms_direct": round(md, 3)}
 
 

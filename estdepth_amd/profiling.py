@@ -113,8 +113,18 @@ class GpuSampler:
 
     @staticmethod
     def _find_card(index):
+        """sysfs node of HIP device ``index``: by its PCI address (a container may see the sysfs nodes of every GPU of the node while HIP
+        sees one: the n-th DRM card is then somebody else's GPU), else the n-th amdgpu card"""
         import glob
         import os
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(index)
+            dev = "/sys/bus/pci/devices/%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            if os.path.exists(os.path.join(dev, "pp_dpm_sclk")) or glob.glob(os.path.join(dev, "hwmon", "hwmon*")):
+                return dev
+        except Exception:
+            pass
         cards = []
         for c in sorted(glob.glob("/sys/class/drm/card[0-9]*")):
             dev = os.path.join(c, "device")

@@ -172,15 +172,21 @@ int estd_conv3d_k3_wino(const estd_conv3d_desc* desc, estd_stream_t stream);
  * hybrid_depth_decoder.py:106) -- output channel 32 on the VALU from the fragments the MFMAs consume; no read-back streams, no statistics.
  * Reads w_wino2 (packing.py::pack_conv3d_wino2).  ESTD_ERR_UNSUPPORTED for any other shape. */
 int estd_conv3d_k3_wino2(const estd_conv3d_desc* desc, estd_stream_t stream);
+#ifdef ESTD_BUILD_AB   /* superseded A/B kernel: built and exported only with ESTD_BUILD_AB=1 (estdepth_amd/build.py) */
 /* The 32 -> 32 instance of estd_conv3d_k3_wino2 (cin_main = 32, n_tiles = 2, no in_extra / out_extra / head; BN, ReLU, residuals, scale,
  * running sum, GroupNorm partials -- the latter without read-back streams; no tanh) on the operand-reuse kernel csrc/conv3d_wino2x.hip:
  * same F(2x2, 3x3) arithmetic, one 512-register wave per SIMD on v_mfma_f32_32x32x2_f32, both transforms in front of the LDS, wave-private
  * operand blocks.  Reads desc->w_wino2, which must then hold the packing of packing.py::pack_conv3d_wino2x: float32
  * [4 sd][3 kw][2 chunks][2 q][4 sh][64 lanes][4].  ESTD_ERR_UNSUPPORTED for any other shape (callers fall back to estd_conv3d_k3_wino2). */
 int estd_conv3d_k3_wino2x(const estd_conv3d_desc* desc, estd_stream_t stream);
-/* The 32 -> 32 instance of estd_conv3d_k3_wino2 (cin_main = 32, n_tiles = 2, no in_extra / out_extra / head / gate; BN,
- * activation, residuals, scale, running sum; GroupNorm partials without read-back streams) with ALL THREE axes in Winograd F(2,3) form -- F(2x2x2, 3x3x3), 8/27 of the direct products
- * (csrc/conv3d_wino3.hip).  Reads desc->w_wino2, which must then hold the packing of packing.py::pack_conv3d_wino3: float32
+#endif
+/* The 32-output-channel instances of estd_conv3d_k3_wino2 (cin_main = 32, n_tiles = 2, no out_extra / head / gate) with ALL THREE axes in
+ * Winograd F(2,3) form -- F(2x2x2, 3x3x3), 8/27 of the direct products (csrc/conv3d_wino3.hip; the default for these launches).  Instances:
+ *   * 32 -> 32: BN, activation (ReLU / tanh / split), residuals, scale, running sum (the read-back epilogues);
+ *   * 32 -> 32 + stats_partials (GroupNorm partial sums; the ConvGRU gate convolution) -- WITHOUT read-back streams;
+ *   * 33 -> 32: in_extra + w_extra, the latter in packing.py::pack_conv3d_wino3_extra form (the key || value convolution,
+ *     hybrid_depth_decoder.py:198-199) -- without read-back streams and without stats_partials.
+ * Reads desc->w_wino2, which must then hold the packing of packing.py::pack_conv3d_wino3: float32
  * [64 blocks ((4 sd + sh) * 2 + cc) * 2 + hh][2 halves][2 tap pairs][64 lanes][4].  ESTD_ERR_UNSUPPORTED for any other shape (callers fall back to
  * estd_conv3d_k3_wino2). */
 int estd_conv3d_k3_wino3(const estd_conv3d_desc* desc, estd_stream_t stream);

@@ -131,3 +131,23 @@ def test_cpu_tensors_are_rejected():
     from estdepth_amd import homo_warping
     with pytest.raises(RuntimeError):
         homo_warping(torch.zeros(1, 4, 8, 8), torch.eye(4)[None], torch.eye(4)[None], torch.ones(1, 4))
+
+
+def test_default_library_exports_nothing_without_a_default_caller(libpath):
+    """The default build carries only kernels with a default caller: the estd_* symbols the library exports are EXACTLY the ones the header
+    declares outside #ifdef ESTD_BUILD_AB (the superseded A/B kernels -- depth-only / row-only Winograd, the bf16 operand splits, the
+    operand-reuse two-axis kernel -- are compiled, exported, bound and tested only with ESTD_BUILD_AB=1), and every one of them is called
+    from the host layer (the ctypes front-end estdepth_amd/ops.py / camera.py or the operator library csrc/torch_ops.cpp)."""
+    from estdepth_amd import _native
+    if _native.has_ab():
+        pytest.skip("library built with ESTD_BUILD_AB=1")
+    out = subprocess.check_output(["nm", "-D", "--defined-only", libpath], text=True)
+    exported = sorted(set(re.findall(r"\b[TW] (estd_[a-z0-9_]+)$", out, flags=re.M)))
+    assert exported == _declared(), (set(exported) ^ set(_declared()))
+    assert not [n for n in exported if any(k in n for k in ("_split", "wino2x")) or n.endswith("_wino")], exported
+    host = ""
+    for rel in ("estdepth_amd/ops.py", "estdepth_amd/camera.py", "estdepth_amd/_native.py", "estdepth_amd/csrc/torch_ops.cpp"):
+        host += open(os.path.join(ROOT, rel)).read()
+    calls = set(re.findall(r"\b(estd_[a-z0-9_]+)\s*\(", host)) | set(re.findall(r"lib\(\)\.(estd_[a-z0-9_]+)", host))
+    meta = {"estd_version"}                 # the ABI version query: for foreign hosts (INTEGRATION.md), no kernel behind it
+    assert not [n for n in exported if n not in calls | meta], [n for n in exported if n not in calls | meta]

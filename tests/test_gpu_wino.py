@@ -29,9 +29,10 @@ def _plan(seed, act="relu"):
 def _run(plan, algo, x, dims, **kw):
     from estdepth_amd import ops
     old, old_x, old_3, old_3x = ops.CONV3D_ALGO, ops.W2X, ops.W3, ops.W3_EXTRA
-    ops.W3_EXTRA = algo == "wino3"                      # (the scalar-channel instance of the three-axis kernel is opt-in)
-    # "wino2x" = the two-axis form on the operand-reuse kernel (csrc/conv3d_wino2x.hip, opt-in: ESTD_W2X=1) for the plain 32 -> 32 instance;
-    # "wino3" = all three axes in Winograd form (csrc/conv3d_wino3.hip, ESTD_W3=1; launches with GroupNorm partials stay on the two-axis kernel)
+    ops.W3_EXTRA = algo == "wino3"                      # (the three-axis kernel's scalar-channel instance: the default of the 33 -> 32 launch, ESTD_W3_EXTRA=1)
+    # "wino2x" = the two-axis form on the operand-reuse kernel (csrc/conv3d_wino2x.hip: ESTD_BUILD_AB=1 builds only, ESTD_W2X=1) for the plain 32 -> 32 instance;
+    # "wino3" = all three axes in Winograd form (csrc/conv3d_wino3.hip, the default, ESTD_W3=1: 32 -> 32 with every read-back epilogue, 32 -> 32 + GroupNorm
+    # partials and 33 -> 32 without read-back streams); "wino2" = the same launches on the two-axis kernel (ESTD_W3=0)
     ops.CONV3D_ALGO, ops.W2X, ops.W3 = ("wino2", True, False) if algo == "wino2x" else ("wino2", False, True) if algo == "wino3" else (algo, False, False)
     try:
         out = kw.pop("out", None)
@@ -54,7 +55,8 @@ def _has_ab():
 
 # depth and row axis in Winograd form (default); "wino" = depth axis only (csrc/conv3d_wino.hip: part of the ESTD_BUILD_AB=1 build)
 ALGOS = ("wino2",) + (("wino",) if _has_ab() else ())
-ALGOS_PLAIN = ALGOS + ("wino2x", "wino3")      # instances without a scalar channel: + the operand-reuse kernel, + the three-axis kernel
+# instances without a scalar channel: + the three-axis kernel (default), + the operand-reuse kernel (superseded: ESTD_BUILD_AB=1 builds only)
+ALGOS_PLAIN = ALGOS + ("wino3",) + (("wino2x",) if _has_ab() else ())
 
 
 @pytest.mark.parametrize("algo", ALGOS_PLAIN)

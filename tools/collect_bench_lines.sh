@@ -1,9 +1,9 @@
 #!/bin/bash
 # The bench.py JSON lines of a round (default command per workload + the A/B lines), without the traces / PMC passes of tools/collect_profiles.sh.
-#   bash tools/collect_bench_lines.sh [round prefix, default r5]
+#   bash tools/collect_bench_lines.sh [round prefix, default r6]
 set -u
 R=$PWD
-P=${1:-r5}
+P=${1:-r6}
 OUT=$R/gpurun_out/profiles_$P
 mkdir -p $OUT
 last() { grep "^{" | tail -1; }
@@ -16,7 +16,6 @@ AB="--no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads"
 for rep in 1 2; do
   python bench.py $AB 2>/dev/null | last > $OUT/${P}_ab_default_$rep.json
   ESTD_W3=0 python bench.py $AB 2>/dev/null | last > $OUT/${P}_ab_two_axis_$rep.json      # 32 -> 32 convolutions on the two-axis kernel (csrc/conv3d_wino2.hip)
-  ESTD_W3=0 ESTD_W2X=1 python bench.py $AB 2>/dev/null | last > $OUT/${P}_ab_w2x_$rep.json
   ESTD_GATE_IN_CONV=0 python bench.py $AB 2>/dev/null | last > $OUT/${P}_ab_gate_pass_$rep.json
 done
 ESTD_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-alt --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_rccl_world1.json

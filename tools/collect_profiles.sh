@@ -1,11 +1,11 @@
 #!/bin/bash
 # Profile collection on the GPU box (writes under gpurun_out/profiles_<round>/; copy what is kept into profiles/).
-#   bash tools/collect_profiles.sh [round prefix, default r5]
+#   bash tools/collect_profiles.sh [round prefix, default r6]
 # (default build: the superseded A/B kernels -- depth-only / row-only Winograd, bf16 operand split -- are not part of it; their lines
 #  of the round-4 collection are gone)
 set -u
 R=$PWD
-P=${1:-r5}
+P=${1:-r6}
 OUT=$R/gpurun_out/profiles_$P
 mkdir -p $OUT tools/bin
 cd /tmp && export TMPDIR=/tmp
@@ -42,7 +42,6 @@ done
 python tools/head_bench.py 2>&1 | grep -v amdgpu >> $OUT/${P}_conv_bench.txt
 python tools/kv_bench.py 2>&1 | grep -v amdgpu >> $OUT/${P}_conv_bench.txt
 python tools/w3_bench.py 3 30 2>&1 | grep -v amdgpu > $OUT/${P}_w3_bench.txt
-ESTD_W3=0 python tools/w2x_bench.py 3 30 2>&1 | grep -v amdgpu > $OUT/${P}_w2x_bench.txt
 python tools/gate_bench.py 2>&1 | grep -v amdgpu > $OUT/${P}_gate_bench.txt
 python tools/conv2d_bench.py 2>&1 | grep -v amdgpu > $OUT/${P}_conv2d_bench.txt
 python tools/psm_small_bench.py 2>&1 | grep -v amdgpu > $OUT/${P}_psm_small_bench.txt
@@ -61,7 +60,6 @@ python bench.py --workload cfg1 2>/dev/null | last > $OUT/${P}_bench_cfg1.json
 python bench.py --workload cfg5 --steps 5 --warmup 2 2>/dev/null | last > $OUT/${P}_bench_cfg5.json
 python bench.py --workload stream --steps 20 2>/dev/null | last > $OUT/${P}_bench_stream.json
 ESTD_W3=0 python bench.py --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_two_axis.json
-ESTD_W3=0 ESTD_W2X=1 python bench.py --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_w2x.json
 ESTD_GATE_IN_CONV=0 python bench.py --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_gate_pass.json
 python bench.py --conv3d-algo direct --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_direct_conv.json
 python bench.py --no-graph --no-cpu-baseline --no-alt --no-replay-profile --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_eager.json
