@@ -307,7 +307,31 @@ def cpu_leg_child(args):
 _DEFAULT_TORCH_THREADS = [0]        # torch's own default (= the physical cores of the box), recorded before anything changes it
 
 
-def cpu_baseline(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses, gpu_outputs, frames, gpu_logits=None, kind="port", pin_socket=False):
+def feature_parity(gpu_feats, nets):
+    """Feature-level bar (round 6): the GPU path's PSM matching features [V,32,H/4,W/4] and the five ResNet scales of the timed step against
+    the 2D networks the oracle ran (the product's plain nn.Modules on torch-CPU, oracle/nets2d.py) -- max |diff|, the reference's range and
+    the two relative figures (max |diff| / range, ||diff||_2 / ||ref||_2).  The end of the pipeline (depth, logits) says little about the
+    2D branches behind a flat softmax; any arithmetic change in them (Winograd tile sizes, operand splits) is held to THESE numbers."""
+    import numpy as np
+    out = {}
+    pairs = [("psm_matching", gpu_feats["matching"], nets.last_matching)]
+    pairs += [("resnet_scale%d" % i, g, r) for i, (g, r) in enumerate(zip(gpu_feats["semantic_features"], nets.last_semantic))]
+    for name, g, r in pairs:
+        g = g.detach().float().cpu().contiguous().numpy().astype(np.float64)
+        r = np.asarray(r, np.float64).reshape(g.shape)
+        d = np.abs(g - r)
+        rng = float(np.abs(r).max())
+        out[name] = {"max_abs_diff": float("%.3g" % d.max()), "ref_range": float("%.3g" % rng), "rel_to_range": float("%.3g" % (d.max() / max(rng, 1e-30))),
+                     "rel_l2": float("%.3g" % (np.sqrt((d * d).sum()) / max(np.sqrt((r * r).sum()), 1e-30))), "elements": int(r.size)}
+    return out
+
+
+# bars of the feature-level comparison (tests/test_gpu_full_config.py holds the same numbers): max |diff| / range of the map
+FEATURE_TOL_REL = {"psm_matching": 2e-5, "resnet": 2e-5}
+
+
+def cpu_baseline(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses, gpu_outputs, frames, gpu_logits=None, kind="port", pin_socket=False,
+                 gpu_feats=None):
     """A CPU restatement of the reference timed on ONE full step of the same workload on the box's host cores: the whole
     DepthNetHybrid.forward of the timed step -- PSM, ResNet, plane sweeps, every 3D convolution, the 2N volume warps + attention +
     ConvGRU per target, soft-argmin, 2D refinement -- on the very inputs (and carried memory) of the GPU step.  Nothing is extrapolated.
@@ -374,6 +398,12 @@ def cpu_baseline(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses,
         parity["logit_volumes_vs_oracle"] = lg
         parity["logit_tolerance"] = 6e-5
         parity["logits_within_tolerance"] = bool(lg and all(v["max_abs_diff"] <= 6e-5 for v in lg.values()))
+    if gpu_feats is not None and nets.last_matching is not None and nets.last_semantic is not None:
+        fp = feature_parity(gpu_feats, nets)
+        parity["features_2d_vs_cpu_modules"] = fp
+        parity["feature_tolerance_rel_to_range"] = FEATURE_TOL_REL
+        parity["features_within_tolerance"] = bool(all(v["rel_to_range"] <= FEATURE_TOL_REL["psm_matching" if k == "psm_matching" else "resnet"]
+                                                       for k, v in fp.items()))
     return base, parity
 
 
@@ -821,6 +851,8 @@ def main():
     gathered = state["allgather"]
     gpu_outputs = {k: v.clone() for k, v in last[0].items()}        # outputs of the timed configuration (for the parity report)
     gpu_logits = {k: v.clone() for k, v in (getattr(model.CostRegNet, "last_logits", None) or {}).items()}
+    f2d = getattr(state["fwd"], "last_features2d", None) or getattr(model, "last_features2d", None)       # stage A's outputs of the last timed step
+    gpu_feats = {"matching": f2d["matching"].clone(), "semantic_features": [t.clone() for t in f2d["semantic_features"]]} if f2d else None
     # "gathered bank equals each owner's tensors bit for bit" -- every rank checks the shard it owns
     bank_ok = None
     if gathered and state["bank"] is not None:
@@ -1097,7 +1129,8 @@ def main():
             for kind, th, pin in legs:
                 if pin and len(_socket_cpus()) < 16:
                     continue                           # (a box without a 16-core socket: the unpinned legs say it all)
-                base, par = cpu_baseline(args.workload, th, x_imgs, x_poses, intr, pre_costs, pre_poses, gpu_outputs, frames, gpu_logits, kind=kind, pin_socket=pin)
+                base, par = cpu_baseline(args.workload, th, x_imgs, x_poses, intr, pre_costs, pre_poses, gpu_outputs, frames, gpu_logits, kind=kind, pin_socket=pin,
+                                         gpu_feats=gpu_feats)
                 runs.append(base)
                 if pin:
                     continue

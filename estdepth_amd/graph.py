@@ -62,6 +62,8 @@ class GraphedForward:
         self.clone_outputs = clone_outputs
         self.zero_copy_memory = zero_copy_memory
         self.memory_logits = None                # after a call: fresh copy of DepthHybridDecoder.memory_logits of that call
+        self.last_features2d = None              # after a call: stage A's static output buffers {"matching": [V,32,H/4,W/4], "semantic_features": 5 maps}
+                                                 # (valid until the next call; the feature-level parity bar of bench.py / the tests reads them)
         self.last_matching = None                # after a call: the PSM features [V,32,H/4,W/4] of its frames (stage A's static buffer: valid until
                                                  # the next call; estdepth_amd.streaming copies the frames it shares with the next call out of it)
         self._graphs = {}
@@ -69,7 +71,8 @@ class GraphedForward:
         self._ring = {}                          # zero-copy mode: kv shape -> {"bufs": [...], "stamp": [...], "last": slot, "clock": n}
 
     def __getattr__(self, name):                 # normalise_images, matchingFeature, ndepths, ... of the wrapped model
-        if name in ("model", "warmup", "_graphs", "clone_outputs", "memory_logits", "zero_copy_memory", "_ring", "last_matching", "reserve_cus", "_pools"):
+        if name in ("model", "warmup", "_graphs", "clone_outputs", "memory_logits", "zero_copy_memory", "_ring", "last_matching", "reserve_cus", "_pools",
+                    "last_features2d"):
             raise AttributeError(name)
         return getattr(self.model, name)
 
@@ -284,6 +287,7 @@ class GraphedForward:
         st["graph_b"].replay()
         outputs, costs, cposes = st["out"]
         self.last_matching = st["feats2d"]["matching"]
+        self.last_features2d = st["feats2d"]
         if st.get("last_logits") is not None:
             self.model.CostRegNet.last_logits = st["last_logits"]
         # the logit volume that travels with the memory bank (parallel.allgather_memory_bank*): a fresh 4.9 MB tensor, like the memory

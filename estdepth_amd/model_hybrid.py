@@ -304,8 +304,10 @@ class DepthNetHybrid(nn.Module):
             matching = self._matching(flat, matching_features)                                             # :128
             semantic_features = self.semanticFeature(flat[1:1 + target_num])                               # :138-139 (batch 1)
         self.last_matching = matching      # [V,32,H/4,W/4]: what a streaming caller slices its next call's ``matching_features`` from
-        return {"matching": matching, "semantic_features": semantic_features, "sv_pre": sv_pre, "views_num": views_num,
-                "device": imgs.device, "dtype": imgs.dtype}
+        feats = {"matching": matching, "semantic_features": semantic_features, "sv_pre": sv_pre, "views_num": views_num,
+                 "device": imgs.device, "dtype": imgs.dtype}
+        self.last_features2d = feats       # (references only: the feature-level parity bar of bench.py / tests reads them after the call)
+        return feats
 
     @torch.no_grad()
     def forward_3d(self, feats, cam_poses, cam_intr, sample, pre_costs=None, pre_cam_poses=None, mode="val", cam_mats=None):

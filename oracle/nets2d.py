@@ -19,6 +19,10 @@ class Nets2D:
     def __init__(self, model=None, decoder=None):
         self.model = model
         self.decoder = decoder if decoder is not None else (model.CostRegNet if model is not None else None)
+        # what the last matching() / semantic() call returned: the feature-level parity bar of bench.py / tests/test_gpu_full_config.py
+        # compares the GPU path's PSM features and ResNet scales with these (references to the arrays handed to the oracle: no copy)
+        self.last_matching = None
+        self.last_semantic = None
 
     @staticmethod
     def _t(a):
@@ -26,11 +30,13 @@ class Nets2D:
 
     def matching(self, x):
         with torch.no_grad():
-            return self.model.matchingFeature(self._t(x)).numpy()
+            self.last_matching = self.model.matchingFeature(self._t(x)).numpy()
+        return self.last_matching
 
     def semantic(self, x):
         with torch.no_grad():
-            return [f.numpy() for f in self.model.semanticFeature(self._t(x))]
+            self.last_semantic = [f.numpy() for f in self.model.semanticFeature(self._t(x))]
+        return self.last_semantic
 
     def semantic_vs(self, feats):
         with torch.no_grad():

@@ -57,7 +57,7 @@ def _np(t):
     return t.detach().float().cpu().contiguous().numpy()
 
 
-def _oracle_forward(workload, x_imgs, x_poses, intr, pre_costs, pre_poses, memory=False):
+def _oracle_forward(workload, x_imgs, x_poses, intr, pre_costs, pre_poses, memory=False, nets_out=None):
     import bench as B
     from oracle import ref_model as M, ref_ops as O
     from oracle.nets2d import Nets2D, sd_numpy
@@ -68,8 +68,11 @@ def _oracle_forward(workload, x_imgs, x_poses, intr, pre_costs, pre_poses, memor
     if pre_costs is not None:
         pc = {"keys": [_np(k) for k in pre_costs["keys"]], "values": [_np(v) for v in pre_costs["values"]]}
         pp = [_np(p) for p in pre_poses]
+    nets = Nets2D(model=cpu_model)
     ref, costs, cposes = M.model_forward(sd_numpy(cpu_model), _np(x_imgs), _np(x_poses), _np(intr), pc, pp,
-                                         Nets2D(model=cpu_model), ndepths=B.WORKLOADS[workload][3], depth_min=0.1, depth_max=10.0)
+                                         nets, ndepths=B.WORKLOADS[workload][3], depth_min=0.1, depth_max=10.0)
+    if nets_out is not None:
+        nets_out.append(nets)          # (.last_matching / .last_semantic: the 2D features the oracle's forward was fed)
     if memory:
         return ref, costs, cposes
     return ref
@@ -103,20 +106,23 @@ def cfg2_joint():
         for _ in range(3):                                          # one capture per ring buffer, then a pure replay
             out_acc, costs_acc, _ = fwd(x_imgs, x_poses, intr, x_sample, pre_costs, list(pre_poses), mode="val")
     out_acc = {k: v.clone() for k, v in out_acc.items()}
+    f2d = fwd.last_features2d
+    feats = {"matching": f2d["matching"].clone(), "semantic_features": [t.clone() for t in f2d["semantic_features"]]}
     torch.cuda.synchronize()
-    ref = _oracle_forward("joint", x_imgs, x_poses, intr, pre_costs, pre_poses)
-    return out_plain, out_acc, ref, _logit_diffs(acc.CostRegNet, ref)
+    nets = []
+    ref = _oracle_forward("joint", x_imgs, x_poses, intr, pre_costs, pre_poses, nets_out=nets)
+    return out_plain, out_acc, ref, _logit_diffs(acc.CostRegNet, ref), B.feature_parity(feats, nets[0])
 
 
 def test_cfg2_accelerated_graph_path_matches_plain_eager_path(cfg2_joint):
-    out_plain, out_acc, _, _ = cfg2_joint
+    out_plain, out_acc = cfg2_joint[:2]
     assert set(out_plain) == set(out_acc) and len(out_plain) == 18           # 3 targets x (4 depths + 2 probabilities)
     for k in out_plain:
         assert float((out_plain[k] - out_acc[k]).abs().max()) < 5e-5, k
 
 
 def test_cfg2_plain_and_accelerated_paths_match_the_oracle(cfg2_joint):
-    out_plain, out_acc, ref, _ = cfg2_joint
+    out_plain, out_acc, ref = cfg2_joint[:3]
     for tag, out in (("plain", out_plain), ("accelerated+hipGraph", out_acc)):
         for k, v in out.items():
             d = float(np.abs(_np(v) - ref[k]).max())
@@ -134,6 +140,22 @@ def _assert_logits(tag, diffs):
 def test_cfg2_logit_volumes_match_the_oracle(cfg2_joint):
     """3 targets x 64 x 120 x 160 logits of both heads, accelerated + hipGraph path vs the oracle (same inputs, same memory)"""
     _assert_logits("cfg2", cfg2_joint[3])
+
+
+def test_cfg2_2d_features_match_the_cpu_modules(cfg2_joint):
+    """Feature-level bar (round 6; bench.py reports the same numbers in parity.features_2d_vs_cpu_modules): the PSM matching features
+    [5,32,120,160] (psm_submodule.py:14-37,44-116: ~25 3x3 convolutions on the F(2x2,3x3) MFMA kernel, SPP, fused BN) and the five
+    ResNet-50 scales (resnet_encoder.py:40-51: 1x1 / 3x3 / 7x7 convolutions, every one in-house) of the timed cfg2 step, accelerated +
+    hipGraph path, against the same nn.Modules evaluated by torch on the CPU (oneDNN).  Neither side is exact -- both are fp32 roundoff
+    through ~50 layers -- so the bar is max |diff| <= FEATURE_TOL_REL x the map's range, about 2x what the default kernels measure
+    (printed); any arithmetic change in the 2D branches (larger Winograd tiles, operand splits) has to fit under it."""
+    import bench as B
+    fp = cfg2_joint[4]
+    assert set(fp) == {"psm_matching"} | {"resnet_scale%d" % i for i in range(5)}
+    for name, v in fp.items():
+        print("cfg2 %s: max |HIP - CPU| = %.3g on a range of %.3g (%.3g of the range, L2 %.3g)" % (name, v["max_abs_diff"], v["ref_range"], v["rel_to_range"], v["rel_l2"]))
+        bar = B.FEATURE_TOL_REL["psm_matching" if name == "psm_matching" else "resnet"]
+        assert v["ref_range"] > 0.05 and np.isfinite(v["max_abs_diff"]) and v["rel_to_range"] < bar, (name, v, bar)
 
 
 # ---- the memory-less call at full size: forward_notransformer (hybrid_depth_decoder.py:294-417, dispatch :423) ----
