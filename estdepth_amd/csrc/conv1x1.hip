@@ -163,6 +163,159 @@ __global__ __launch_bounds__(256) void conv1x1_nhwc_kernel(const estd_conv1x1_de
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// LDS-tiled form (round 6).  The direct form above streams every operand quad of every WAVE from L1 / L2: a 64 x 64 wave block reads
+// 128 bytes per MFMA, the smaller blocks of the small maps 256-384, and the K-heavy layers lose to the library.  Here a WORKGROUP owns a
+// BN (output channels) x BM (pixels) tile, its four waves WN x WM sub-tiles of it, and both operand panels are staged ONCE per workgroup:
+//   * global -> LDS with global_load_lds_dwordx4 (no staging registers, no ds_write pass): one wave-instruction moves a 1 KiB block of
+//     16 rows x 16 channels; a stage holds U sub-chunks of 16 channels of the BN weight rows and the BM pixel rows, NS stages rotate;
+//   * the LDS destination of a wave-instruction is linear (base + 16 lane), so the bank swizzle is applied on the GLOBAL side: lane j of a
+//     block fetches row j / 4, 16-byte k-slot (j % 4) ^ F[(j / 4) / 4] with F = {0, 3, 2, 1}; a fragment read (lane (g, i) wants row i,
+//     k-slot g) is the 16 bytes at i * 64 + ((g ^ F[i / 4]) * 16): conflict-free in every one of ds_read_b128's four 16-lane groups
+//     ({0-3, 12-15, 20-27}, ... -- MI355X_MICROARCH.md LDS table): per row residue i % 4 the four lanes of a group land on the slots
+//     {F0, F1^1, F2^1, F3} (+ the group's constant) = {0, 2, 3, 1};
+//   * as above, the k index a lane group multiplies at step e of a 16-channel chunk is channel 4 g + e on both sides (any bijection is
+//     a valid dot product), so one ds_read_b128 per 16 x 16 operand tile and chunk feeds four MFMAs per partner tile;
+//   * one __syncthreads() per stage: it publishes stage c (requested two iterations ago: a whole iteration of MFMAs to land) and frees
+//     stage c + NS - 1 (read in iteration c - 1) for the request that follows it;
+//   * workgroup -> tile mapping in XCD-sized runs (workgroup b runs on XCD b % 8): the tiles of one XCD are consecutive, so the channel
+//     tiles that share a pixel panel meet in one L2.
+// Pixel rows beyond the map (the last pixel tile) are clamped to the last pixel for the loads and never stored.
+template <int BM, int BN, int WM, int WN, int U, int NS>
+__global__ __launch_bounds__(256) void conv1x1_lds_kernel(const estd_conv1x1_desc p, int Ho, int Wo, int tiles_m, int tiles_n, int per_xcd)
+{
+    constexpr int TM = BM / (16 * WM), TN = BN / (16 * WN);
+    constexpr int NBLK = (BM + BN) / 16;                  // 1 KiB blocks per 16-channel sub-chunk: weight rows first, then pixel rows
+    constexpr int STAGE = NBLK * U * 1024;
+    constexpr int LPW = NBLK * U / 4;                     // global_load_lds instructions per wave and stage
+    static_assert(WM * WN == 4 && (NBLK * U) % 4 == 0 && TM >= 1 && TN >= 1, "tile shape");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, i = lane & 15;
+    const int t = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (t >= tiles_m * tiles_n) return;                   // (workgroup-uniform)
+    const int tn = t % tiles_n, tm = t / tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int Mtot = p.N * Ho * Wo;
+    const int cin = p.cin, cout = p.cout;
+
+    // ---- this lane's global sources: LPW blocks, the same rows in every stage (only the channel offset moves) ----
+    const float* src[LPW];
+    const int jr = lane >> 2, ps = lane & 3;              // row of the block, physical 16-byte slot
+    const int ks = ps ^ ((4 - (jr >> 2)) & 3);            // k-slot that lands there (F = {0, 3, 2, 1})
+#pragma unroll
+    for (int j = 0; j < LPW; ++j) {
+        const int q = wave * LPW + j;                     // block of the stage (wave-uniform): sub-chunk q / NBLK, block q % NBLK
+        const int u = q / NBLK, blk = q % NBLK;
+        if (blk < BN / 16) {
+            int n = n0 + blk * 16 + jr;
+            n = n < cout ? n : cout - 1;
+            src[j] = p.w + (size_t)n * cin + u * 16 + ks * 4;
+        } else {
+            int m = m0 + (blk - BN / 16) * 16 + jr;
+            m = m < Mtot ? m : Mtot - 1;
+            const int x = m % Wo, r = m / Wo;
+            const int y = r % Ho, n = r / Ho;
+            src[j] = p.in + (((size_t)n * p.H + y * p.stride) * p.W + x * p.stride) * cin + u * 16 + ks * 4;
+        }
+    }
+    auto request = [&](int c) {                           // chunk c (16 U channels) -> stage c % NS
+        unsigned char* base = lds + (c % NS) * STAGE + wave * LPW * 1024;
+#pragma unroll
+        for (int j = 0; j < LPW; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (size_t)c * 16 * U),
+                                             (__attribute__((address_space(3))) void*)(base + j * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int wn = wave % WN, wm = wave / WN;
+    const int frag = i * 64 + ((g ^ ((4 - (i >> 2)) & 3)) << 4);        // this lane's 16 bytes inside a 1 KiB block
+    const int woff = wn * TN * 1024 + frag, xoff = (BN / 16 + wm * TM) * 1024 + frag;
+    const int nchunks = cin / (16 * U);
+#pragma unroll
+    for (int c = 0; c < NS - 1; ++c)
+        if (c < nchunks) request(c);
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();                                  // stage c has landed (vmcnt(0) in front of the barrier); stage c - 1 is free
+        if (c + NS - 1 < nchunks) request(c + NS - 1);
+        const unsigned char* st = lds + (c % NS) * STAGE;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float4 wq[TN], xq[TM];
+#pragma unroll
+            for (int a = 0; a < TN; ++a) wq[a] = *reinterpret_cast<const float4*>(st + u * NBLK * 1024 + woff + a * 1024);
+#pragma unroll
+            for (int b = 0; b < TM; ++b) xq[b] = *reinterpret_cast<const float4*>(st + u * NBLK * 1024 + xoff + b * 1024);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int a = 0; a < TN; ++a) {
+                    const float wv = e == 0 ? wq[a].x : e == 1 ? wq[a].y : e == 2 ? wq[a].z : wq[a].w;
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) {
+                        const float xv = e == 0 ? xq[b].x : e == 1 ? xq[b].y : e == 2 ? xq[b].z : xq[b].w;
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc[a][b], 0, 0, 0);
+                    }
+                }
+        }
+    }
+
+    // ---- epilogue: folded BatchNorm, + residual, ReLU; 16-byte stores (as in the direct form) ----
+    const __amdgpu_buffer_rsrc_t rs_o = make_rsrc(p.out, (size_t)Mtot * cout * 4);
+    const __amdgpu_buffer_rsrc_t rs_r = make_rsrc(p.residual ? p.residual : p.out, (size_t)Mtot * cout * 4);
+    const float floor_ = p.relu ? 0.0f : ESTD_NO_FLOOR;
+    const int mw = m0 + wm * TM * 16, nw = n0 + wn * TN * 16;
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+        const int cb = nw + 16 * a + 4 * g;
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool cok = cb < cout;                       // (cout is a multiple of 32: whole 16-channel tiles)
+        if (p.scale && cok) sc = *reinterpret_cast<const float4*>(p.scale + cb);
+        if (p.shift && cok) sh = *reinterpret_cast<const float4*>(p.shift + cb);
+        unsigned ooff[TM];
+        float4 res[TM];
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+            const int m = mw + 16 * b + i;
+            ooff[b] = (m < Mtot && cok) ? (unsigned)((size_t)m * cout + cb) * 4u : OOB_OFFSET;
+        }
+        if (p.residual) {
+#pragma unroll
+            for (int b = 0; b < TM; ++b) res[b] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_r, ooff[b], 0, 0));
+        }
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+            float4 v;
+            v.x = fmaf(acc[a][b][0], sc.x, sh.x); v.y = fmaf(acc[a][b][1], sc.y, sh.y);
+            v.z = fmaf(acc[a][b][2], sc.z, sh.z); v.w = fmaf(acc[a][b][3], sc.w, sh.w);
+            if (p.residual) { v.x += res[b].x; v.y += res[b].y; v.z += res[b].z; v.w += res[b].w; }
+            v.x = fmaxf(v.x, floor_); v.y = fmaxf(v.y, floor_); v.z = fmaxf(v.z, floor_); v.w = fmaxf(v.w, floor_);
+            u32x4 bits;
+            __builtin_memcpy(&bits, &v, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(bits, rs_o, ooff[b], 0, 0);
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int U, int NS>
+int launch1x1_lds(const estd_conv1x1_desc& d, int Ho, int Wo, hipStream_t stream)
+{
+    constexpr int LDS_BYTES = (BM + BN) / 16 * U * 1024 * NS;
+    const long long Mtot = (long long)d.N * Ho * Wo;
+    const int tiles_m = (int)((Mtot + BM - 1) / BM), tiles_n = (d.cout + BN - 1) / BN;
+    const int per_xcd = (tiles_m * tiles_n + 7) / 8;
+    estd_allow_dynamic_lds<conv1x1_lds_kernel<BM, BN, WM, WN, U, NS>>(LDS_BYTES);
+    hipLaunchKernelGGL((conv1x1_lds_kernel<BM, BN, WM, WN, U, NS>), dim3((unsigned)per_xcd * 8), dim3(256), LDS_BYTES, stream, d, Ho, Wo, tiles_m, tiles_n,
+                       per_xcd);
+    return ESTD_LAUNCH_CHECK();
+}
+
 template <int TM, int TN, int PF, int SK>
 int launch1x1(const estd_conv1x1_desc& d, int Ho, int Wo, hipStream_t stream)
 {
@@ -196,6 +349,32 @@ extern "C" int estd_conv1x1_nhwc(const estd_conv1x1_desc* dp, estd_stream_t s)
     auto tiles = [&](int tm, int tn) { return ((Mtot + 16 * tm - 1) / (16 * tm)) * (d.cout / (16 * tn)); };
     const bool sk4 = (d.cin & 63) == 0 && d.cin >= 256;                                 // four K ranges of whole chunks, long enough to be worth the exchange
     int cfg = cfg_env;
+    // LDS-tiled form: cfg = 1000 + 100 (BM / 32) + 10 (BN / 32) + U  (ESTD_C1X1_CFG forces one; ESTD_C1X1_LDS=0: direct form only)
+    static const int lds_env = [] { const char* e = getenv("ESTD_C1X1_LDS"); return e ? atoi(e) : 1; }();
+    if (cfg == 0 && lds_env && (d.cin & 31) == 0) {
+        auto wgs = [&](int bm, int bn) { return ((Mtot + bm - 1) / bm) * ((d.cout + bn - 1) / bn); };
+        const long long cus = estd_device_cus();
+        if ((d.cout & 127) == 0 && wgs(128, 128) >= cus * 7 / 8) cfg = 1441;
+        else if ((d.cout & 63) == 0 && wgs(128, 64) >= cus * 7 / 8) cfg = 1422;
+        else if ((d.cout & 63) == 0 && wgs(64, 64) >= cus * 7 / 8) cfg = 1222;
+        else if ((d.cout & 63) == 0 && wgs(32, 64) >= cus * 3 / 4) cfg = 1122;
+    }
+    if (cfg >= 1000 && (d.cin % (16 * (cfg % 10)))) cfg = 0;                              // whole stages only
+    switch (cfg) {
+    case 1441: return launch1x1_lds<128, 128, 2, 2, 1, 3>(d, Ho, Wo, stream);
+    case 1442: return launch1x1_lds<128, 128, 2, 2, 2, 3>(d, Ho, Wo, stream);
+    case 1421: return launch1x1_lds<128, 64, 2, 2, 1, 3>(d, Ho, Wo, stream);
+    case 1422: return launch1x1_lds<128, 64, 2, 2, 2, 3>(d, Ho, Wo, stream);
+    case 1241: return launch1x1_lds<64, 128, 2, 2, 1, 3>(d, Ho, Wo, stream);
+    case 1242: return launch1x1_lds<64, 128, 2, 2, 2, 3>(d, Ho, Wo, stream);
+    case 1221: return launch1x1_lds<64, 64, 2, 2, 1, 4>(d, Ho, Wo, stream);
+    case 1222: return launch1x1_lds<64, 64, 2, 2, 2, 3>(d, Ho, Wo, stream);
+    case 1224: return launch1x1_lds<64, 64, 2, 2, 4, 3>(d, Ho, Wo, stream);
+    case 1122: return launch1x1_lds<32, 64, 1, 4, 2, 3>(d, Ho, Wo, stream);
+    case 1124: return launch1x1_lds<32, 64, 1, 4, 4, 3>(d, Ho, Wo, stream);
+    default: break;
+    }
+    if (cfg >= 1000) cfg = 0;
     if (cfg == 0) {
         const bool c64 = (d.cout & 63) == 0;
         if (c64 && tiles(4, 4) >= want) cfg = 441;
