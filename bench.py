@@ -1029,6 +1029,15 @@ def main():
                                                    n=10, device=device, peak_gbs=HBM_PEAK_GBS)
             except Exception as e:
                 hbm_alone = {"error": "%s: %s" % (type(e).__name__, str(e)[:100])}
+            if args.workload == "joint" and isinstance(hbm_alone, dict) and "error" not in hbm_alone:
+                # ... and the fused warp + attention at the HBM stress size (cfg5: 128 x 240 x 320 voxels, 2 memory volumes): the HBM kernel
+                # furthest below its roof, at the size where it weighs most
+                try:
+                    big = hbm_kernels_standalone(128, 240, 320, n=5, device=device, peak_gbs=HBM_PEAK_GBS, only_attention=(2,))
+                    hbm_alone["warp_attention N=2 @cfg5 (128x240x320)"] = big["warp_attention N=2"]
+                    torch.cuda.empty_cache()
+                except Exception as e:
+                    hbm_alone["warp_attention N=2 @cfg5 (128x240x320)"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:100])}
         kname = {"wino3": "conv3d_wino3_kernel (3x3x3 conv 32->32, fp32 MFMA 16x16x4, all three axes in Winograd F(2,3) form: 8/27 of the products)",
                  "wino2": "conv3d_wino2_kernel (3x3x3 conv 32->32, fp32 MFMA 16x16x4, depth and row axis in Winograd F(2,3) form: 12/27 of the products)",
                  "wino": "conv3d_wino_kernel (3x3x3 conv 32->32, fp32 MFMA 16x16x4, depth axis in Winograd F(2,3) form: 18/27 of the products)",

@@ -185,6 +185,9 @@ __global__ __launch_bounds__(256) void warp_volume_ex_kernel(const float* __rest
 #ifndef WA_SHARE
 #define WA_SHARE 0   // 1: dx = 1 corner records from the x-neighbour's registers (DPP) instead of a second gather -- measured SLOWER (348 vs 255 us at N = 3, profiles/r3_warp_attention_share_pmc.csv): A/B switch only
 #endif
+#ifndef ESTD_WA_ABL
+#define ESTD_WA_ABL 0   // timing ablations only (results are wrong for the consumers when != 0): what writing only h would buy (profiles/r6_warp_attention_honly.txt)
+#endif
 #ifndef WA_TD
 #define WA_TD 2      // target brick of one 256-thread workgroup (64 voxels x 4 lanes): depth x rows x columns
 #define WA_TY 4
@@ -231,7 +234,9 @@ __global__ __launch_bounds__(256) void warp_attention_kernel(const float* __rest
     const float dep = dvals[d];
 
     const float4* t4 = reinterpret_cast<const float4*>(kv_t) + idx * 8;
+#if ESTD_WA_ABL == 0
     const float4 vt = t4[sub];        // target value chunk
+#endif
     const float4 kt = t4[4 + sub];    // target key chunk
 
     float corr[NS];
@@ -325,9 +330,15 @@ __global__ __launch_bounds__(256) void warp_attention_kernel(const float* __rest
     }
     const float inv_n = 1.0f / (float)n_src;
     h.x *= inv_n; h.y *= inv_n; h.z *= inv_n; h.w *= inv_n;
+#if ESTD_WA_ABL == 1        // timing ablation: only h, as a compact 16-channel volume (64 B per voxel, whole lines), no V_t load / copy
+    reinterpret_cast<float4*>(xh)[idx * 4 + sub] = h;
+#elif ESTD_WA_ABL == 2      // timing ablation: only h, into its half of the 32-channel record (64 of every 128 bytes), no V_t load / copy
+    reinterpret_cast<float4*>(xh)[idx * 8 + 4 + sub] = h;
+#else
     float4* o4 = reinterpret_cast<float4*>(xh) + idx * 8;
     o4[sub] = vt;
     o4[4 + sub] = h;
+#endif
 }
 
 // Attention over ALREADY WARPED key/value volumes (the level-1 EpipolarTransformer.forward signature,

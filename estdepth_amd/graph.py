@@ -41,7 +41,6 @@ from .hybrid_depth_decoder import kv_from_pair, kv_views
 from .layers_op import PlanCache
 
 
-UPLOAD_STREAM = os.environ.get("ESTD_GRAPH_UPLOAD_STREAM", "side")      # A/B switch, read once at import (see __call__)
 SHARE_POOL = os.environ.get("ESTD_GRAPH_SHARE_POOL", "1") == "1"        # one graph memory pool per call shape (0: one per capture)
 
 
@@ -270,19 +269,11 @@ class GraphedForward:
             # after the previous replay of stage B, which read these buffers (the side stream waited for it above), runs BESIDE stage A
             # on a hardware queue of its own, and stage B waits for it.  (A third stream for the uploads shared the main stream's
             # hardware queue: its three 5 us copies ran behind stage A, in series with stage B's first kernels.)
-            up = side
-            if UPLOAD_STREAM == "own":                   # A/B: the third stream of before
-                up = st.get("upload_stream")
-                if up is None:
-                    up = st["upload_stream"] = torch.cuda.Stream()
-                up.wait_stream(side)
-            with torch.cuda.stream(up):
+            with torch.cuda.stream(side):
                 cam = camera.finish(pending)
                 for name, t in cam.items():
                     if t is not None:
                         st["cam"][name].copy_(t)
-            if up is not side:
-                main.wait_stream(up)
         main.wait_stream(side)
         st["graph_b"].replay()
         outputs, costs, cposes = st["out"]

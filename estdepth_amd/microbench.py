@@ -31,8 +31,9 @@ def _timeit(fn, n):
     return e0.elapsed_time(e1) / n * 1e-3
 
 
-def hbm_kernels_standalone(D=64, H=120, W=160, n=20, device=None, peak_gbs=8000.0):
-    """{kernel: {"avg_launch_us", "algorithmic_mb_per_launch", "achieved_gbs", "frac"}} at one volume size (default cfg2/cfg3)."""
+def hbm_kernels_standalone(D=64, H=120, W=160, n=20, device=None, peak_gbs=8000.0, only_attention=None):
+    """{kernel: {"avg_launch_us", "algorithmic_mb_per_launch", "achieved_gbs", "frac"}} at one volume size (default cfg2/cfg3).
+    ``only_attention=(2,)``: just warp_attention with these source counts (the cfg5-size entry of bench.py's joint line)."""
     dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
     vox = D * H * W
     g = torch.Generator(device=dev).manual_seed(0)
@@ -49,10 +50,16 @@ def hbm_kernels_standalone(D=64, H=120, W=160, n=20, device=None, peak_gbs=8000.
     dv = (torch.arange(D, dtype=torch.float32) * (9.9 / (D - 1)) + 0.1).to(dev)
     src = torch.randn(H, W, 32, device=dev, generator=g)
     ref = torch.randn(H, W, 32, device=dev, generator=g)
+    kvs = [torch.randn(D, H, W, 32, device=dev, generator=g) for _ in range(4)]
+    if only_attention:
+        for ns in only_attention:
+            mats = torch.stack([ops.cam_volume_mats(poses[j + 1], poses[0], K) for j in range(ns)])
+            report("warp_attention N=%d" % ns, _timeit(lambda: ops.warp_attention(kvs[0], kvs[1:1 + ns], mats, dv, 0.1, 9.9 / (D - 1)), n),
+                   4 * 16 * vox * (2 + 2 * ns))
+        return res
     proj = ops.cam_sweep_proj(poses[1], poses[0], K)
     out = torch.empty(D, H, W, 32, device=dev)
     report("homo_warp_costvol", _timeit(lambda: ops.homo_warp_costvol(src, ref, proj, dv, D, out=out), n), 4 * (2 * 32 * H * W + 32 * vox))
-    kvs = [torch.randn(D, H, W, 32, device=dev, generator=g) for _ in range(4)]
     for ns in (1, 2, 3):
         mats = torch.stack([ops.cam_volume_mats(poses[j + 1], poses[0], K) for j in range(ns)])
         report("warp_attention N=%d" % ns, _timeit(lambda: ops.warp_attention(kvs[0], kvs[1:1 + ns], mats, dv, 0.1, 9.9 / (D - 1)), n),

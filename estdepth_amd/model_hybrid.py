@@ -25,7 +25,6 @@ Align_Corners_Range = False
 FAST_PATH = os.environ.get("ESTD_FAST_PATH", "1") == "1"
 FUSED_NORM = os.environ.get("ESTD_FUSED_NORM", "1") == "1"     # image normalisation + NHWC layout in one kernel
 MIX_GEMM = os.environ.get("ESTD_MIX_GEMM", "1") == "1"         # pre0 halves as two library GEMMs on NHWC features
-SEMANTIC_PRIO = int(os.environ.get("ESTD_SEMANTIC_PRIO", "0"))    # A/B: HIP stream priority of the semantic branch's side stream (lower = more urgent)
 MIX_HIP = os.environ.get("ESTD_MIX_HIP", "1") == "1"           # ... as two 1x1 convolutions on csrc/conv1x1.hip instead (A/B switch)
 R50_HIP = os.environ.get("ESTD_R50_HIP", "1") == "1"           # ResNet stride-1 3x3 convolutions on the MFMA conv2d kernel
 HIP_REFINE = os.environ.get("ESTD_HIP_REFINE", "1") == "1"     # decoder 2D tail glue kernels (csrc/refine2d.hip)
@@ -288,7 +287,7 @@ class DepthNetHybrid(nn.Module):
             # PSM -> plane sweep -> pre1/pre2 chain; joined in the decoder right before dres2 needs the plane scores
             main = torch.cuda.current_stream()
             if getattr(self, "_side_stream", None) is None:
-                self._side_stream = torch.cuda.Stream(priority=SEMANTIC_PRIO)
+                self._side_stream = torch.cuda.Stream()          # (stream priorities changed nothing: stage A is the sum of its kernels' work, DESIGN)
             side = self._side_stream
             side.wait_stream(main)
             with torch.cuda.stream(side):

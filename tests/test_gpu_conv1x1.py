@@ -29,6 +29,11 @@ CASES = [  # N, H, W, cin, cout, stride, relu, residual, affine
     (1, 7, 9, 16, 32, 1, False, False, False),        # smallest channels, ragged pixel count, no affine
     (1, 15, 20, 2048, 512, 1, True, False, True),     # layer4 conv1: long K, few pixels
     (2, 5, 7, 48, 96, 2, True, True, True),           # odd chunk count (cin = 48), odd map with stride 2, residual
+    # the LDS-tiled form (round 6; default wherever there are >= ~224 workgroup tiles of 64 x 64):
+    (1, 61, 83, 64, 256, 1, True, True, True),        # 16-channel stages, ragged last pixel tile (5063 pixels), residual
+    (3, 60, 80, 512, 128, 1, True, False, True),      # 32-channel stages (layer2 conv1)
+    (3, 30, 40, 1024, 256, 1, False, False, True),    # 32-pixel tiles, 64-channel stages (layer3 conv1), no ReLU
+    (3, 59, 81, 128, 512, 2, True, True, True),       # stride 2 on an odd map through the tiled form, residual
 ]
 
 
@@ -58,6 +63,30 @@ def test_conv1x1_vs_fp64(case, binding):
     mag = ref.abs().max().item()
     # fp32 accumulation over cin products: the error of a length-cin fp32 dot product
     assert err < 2e-7 * np.sqrt(cin) * max(mag, 1.0) + 1e-6, (err, mag)
+
+
+@pytest.mark.parametrize("cfg", ["1441", "1422", "1242", "1224", "1122"])
+def test_conv1x1_forced_tile_configurations(cfg):
+    """every other workgroup tile of the LDS-tiled form (ESTD_C1X1_CFG is latched at the first call: one child process per configuration),
+    ragged pixel count, 96 output channels short of a whole 128-channel tile is NOT allowed (cout % 64 == 0 is the form's condition) --
+    320 channels leave a half-empty last 128-channel tile instead."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import torch, numpy as np\n"
+        "from estdepth_amd import ops\n"
+        "g = torch.Generator().manual_seed(5)\n"
+        "x = torch.randn(2, 37, 53, 128, generator=g); w = torch.randn(320, 128, generator=g) / 128 ** 0.5\n"
+        "sc = torch.rand(320, generator=g) + 0.5; sh = torch.randn(320, generator=g); r = torch.randn(2, 37, 53, 320, generator=g)\n"
+        "ref = (torch.einsum('nhwc,oc->nhwo', x.double(), w.double()) * sc.double() + sh.double() + r.double()).clamp_min(0)\n"
+        "out = ops.conv1x1_nhwc(x.cuda(), w.cuda(), sc.cuda(), sh.cuda(), 1, True, r.cuda())\n"
+        "err = float((out.double().cpu() - ref).abs().max()); mag = float(ref.abs().max())\n"
+        "assert err < 2e-7 * np.sqrt(128) * mag + 1e-6, (err, mag)\n"
+        "print('OK', err)\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, ESTD_C1X1_CFG=cfg), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, (cfg, r.stdout[-300:], r.stderr[-600:])
 
 
 def test_conv1x1_rejects_what_it_has_no_instance_for():
@@ -96,7 +125,7 @@ def test_bottleneck_fused_path(policy):
     finally:
         backbones.HIP_1X1 = old
     names = [e.key for e in prof.key_averages()]
-    assert sum("conv1x1_nhwc_kernel" in n for n in names) >= 1, names
+    assert sum(("conv1x1_nhwc_kernel" in n) or ("conv1x1_lds_kernel" in n) for n in names) >= 1, names
     if policy == "all":
         assert not any(("Cijk" in n) or ("gemm" in n.lower()) or ("bn_act" in n) or ("miopen" in n.lower()) for n in names), names
     scale = float(ref.abs().max())
@@ -123,6 +152,8 @@ def test_semantic_encoder_launches_no_library_gemm():
             torch.cuda.synchronize()
     ev = {e.key: e.count for e in prof.key_averages()}
     assert not any("Cijk" in k for k in ev), [k for k in ev if "Cijk" in k]
-    assert sum(c for k, c in ev.items() if "conv1x1_nhwc_kernel" in k) == 36           # 16 bottlenecks x (conv1, conv3) + 4 downsample convolutions
+    # 16 bottlenecks x (conv1, conv3) + 4 downsample convolutions, on the direct or the LDS-tiled form of csrc/conv1x1.hip
+    assert sum(c for k, c in ev.items() if "conv1x1_nhwc_kernel" in k or "conv1x1_lds_kernel" in k) == 36
+    assert sum(c for k, c in ev.items() if "conv1x1_lds_kernel" in k) >= 12             # (the tiled form is the default of most of them)
     assert sum(c for k, c in ev.items() if "conv2d_wino2_kernel" in k) == 13           # the stride-1 3x3 convolutions
     assert sum(c for k, c in ev.items() if "igemm" in k or "gemm" in k.lower() and "Cijk" not in k) <= 6, ev

@@ -28,6 +28,7 @@ NAMES = {
     "(anonymous namespace)::gru_blend_kernel(float const*)": "gru_elementwise",
     "(anonymous namespace)::conv2d_wino2_kernel(estd_conv2d_desc, int, int, int)": None,
     "void (anonymous namespace)::conv1x1_nhwc_kernel<4, 4, 2>(estd_conv1x1_desc, int, int, int, int)": None,
+    "void (anonymous namespace)::conv1x1_lds_kernel<64, 64, 2, 2, 1, 4>(estd_conv1x1_desc, int, int, int, int, int)": None,
     "Cijk_Ailk_Bljk_S_B_Bias_HA_S_SAV_UserArgs_MT128x128x16": None,
 }
 
