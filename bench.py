@@ -1009,7 +1009,7 @@ def main():
         # volumes per launch; null if the file is absent
         traffic, traffic_src = None, None
         vox = WORKLOADS[args.workload][3] * (WORKLOADS[args.workload][1] // 4) * (WORKLOADS[args.workload][2] // 4)
-        for name in ("r5_conv3d_pmc.json", "r4_conv3d_pmc.json", "r3_conv3d_pmc.json", "r2_conv3d_pmc.json", "r1_conv3d_pmc.json"):
+        for name in ("r6_conv3d_pmc.json", "r5_conv3d_pmc.json", "r4_conv3d_pmc.json", "r3_conv3d_pmc.json", "r2_conv3d_pmc.json", "r1_conv3d_pmc.json"):
             pmc_file = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc_file) and dom["launches"] and args.workload in ("joint", "estm") and args.conv3d_arith == "f32":
                 rec = json.load(open(pmc_file))

@@ -26,6 +26,7 @@ for algo in wino3 wino2 direct; do
   env $(algo_env $algo) bash $R/tools/pmc_collect.sh "FETCH_SIZE WRITE_SIZE" $OUT/${P}_conv3d_${algo}_pmc.csv -- python $R/tools/conv_bench.py 3 10 > /dev/null 2>&1
 done
 python $R/tools/pmc_json.py $OUT $P          # ${P}_conv3d_pmc.json: what bench.py reads for roofline.traffic (from profiles/)
+cp $OUT/${P}_conv3d_pmc.json $R/profiles/ 2>/dev/null      # (this run's copy of the tree: the bench lines below then carry THIS round's traffic figure)
 bash $R/tools/pmc_collect.sh "FETCH_SIZE WRITE_SIZE" $OUT/${P}_hbm_kernels_pmc.csv -- python $R/tools/hbm_bench.py > /dev/null 2>&1
 # the hardware's own matrix-pipe utilisation counter of every convolution kernel, stand-alone benches
 for b in "conv_bench.py 3 10" "conv_bench.py 1 10" "kv_bench.py" "head_bench.py" "conv2d_bench.py" "conv1x1_bench.py" "taps_bench.py"; do
@@ -46,6 +47,21 @@ python tools/gate_bench.py 2>&1 | grep -v amdgpu > $OUT/${P}_gate_bench.txt
 python tools/conv2d_bench.py 2>&1 | grep -v amdgpu > $OUT/${P}_conv2d_bench.txt
 python tools/psm_small_bench.py 2>&1 | grep -v amdgpu > $OUT/${P}_psm_small_bench.txt
 python tools/conv1x1_bench.py 2>&1 | grep -v amdgpu > $OUT/${P}_conv1x1_bench.txt
+python tools/conv1x1_cfg_sweep.py 2>&1 | grep -v amdgpu > $OUT/${P}_conv1x1_sweep.txt
+python tools/overlap_probe.py 40 2>&1 | grep -v amdgpu > $OUT/${P}_overlap_probe.txt
+# what writing only h in warp_attention would buy (timing ablations: variant libraries built before the gpurun call, ctypes binding) + the texture-address unit's account of it
+for v in "" _waabl1 _waabl2; do
+  [ -f estdepth_amd/lib/libestd_hip$v.so ] || continue
+  echo "# libestd_hip$v.so (ESTD_WA_ABL: '' = default [V_t | h] record, 1 = h only as a compact 16-channel volume, 2 = h only into its half of the record); cfg2 size, then cfg5 size" >> $OUT/${P}_warp_attention_honly.txt
+  ESTD_BINDING=ctypes ESTD_LIB=$R/estdepth_amd/lib/libestd_hip$v.so python tools/hbm_bench.py 2>&1 | grep "warp_att" >> $OUT/${P}_warp_attention_honly.txt
+  ESTD_BINDING=ctypes ESTD_LIB=$R/estdepth_amd/lib/libestd_hip$v.so python tools/hbm_bench.py 128 240 320 2>&1 | grep "warp_att" >> $OUT/${P}_warp_attention_honly.txt
+done
+for v in "" _waabl1; do
+  [ -f estdepth_amd/lib/libestd_hip$v.so ] || continue
+  ESTD_BINDING=ctypes ESTD_LIB=$R/estdepth_amd/lib/libestd_hip$v.so bash $R/tools/pmc_collect.sh "TA_TA_BUSY_sum SQ_BUSY_CU_CYCLES TCP_TCC_READ_REQ_sum FETCH_SIZE WRITE_SIZE" /tmp/wa_pmc.csv -- python $R/tools/hbm_bench.py > /dev/null 2>&1
+  echo "# libestd_hip$v.so" >> $OUT/${P}_warp_attention_honly_pmc.csv; grep "kernel,\|warp_attention" /tmp/wa_pmc.csv >> $OUT/${P}_warp_attention_honly_pmc.csv
+done
+cd $R
 python tools/taps_bench.py 2>&1 | grep -v amdgpu > $OUT/${P}_taps_bench.txt
 # (built here, before the gpurun call: /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/src/mfma_valu_overlap.hip -o tools/bin/mfma_valu_overlap)
 [ -x tools/bin/mfma_valu_overlap ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/src/mfma_valu_overlap.hip -o tools/bin/mfma_valu_overlap
@@ -54,7 +70,8 @@ tools/bin/mfma_valu_overlap > $OUT/${P}_mfma_valu_overlap.txt 2>&1
 [ "${ESTD_COLLECT_LINES:-1}" = 1 ] || { ls -la $OUT; exit 0; }
 # default bench lines (with cpu_baseline + parity) of every workload; algorithm A/B; the world-size-1 RCCL run
 last() { grep "^{" | tail -1; }
-python bench.py 2>/dev/null | last > $OUT/${P}_bench_joint.json
+python bench.py --steps 20 --warmup 5 2>/dev/null | last > $OUT/${P}_bench_joint.json
+python bench.py --steps 20 --warmup 5 --sustained-s 60 --no-cpu-baseline --no-other-workloads --no-replay-profile 2>/dev/null | last > $OUT/${P}_bench_joint_sustained60.json
 python bench.py --workload estm 2>/dev/null | last > $OUT/${P}_bench_estm.json
 python bench.py --workload cfg1 2>/dev/null | last > $OUT/${P}_bench_cfg1.json
 python bench.py --workload cfg5 --steps 5 --warmup 2 2>/dev/null | last > $OUT/${P}_bench_cfg5.json
