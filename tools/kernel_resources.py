@@ -16,7 +16,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.j
 
 def demangle(names):
     try:
-        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"] + names, capture_output=True, text=True).stdout.splitlines()
+        out = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.splitlines()
         return dict(zip(names, out))
     except Exception:
         return {n: n for n in names}
