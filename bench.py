@@ -71,6 +71,10 @@ def parse():
                     help="skip the rocprofv3 kernel trace of a short child run (per-kernel durations INSIDE the hipGraph replay)")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip the short timed loops of the other single-GPU workloads (ESTM window, cfg5, stream) reported beside the headline")
+    ap.add_argument("--pipeline", default=os.environ.get("ESTD_PIPELINE", "auto"), choices=["auto", "on", "off"],
+                    help="hipGraph replay: stage A (2D networks) of step k + 1 beside stage B of step k (GraphedForward(pipeline=True): two lanes of captures, "
+                         "stage A and stage B on streams of their own; the only dependence between consecutive calls is the memory record stage B hands on).  "
+                         "auto = on for single-GPU runs without the memory-bank exchange; every step's work is inside the timed region either way")
     ap.add_argument("--sustained-s", type=float, default=float(os.environ.get("ESTD_SUSTAINED_S", "20")),
                     help="after the K timed steps: the same step for about this many seconds in buckets of --sustained-bucket steps, shader clock and "
                          "board power sampled beside it by a host thread (config.sustained, config.sustained_ms_per_step, "
@@ -570,7 +574,7 @@ def replay_profile(args):
     cmd = [rp, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
            "--workload", args.workload, "--steps", str(steps), "--warmup", "2", "--no-cpu-baseline", "--no-alt",
            "--conv3d-arith", args.conv3d_arith, "--conv2d-arith", args.conv2d_arith, "--conv3d-algo", args.conv3d_algo,
-           "--graph-memory", args.graph_memory] + (["--no-graph"] if args.no_graph else [])
+           "--graph-memory", args.graph_memory, "--pipeline", args.pipeline, "--sustained-s", "0"] + (["--no-graph"] if args.no_graph else [])
     t0 = time.time()
     try:
         r = subprocess.run(cmd, cwd=tempfile.gettempdir(), env=env, capture_output=True, text=True, timeout=600)
@@ -794,7 +798,10 @@ def main():
         state["reserved_cus"], state["reserve_scope"], state["reserve_probe"] = n_res, scope, probe
         if args.no_graph:
             ops.set_reserved_cus(n_res)                                # eager launches: the process-wide setting, every kernel
-    fwd = model if args.no_graph else GraphedForward(model, zero_copy_memory=zero_copy, reserve_cus=reserve)     # hipGraph replay of the same forward (same kernels)
+    pipelined = (not args.no_graph) and (args.pipeline == "on" or (args.pipeline == "auto" and not dist_on))
+    if pipelined and state["allgather"]:
+        raise SystemExit("bench.py: --pipeline on needs --no-allgather in a distributed run (the exchange consumes every step's record on the caller's stream)")
+    fwd = model if args.no_graph else GraphedForward(model, zero_copy_memory=zero_copy, reserve_cus=reserve, pipeline=pipelined)     # hipGraph replay of the same forward (same kernels)
     state["fwd"] = fwd
     if oversub:
         state["notes"].append("%d ranks share %d GPU(s), gloo collectives: code-path check, not a scaling measurement" % (world, oversub))
@@ -835,7 +842,7 @@ def main():
         torch.cuda.synchronize()
 
     if not args.no_graph:
-        for _ in range(GRAPH_PRIME):       # the captures (zero-copy memory alternates between two ring buffers = two captures): untimed set-up
+        for _ in range(GRAPH_PRIME * (2 if pipelined else 1)):       # the captures (zero-copy memory alternates between two ring buffers = two captures; x 2 lanes when pipelined): untimed set-up
             step()
     for _ in range(args.warmup):
         step()
@@ -845,6 +852,8 @@ def main():
     for _ in range(args.steps):
         last = step()
     drain()                                # the last window's all-gather is inside the timed region
+    if pipelined and state["fwd"] is not model:
+        state["fwd"].join()                # (the trace marker below belongs behind the last step's stage B, which runs on a stream of its own)
     ops.profile_mark(1)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -1052,7 +1061,9 @@ def main():
             "config": {"workload": WORKLOADS[args.workload][6],
                        "depth_frames_per_step": frames, "input_frames_per_step": x_imgs.shape[1],
                        "input_frames_per_s": round(x_imgs.shape[1] * world * args.steps / elapsed, 3),
-                       "launch": "eager" if (args.no_graph or state["fwd"] is model) else "hipGraph replay",
+                       "launch": "eager" if (args.no_graph or state["fwd"] is model) else
+                                 ("hipGraph replay, stage A of step k + 1 beside stage B of step k (two lanes of captures)" if pipelined else "hipGraph replay"),
+                       "pipeline": bool(pipelined and not args.no_graph),
                        "graph_memory": None if (args.no_graph or state["fwd"] is model) else args.graph_memory,
                        "conv3d_arith": args.conv3d_arith, "conv2d_arith": args.conv2d_arith,
                        "conv3d_algo_32to32": kalgo,

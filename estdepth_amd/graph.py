@@ -28,6 +28,16 @@ costs (0.14 ms of a 17.7 ms Joint step):
     them (ring buffers: a bounded set; at most ``MAX_FOREIGN`` other address sets per call shape, then the static-copy path);
   * the tensors of ``outputs`` are overwritten by the next call of ANY signature (the captures of a call shape share nothing, but
     replays alternate between them).
+``pipeline=True`` (opt-in; bench.py's single-GPU default): consecutive calls are software-pipelined -- stage A of call k + 1 runs BESIDE stage B of
+call k.  The only dependence between consecutive calls of the reference's protocols is the memory record stage B hands on (eval_hybrid.py:229-243,
+eval_hybrid_seq.py:160-193): stage A reads the images alone.  Stage A is replayed on one internal stream, stage B on another; calls alternate
+between two LANES of captures (own static inputs, own 2D feature buffers, own graph memory pool: the intermediates of lane 1's stage A never
+alias lane 0's stage B); stage A of a lane waits for the lane's previous stage B (two calls back), stage B follows its own stage A and the
+previous call's stage B in stream order -- which is also what orders the memory record.  Contract differences:
+  * a call returns when its launches are queued and does NOT make the caller's stream wait for them (that wait is what would serialise the next
+    call's stage A behind this call's stage B): call ``join()`` before consuming the returned tensors on the caller's stream (memory records
+    passed back as ``pre_costs`` need no join: stage B reads them in its own stream order);
+  * the tensors of ``outputs`` survive ONE further call (they are overwritten two calls later).
 A capture is keyed by (input shape, number of memory volumes, number of frames whose matching features are handed in, mode, convolution arithmetic,
 weights epoch of the model): ``load_state_dict`` / ``.to()`` bump the epoch and force a re-capture; call
 ``invalidate()`` after editing parameters in place.
@@ -47,7 +57,7 @@ SHARE_POOL = os.environ.get("ESTD_GRAPH_SHARE_POOL", "1") == "1"        # one gr
 class GraphedForward:
     MAX_FOREIGN = 2          # zero-copy mode: address sets of memory records that do not lie in the ring, per call shape
 
-    def __init__(self, model, warmup=2, clone_outputs=False, zero_copy_memory=False, reserve_cus=None):
+    def __init__(self, model, warmup=2, clone_outputs=False, zero_copy_memory=False, reserve_cus=None, pipeline=False):
         """``clone_outputs=True``: the returned ``outputs`` dict holds fresh tensors (18 device copies of [1,1,Hi,Wi] maps per
         Joint call) instead of the graph's static output buffers -- a true drop-in for callers that keep outputs across calls.
         ``zero_copy_memory=True``: see the module docstring.
@@ -57,6 +67,10 @@ class GraphedForward:
         only, ``(8, 0)``; None = whatever the process-wide setting is at capture time."""
         self.model = model
         self.reserve_cus = reserve_cus
+        self.pipeline = bool(pipeline)               # see the module docstring; join() before consuming results on the caller's stream
+        self._lane = 0                               # pipeline mode: the lane the NEXT call takes
+        self._lane_done = [None, None]               # ... event behind the last stage B of each lane
+        self._pipe_streams = None                    # ... (stage-A stream, stage-B stream)
         self.warmup = warmup
         self.clone_outputs = clone_outputs
         self.zero_copy_memory = zero_copy_memory
@@ -71,7 +85,7 @@ class GraphedForward:
 
     def __getattr__(self, name):                 # normalise_images, matchingFeature, ndepths, ... of the wrapped model
         if name in ("model", "warmup", "_graphs", "clone_outputs", "memory_logits", "zero_copy_memory", "_ring", "last_matching", "reserve_cus", "_pools",
-                    "last_features2d"):
+                    "last_features2d", "pipeline", "_lane", "_lane_done", "_pipe_streams"):
             raise AttributeError(name)
         return getattr(self.model, name)
 
@@ -80,18 +94,26 @@ class GraphedForward:
         self._graphs.clear()
         self._pools.clear()
 
-    def _signature(self, imgs, pre_costs, mode, matching_features, placement=(None, None)):
+    def join(self):
+        """pipeline mode: make the CURRENT stream wait for everything the calls so far have queued (no-op otherwise)."""
+        if self._pipe_streams is not None:
+            cur = torch.cuda.current_stream()
+            for s_ in self._pipe_streams:
+                cur.wait_stream(s_)
+
+    def _signature(self, imgs, pre_costs, mode, matching_features, placement=(None, None), lane=0):
         n_mem = 0 if pre_costs is None else len(pre_costs["keys"])
         from . import ops, epipolar_transformer as ET
         return (tuple(imgs.shape), n_mem, None if matching_features is None else int(matching_features.shape[0]), mode, ops.CONV3D_ARITH, ops.CONV2D_ARITH,
                 ops.CONV3D_ALGO, getattr(ops, "CONV2D_ALGO", None), getattr(ops, "CONV2D_NT", None),      # a graph bakes the kernel choice in:
                 # ... the module-level kernel switches tests and tools flip at run time, and the grid sizes of the two stages
                 (ops.W3, ops.W3_EXTRA, ops.W2X, ops.W2_XOUT, ET.GATE_IN_CONV), self.reserve_cus,
+                lane,                                              # pipeline mode: the lane's own buffers and graph memory pool (0 otherwise)
                 self.model.camera_algebra,
                 placement,                                         # zero-copy mode: (addresses of the memory records, output ring slot)
                 getattr(self.model, "_estd_weights_epoch", 0))     # (last) a captured graph bakes kernel choice and weight buffers in
 
-    def _place_memory(self, imgs, pre_costs, mode, matching_features):
+    def _place_memory(self, imgs, pre_costs, mode, matching_features, lane=0):
         """zero-copy mode: where this call reads its memory records and which ring buffer it writes -> (addresses or None, slot)."""
         m = self.model
         V, Hi, Wi = imgs.shape[1], imgs.shape[3], imgs.shape[4]
@@ -106,7 +128,7 @@ class GraphedForward:
                 ptrs = tuple(kv.data_ptr() for kv in kvs)
                 busy = {resident[q] for q in ptrs if q in resident}
                 if any(q not in resident for q in ptrs):           # records from elsewhere: a bounded number of captures, then the copy path
-                    base = self._signature(imgs, pre_costs, mode, matching_features)
+                    base = self._signature(imgs, pre_costs, mode, matching_features, lane=lane)
                     seen = {k[-2][0] for k in self._graphs if k[:-2] == base[:-2] and k[-2][0] is not None
                             and any(q not in resident for q in k[-2][0])}
                     if ptrs not in seen and len(seen) >= self.MAX_FOREIGN:
@@ -142,6 +164,8 @@ class GraphedForward:
         st["cam"] = camera.finish(pending) if pending is not None else None
 
         from . import ops
+        if self.pipeline:
+            torch.cuda.synchronize()                 # nothing of an earlier call runs beside the eager warm-up / the capture
         prev_reserve = ops.get_reserved_cus() if self.reserve_cus is not None else None
 
         def reserve(stage):                              # the persistent grids of this stage leave that many CUs free (baked into the capture)
@@ -226,11 +250,14 @@ class GraphedForward:
             raise RuntimeError("GraphedForward replays mode='val' only: mode=%r needs host-side masking/metrics "
                                "(call the model eagerly, or evaluate the metrics on the returned outputs)" % (mode,))
         placement, kv_out, ring = (None, None), None, None
+        lane = 0
+        if self.pipeline:
+            lane, self._lane = self._lane, self._lane ^ 1
         if self.zero_copy_memory:
-            shape, ptrs, slot = self._place_memory(imgs, pre_costs, mode, matching_features)
+            shape, ptrs, slot = self._place_memory(imgs, pre_costs, mode, matching_features, lane)
             ring = self._ring[shape]
             placement, kv_out = (ptrs, slot), ring["bufs"][slot]
-        key = self._signature(imgs, pre_costs, mode, matching_features, placement)
+        key = self._signature(imgs, pre_costs, mode, matching_features, placement, lane)
         st = self._graphs.get(key)
         if st is None:
             st = self._capture(key, imgs, cam_poses, cam_intr, sample, pre_costs, pre_cam_poses, mode, matching_features, kv_out)
@@ -244,6 +271,20 @@ class GraphedForward:
         if side is None:
             side = st["copy_stream"] = torch.cuda.Stream()
         side.wait_stream(main)
+        s_a = s_b = main
+        if self.pipeline:
+            # stage A / stage B on streams of their own.  Both start behind the producers of this call's arguments (the caller's stream
+            # as it stands -- which has NOT been made to wait for the previous call's stage B) and behind the lane's previous stage B
+            # (two calls back), which read the static buffers written below and the 2D features stage A is about to overwrite, and whose
+            # intermediates share this lane's graph memory pool.
+            if self._pipe_streams is None:
+                self._pipe_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+            s_a, s_b = self._pipe_streams
+            s_a.wait_stream(main)
+            done = self._lane_done[lane]
+            if done is not None:
+                s_a.wait_event(done)
+                side.wait_event(done)
         with torch.cuda.stream(side):
             pending = self.model.camera_begin(cam_poses, cam_intr, pre_cam_poses)
             st["poses"].copy_(cam_poses)
@@ -258,12 +299,13 @@ class GraphedForward:
                         dst.copy_(src)
                 for dst, p in zip(st["mem_poses"], pre_cam_poses):
                     dst.copy_(p)
-        st["imgs"].copy_(imgs)
-        if matching_features is not None:
-            st["feats"].copy_(matching_features)
-        # stage A (the 2D networks, ~30 % of a step) is launched; while it runs the host waits for the pose copy, composes the
-        # camera matrices with the reference's own torch-CPU calls and queues their upload; then stage B.
-        st["graph_a"].replay()
+        with torch.cuda.stream(s_a):
+            st["imgs"].copy_(imgs)
+            if matching_features is not None:
+                st["feats"].copy_(matching_features)
+            # stage A (the 2D networks, ~30 % of a step) is launched; while it runs the host waits for the pose copy, composes the
+            # camera matrices with the reference's own torch-CPU calls and queues their upload; then stage B.
+            st["graph_a"].replay()
         if pending is not None:
             # the upload of the composed matrices goes to the same side stream (the host is ready long before stage A ends): it is ordered
             # after the previous replay of stage B, which read these buffers (the side stream waited for it above), runs BESIDE stage A
@@ -274,30 +316,44 @@ class GraphedForward:
                 for name, t in cam.items():
                     if t is not None:
                         st["cam"][name].copy_(t)
-        main.wait_stream(side)
-        st["graph_b"].replay()
-        outputs, costs, cposes = st["out"]
-        self.last_matching = st["feats2d"]["matching"]
-        self.last_features2d = st["feats2d"]
-        if st.get("last_logits") is not None:
-            self.model.CostRegNet.last_logits = st["last_logits"]
-        # the logit volume that travels with the memory bank (parallel.allgather_memory_bank*): a fresh 4.9 MB tensor, like the memory
-        ml = st.get("memory_logits")
-        self.memory_logits = ml.clone() if ml is not None else None
-        if self.clone_outputs:
-            outputs = {k: v.clone() for k, v in outputs.items()}
-        key_t, value_t = costs["keys"][0], costs["values"][0]
-        if ring is not None:
-            # zero-copy mode: the record lies in the ring buffer this capture writes; it is handed out as it is
-            self._mark_written(ring, placement[1])
-            return outputs, {"keys": [key_t], "values": [value_t]}, [p.clone() for p in cposes]
-        # memory handed back to the caller: fresh tensors (they outlive the next replay)
-        kv = getattr(value_t, "_estd_kv", None)
-        if kv is not None and getattr(key_t, "_estd_kv", None) is kv:
-            k2, v2 = kv_views(kv.clone())
-        else:
-            k2, v2 = key_t.clone(), value_t.clone()
-        return outputs, {"keys": [k2], "values": [v2]}, [p.clone() for p in cposes]
+        if s_b is not s_a:
+            s_b.wait_stream(s_a)                         # stage B behind its own stage A (and, in stream order, behind the previous call's stage B)
+        s_b.wait_stream(side)
+        with torch.cuda.stream(s_b):
+            st["graph_b"].replay()
+            outputs, costs, cposes = st["out"]
+            self.last_matching = st["feats2d"]["matching"]
+            self.last_features2d = st["feats2d"]
+            if st.get("last_logits") is not None:
+                self.model.CostRegNet.last_logits = st["last_logits"]
+            # the logit volume that travels with the memory bank (parallel.allgather_memory_bank*): a fresh 4.9 MB tensor, like the memory
+            ml = st.get("memory_logits")
+            self.memory_logits = ml.clone() if ml is not None else None
+            if self.clone_outputs:
+                outputs = {k: v.clone() for k, v in outputs.items()}
+            key_t, value_t = costs["keys"][0], costs["values"][0]
+            poses_out = [p.clone() for p in cposes]
+            if ring is not None:
+                # zero-copy mode: the record lies in the ring buffer this capture writes; it is handed out as it is
+                self._mark_written(ring, placement[1])
+                costs_out = {"keys": [key_t], "values": [value_t]}
+            else:
+                # memory handed back to the caller: fresh tensors (they outlive the next replay)
+                kv = getattr(value_t, "_estd_kv", None)
+                if kv is not None and getattr(key_t, "_estd_kv", None) is kv:
+                    k2, v2 = kv_views(kv.clone())
+                else:
+                    k2, v2 = key_t.clone(), value_t.clone()
+                costs_out = {"keys": [k2], "values": [v2]}
+            if self.pipeline:
+                self._lane_done[lane] = torch.cuda.Event()
+                self._lane_done[lane].record(s_b)
+                # fresh tensors allocated on the stage-B stream are the caller's from here on (after join()): tell the allocator
+                for t_ in poses_out + ([self.memory_logits] if self.memory_logits is not None else []) + (list(outputs.values()) if self.clone_outputs else []) \
+                        + ([] if ring is not None else [getattr(costs_out["values"][0], "_estd_kv", None), costs_out["keys"][0], costs_out["values"][0]]):
+                    if t_ is not None:
+                        t_.record_stream(main)
+        return outputs, costs_out, poses_out
 
 
 class GraphedModule:
