@@ -71,6 +71,7 @@ class GraphedForward:
         self._lane = 0                               # pipeline mode: the lane the NEXT call takes
         self._lane_done = [None, None]               # ... event behind the last stage B of each lane
         self._pipe_streams = None                    # ... (stage-A stream, stage-B stream)
+        self.last_event = None                       # ... event behind the stage B of the LAST call (join(event=...))
         self.warmup = warmup
         self.clone_outputs = clone_outputs
         self.zero_copy_memory = zero_copy_memory
@@ -85,7 +86,7 @@ class GraphedForward:
 
     def __getattr__(self, name):                 # normalise_images, matchingFeature, ndepths, ... of the wrapped model
         if name in ("model", "warmup", "_graphs", "clone_outputs", "memory_logits", "zero_copy_memory", "_ring", "last_matching", "reserve_cus", "_pools",
-                    "last_features2d", "pipeline", "_lane", "_lane_done", "_pipe_streams"):
+                    "last_features2d", "pipeline", "_lane", "_lane_done", "_pipe_streams", "last_event"):
             raise AttributeError(name)
         return getattr(self.model, name)
 
@@ -94,10 +95,15 @@ class GraphedForward:
         self._graphs.clear()
         self._pools.clear()
 
-    def join(self):
-        """pipeline mode: make the CURRENT stream wait for everything the calls so far have queued (no-op otherwise)."""
+    def join(self, event=None):
+        """pipeline mode: make the CURRENT stream wait for everything the calls so far have queued -- or, with ``event`` = the
+        ``last_event`` attribute read right after a call, for THAT call's stage B only (a consumer that waits for call k alone does not
+        put the stage A of call k + 2 behind the stage B of call k + 1).  No-op outside pipeline mode."""
         if self._pipe_streams is not None:
             cur = torch.cuda.current_stream()
+            if event is not None:
+                cur.wait_event(event)
+                return
             for s_ in self._pipe_streams:
                 cur.wait_stream(s_)
 
@@ -348,6 +354,7 @@ class GraphedForward:
             if self.pipeline:
                 self._lane_done[lane] = torch.cuda.Event()
                 self._lane_done[lane].record(s_b)
+                self.last_event = self._lane_done[lane]
                 # fresh tensors allocated on the stage-B stream are the caller's from here on (after join()): tell the allocator
                 for t_ in poses_out + ([self.memory_logits] if self.memory_logits is not None else []) + (list(outputs.values()) if self.clone_outputs else []) \
                         + ([] if ring is not None else [getattr(costs_out["values"][0], "_estd_kv", None), costs_out["keys"][0], costs_out["values"][0]]):

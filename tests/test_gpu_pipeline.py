@@ -35,8 +35,7 @@ def _run(fwd, protocol, imgs, poses, intr, n_calls):
             keep = (keep + [(costs, cposes)])[-2:]
             mem_c = {"keys": [k["keys"][0] for k, _ in keep], "values": [k["values"][0] for k, _ in keep]}
             mem_p = [p[0] for _, p in keep]
-        if hasattr(fwd, "join"):
-            fwd.join()
+        fwd.join(fwd.last_event)                # (this call's stage B alone; a no-op for the serial replay)
         res.append(({k: v.clone() for k, v in out.items()}, costs["values"][0].double().sum().item(), costs["keys"][0].double().sum().item(), cposes[0].clone()))
     torch.cuda.synchronize()
     return res
