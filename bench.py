@@ -574,7 +574,7 @@ def replay_profile(args):
     cmd = [rp, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
            "--workload", args.workload, "--steps", str(steps), "--warmup", "2", "--no-cpu-baseline", "--no-alt",
            "--conv3d-arith", args.conv3d_arith, "--conv2d-arith", args.conv2d_arith, "--conv3d-algo", args.conv3d_algo,
-           "--graph-memory", args.graph_memory, "--pipeline", args.pipeline, "--sustained-s", "0"] + (["--no-graph"] if args.no_graph else [])
+           "--graph-memory", args.graph_memory, "--pipeline", "off", "--sustained-s", "0"] + (["--no-graph"] if args.no_graph else [])
     t0 = time.time()
     try:
         r = subprocess.run(cmd, cwd=tempfile.gettempdir(), env=env, capture_output=True, text=True, timeout=600)
@@ -592,7 +592,9 @@ def replay_profile(args):
                 child_ms = json.loads(line).get("ms_per_step")
                 break
         info.update({"how": "rocprofv3 --kernel-trace of a child run of this command (%d steps, %s), kernels between the two estd_mark_kernel "
-                            "launches of its timed loop" % (steps, "eager launches" if args.no_graph else "hipGraph replay"),
+                            "launches of its timed loop" % (steps, "eager launches" if args.no_graph else
+                                                            "hipGraph replay, SERIAL (--pipeline off: per-kernel durations without the next step's stage A beside "
+                                                            "them; config.serial_replay is this configuration timed in the parent)"),
                      "child_ms_per_step_under_the_profiler": child_ms, "wall_s": round(time.time() - t0, 1)})
         return fams, info
     except Exception as e:
@@ -877,6 +879,27 @@ def main():
     if args.sustained_s > 0 and os.environ.get("ESTD_BENCH_CHILD") != "1":
         sustained = sustained_loop(step, drain, barrier, args, elapsed, device, dist if world > 1 else None, local_rank)
 
+    # ---- pipelined replay: the SAME K steps once more on the serial replay (stage A and stage B of a step back to back on one stream, no
+    #      overlap between steps): the A/B of the pipeline inside every line, and the configuration the per-kernel trace below describes ----
+    serial = None
+    if pipelined and state["fwd"] is not model and os.environ.get("ESTD_BENCH_CHILD") != "1":
+        try:
+            f_ser = GraphedForward(model, zero_copy_memory=zero_copy, reserve_cus=reserve, pipeline=False)
+            for _ in range(GRAPH_PRIME + args.warmup):
+                step(f_ser)
+            barrier()
+            ts = time.perf_counter()
+            for _ in range(args.steps):
+                step(f_ser)
+            barrier()
+            t_ser = time.perf_counter() - ts
+            serial = {"ms_per_step": round(1e3 * t_ser / args.steps, 3), "value": round(frames * args.steps / t_ser, 3),
+                      "pipelined_over_serial": round(t_ser / elapsed, 4),
+                      "what": "GraphedForward(pipeline=False): the round-5 launch path, same kernels, same K steps"}
+            del f_ser
+        except Exception as e:
+            serial = {"error": "%s: %s" % (type(e).__name__, str(e)[:100])}
+
     # ---- the collective alone (N > 1): bytes per rank and achieved bus bandwidth ----
     ag = None
     if dist_on and gathered:
@@ -1064,6 +1087,7 @@ def main():
                        "launch": "eager" if (args.no_graph or state["fwd"] is model) else
                                  ("hipGraph replay, stage A of step k + 1 beside stage B of step k (two lanes of captures)" if pipelined else "hipGraph replay"),
                        "pipeline": bool(pipelined and not args.no_graph),
+                       "serial_replay": serial,
                        "graph_memory": None if (args.no_graph or state["fwd"] is model) else args.graph_memory,
                        "conv3d_arith": args.conv3d_arith, "conv2d_arith": args.conv2d_arith,
                        "conv3d_algo_32to32": kalgo,
