@@ -330,8 +330,10 @@ def feature_parity(gpu_feats, nets):
     return out
 
 
-# bars of the feature-level comparison (tests/test_gpu_full_config.py holds the same numbers): max |diff| / range of the map
-FEATURE_TOL_REL = {"psm_matching": 2e-5, "resnet": 2e-5}
+# bars of the feature-level comparison (tests/test_gpu_full_config.py reads them from here): max |diff| / range of the map.  Measured with the
+# default kernels (round 6, cfg2 step): PSM 1.1e-6, ResNet scales 4.3e-7 .. 1.4e-6 -- the bar leaves ~3x; the emulation of tools/wino2d_f43_error.py puts
+# F(4,3) on one axis of the PSM convolutions at 2.2e-6 (inside) and F(4x4) at 6e-6 (outside)
+FEATURE_TOL_REL = {"psm_matching": 4e-6, "resnet": 4e-6}
 
 
 def cpu_baseline(workload, threads, x_imgs, x_poses, intr, pre_costs, pre_poses, gpu_outputs, frames, gpu_logits=None, kind="port", pin_socket=False,

@@ -147,7 +147,7 @@ def test_cfg2_2d_features_match_the_cpu_modules(cfg2_joint):
     [5,32,120,160] (psm_submodule.py:14-37,44-116: ~25 3x3 convolutions on the F(2x2,3x3) MFMA kernel, SPP, fused BN) and the five
     ResNet-50 scales (resnet_encoder.py:40-51: 1x1 / 3x3 / 7x7 convolutions, every one in-house) of the timed cfg2 step, accelerated +
     hipGraph path, against the same nn.Modules evaluated by torch on the CPU (oneDNN).  Neither side is exact -- both are fp32 roundoff
-    through ~50 layers -- so the bar is max |diff| <= FEATURE_TOL_REL x the map's range, about 2x what the default kernels measure
+    through ~50 layers -- so the bar is max |diff| <= FEATURE_TOL_REL (4e-6) x the map's range, about 3x what the default kernels measure
     (printed); any arithmetic change in the 2D branches (larger Winograd tiles, operand splits) has to fit under it."""
     import bench as B
     fp = cfg2_joint[4]
