@@ -28,7 +28,10 @@ costs (0.14 ms of a 17.7 ms Joint step):
     them (ring buffers: a bounded set; at most ``MAX_FOREIGN`` other address sets per call shape, then the static-copy path);
   * the tensors of ``outputs`` are overwritten by the next call of ANY signature (the captures of a call shape share nothing, but
     replays alternate between them).
-``pipeline=True`` (opt-in; bench.py's single-GPU default): consecutive calls are software-pipelined -- stage A of call k + 1 runs BESIDE stage B of
+``pipeline=True`` (opt-in, round 6; correct -- tests/test_gpu_pipeline.py: bit-identical to the serial replay -- and measured SLOWER on the Joint step,
+15.87-16.12 vs 15.55-15.80 ms, profiles/r6_pipeline_ab.txt: the 3D convolutions of stage B own every CU with one 512-thread workgroup that holds the whole
+register file and ~150 KB of LDS and walks a static tile range, so a stage-A workgroup scheduled between two of their launches only displaces one of theirs;
+stream priorities make it worse, 18 ms.  Two free-running streams of whole steps gain 3 %, tools/overlap_probe.py: the alignment matters): consecutive calls are software-pipelined -- stage A of call k + 1 runs BESIDE stage B of
 call k.  The only dependence between consecutive calls of the reference's protocols is the memory record stage B hands on (eval_hybrid.py:229-243,
 eval_hybrid_seq.py:160-193): stage A reads the images alone.  Stage A is replayed on one internal stream, stage B on another; calls alternate
 between two LANES of captures (own static inputs, own 2D feature buffers, own graph memory pool: the intermediates of lane 1's stage A never
@@ -284,7 +287,7 @@ class GraphedForward:
             # (two calls back), which read the static buffers written below and the 2D features stage A is about to overwrite, and whose
             # intermediates share this lane's graph memory pool.
             if self._pipe_streams is None:
-                self._pipe_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+                self._pipe_streams = (torch.cuda.Stream(), torch.cuda.Stream())      # (a high-priority stream for either stage: 18.1 / 18.6 ms, measured)
             s_a, s_b = self._pipe_streams
             s_a.wait_stream(main)
             done = self._lane_done[lane]

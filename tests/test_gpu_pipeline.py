@@ -26,7 +26,7 @@ def _run(fwd, protocol, imgs, poses, intr, n_calls):
             sl = slice(3 * c, 3 * c + 5)
         else:
             sl = slice(c, c + 3)
-        sample = {"dmaps": torch.ones(1, sl.stop - sl.start, 1, 64, 96, device=DEV), "dmasks": torch.ones(1, sl.stop - sl.start, 1, 64, 96, dtype=torch.bool, device=DEV)}
+        sample = {"dmaps": torch.ones(1, sl.stop - sl.start, 1, 128, 160, device=DEV), "dmasks": torch.ones(1, sl.stop - sl.start, 1, 128, 160, dtype=torch.bool, device=DEV)}
         with torch.no_grad():
             out, costs, cposes = fwd(imgs[:, sl].contiguous(), poses[:, sl].contiguous(), intr, sample, mem_c, mem_p, mode="val")
         if protocol == "joint":
@@ -49,7 +49,7 @@ def test_pipelined_replay_equals_serial_replay(protocol, zero_copy):
     torch.backends.cudnn.allow_tf32 = False
     n_calls = 6
     frames = 5 + 3 * (n_calls - 1) if protocol == "joint" else n_calls + 2
-    imgs, poses, intr, _ = synth.make_sequence(frames, 64, 96, seed=77)
+    imgs, poses, intr, _ = synth.make_sequence(frames, 128, 160, seed=77)
     imgs, poses, intr = imgs.to(DEV), poses.to(DEV), intr.to(DEV)
     model = _model()
     serial = _run(GraphedForward(model, zero_copy_memory=zero_copy), protocol, imgs, poses, intr, n_calls)
@@ -67,10 +67,10 @@ def test_pipelined_calls_without_join_in_between():
     calls' outputs (one per lane) equal the serial replay's."""
     from estdepth_amd import synth
     from estdepth_amd.graph import GraphedForward
-    imgs, poses, intr, _ = synth.make_sequence(8, 64, 96, seed=78)
+    imgs, poses, intr, _ = synth.make_sequence(8, 128, 160, seed=78)
     imgs, poses, intr = imgs.to(DEV), poses.to(DEV), intr.to(DEV)
     model = _model()
-    sample = lambda n: {"dmaps": torch.ones(1, n, 1, 64, 96, device=DEV), "dmasks": torch.ones(1, n, 1, 64, 96, dtype=torch.bool, device=DEV)}
+    sample = lambda n: {"dmaps": torch.ones(1, n, 1, 128, 160, device=DEV), "dmasks": torch.ones(1, n, 1, 128, 160, dtype=torch.bool, device=DEV)}
     with torch.no_grad():
         _, c0, p0 = model(imgs[:, 0:5], poses[:, 0:5], intr, sample(5), None, None, mode="val")
         x = (imgs[:, 3:8].contiguous(), poses[:, 3:8].contiguous(), intr, sample(5), c0, list(p0))
