@@ -54,6 +54,7 @@ from .hybrid_depth_decoder import kv_from_pair, kv_views
 from .layers_op import PlanCache
 
 
+PIPE_RELEASE = os.environ.get("ESTD_PIPE_RELEASE", "mid")              # pipeline mode A/B: "mid" = the next stage A waits for the previous call's B1; "start" = it does not
 SHARE_POOL = os.environ.get("ESTD_GRAPH_SHARE_POOL", "1") == "1"        # one graph memory pool per call shape (0: one per capture)
 
 
@@ -75,6 +76,7 @@ class GraphedForward:
         self._lane_done = [None, None]               # ... event behind the last stage B of each lane
         self._pipe_streams = None                    # ... (stage-A stream, stage-B stream)
         self.last_event = None                       # ... event behind the stage B of the LAST call (join(event=...))
+        self._mid_event = None                       # ... event between the two stage-B graphs of the LAST call
         self.warmup = warmup
         self.clone_outputs = clone_outputs
         self.zero_copy_memory = zero_copy_memory
@@ -89,7 +91,7 @@ class GraphedForward:
 
     def __getattr__(self, name):                 # normalise_images, matchingFeature, ndepths, ... of the wrapped model
         if name in ("model", "warmup", "_graphs", "clone_outputs", "memory_logits", "zero_copy_memory", "_ring", "last_matching", "reserve_cus", "_pools",
-                    "last_features2d", "pipeline", "_lane", "_lane_done", "_pipe_streams", "last_event"):
+                    "last_features2d", "pipeline", "_lane", "_lane_done", "_pipe_streams", "last_event", "_mid_event"):
             raise AttributeError(name)
         return getattr(self.model, name)
 
@@ -234,9 +236,34 @@ class GraphedForward:
         # thread_local: other threads (e.g. the RCCL watchdog polling events) may keep issuing HIP calls during capture
         with torch.no_grad(), torch.cuda.graph(ga, pool=pool, capture_error_mode="thread_local"):
             feats = run_a()
-        with torch.no_grad(), torch.cuda.graph(gb, pool=pool, capture_error_mode="thread_local"):
-            out = run_b(feats)
-        return ga, gb, feats, out
+        if not self.pipeline:
+            with torch.no_grad(), torch.cuda.graph(gb, pool=pool, capture_error_mode="thread_local"):
+                out = run_b(feats)
+            return ga, gb, feats, out
+        # pipeline mode: stage B as TWO graphs, cut by the decoder's split hook behind the key || value convolution: the next call's stage A is
+        # released when the first one (B1: the 3D-convolution chain) has finished and runs beside the second (B2: heads, EST loop, refinement)
+        gb2 = torch.cuda.CUDAGraph()
+        ctx = [torch.cuda.graph(gb, pool=pool, capture_error_mode="thread_local")]
+        cut = []
+
+        def split():
+            ctx[0].__exit__(None, None, None)
+            ctx[0] = torch.cuda.graph(gb2, pool=pool, capture_error_mode="thread_local")
+            ctx[0].__enter__()
+            cut.append(True)
+        self.model.CostRegNet.__dict__["_stage_split"] = split
+        try:
+            with torch.no_grad():
+                ctx[0].__enter__()
+                try:
+                    out = run_b(feats)
+                finally:
+                    ctx[0].__exit__(None, None, None)
+        finally:
+            self.model.CostRegNet.__dict__.pop("_stage_split", None)
+        if not cut:
+            raise RuntimeError("pipeline mode: the decoder never reached its stage-split point")
+        return ga, (gb, gb2), feats, out
 
     def _finish_capture(self, key, st):
         m = self.model
@@ -290,6 +317,8 @@ class GraphedForward:
                 self._pipe_streams = (torch.cuda.Stream(), torch.cuda.Stream())      # (a high-priority stream for either stage: 18.1 / 18.6 ms, measured)
             s_a, s_b = self._pipe_streams
             s_a.wait_stream(main)
+            if self._mid_event is not None and PIPE_RELEASE == "mid":
+                s_a.wait_event(self._mid_event)          # the previous call's 3D-convolution chain (B1) has the GPU to itself
             done = self._lane_done[lane]
             if done is not None:
                 s_a.wait_event(done)
@@ -329,7 +358,13 @@ class GraphedForward:
             s_b.wait_stream(s_a)                         # stage B behind its own stage A (and, in stream order, behind the previous call's stage B)
         s_b.wait_stream(side)
         with torch.cuda.stream(s_b):
-            st["graph_b"].replay()
+            if isinstance(st["graph_b"], tuple):         # pipeline mode: B1, the event that releases the next call's stage A, B2
+                st["graph_b"][0].replay()
+                self._mid_event = torch.cuda.Event()
+                self._mid_event.record(s_b)
+                st["graph_b"][1].replay()
+            else:
+                st["graph_b"].replay()
             outputs, costs, cposes = st["out"]
             self.last_matching = st["feats2d"]["matching"]
             self.last_features2d = st["feats2d"]

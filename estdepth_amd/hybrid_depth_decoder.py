@@ -276,6 +276,12 @@ class DepthHybridDecoder(nn.Module):
         if kv is None:
             kv = torch.empty((T, D, H, W, 32), device=dev, dtype=torch.float32)
         P["kv"].run(a, dims, in_extra=extra, out=kv, out_stride=32)
+        # GraphedForward(pipeline=True) ends the first stage-B graph here: what precedes is the back-to-back chain of 3D convolutions that own
+        # every CU (cost volumes, dres0..2, key || value), what follows (heads, EST fusion loop, soft-argmin, 2D refinement) has the HBM /
+        # gather bound kernels the next call's 2D networks can run beside
+        split = self.__dict__.get("_stage_split")
+        if split is not None:
+            split()
         init_logits = torch.empty((T, D, H, W), device=dev, dtype=torch.float32)
         dv = depth_values.reshape(-1)[:D].contiguous().float()
         if side is None:

@@ -65,6 +65,7 @@ NOTES = {
     "ESTD_AG_AUTO_RETIME": "bench.py: 0 = do not re-time on the chosen exchange algorithm",
     "ESTD_BENCH_CHILD": "bench.py (internal): the traced child run of replay_profile()",
     "ESTD_GRAPH_MEMORY": "bench.py: zero-copy (default) | copy",
+    "ESTD_PIPELINE": "bench.py: off (default) | on: GraphedForward(pipeline=True), stage A of step k + 1 beside stage B of step k (measured slower: profiles/r6_pipeline_ab.txt)",
     "ESTD_SUSTAINED_S": "bench.py: seconds of the sustained loop (20; 0 = skip)",
     "ESTD_CPU_LEG_CPUS": "bench.py (internal): cpu list of the pinned CPU-baseline child",
     "ESTD_NCHW_2D": "bench.py A/B: 1 = plain NCHW library 2D networks",
