@@ -72,11 +72,11 @@ def parse():
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip the short timed loops of the other single-GPU workloads (ESTM window, cfg5, stream) reported beside the headline")
     ap.add_argument("--pipeline", default=os.environ.get("ESTD_PIPELINE", "off"), choices=["on", "off"],
-                    help="hipGraph replay: on = stage A (2D networks) of step k + 1 beside stage B of step k (GraphedForward(pipeline=True): two lanes of "
-                         "captures, stage A and stage B on streams of their own; the only dependence between consecutive calls is the memory record stage B "
-                         "hands on).  Measured SLOWER than the serial replay (round 6: 15.87-16.12 vs 15.55-15.80 ms per Joint step, profiles/r6_pipeline_ab.txt): "
-                         "the 3D convolutions own every CU (one 512-thread workgroup with the whole register file and ~150 KB of LDS per CU, static tile "
-                         "ranges), so a stage-A workgroup beside them only displaces one of theirs; default off.  A line with it on carries the serial A/B")
+                    help="hipGraph replay: on = stage A (2D networks) of step k + 1 beside the SECOND half of stage B of step k (GraphedForward(pipeline=True): "
+                         "two lanes of captures, stage B cut into two graphs behind the key||value convolution; the only dependence between consecutive calls is "
+                         "the memory record stage B hands on).  Bit-identical results; measured +0.2 .. +1.2 %% on the Joint step, +1.8 %% ESTM, +4.7 %% cfg1 "
+                         "(profiles/r6_pipeline_ab.txt) -- inside the box-to-box spread, so the default stays the serial replay the per-kernel trace describes; "
+                         "a line with it on carries the serial A/B of the same process (config.serial_replay)")
     ap.add_argument("--sustained-s", type=float, default=float(os.environ.get("ESTD_SUSTAINED_S", "20")),
                     help="after the K timed steps: the same step for about this many seconds in buckets of --sustained-bucket steps, shader clock and "
                          "board power sampled beside it by a host thread (config.sustained, config.sustained_ms_per_step, "

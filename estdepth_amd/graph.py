@@ -28,15 +28,18 @@ costs (0.14 ms of a 17.7 ms Joint step):
     them (ring buffers: a bounded set; at most ``MAX_FOREIGN`` other address sets per call shape, then the static-copy path);
   * the tensors of ``outputs`` are overwritten by the next call of ANY signature (the captures of a call shape share nothing, but
     replays alternate between them).
-``pipeline=True`` (opt-in, round 6; correct -- tests/test_gpu_pipeline.py: bit-identical to the serial replay -- and measured SLOWER on the Joint step,
-15.87-16.12 vs 15.55-15.80 ms, profiles/r6_pipeline_ab.txt: the 3D convolutions of stage B own every CU with one 512-thread workgroup that holds the whole
-register file and ~150 KB of LDS and walks a static tile range, so a stage-A workgroup scheduled between two of their launches only displaces one of theirs;
-stream priorities make it worse, 18 ms.  Two free-running streams of whole steps gain 3 %, tools/overlap_probe.py: the alignment matters): consecutive calls are software-pipelined -- stage A of call k + 1 runs BESIDE stage B of
+``pipeline=True`` (opt-in, round 6; bit-identical to the serial replay -- tests/test_gpu_pipeline.py -- and a small gain: Joint step +0.2 .. +1.2 %, ESTM
+window +1.8 %, cfg1 +4.7 %, profiles/r6_pipeline_ab.txt): consecutive calls are software-pipelined -- stage A of call k + 1 runs BESIDE stage B of
 call k.  The only dependence between consecutive calls of the reference's protocols is the memory record stage B hands on (eval_hybrid.py:229-243,
 eval_hybrid_seq.py:160-193): stage A reads the images alone.  Stage A is replayed on one internal stream, stage B on another; calls alternate
 between two LANES of captures (own static inputs, own 2D feature buffers, own graph memory pool: the intermediates of lane 1's stage A never
 alias lane 0's stage B); stage A of a lane waits for the lane's previous stage B (two calls back), stage B follows its own stage A and the
-previous call's stage B in stream order -- which is also what orders the memory record.  Contract differences:
+previous call's stage B in stream order -- which is also what orders the memory record.  WHICH part of stage B the next stage A meets decides
+the sign: the first 6.8 ms of a Joint stage B are back-to-back 3D convolutions that own every CU (one 512-thread workgroup with the whole
+register file and ~150 KB of LDS per CU, static tile ranges) -- a stage-A workgroup between two of their launches only displaces one of theirs
+(released at the start of stage B: 15.9 vs 15.55 ms; with a high-priority stream for either stage 18 ms).  So stage B is captured as TWO graphs,
+cut by the decoder behind the key||value convolution, and the next call's stage A is released by the first: it runs beside the heads, the EST
+fusion loop (gather / HBM bound kernels between single-volume convolutions), soft-argmin and the 2D refinement.  Contract differences:
   * a call returns when its launches are queued and does NOT make the caller's stream wait for them (that wait is what would serialise the next
     call's stage A behind this call's stage B): call ``join()`` before consuming the returned tensors on the caller's stream (memory records
     passed back as ``pre_costs`` need no join: stage B reads them in its own stream order);
