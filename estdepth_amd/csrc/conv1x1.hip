@@ -163,6 +163,9 @@ __global__ __launch_bounds__(256) void conv1x1_nhwc_kernel(const estd_conv1x1_de
     }
 }
 
+#ifndef ESTD_C1X1_COUNTED
+#define ESTD_C1X1_COUNTED 1     // 1: counted vmcnt + raw s_barrier per stage (stages stay in flight across the barrier); 0: __syncthreads() (A/B)
+#endif
 // ---------------------------------------------------------------------------------------------------------------------------------
 // LDS-tiled form (round 6).  The direct form above streams every operand quad of every WAVE from L1 / L2: a 64 x 64 wave block reads
 // 128 bytes per MFMA, the smaller blocks of the small maps 256-384, and the K-heavy layers lose to the library.  Here a WORKGROUP owns a
@@ -220,12 +223,29 @@ __global__ __launch_bounds__(256) void conv1x1_lds_kernel(const estd_conv1x1_des
             src[j] = p.in + (((size_t)n * p.H + y * p.stride) * p.W + x * p.stride) * cin + u * 16 + ks * 4;
         }
     }
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;       // LDS byte address of the stage ring
     auto request = [&](int c) {                           // chunk c (16 U channels) -> stage c % NS
+#if ESTD_C1X1_COUNTED
+        // The request as inline assembly: behind the BUILTIN hipcc puts an s_waitcnt vmcnt(0) in front of the next ds_read of this loop (it cannot
+        // see that the stage being written is not the stage being read: one extern LDS array), i.e. every iteration would wait for the requests it
+        // has just issued -- no prefetch at all (what the first version of this kernel did: MfmaUtil 27-41 %).  The counted waits at the top of
+        // the loop are the only synchronisation of these loads.  m0 = wave-uniform LDS destination, one wait state before its use.
+        const unsigned dst = lds_base + (unsigned)((c % NS) * STAGE + wave * LPW * 1024);
+#pragma unroll
+        for (int j = 0; j < LPW; ++j) {
+            const float* g_ = src[j] + (size_t)c * 16 * U;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"          // (m0 is a reserved register: nothing else in this kernel depends on it)
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g_), "s"(dst + j * 1024) : "memory", "m0");
+#pragma clang diagnostic pop
+        }
+#else
         unsigned char* base = lds + (c % NS) * STAGE + wave * LPW * 1024;
 #pragma unroll
         for (int j = 0; j < LPW; ++j)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (size_t)c * 16 * U),
                                              (__attribute__((address_space(3))) void*)(base + j * 1024), 16, 0, 0);
+#endif
     };
 
     f32x4 acc[TN][TM];
@@ -242,7 +262,19 @@ __global__ __launch_bounds__(256) void conv1x1_lds_kernel(const estd_conv1x1_des
     for (int c = 0; c < NS - 1; ++c)
         if (c < nchunks) request(c);
     for (int c = 0; c < nchunks; ++c) {
+#if ESTD_C1X1_COUNTED
+        // stage c has landed when at most the requests of the stages behind it are outstanding (a wave's requests complete in order): a COUNTED
+        // wait keeps NS - 2 stages in flight across the barrier where __syncthreads() drains them all (vmcnt(0)) and leaves a request one
+        // iteration -- 512..2048 matrix cycles -- to come back from L2 / HBM.  Raw barrier: nothing else of this loop touches vector memory.
+        {
+            const int ahead = (c + NS - 1 < nchunks ? c + NS - 1 : nchunks) - (c + 1);      // stages requested beyond stage c (wave-uniform)
+            if (NS >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(2 * LPW) : "memory");
+            else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(LPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+#else
         __syncthreads();                                  // stage c has landed (vmcnt(0) in front of the barrier); stage c - 1 is free
+#endif
         if (c + NS - 1 < nchunks) request(c + NS - 1);
         const unsigned char* st = lds + (c % NS) * STAGE;
 #pragma unroll
