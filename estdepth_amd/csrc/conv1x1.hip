@@ -384,19 +384,17 @@ extern "C" int estd_conv1x1_nhwc(const estd_conv1x1_desc* dp, estd_stream_t s)
     // LDS-tiled form: cfg = 1000 + 100 (BM / 32) + 10 (BN / 32) + U  (ESTD_C1X1_CFG forces one; ESTD_C1X1_LDS=0: direct form only)
     static const int lds_env = [] { const char* e = getenv("ESTD_C1X1_LDS"); return e ? atoi(e) : 1; }();
     if (cfg == 0 && lds_env && (d.cout & 63) == 0) {
-        // Which form, from the sweep of tools/conv1x1_cfg_sweep.py over the sixteen ResNet-50 shapes (profiles/r6_conv1x1_sweep.txt): the
-        // direct form's 64 x 64 wave blocks keep the big maps with >= 256 input channels (256 -> 64 / 128 at 120x160, 256 -> 512 stride 2,
-        // 512 -> 256 at 60x80: 1-4 % ahead of the tiled form there, no barrier); everything else with at least ~one 64 x 64 workgroup tile per CU
-        // runs LDS-tiled -- 16-channel stages up to 256 input channels, 32-channel stages from 512 on; maps with
-        // fewer tiles take 32-pixel tiles and 64-channel stages (1024 -> 256 at 30x40); below ~one of THOSE per CU (2048 -> 512 at 15x20)
-        // the direct form's K split over the four waves of a workgroup stays.
+        // Which form, from the sweep of tools/conv1x1_cfg_sweep.py over the sixteen ResNet-50 shapes (profiles/r6_conv1x1_sweep.txt; with the counted
+        // waits the tiled form is at or ahead of the direct form on every one of them): 64 x 64 workgroup tiles wherever there is about one per CU
+        // -- 16-channel stages up to 256 input channels, 32-channel stages from 512 on; maps with fewer tiles take 32-pixel tiles and 64-channel
+        // stages (1024 -> 256 at 30x40, 2048 -> 512 at 15x20); below that the direct form (K split over the four waves of a workgroup) stays.
         auto wgs = [&](int bm, int bn) { return ((Mtot + bm - 1) / bm) * ((d.cout + bn - 1) / bn); };
         const long long cus = estd_device_cus();
-        const bool direct441 = d.cin >= 256 && tiles(4, 4) >= want && Mtot >= 8192;
-        if (direct441) cfg = 0;
-        else if (wgs(64, 64) >= cus * 7 / 4) cfg = (d.cin >= 512 && (d.cin & 31) == 0) ? 1222 : 1221;
+        const int c64 = (d.cin >= 512 && (d.cin & 31) == 0) ? 1222 : 1221;
+        if (wgs(64, 64) >= cus * 7 / 4) cfg = c64;
         else if (wgs(32, 64) >= cus * 7 / 4 && (d.cin & 63) == 0) cfg = 1124;
-        else if (wgs(64, 64) >= cus * 7 / 8) cfg = (d.cin >= 512 && (d.cin & 31) == 0) ? 1222 : 1221;
+        else if (wgs(64, 64) >= cus * 7 / 8) cfg = c64;
+        else if (wgs(32, 64) >= cus * 3 / 4 && (d.cin & 63) == 0) cfg = 1124;
     }
     if (cfg >= 1000 && (d.cin % (16 * (cfg % 10)))) cfg = 0;                              // whole stages only
     switch (cfg) {
