@@ -261,40 +261,64 @@ __global__ __launch_bounds__(256) void conv1x1_lds_kernel(const estd_conv1x1_des
 #pragma unroll
     for (int c = 0; c < NS - 1; ++c)
         if (c < nchunks) request(c);
-    for (int c = 0; c < nchunks; ++c) {
+    // wait for stage c (requests of the stages behind it may stay in flight: a wave's requests complete in order) + workgroup barrier.  A COUNTED
+    // wait keeps NS - 2 stages in flight across the barrier where __syncthreads() drains them all.  Raw barrier: nothing else in the loop
+    // touches vector memory; the memory clobber keeps the fragment reads behind it.
+    auto publish = [&](int c) {
 #if ESTD_C1X1_COUNTED
-        // stage c has landed when at most the requests of the stages behind it are outstanding (a wave's requests complete in order): a COUNTED
-        // wait keeps NS - 2 stages in flight across the barrier where __syncthreads() drains them all (vmcnt(0)) and leaves a request one
-        // iteration -- 512..2048 matrix cycles -- to come back from L2 / HBM.  Raw barrier: nothing else of this loop touches vector memory.
-        {
-            const int ahead = (c + NS - 1 < nchunks ? c + NS - 1 : nchunks) - (c + 1);      // stages requested beyond stage c (wave-uniform)
-            if (NS >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(2 * LPW) : "memory");
-            else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(LPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        }
+        const int ahead = (c + NS - 1 < nchunks ? c + NS - 1 : nchunks) - (c + 1);      // stages requested beyond stage c (wave-uniform)
+        if (NS >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(2 * LPW) : "memory");
+        else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(LPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #else
-        __syncthreads();                                  // stage c has landed (vmcnt(0) in front of the barrier); stage c - 1 is free
+        __syncthreads();
 #endif
-        if (c + NS - 1 < nchunks) request(c + NS - 1);
-        const unsigned char* st = lds + (c % NS) * STAGE;
+    };
+    auto fragments = [&](int c, int u, float4 (&wq)[TN], float4 (&xq)[TM]) {
+        const unsigned char* st = lds + (c % NS) * STAGE + u * NBLK * 1024;
+#pragma unroll
+        for (int a = 0; a < TN; ++a) wq[a] = *reinterpret_cast<const float4*>(st + woff + a * 1024);
+#pragma unroll
+        for (int b = 0; b < TM; ++b) xq[b] = *reinterpret_cast<const float4*>(st + xoff + b * 1024);
+    };
+    auto multiply = [&](const float4 (&wq)[TN], const float4 (&xq)[TM]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                const float wv = e == 0 ? wq[a].x : e == 1 ? wq[a].y : e == 2 ? wq[a].z : wq[a].w;
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+                    const float xv = e == 0 ? xq[b].x : e == 1 ? xq[b].y : e == 2 ? xq[b].z : xq[b].w;
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc[a][b], 0, 0, 0);
+                }
+            }
+    };
+    // Software pipeline over (stage, sub-chunk): the fragments of the NEXT sub-chunk are read before the MFMAs of the current one -- across
+    // the stage boundary too: the wait + barrier that publishes stage c + 1 sits in front of the LAST sub-chunk's MFMAs of stage c (every wave
+    // has read all of stage c by then: its slot is free for the request at the top of iteration c + 1), so neither the LDS latency nor the
+    // barrier skew is exposed once per stage (one wave per SIMD on the small maps: nobody else would hide it).
+    float4 wq[2][TN], xq[2][TM];
+    publish(0);
+    fragments(0, 0, wq[0], xq[0]);
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + NS - 1 < nchunks) request(c + NS - 1);   // into the slot of stage c - 1 (released by the barrier of the previous iteration)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            float4 wq[TN], xq[TM];
+            const int cur = u & 1, nxt = cur ^ 1;
+            if (u + 1 < U) {
+                fragments(c, u + 1, wq[nxt], xq[nxt]);
+            } else if (c + 1 < nchunks) {                 // (wave-uniform)
+                publish(c + 1);
+                fragments(c + 1, 0, wq[(U & 1) ? nxt : 0], xq[(U & 1) ? nxt : 0]);
+            }
+            multiply(wq[cur], xq[cur]);
+        }
+        if (U & 1) {                                      // odd U: the buffers have swapped roles for the next stage -- swap them back (register moves)
 #pragma unroll
-            for (int a = 0; a < TN; ++a) wq[a] = *reinterpret_cast<const float4*>(st + u * NBLK * 1024 + woff + a * 1024);
+            for (int a = 0; a < TN; ++a) wq[0][a] = wq[1][a];
 #pragma unroll
-            for (int b = 0; b < TM; ++b) xq[b] = *reinterpret_cast<const float4*>(st + u * NBLK * 1024 + xoff + b * 1024);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int a = 0; a < TN; ++a) {
-                    const float wv = e == 0 ? wq[a].x : e == 1 ? wq[a].y : e == 2 ? wq[a].z : wq[a].w;
-#pragma unroll
-                    for (int b = 0; b < TM; ++b) {
-                        const float xv = e == 0 ? xq[b].x : e == 1 ? xq[b].y : e == 2 ? xq[b].z : xq[b].w;
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xv, acc[a][b], 0, 0, 0);
-                    }
-                }
+            for (int b = 0; b < TM; ++b) xq[0][b] = xq[1][b];
         }
     }
 
