@@ -71,13 +71,13 @@ def parse():
                     help="skip the rocprofv3 kernel trace of a short child run (per-kernel durations INSIDE the hipGraph replay)")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip the short timed loops of the other single-GPU workloads (ESTM window, cfg5, stream) reported beside the headline")
-    ap.add_argument("--pipeline", default=os.environ.get("ESTD_PIPELINE", "auto"), choices=["auto", "on", "off"],
+    ap.add_argument("--pipeline", default=os.environ.get("ESTD_PIPELINE", "off"), choices=["on", "off"],
                     help="hipGraph replay: on = stage A (2D networks) of step k + 1 beside the SECOND half of stage B of step k (GraphedForward(pipeline=True): "
                          "two lanes of captures, stage B cut into two graphs behind the key||value convolution; the only dependence between consecutive calls is "
-                         "the memory record stage B hands on).  Bit-identical results (tests/test_gpu_pipeline.py); +0.2 .. +1.2 %% on the Joint step, +1.8 %% ESTM, "
-                         "+4.7 %% cfg1 on four boxes, never slower (profiles/r6_pipeline_ab.txt).  auto (default) = on for single-GPU runs without the memory-bank "
-                         "exchange; every step's work is inside the timed region, the line carries the serial replay of the same process (config.serial_replay) "
-                         "and the per-kernel trace is taken on the serial replay")
+                         "the memory record stage B hands on).  Bit-identical results (tests/test_gpu_pipeline.py) but NOT a robust gain: +0.2 .. +1.2 %% on the "
+                         "Joint step in 40-step A/B pairs on four boxes, -2 .. -7 %% in the default 10-step command on a fifth, 200-step buckets between 15.7 and "
+                         "16.3 ms where the serial replay holds 15.5 +- 0.05 (profiles/r6_pipeline_ab.txt): what the next stage A meets is left to the hardware "
+                         "queues.  Default off; a line with it on carries the serial replay of the same process (config.serial_replay)")
     ap.add_argument("--sustained-s", type=float, default=float(os.environ.get("ESTD_SUSTAINED_S", "20")),
                     help="after the K timed steps: the same step for about this many seconds in buckets of --sustained-bucket steps, shader clock and "
                          "board power sampled beside it by a host thread (config.sustained, config.sustained_ms_per_step, "
@@ -599,7 +599,7 @@ def replay_profile(args):
         info.update({"how": "rocprofv3 --kernel-trace of a child run of this command (%d steps, %s), kernels between the two estd_mark_kernel "
                             "launches of its timed loop" % (steps, "eager launches" if args.no_graph else
                                                             "hipGraph replay" + (", SERIAL (--pipeline off: per-kernel durations without the next step's stage A beside them; "
-                                                                               "config.serial_replay is this configuration timed in the parent)" if args.pipeline != "off" else "")),
+                                                                               "config.serial_replay is this configuration timed in the parent)" if args.pipeline == "on" else "")),
                      "child_ms_per_step_under_the_profiler": child_ms, "wall_s": round(time.time() - t0, 1)})
         return fams, info
     except Exception as e:
@@ -805,7 +805,7 @@ def main():
         state["reserved_cus"], state["reserve_scope"], state["reserve_probe"] = n_res, scope, probe
         if args.no_graph:
             ops.set_reserved_cus(n_res)                                # eager launches: the process-wide setting, every kernel
-    pipelined = (not args.no_graph) and (args.pipeline == "on" or (args.pipeline == "auto" and not dist_on))
+    pipelined = (not args.no_graph) and args.pipeline == "on"
     if pipelined and state["allgather"]:
         raise SystemExit("bench.py: --pipeline on needs --no-allgather in a distributed run (the exchange consumes every step's record on the caller's stream)")
     fwd = model if args.no_graph else GraphedForward(model, zero_copy_memory=zero_copy, reserve_cus=reserve, pipeline=pipelined)     # hipGraph replay of the same forward (same kernels)

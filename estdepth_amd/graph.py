@@ -28,8 +28,9 @@ costs (0.14 ms of a 17.7 ms Joint step):
     them (ring buffers: a bounded set; at most ``MAX_FOREIGN`` other address sets per call shape, then the static-copy path);
   * the tensors of ``outputs`` are overwritten by the next call of ANY signature (the captures of a call shape share nothing, but
     replays alternate between them).
-``pipeline=True`` (opt-in, round 6; bit-identical to the serial replay -- tests/test_gpu_pipeline.py -- and a small gain: Joint step +0.2 .. +1.2 %, ESTM
-window +1.8 %, cfg1 +4.7 %, profiles/r6_pipeline_ab.txt): consecutive calls are software-pipelined -- stage A of call k + 1 runs BESIDE stage B of
+``pipeline=True`` (opt-in, round 6; bit-identical to the serial replay -- tests/test_gpu_pipeline.py -- but NOT a robust gain: Joint step +0.2 .. +1.2 % in
+40-step A/B pairs on four boxes, -2 .. -7 % in a 10-step run on a fifth, 200-step buckets between 15.7 and 16.3 ms where the serial replay holds
+15.5 +- 0.05, profiles/r6_pipeline_ab.txt): consecutive calls are software-pipelined -- stage A of call k + 1 runs BESIDE stage B of
 call k.  The only dependence between consecutive calls of the reference's protocols is the memory record stage B hands on (eval_hybrid.py:229-243,
 eval_hybrid_seq.py:160-193): stage A reads the images alone.  Stage A is replayed on one internal stream, stage B on another; calls alternate
 between two LANES of captures (own static inputs, own 2D feature buffers, own graph memory pool: the intermediates of lane 1's stage A never

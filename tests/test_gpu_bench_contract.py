@@ -71,13 +71,8 @@ def test_bench_headline_workload_roofline_fields_are_hardware_fractions():
     d = _last_json(out.stdout)
     r = d["roofline"]
     assert r["replay_trace"] and "error" not in r["replay_trace"], r["replay_trace"]
-    # the timed loop is the pipelined replay (round 6: stage A of step k + 1 beside the second half of stage B of step k); the line carries the
-    # serial replay of the same process, which the pipeline never loses to, and the per-kernel trace is taken on the serial replay
-    ser = d["config"]["serial_replay"]
-    assert d["config"]["pipeline"] is True and "error" not in ser and ser["ms_per_step"] > 0
-    assert ser["pipelined_over_serial"] > 0.985, ser
-    assert abs(r["replay_trace"]["ms_per_step"] / ser["ms_per_step"] - 1.0) < 0.10          # the traced child ran the same (serial) step
-    assert abs(r["replay_trace"]["ms_per_step"] / d["ms_per_step"] - 1.0) < 0.10
+    assert d["config"]["pipeline"] is False and d["config"]["serial_replay"] is None      # (the pipelined replay is opt-in: --pipeline on)
+    assert abs(r["replay_trace"]["ms_per_step"] / d["ms_per_step"] - 1.0) < 0.10           # the traced child ran the same step
     fams = dict(r["mfma_kernels"], **r["hbm_kernels"])
     assert {"conv3d:32->32", "conv3d:33->32", "conv3d:33->33", "conv3d:16->16", "conv3d:32->16", "warp_attention", "homo_warp_costvol",
             "softargmin", "gru_elementwise"} <= set(fams)

@@ -65,7 +65,7 @@ NOTES = {
     "ESTD_AG_AUTO_RETIME": "bench.py: 0 = do not re-time on the chosen exchange algorithm",
     "ESTD_BENCH_CHILD": "bench.py (internal): the traced child run of replay_profile()",
     "ESTD_GRAPH_MEMORY": "bench.py: zero-copy (default) | copy",
-    "ESTD_PIPELINE": "bench.py: auto (default: on for single-GPU runs without the exchange) | on | off: GraphedForward(pipeline=True), stage A of step k + 1 beside the second half of stage B of step k (+0.2 .. +1.2 % Joint: profiles/r6_pipeline_ab.txt)",
+    "ESTD_PIPELINE": "bench.py: off (default) | on: GraphedForward(pipeline=True), stage A of step k + 1 beside the second half of stage B of step k (not a robust gain: profiles/r6_pipeline_ab.txt)",
     "ESTD_PIPE_RELEASE": "pipeline mode A/B: mid (default: the next stage A waits for the previous call's 3D-convolution chain) | start (it does not: slower)",
     "ESTD_SUSTAINED_S": "bench.py: seconds of the sustained loop (20; 0 = skip)",
     "ESTD_CPU_LEG_CPUS": "bench.py (internal): cpu list of the pinned CPU-baseline child",
