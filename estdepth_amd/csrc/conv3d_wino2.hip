@@ -731,7 +731,9 @@ __global__ __launch_bounds__(64 * NW, 1) void conv3d_wino2_kernel(const estd_con
 #define ESTD_W2BD 3     // since the column-keyed swizzle the registers are there (242 VGPRs, no spill): N = 3 plain 0.819 -> 0.810 ms, + running sum 0.853 -> 0.838,
 #endif                  // + residual 0.862 -> 0.847, two residuals 0.911 -> 0.893, 33 -> 32 0.861 -> 0.850, 32 -> 16 0.158 -> 0.155 (profiles/r4_wino2_ablation.txt)
             // the 33 -> 33 instance keeps one step of cover: with two it spills (0.982 -> 1.124 ms)
-            constexpr int BD = NW == 4 ? 3 : XOUT ? 2 : ESTD_W2BD;  // weight buffers in flight
+            // ... and so does the reset-gated 32 -> 16 instance (round 6): with two steps of cover it carries 16 spilled registers reloaded once per tile
+            // (profiles/r6_kernel_resources.txt); with one, none -- one ConvGRU 0.5297 -> 0.5265 ms, Joint step -0.04 ms (three alternating pairs)
+            constexpr int BD = NW == 4 ? 3 : (XOUT || (O16 && GATE)) ? 2 : ESTD_W2BD;  // weight buffers in flight
             constexpr bool QSCHED = ESTD_W2_QSCHED != 0 && NW == 8;
             float4 bq[BD][4][NHW];                       // [buffer][sh][channel half]: one step's quad of the four taps of a group
             f32x2 T[2][4];                               // [component pair][sh]
