@@ -197,3 +197,41 @@ def test_new_weights_force_a_recapture(zero_copy):
             for k in eb:
                 assert (eb[k] - gb[k]).abs().max().item() < 2e-5, k
     assert all(k[-1] == m._estd_weights_epoch for k in gf._graphs)                  # nothing of the old weights is kept
+
+
+def test_kernel_switches_flipped_at_run_time_force_a_recapture():
+    """A capture bakes the kernel choice in.  The module-level switches tests and tools flip at run time (ops.W3: three-axis vs two-axis 3D
+    convolution; epipolar_transformer.GATE_IN_CONV: reset gate folded into the output convolution vs its own pass) are part of the capture key
+    (round 6, ADVICE): a live GraphedForward re-captures instead of silently replaying the old kernels -- an A/B through one wrapper compares
+    two different graphs -- and each graph keeps replaying its own choice."""
+    from estdepth_amd import ops
+    from estdepth_amd import epipolar_transformer as ET
+    from estdepth_amd.graph import GraphedForward
+    m = _model()
+    imgs, poses, intr, smp = _inputs(5)
+    sl = slice(1, 4)
+    old_w3, old_gate = ops.W3, ET.GATE_IN_CONV
+    try:
+        with torch.no_grad():
+            _, c0, p0 = m(imgs[:, 0:3], poses[:, 0:3], intr, smp(slice(0, 3)), None, None, mode="val")
+            pc = {"keys": [c0["keys"][0].clone()], "values": [c0["values"][0].clone()]}
+            gf = GraphedForward(m, clone_outputs=True)
+            args = (imgs[:, sl], poses[:, sl], intr, smp(sl), pc, [p0[0]])
+            a, _, _ = gf(*args, mode="val")
+            assert len(gf._graphs) == 1
+            ops.W3 = not old_w3
+            b, _, _ = gf(*args, mode="val")
+            assert len(gf._graphs) == 2                      # a second capture, the first one is kept
+            ET.GATE_IN_CONV = not old_gate
+            c, _, _ = gf(*args, mode="val")
+            assert len(gf._graphs) == 3
+            ops.W3, ET.GATE_IN_CONV = old_w3, old_gate
+            a2, _, _ = gf(*args, mode="val")
+            assert len(gf._graphs) == 3                      # back on the first capture
+        for k in a:
+            assert torch.equal(a[k], a2[k]), k
+            assert (a[k] - b[k]).abs().max().item() < 2e-5 and (a[k] - c[k]).abs().max().item() < 2e-5, k
+        # different kernels round differently: the two-axis and the three-axis convolution do not agree bit for bit on every output
+        assert any(not torch.equal(a[k], b[k]) for k in a)
+    finally:
+        ops.W3, ET.GATE_IN_CONV = old_w3, old_gate
