@@ -30,7 +30,8 @@ PEAK_FP32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f
 PEAK_BF16_MATRIX_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak; the 3xbf16 split spends 6 bf16 FLOPs per fp32 FLOP
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E spec peak (about 6.3 TB/s is achievable by a copy)
 # fraction of the direct convolution's 27-tap MFMA products a kernel actually issues (the rest is removed by exact Winograd identities)
-EXECUTED_FACTOR = {"direct": 1.0, "wino": 18.0 / 27.0, "wino2": 12.0 / 27.0, "wino3": 8.0 / 27.0}
+EXECUTED_FACTOR = {"direct": 1.0, "wino": 18.0 / 27.0, "wino2": 12.0 / 27.0, "wino3": 8.0 / 27.0,
+                   "taps": 32.0 * 36.0 / (27.0 * 33.0)}       # conv3d_xout: 32 tap rows x 36 channel steps issued for 27 x 33 useful products
 
 #            name:  (views, Hi,  Wi,   D,  resnet, EST,   description)
 WORKLOADS = {
@@ -619,6 +620,8 @@ def conv3d_algo_of(group, algo, arith):
         return "wino3"                                   # all three axes in Winograd form (csrc/conv3d_wino3.hip: 8/27 of the products)
     if group in ("conv3d:32->32", "conv3d:33->32"):      # the key || value convolution (33 -> 32) has a wino2 instance as well
         return algo
+    if group == "conv3d:33->1":                              # dres2's 33rd output channel: the taps as matrix rows (csrc/conv3d_xout.hip)
+        return "taps"
     if group == "conv3d:33->33":
         if algo == "wino2":
             return "wino2" if ops.W2_XOUT else "wino"

@@ -98,6 +98,7 @@ _SIGNATURES = {
     "estd_conv3d_k3_wino2": (ctypes.c_int, [ctypes.POINTER(Conv3dDesc), c_stream]),
     "estd_conv3d_k3_wino2x": (ctypes.c_int, [ctypes.POINTER(Conv3dDesc), c_stream]),
     "estd_conv3d_k3_wino3": (ctypes.c_int, [ctypes.POINTER(Conv3dDesc), c_stream]),
+    "estd_conv3d_k3_xout": (ctypes.c_int, [ctypes.POINTER(Conv3dDesc), c_stream]),
     "estd_conv2d_k3": (ctypes.c_int, [ctypes.POINTER(Conv2dDesc), c_stream]),
     "estd_conv2d_k3_split": (ctypes.c_int, [ctypes.POINTER(Conv2dDesc), c_stream]),
     "estd_conv2d_k3_wino": (ctypes.c_int, [ctypes.POINTER(Conv2dDesc), c_stream]),

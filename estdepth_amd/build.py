@@ -24,7 +24,7 @@ LIB = os.path.join(OUT_DIR, "libestd_hip%s.so" % os.environ.get("ESTD_LIB_SUFFIX
 # operand-split kernels (none has a default caller since round 4; the two-axis Winograd kernels cover every instance and are faster),
 # the operand-reuse rebuild of the two-axis 32 -> 32 instance (conv3d_wino2x.hip: at parity with the 8-wave kernel, superseded by conv3d_wino3.hip) --
 # are built, exported (include/estd_hip.h: #ifdef ESTD_BUILD_AB), bound and tested only with ESTD_BUILD_AB=1 in the environment.
-SOURCES = ["conv3d_mfma.hip", "conv3d_wino2.hip", "conv3d_wino3.hip", "conv3d_wino2_c16.hip", "conv2d_mfma.hip", "conv2d_wino2.hip",
+SOURCES = ["conv3d_mfma.hip", "conv3d_wino2.hip", "conv3d_wino3.hip", "conv3d_xout.hip", "conv3d_wino2_c16.hip", "conv2d_mfma.hip", "conv2d_wino2.hip",
            "plane_sweep.hip", "est_fusion.hip", "refine2d.hip", "conv1x1.hip", "conv2d_taps.hip"]
 AB_SOURCES = ["conv3d_wino.hip", "conv3d_split_bf16.hip", "conv2d_wino.hip", "conv2d_split_bf16.hip", "conv3d_wino2x.hip"]
 BUILD_AB = os.environ.get("ESTD_BUILD_AB", "0") == "1"

@@ -227,6 +227,9 @@ void conv3d_k3(const Tensor& x, const OptTensor& x_extra, const OptTensor& w_mai
     } else if (variant == 5) {          // the 32 -> 32 instance with all three axes in Winograd form (w_alt = packing.pack_conv3d_wino3)
         d.w_wino2 = fptr(*w_alt, "3-axis Winograd-packed weights");
         check_status(estd_conv3d_k3_wino3(&d, cur_stream()), "estd_conv3d_k3_wino3");
+    } else if (variant == 6) {          // output channel 32 of the 33 -> 33 instance alone (w_alt = packing.pack_conv3d_xout_taps)
+        d.w_xout = fptr(*w_alt, "tap-major weights of output channel 32");
+        check_status(estd_conv3d_k3_xout(&d, cur_stream()), "estd_conv3d_k3_xout");
     } else {
         TORCH_CHECK(variant == 0, "conv3d_k3: unknown variant ", variant);
         check_status(estd_conv3d_k3(&d, cur_stream()), "estd_conv3d_k3");

@@ -88,6 +88,9 @@ W2X = os.environ.get("ESTD_W2X", "0") != "0"
 W3 = os.environ.get("ESTD_W3", "1") != "0"
 # the key || value convolution (33 -> 32) on the three-axis kernel's scalar-channel instance as well (0.73 vs 0.85 ms for 3 volumes; "0": two-axis kernel)
 W3_EXTRA = os.environ.get("ESTD_W3_EXTRA", "1") != "0"
+# dres2 (33 -> 33): the 32 main output channels on the three-axis kernel's scalar-channel instance + output channel 32 as a pass of its own
+# (csrc/conv3d_xout.hip: taps as matrix rows) instead of the two-axis kernel's 33 -> 33 instance ("0")
+W3_XOUT = os.environ.get("ESTD_W3_XOUT", "1") != "0"
 # same choice for the 3x3 / dilation-1 NHWC convolutions: row axis in Winograd F(2,3) form (csrc/conv2d_wino.hip) or direct
 CONV2D_ALGO = os.environ.get("ESTD_CONV2D_ALGO", "wino2")
 CONV2D_NT = os.environ.get("ESTD_CONV2D_NT", "auto")
@@ -280,10 +283,12 @@ class Conv3dPlan:
                 P.define("w_wino2x", lambda: packing.pack_conv3d_wino2x(weight, main_idx, out_idx[:32]))
         if wino_ok:
             P.define("w_wino2", lambda: packing.pack_conv3d_wino2(weight, main_idx, out_idx[:32]))
-            if n_tiles == 2:
+            if n_tiles == 2 or (n_tiles == 3 and extra_idx is not None):
                 P.define("w_wino3", lambda: packing.pack_conv3d_wino3(weight, main_idx, out_idx[:32]))
                 if extra_idx is not None:
                     P.define("w_wino3_extra", lambda: packing.pack_conv3d_wino3_extra(weight, extra_idx, out_idx[:32]))
+            if n_tiles == 3 and extra_idx is not None:      # ... + output channel 32 as a pass of its own (csrc/conv3d_xout.hip)
+                P.define("w_xout_taps", lambda: packing.pack_conv3d_xout_taps(weight, main_idx, extra_idx, out_idx[32]))
             if extra_idx is not None:
                 P.define("w_wino2_extra", lambda: packing.pack_conv3d_wino2_extra(weight, extra_idx, out_idx[:32]))
             if n_tiles == 3:       # 33 -> 33 (dres2): the 33rd output channel of the wino2 kernel's XOUT instance
@@ -301,6 +306,38 @@ class Conv3dPlan:
         self.act_split = act_split if act_b is not None else 0
         self.head_w = head_w.float().contiguous().to(device) if head_w is not None else None
         self.head_b = head_b.float().contiguous().to(device) if head_b is not None else None
+
+    def _run_split33(self, x, dims, in_stride, in_extra, out, out_stride, out_extra):
+        """the 33 -> 33 instance as two launches: estd_conv3d_k3_wino3 (33 -> 32, the main output channels) + estd_conv3d_k3_xout (33 -> 1)"""
+        Nn, D, H, W = dims
+        cin = self.cin_main + 1
+        vox = float(Nn) * D * H * W
+        if _use_torch():
+            # (two profile groups: the launches belong to two kernel families of the replay trace)
+            with _Prof("conv3d:%d->32" % cin, 2.0 * 27 * cin * 32 * vox):
+                T().conv3d_k3(x, in_extra, None, self.w_wino3_extra, None, self.w_wino3, self.scale, self.shift, (Nn, D, H, W), self.cin_main, in_stride, 2,
+                              self.act_a, self.act_b, self.act_split, out, out_stride, 32, None, None, 1.0, False, None, None, None, None, None, 5,
+                              None, None, None, None)
+            with _Prof("conv3d:%d->1" % cin, 2.0 * 27 * cin * vox):
+                T().conv3d_k3(x, in_extra, None, self.w_wino3_extra, None, self.w_xout_taps, self.scale, self.shift, (Nn, D, H, W), self.cin_main, in_stride, 3,
+                              self.act_a, self.act_b, self.act_split, None, out_stride, 32, None, None, 1.0, False, out_extra, None, None, None, None, 6,
+                              None, None, None, None)
+            return
+        d = N.Conv3dDesc()
+        d.N, d.D, d.H, d.W = Nn, D, H, W
+        d.cin_main, d.in_stride, d.n_tiles = self.cin_main, in_stride, 2
+        d.in_main, d.in_extra = x.data_ptr(), in_extra.data_ptr()
+        d.scale, d.shift = self.scale.data_ptr(), self.shift.data_ptr()
+        d.act_a, d.act_b, d.act_split = self.act_a, self.act_b, self.act_split
+        d.out_main, d.out_stride, d.out_channels = out.data_ptr(), out_stride, 32
+        d.out_scale = 1.0
+        d.w_wino2, d.w_extra = self.w_wino3.data_ptr(), self.w_wino3_extra.data_ptr()
+        with _Prof("conv3d:%d->32" % cin, 2.0 * 27 * cin * 32 * vox):
+            N.check(N.lib().estd_conv3d_k3_wino3(ctypes.byref(d), _stream()), "estd_conv3d_k3_wino3")
+        d.n_tiles, d.out_main, d.w_wino2, d.w_extra = 3, None, None, None
+        d.w_xout, d.out_extra = self.w_xout_taps.data_ptr(), out_extra.data_ptr()
+        with _Prof("conv3d:%d->1" % cin, 2.0 * 27 * cin * vox):
+            N.check(N.lib().estd_conv3d_k3_xout(ctypes.byref(d), _stream()), "estd_conv3d_k3_xout")
 
     def with_shift_scaled(self, k):
         """same packed weights, BN shift multiplied by k: sum of k conv+BN results of a LINEAR layer computed as ONE
@@ -364,6 +401,11 @@ class Conv3dPlan:
         wino3 = wino2 and W3 and has("w_wino3") and self.n_tiles == 2 and (stats_partials is None or plain_epi) \
             and (in_extra is None or (W3_EXTRA and has("w_wino3_extra") and plain_epi and stats_partials is None))
         wino2x = wino2x and not wino3
+        # 33 -> 33 (dres2): 32 outputs on the three-axis kernel's 33 -> 32 instance, then output channel 32 alone
+        split33 = wino2 and self.n_tiles == 3 and W3 and W3_EXTRA and W3_XOUT and has("w_wino3") and has("w_wino3_extra") and has("w_xout_taps") \
+            and in_extra is not None and out_extra is not None
+        if split33:
+            return self._run_split33(x, dims, in_stride, in_extra, out, out_stride, out_extra)
         variant, alt = (1, "w_split") if split else (3, "w_wino2_c16") if c16 else (3, "w_wino2_o16") if o16 else (5, "w_wino3") if wino3 \
             else (4, "w_wino2x") if wino2x \
             else (3, "w_wino2") if wino2 else (2, "w_wino") if wino else (0, None)

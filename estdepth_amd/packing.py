@@ -53,6 +53,29 @@ def pack_xout(weight, main_idx, extra_idx, out_channel):
     return torch.from_numpy(out)
 
 
+def pack_conv3d_xout_taps(weight, main_idx, extra_idx, out_channel):
+    """ONE output channel of a 33-input-channel 3x3x3 convolution for csrc/conv3d_xout.hip (the taps are the matrix core's rows): float32
+    [2 chunks][2 tap tiles][64 lanes][4] -- lane (g, i) of (chunk c, tile t) holds w[out_channel][main_idx[16 c + 4 g + e]][tap 16 t + i], e = 0..3
+    (taps 27..31 are zero) -- followed by [2 tap tiles][64 lanes]: the scalar input channel's weight of tap 16 t + i for lane group g = 0, zero
+    for the others (its k-step is (s, 0, 0, 0)).  Tap = (kd * 3 + kh) * 3 + kw."""
+    w = weight.detach().double().cpu().numpy().reshape(weight.shape[0], weight.shape[1], 27)
+    out = np.zeros(4 * 64 * 4 + 2 * 64, np.float32)
+    main = out[:1024].reshape(2, 2, 64, 4)
+    ext = out[1024:].reshape(2, 64)
+    for lane in range(64):
+        g, i = lane >> 4, lane & 15
+        for t in range(2):
+            tap = 16 * t + i
+            if tap > 26:
+                continue
+            for c in range(2):
+                for e in range(4):
+                    main[c, t, lane, e] = w[out_channel, main_idx[16 * c + 4 * g + e], tap]
+            if g == 0 and extra_idx is not None:
+                ext[t, lane] = w[out_channel, extra_idx, tap]
+    return torch.from_numpy(out)
+
+
 def pack_conv3d(weight, main_idx, extra_idx, out_idx, n_tiles):
     """weight: [Cout, Cin, 3,3,3] tensor.  main_idx: list of 16/32 input-channel indices (order = main
     channel order in memory).  extra_idx: index of the scalar input channel or None.

@@ -15,6 +15,7 @@ _W2 = re.compile(r"conv3d_wino2_kernel<\s*(\d+),\s*(\d+|true|false),\s*(true|fal
 _W2X = re.compile(r"conv3d_wino2x_kernel<")          # the operand-reuse form of the 32 -> 32 instance (csrc/conv3d_wino2x.hip, opt-in)
 _W3 = re.compile(r"conv3d_wino3_kernel<\s*(\d+),\s*(true|false),\s*(true|false)\s*>")            # the 32 -> 32 instances with all three axes in Winograd form (csrc/conv3d_wino3.hip, default since round 5)
 _W2H = re.compile(r"conv3d_wino2_c16_kernel")
+_XO = re.compile(r"conv3d_xout_kernel")              # output channel 32 of dres2 as a pass of its own (csrc/conv3d_xout.hip, round 6)
 _W1 = re.compile(r"conv3d_wino_kernel<\s*(true|false),\s*(true|false)\s*>")
 _K3 = re.compile(r"conv3d_k3_kernel<\s*(\d+),\s*(\d+),\s*(true|false),\s*(true|false)\s*>")
 
@@ -36,6 +37,8 @@ def family_of(kernel_name):
         return "conv3d:33->32" if m.group(3) == "true" else "conv3d:32->32"      # <read-back kind, GroupNorm partials, scalar 33rd input channel>
     if _W2X.search(n):
         return "conv3d:32->32"
+    if _XO.search(n):
+        return "conv3d:33->1"
     if _W2H.search(n):
         return "conv3d:16->16"
     m = _W1.search(n)

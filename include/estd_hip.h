@@ -190,6 +190,12 @@ int estd_conv3d_k3_wino2x(const estd_conv3d_desc* desc, estd_stream_t stream);
  * [64 blocks ((4 sd + sh) * 2 + cc) * 2 + hh][2 halves][2 tap pairs][64 lanes][4].  ESTD_ERR_UNSUPPORTED for any other shape (callers fall back to
  * estd_conv3d_k3_wino2). */
 int estd_conv3d_k3_wino3(const estd_conv3d_desc* desc, estd_stream_t stream);
+/* Output channel 32 ALONE of the 33 -> 33 instance (n_tiles = 3: dres2, hybrid_depth_decoder.py:93-95,:196): out_extra = act(conv(in_main[32] | in_extra
+ * -> 1 channel) * scale[32] + shift[32]) -- the pass that lets the 32 main output channels of that layer run on estd_conv3d_k3_wino3's 33 -> 32
+ * instance (csrc/conv3d_xout.hip: the 27 taps as the matrix core's rows, a shifted sum of scalars behind it).  Reads desc->w_xout in the packing of
+ * packing.py::pack_conv3d_xout_taps (float32 [2][2][64][4] + [2][64]); cin_main = 32, in_extra, scale / shift with 33 entries and out_extra required;
+ * out_main and every other output field are ignored.  ESTD_ERR_UNSUPPORTED for any other shape. */
+int estd_conv3d_k3_xout(const estd_conv3d_desc* desc, estd_stream_t stream);
 /* number of thread blocks estd_conv3d_k3 launches for a volume (size of stats_partials / 4 doubles) */
 int estd_conv3d_k3_grid(int N, int D, int H, int W);
 

@@ -171,12 +171,14 @@ def test_wino_extra_input_channel_matches_direct_kernel_and_fp64(dims, algo):
     assert float((a - b).abs().max()) < 5e-6 * max(1.0, mag)
 
 
-@pytest.mark.parametrize("algo", ALGOS)
-@pytest.mark.parametrize("dims", [(1, 4, 8, 32), (3, 5, 13, 50), (2, 1, 9, 33), (1, 64, 24, 32), (1, 3, 120, 160)])
+@pytest.mark.parametrize("algo", ALGOS + ("wino3",))
+@pytest.mark.parametrize("dims", [(1, 4, 8, 32), (3, 5, 13, 50), (2, 1, 9, 33), (1, 64, 24, 32), (1, 3, 120, 160), (2, 17, 37, 21)])
 def test_wino_33_to_33_matches_direct_kernel_and_fp64(dims, algo):
     """dres2's shape: input = [scalar channel 0 | 32 channels-last], output = 32 channels-last + a scalar 33rd volume (ReLU).  wino2:
     the XOUT instance of the 2-axis kernel (the 33rd output channel on the VALU from the row-transformed fragments, split over the
-    two waves of a SIMD, cross-wave sum through LDS)."""
+    two waves of a SIMD, cross-wave sum through LDS).  wino3 (the default, round 6): the 32 main outputs on the three-axis kernel's 33 -> 32
+    instance + output channel 32 as a pass of its own with the taps as matrix rows (csrc/conv3d_xout.hip); ragged tiles, depth segments
+    that end inside a 16-plane segment, a single plane."""
     from estdepth_amd import ops
     N, D, H, W = dims
     g = torch.Generator().manual_seed(3 + sum(dims))

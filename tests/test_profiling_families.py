@@ -12,6 +12,7 @@ NAMES = {
     "void (anonymous namespace)::conv3d_wino2_kernel<8, 0, false, true, false, true>(estd_conv3d_desc, int, int, int, int)": "conv3d:32->16",   # reset-gated
     "void (anonymous namespace)::conv3d_wino2_kernel<8, 0, false, false, false, false>(estd_conv3d_desc, int, int, int, int)": "conv3d:32->32",
     "void (anonymous namespace)::conv3d_wino2_kernel<8, 0, true, false, true, false>(estd_conv3d_desc, int, int, int, int)": "conv3d:33->33",
+    "void (anonymous namespace)::conv3d_xout_kernel(estd_conv3d_desc, int, int, int)": "conv3d:33->1",
     "void (anonymous namespace)::conv3d_wino2x_kernel<0, false>(estd_conv3d_desc, int, int, int, int)": "conv3d:32->32",
     "void (anonymous namespace)::conv3d_wino3_kernel<0, false, false>(estd_conv3d_desc, int, int, int, int)": "conv3d:32->32",     # three-axis kernel: <read-back kind, GroupNorm, scalar channel>
     "void (anonymous namespace)::conv3d_wino3_kernel<2, false, false>(estd_conv3d_desc, int, int, int, int)": "conv3d:32->32",
