@@ -33,7 +33,7 @@ constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;
 constexpr int TH = 16, TW = 16, IN_H = TH + 2, IN_W = TW + 2, HALO = IN_H * IN_W;       // 324 halo voxels per plane
 constexpr int GROUPS = (HALO + 15) / 16;                                                // 21 groups of 16 MFMA columns
 constexpr int PITCH = 33;                                                               // floats per voxel of P (27 taps used)
-constexpr int DSEG = 16;                                                                // output planes per workgroup
+constexpr int DSEG = 32;                                                                // output planes per workgroup (+ 2 halo planes)
 
 __device__ __forceinline__ float4 as_float4(u32x4 v) { float4 f; __builtin_memcpy(&f, &v, 16); return f; }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, size_t elems)
@@ -86,33 +86,46 @@ __global__ __launch_bounds__(256) void conv3d_xout_kernel(const estd_conv3d_desc
     const bool ovalid = h0 + oy < H && w0 + ox < W;
     const int pbase = (oy * IN_W + ox) * PITCH;
 
+    // one plane's operands of this lane: two quads of the 32 main channels + the scalar channel per column group
+    struct Plane {
+        float4 x0[GPW], x1[GPW];
+        float xe[GPW];
+    };
+    auto request = [&](int d, Plane& q) {                 // input plane d (absent planes: nothing is requested, nothing is multiplied)
+        if (d < 0 || d >= D) return;
+        const unsigned plane = (unsigned)d * (unsigned)HW;
+#pragma unroll
+        for (int k = 0; k < GPW; ++k) {
+            if (wave + 4 * k < GROUPS) {                  // (wave-uniform)
+                const bool in = voff[k] != 0xFFFFFFFFu;
+                const unsigned vo = in ? (plane + voff[k]) : 0u;
+                const unsigned bo = in ? vo * (unsigned)p.in_stride * 4u + (unsigned)g * 16u : OOB_OFFSET;
+                q.x0[k] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, bo, 0, 0));
+                q.x1[k] = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, bo, 64, 0));
+                q.xe[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ex, (in && g == 0) ? vo * 4u : OOB_OFFSET, 0, 0));
+            }
+        }
+    };
     float A = 0.0f, B = 0.0f;                             // running sums: output plane d - 1 (depth taps 0, 1 so far) and d (depth tap 0)
-    for (int d = d0 - 1; d <= d1; ++d) {                  // INPUT planes
+    auto step = [&](int d, const Plane& q) {              // multiply input plane d, fold it into the running sums, finish output plane d - 1
         float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
         if (d >= 0 && d < D) {                            // (workgroup-uniform)
-            const unsigned plane = (unsigned)d * (unsigned)HW;
 #pragma unroll
             for (int k = 0; k < GPW; ++k) {
                 const int grp = wave + 4 * k;
-                if (grp < GROUPS) {                       // (wave-uniform)
-                    const bool in = voff[k] != 0xFFFFFFFFu;
-                    const unsigned vo = in ? (plane + voff[k]) : 0u;
-                    const unsigned bo = in ? vo * (unsigned)p.in_stride * 4u + (unsigned)g * 16u : OOB_OFFSET;
-                    const float4 x0 = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, bo, 0, 0));
-                    const float4 x1 = as_float4(__builtin_amdgcn_raw_buffer_load_b128(rs_in, bo, 64, 0));
-                    const float xe = (in && g == 0) ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ex, vo * 4u, 0, 0)) : 0.0f;
+                if (grp < GROUPS) {
                     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float xv0 = e == 0 ? x0.x : e == 1 ? x0.y : e == 2 ? x0.z : x0.w;
-                        const float xv1 = e == 0 ? x1.x : e == 1 ? x1.y : e == 2 ? x1.z : x1.w;
+                        const float xv0 = e == 0 ? q.x0[k].x : e == 1 ? q.x0[k].y : e == 2 ? q.x0[k].z : q.x0[k].w;
+                        const float xv1 = e == 0 ? q.x1[k].x : e == 1 ? q.x1[k].y : e == 2 ? q.x1[k].z : q.x1[k].w;
                         a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(e == 0 ? wm[0][0].x : e == 1 ? wm[0][0].y : e == 2 ? wm[0][0].z : wm[0][0].w, xv0, a0, 0, 0, 0);
                         a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(e == 0 ? wm[0][1].x : e == 1 ? wm[0][1].y : e == 2 ? wm[0][1].z : wm[0][1].w, xv0, a1, 0, 0, 0);
                         a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(e == 0 ? wm[1][0].x : e == 1 ? wm[1][0].y : e == 2 ? wm[1][0].z : wm[1][0].w, xv1, a0, 0, 0, 0);
                         a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(e == 0 ? wm[1][1].x : e == 1 ? wm[1][1].y : e == 2 ? wm[1][1].z : wm[1][1].w, xv1, a1, 0, 0, 0);
                     }
-                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wx0, xe, a0, 0, 0, 0);          // the scalar channel: k-step (s, 0, 0, 0)
-                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wx1, xe, a1, 0, 0, 0);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wx0, q.xe[k], a0, 0, 0, 0);     // the scalar channel: k-step (s, 0, 0, 0)
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wx1, q.xe[k], a1, 0, 0, 0);
                     float* pv = P + (grp * 16 + i) * PITCH + 4 * g;                             // taps 4 g .. and 16 + 4 g .. of voxel i
                     pv[0] = a0[0]; pv[1] = a0[1]; pv[2] = a0[2]; pv[3] = a0[3];
                     pv[16] = a1[0]; pv[17] = a1[1]; pv[18] = a1[2]; pv[19] = a1[3];
@@ -123,10 +136,10 @@ __global__ __launch_bounds__(256) void conv3d_xout_kernel(const estd_conv3d_desc
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
-                    const float* q = P + pbase + (kh * IN_W + kw) * PITCH + kh * 3 + kw;
-                    s0 += q[0];
-                    s1 += q[9];
-                    s2 += q[18];
+                    const float* r = P + pbase + (kh * IN_W + kw) * PITCH + kh * 3 + kw;
+                    s0 += r[0];
+                    s1 += r[9];
+                    s2 += r[18];
                 }
             __syncthreads();                              // P is rewritten by the next plane
         }
@@ -138,6 +151,17 @@ __global__ __launch_bounds__(256) void conv3d_xout_kernel(const estd_conv3d_desc
         if (od >= d0 && od < d1 && ovalid) {
             const float v = fmaxf(fmaf(done, sc, sh), floor_);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, (unsigned)(((size_t)od * HW + (size_t)(h0 + oy) * W + (w0 + ox)) * 4u), 0, 0);
+        }
+    };
+    // two register sets in turn: the next plane is requested before the current one is multiplied
+    Plane qa, qb;
+    request(d0 - 1, qa);
+    for (int d = d0 - 1; d <= d1; d += 2) {               // INPUT planes d0 - 1 .. d1
+        request(d + 1, qb);
+        step(d, qa);
+        if (d + 1 <= d1) {
+            request(d + 2, qa);
+            step(d + 1, qb);
         }
     }
 }
