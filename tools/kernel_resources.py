@@ -10,7 +10,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "estdepth_amd", "csrc")
-FILES = sys.argv[1:] or ["conv3d_wino3.hip", "conv3d_wino2.hip", "conv3d_wino2_c16.hip", "conv2d_wino2.hip", "conv1x1.hip", "est_fusion.hip"]
+FILES = sys.argv[1:] or ["conv3d_wino3.hip", "conv3d_xout.hip", "conv3d_wino2.hip", "conv3d_wino2_c16.hip", "conv2d_wino2.hip", "conv1x1.hip", "est_fusion.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 

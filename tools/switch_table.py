@@ -23,6 +23,7 @@ NOTES = {
     "ESTD_CONV2D_NT": "auto | 2 | 4: output-channel tiles per work item of the direct / row-only 2D kernels",
     "ESTD_W3": "1 (default): 32-output-channel 3x3x3 convolutions on the three-axis Winograd kernel; 0: two-axis kernel (the r5 A/B: 0.65 vs 0.81 ms)",
     "ESTD_W3_EXTRA": "1 (default): the key||value convolution (33 -> 32) on the three-axis kernel too; 0: two-axis kernel (0.73 vs 0.85 ms)",
+    "ESTD_W3_XOUT": "1 (default, round 6): dres2 (33 -> 33) = 33 -> 32 on the three-axis kernel + output channel 32 as a pass of its own (csrc/conv3d_xout.hip); 0: the two-axis kernel's 33 -> 33 instance (1.00 vs 0.88 ms)",
     "ESTD_W2_XOUT": "1 (default): dres2 (33 -> 33) on the two-axis kernel's XOUT instance; 0: depth-only kernel (ESTD_BUILD_AB builds) or direct",
     "ESTD_W2X": "0 (default) | 1: plain 32 -> 32 on the operand-reuse two-axis kernel (ESTD_BUILD_AB builds; measured dead end, r5)",
     "ESTD_C2W2_DIL2": "1 (default): dilation-2 3x3 convolutions on the F(2x2,3x3) kernel; 0: direct kernel",
