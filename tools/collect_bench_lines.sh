@@ -19,6 +19,7 @@ for rep in 1 2; do
   ESTD_GATE_IN_CONV=0 python bench.py $AB 2>/dev/null | last > $OUT/${P}_ab_gate_pass_$rep.json
   python bench.py $AB --pipeline on 2>/dev/null | last > $OUT/${P}_ab_pipeline_$rep.json                 # stage A of step k + 1 beside the second half of stage B of step k (+ the serial A/B of the same process)
   ESTD_C1X1_LDS=0 python bench.py $AB 2>/dev/null | last > $OUT/${P}_ab_conv1x1_direct_$rep.json          # 1x1 convolutions on the direct form only
+  ESTD_W3_XOUT=0 python bench.py $AB 2>/dev/null | last > $OUT/${P}_ab_dres2_one_launch_$rep.json          # dres2 on the two-axis kernel's 33 -> 33 instance
 done
 ESTD_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-alt --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_rccl_world1.json
 ESTD_FORCE_DIST=1 ESTD_RESERVE_SCOPE=AB python bench.py --no-cpu-baseline --no-alt --no-other-workloads 2>/dev/null | last > $OUT/${P}_bench_joint_rccl_world1_reserve_ab.json
