@@ -286,3 +286,40 @@ def test_stem7x7_and_taps_packers_reproduce_the_convolution():
     for ky in range(3):
         for kx in range(3):
             assert torch.equal(wt[ky * 3 + kx], w3[:, :, ky, kx])
+
+
+def test_pack_conv3d_xout_taps_reproduces_the_direct_convolution():
+    """csrc/conv3d_xout.hip (round 6): ONE output channel of a 33-input-channel convolution with the 27 taps as the matrix core's rows -- lane (g, i)
+    of (chunk c, tap tile t) holds w[out][main_idx[16 c + 4 g + e]][tap 16 t + i], the scalar channel's taps sit in lane group 0 of their own k-step.
+    Unpacked with that indexing, P[u][tap] = sum_c w[c][tap] x[u][c] followed by the shifted sum y[v] = sum_tap P[v + offset(tap)][tap]
+    (tap = (kd 3 + kh) 3 + kw) is the direct cross-correlation."""
+    rng = np.random.default_rng(5)
+    w = rng.standard_normal((33, 33, 3, 3, 3))
+    main_idx, extra_idx, out_ch = list(range(1, 33)), 0, 32                 # dres2: scalar channel first in the weight, last output channel
+    packed = packing.pack_conv3d_xout_taps(torch.from_numpy(w).float(), main_idx, extra_idx, out_ch).numpy().astype(np.float64)
+    main, ext = packed[:1024].reshape(2, 2, 64, 4), packed[1024:].reshape(2, 64)
+    wt = np.zeros((33, 32))                                                  # [channel in MEMORY order: 32 main then the scalar][tap row]
+    for lane in range(64):
+        g, i = lane >> 4, lane & 15
+        for t in range(2):
+            for c in range(2):
+                for e in range(4):
+                    wt[16 * c + 4 * g + e, 16 * t + i] = main[c, t, lane, e]
+            if g == 0:
+                wt[32, 16 * t + i] = ext[t, lane]
+            else:
+                assert ext[t, lane] == 0.0                                   # the scalar channel's k-step is (s, 0, 0, 0)
+    assert np.all(wt[:, 27:] == 0.0)
+    D, H, W = 4, 5, 6
+    x_main, x_s = rng.standard_normal((32, D, H, W)), rng.standard_normal((D, H, W))
+    xm = np.concatenate([x_main, x_s[None]], 0)                              # memory order of the kernel's operands
+    P = np.einsum("ct,cdhw->tdhw", wt, xm)                                   # the pointwise product
+    Pp = np.zeros((32, D + 2, H + 2, W + 2)); Pp[:, 1:-1, 1:-1, 1:-1] = P
+    y = np.zeros((D, H, W))
+    for kd in range(3):
+        for kh in range(3):
+            for kw in range(3):
+                y += Pp[(kd * 3 + kh) * 3 + kw, kd:kd + D, kh:kh + H, kw:kw + W]
+    x_ref = np.concatenate([x_s[None], x_main], 0)                           # the weight's channel order: scalar channel 0, then the 32 main ones
+    ref = _direct3d(x_ref, w.astype(np.float32).astype(np.float64))[out_ch]          # (the packer stores float32)
+    assert np.abs(y - ref).max() < 1e-5 * np.abs(ref).max()
