@@ -30,8 +30,12 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((__vector_size__(16)));
 constexpr unsigned OOB_OFFSET = 0xFFFFFF00u;
-constexpr int TH = 16, TW = 16, IN_H = TH + 2, IN_W = TW + 2, HALO = IN_H * IN_W;       // 324 halo voxels per plane
-constexpr int GROUPS = (HALO + 15) / 16;                                                // 21 groups of 16 MFMA columns
+#ifndef ESTD_XOUT_TW
+#define ESTD_XOUT_TW 16      // tile width: 16 (256 threads, 21 column groups over 4 waves) | 32 (512 threads, 39 groups over 8 waves; A/B: 0.170 vs 0.175 ms, within noise in dres2)
+#endif
+constexpr int TH = 16, TW = ESTD_XOUT_TW, IN_H = TH + 2, IN_W = TW + 2, HALO = IN_H * IN_W;       // 324 (612) halo voxels per plane
+constexpr int NT = TH * TW, NWAVES = NT / 64;                                           // one thread per output pixel
+constexpr int GROUPS = (HALO + 15) / 16;                                                // 21 (39) groups of 16 MFMA columns
 constexpr int PITCH = 33;                                                               // floats per voxel of P (27 taps used)
 constexpr int DSEG = 32;                                                                // output planes per workgroup (+ 2 halo planes)
 
@@ -41,9 +45,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, s
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)(elems * 4), 0x00020000);
 }
 
-__global__ __launch_bounds__(256) void conv3d_xout_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int dsegs)
+__global__ __launch_bounds__(NT) void conv3d_xout_kernel(const estd_conv3d_desc p, int tiles_w, int tiles_h, int dsegs)
 {
-    __shared__ float P[GROUPS * 16 * PITCH];              // 44 352 bytes
+    extern __shared__ __attribute__((aligned(16))) float P[];     // [GROUPS * 16][PITCH]: 44 352 (82 368) bytes
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, i = lane & 15;
@@ -72,17 +76,17 @@ __global__ __launch_bounds__(256) void conv3d_xout_kernel(const estd_conv3d_desc
     const float floor_ = (32 < p.act_split ? p.act_a : p.act_b) == ESTD_ACT_RELU ? 0.0f : ESTD_NO_FLOOR;
 
     // this wave's MFMA column groups of a plane (wave w takes groups w, w + 4, ...) and, per group, this lane's halo voxel -> in-plane offset
-    constexpr int GPW = (GROUPS + 3) / 4;                 // 6
+    constexpr int GPW = (GROUPS + NWAVES - 1) / NWAVES;   // 6 (5)
     unsigned voff[GPW];                                   // voxel index inside a plane (y * W + x), or OOB
 #pragma unroll
     for (int k = 0; k < GPW; ++k) {
-        const int grp = wave + 4 * k, u = grp * 16 + i;
+        const int grp = wave + NWAVES * k, u = grp * 16 + i;
         const int hy = u / IN_W, hx = u - hy * IN_W;
         const int y = h0 + hy - 1, x = w0 + hx - 1;
         voff[k] = (grp < GROUPS && u < HALO && y >= 0 && y < H && x >= 0 && x < W) ? (unsigned)(y * W + x) : 0xFFFFFFFFu;
     }
     // the output pixel of this thread and its 9 in-plane stencil offsets into P
-    const int oy = tid >> 4, ox = tid & 15;
+    const int oy = tid / TW, ox = tid % TW;
     const bool ovalid = h0 + oy < H && w0 + ox < W;
     const int pbase = (oy * IN_W + ox) * PITCH;
 
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256) void conv3d_xout_kernel(const estd_conv3d_desc
         const unsigned plane = (unsigned)d * (unsigned)HW;
 #pragma unroll
         for (int k = 0; k < GPW; ++k) {
-            if (wave + 4 * k < GROUPS) {                  // (wave-uniform)
+            if (wave + NWAVES * k < GROUPS) {                  // (wave-uniform)
                 const bool in = voff[k] != 0xFFFFFFFFu;
                 const unsigned vo = in ? (plane + voff[k]) : 0u;
                 const unsigned bo = in ? vo * (unsigned)p.in_stride * 4u + (unsigned)g * 16u : OOB_OFFSET;
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256) void conv3d_xout_kernel(const estd_conv3d_desc
         if (d >= 0 && d < D) {                            // (workgroup-uniform)
 #pragma unroll
             for (int k = 0; k < GPW; ++k) {
-                const int grp = wave + 4 * k;
+                const int grp = wave + NWAVES * k;
                 if (grp < GROUPS) {
                     f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -179,6 +183,8 @@ extern "C" int estd_conv3d_k3_xout(const estd_conv3d_desc* dp, estd_stream_t s)
     const int tiles_w = (d.W + TW - 1) / TW, tiles_h = (d.H + TH - 1) / TH, dsegs = (d.D + DSEG - 1) / DSEG;
     const long long grid = (long long)d.N * tiles_h * tiles_w * dsegs;
     if (grid > 0x7fffffffLL) return ESTD_ERR_ARG;
-    hipLaunchKernelGGL(conv3d_xout_kernel, dim3((unsigned)grid), dim3(256), 0, estd_stream(s), d, tiles_w, tiles_h, dsegs);
+    constexpr int LDS_BYTES = GROUPS * 16 * PITCH * 4;
+    estd_allow_dynamic_lds<conv3d_xout_kernel>(LDS_BYTES);
+    hipLaunchKernelGGL(conv3d_xout_kernel, dim3((unsigned)grid), dim3(NT), LDS_BYTES, estd_stream(s), d, tiles_w, tiles_h, dsegs);
     return ESTD_LAUNCH_CHECK();
 }
